@@ -1,0 +1,222 @@
+/*
+ * rtc.h — C ABI of the MI355X render path (librtc_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of SinclaM/ray-tracer-challenge:
+ *
+ *     Camera(T).render(self, allocator, world) !Canvas(T)      src/raytracer/camera.zig:80-125
+ *       -> rayForPixel                                         src/raytracer/camera.zig:64-76
+ *       -> World.colorAt(ray, 5)                               src/raytracer/world.zig:111-121
+ *            intersect / shadeHit / isShadowed /
+ *            reflectedColor / refractedColor                   src/raytracer/world.zig:71-189
+ *
+ * The reference has no FFI for this path (it is pure Zig); the only C-ABI
+ * precedent is the WASM export table src/lib.zig:233-309 (global renderer,
+ * error returned as a NUL-terminated error *name*).  A Zig host binds the
+ * functions below with `extern fn` declarations and calls
+ * them from the body of Camera.render; the JSON scene loader and the
+ * canvas/PPM writer stay untouched.
+ *
+ * Conventions
+ *   - all reals are IEEE binary64 (the reference renders scenes in f64:
+ *     src/main.zig:71, src/lib.zig:194,223);
+ *   - matrices are row-major 4x4 (src/raytracer/matrix.zig:15), 16 doubles;
+ *   - all input arrays are caller-owned and are copied by rtc_scene_create();
+ *     the library never retains a host pointer;
+ *   - every function returns an rtc_status; the message/name of the last
+ *     failure on the calling thread is available from rtc_last_error();
+ *   - a handle may be used from one thread at a time; distinct handles are
+ *     independent.
+ */
+#ifndef RTC_H
+#define RTC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTC_ABI_VERSION 1u
+
+/* ---- status codes; names mirror the reference's Zig error names where one exists ---- */
+typedef enum rtc_status {
+  RTC_OK = 0,
+  RTC_ERR_INVALID_ARGUMENT = 1, /* null pointer, zero-sized image, tile out of range ...           */
+  RTC_ERR_OUT_OF_MEMORY = 2,    /* Zig: error.OutOfMemory -> @panic in camera.zig:118               */
+  RTC_ERR_NOT_INVERTIBLE = 3,   /* Zig: MatrixError.NotInvertible, matrix.zig:7                     */
+  RTC_ERR_UNSUPPORTED = 4,      /* a shape/pattern kind this build of the kernel does not implement */
+  RTC_ERR_BAD_INDEX = 5,        /* an index array points outside its table                          */
+  RTC_ERR_NO_DEVICE = 6,        /* no HIP device / HIP runtime failure; message carries hipError    */
+  RTC_ERR_NOT_AFFINE = 7,       /* a shape/pattern inverse whose last row is not (0,0,0,1)          */
+  RTC_ERR_OVERFLOW = 8          /* a per-ray device stack overflowed (BVH deeper than RTC_MAX_STACK) */
+} rtc_status;
+
+/* ---- leaf kinds: the Shape(T).Variant tags that can be hit (shape.zig:99-111) ---- */
+enum {
+  RTC_SPHERE = 0,          /* shapes/sphere.zig   */
+  RTC_PLANE = 1,           /* shapes/plane.zig    */
+  RTC_CUBE = 2,            /* shapes/cube.zig     */
+  RTC_CYLINDER = 3,        /* shapes/cylinder.zig */
+  RTC_TRIANGLE = 4,        /* shapes/triangle.zig:17-81   */
+  RTC_SMOOTH_TRIANGLE = 5, /* shapes/triangle.zig:210-274 */
+  RTC_CONE = 6             /* shapes/cone.zig (not implemented by the kernel yet -> RTC_ERR_UNSUPPORTED) */
+};
+
+/* ---- pattern kinds: Pattern(T).Variant tags (patterns/pattern.zig:34-45) ---- */
+enum {
+  RTC_PAT_SOLID = 0,           /* patterns/solid.zig    */
+  RTC_PAT_STRIPES = 1,         /* patterns/stripes.zig  */
+  RTC_PAT_RINGS = 2,           /* patterns/rings.zig    */
+  RTC_PAT_GRADIENT = 3,        /* patterns/gradient.zig */
+  RTC_PAT_RADIAL_GRADIENT = 4, /* patterns/gradient.zig */
+  RTC_PAT_CHECKERS = 5,        /* patterns/checkers.zig */
+  RTC_PAT_BLEND = 6,           /* patterns/blend.zig    */
+  RTC_PAT_PERTURB = 7,         /* patterns/perturb.zig  (unsupported) */
+  RTC_PAT_TEXTURE_MAP = 8,     /* patterns/texture_map.zig (unsupported) */
+  RTC_PAT_TEST = 9             /* TestPattern, pattern.zig:136-150: colour = pattern-space point */
+};
+
+/* Children / roots are encoded as one u32: high bit set = group node index, else leaf index. */
+#define RTC_CHILD_NODE_BIT 0x80000000u
+
+/* Number of doubles per material row: ambient, diffuse, specular, shininess,
+ * reflective, transparency, refractive_index (material.zig:18-25).              */
+#define RTC_MAT_STRIDE 7
+
+/*
+ * Flattened World(T) (world.zig:24-25): SoA tables, caller-owned.
+ *
+ * Leaves are the hit-able Shapes; `leaf_*` arrays are indexed by leaf.  The
+ * order in which leaves are reached by a depth-first walk of roots[] /
+ * children[] is the order the reference's nested stable sorts preserve for
+ * equal-t intersections (world.zig:81, group.zig:59) and is used as the
+ * tie-break; the leaf arrays themselves may be in any order.
+ *
+ * Groups store no transform of their own (shape.zig:286-296): every leaf holds
+ * the full world<->object matrices, so only the inverse and its transpose are
+ * needed on the path (shape.zig:133-145, 313-318).  Transforms are a table so
+ * that the thousands of triangles of one OBJ instance share one entry.
+ */
+typedef struct rtc_scene_desc {
+  uint32_t abi_version;      /* RTC_ABI_VERSION */
+
+  uint32_t n_xforms;
+  const double *xf_inv;      /* [n_xforms][16]  Shape._inverse_transform           */
+  const double *xf_inv_t;    /* [n_xforms][16]  Shape._inverse_transform_transpose */
+
+  uint32_t n_leaves;
+  const uint8_t *leaf_kind;      /* RTC_SPHERE ...                                        */
+  const uint32_t *leaf_xform;    /* index into xf_*                                       */
+  const uint32_t *leaf_material; /* index into mat_*                                      */
+  const uint8_t *leaf_shadow;    /* Shape.casts_shadow (shape.zig:119)                    */
+  const uint32_t *leaf_id;       /* Shape.id (shape.zig:113): containers walk identity    */
+  const uint32_t *leaf_geom;     /* cylinder/cone: index into cyl_*; triangles: into tri_* */
+
+  uint32_t n_cyls;               /* cylinder.zig:26-28 (also cones) */
+  const double *cyl_min;
+  const double *cyl_max;
+  const uint8_t *cyl_closed;
+
+  uint32_t n_tris;               /* triangle.zig:21-26, 214-221 */
+  const double *tri_p1;          /* [n_tris][3] */
+  const double *tri_e1;          /* [n_tris][3] p2 - p1 */
+  const double *tri_e2;          /* [n_tris][3] p3 - p1 */
+  const double *tri_n1;          /* [n_tris][3] smooth: n1; flat: the stored face normal (shape.zig:190) */
+  const double *tri_n2;          /* [n_tris][3] smooth only */
+  const double *tri_n3;          /* [n_tris][3] smooth only */
+
+  uint32_t n_materials;
+  const double *mat_params;      /* [n_materials][RTC_MAT_STRIDE] */
+  const uint32_t *mat_pattern;   /* index into pat_*              */
+
+  uint32_t n_patterns;
+  const uint8_t *pat_kind;       /* RTC_PAT_*                                              */
+  const double *pat_inv;         /* [n_patterns][16] Pattern._inverse_transform            */
+  const double *pat_rgb;         /* [n_patterns][3]  solid colour                          */
+  const uint32_t *pat_a;         /* sub-pattern a (stripes/checkers/...), else 0           */
+  const uint32_t *pat_b;         /* sub-pattern b                                          */
+
+  uint32_t n_nodes;              /* one node per reference Group (group.zig:17-23)         */
+  const double *node_min;        /* [n_nodes][3] Group._bbox min (bounding_box.zig:21)     */
+  const double *node_max;        /* [n_nodes][3]                                           */
+  const uint32_t *node_first;    /* first entry of this group's children in children[]     */
+  const uint32_t *node_count;    /* Group.children.items.len                               */
+  uint32_t n_children;
+  const uint32_t *children;      /* mixed list, RTC_CHILD_NODE_BIT marks a sub-group       */
+
+  uint32_t n_roots;              /* World.objects (world.zig:24), in order                 */
+  const uint32_t *roots;         /* same encoding as children[]                            */
+
+  uint32_t n_lights;             /* World.lights (world.zig:25), point lights (light.zig)  */
+  const double *light_pos;       /* [n_lights][3] */
+  const double *light_rgb;       /* [n_lights][3] */
+} rtc_scene_desc;
+
+/* Camera(T) after Camera.new + setTransform (camera.zig:18-61). */
+typedef struct rtc_camera {
+  uint32_t hsize, vsize;
+  double half_width, half_height, pixel_size; /* camera.zig:33-52 */
+  double inv_view[16];                        /* Camera._inverse_transform */
+} rtc_camera;
+
+/* Ray counters of the most recent render on a handle ("ray" = one World.intersect call). */
+typedef struct rtc_stats {
+  uint64_t primary;       /* camera.zig:117-118: one per pixel                                  */
+  uint64_t secondary;     /* reflectedColor + refractedColor calls that recurse (world.zig:164,186) */
+  uint64_t shadow_calls;  /* isShadowed calls the reference makes (world.zig:92)                */
+  uint64_t shadow_traced; /* shadow rays this library actually traced (skips provably inert ones) */
+  uint64_t overflow;      /* lanes whose traversal stack overflowed (must be 0)                 */
+} rtc_stats;
+
+typedef struct rtc_scene rtc_scene; /* opaque; owns the device copies and one HIP stream */
+
+/* Validates `desc`, copies it into HBM on the current HIP device. */
+int rtc_scene_create(const rtc_scene_desc *desc, rtc_scene **out);
+void rtc_scene_destroy(rtc_scene *scene);
+
+/*
+ * Replaces Camera.render (camera.zig:80-125) for the tile [x0,x0+w) x [y0,y0+h):
+ * rgb_out[(y-y0)*w + (x-x0)][0..2] = colorAt(rayForPixel(x,y), max_depth).
+ * The reference value of max_depth is 5 (camera.zig:118).  `rgb_out` is host
+ * memory, [h][w][3] doubles.  Synchronous.
+ */
+int rtc_render(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
+               uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, double *rgb_out);
+
+/*
+ * Same, but `d_rgb_out` is device memory on the scene's device and the work is
+ * enqueued on `hip_stream` (a hipStream_t; NULL = the handle's own stream)
+ * without synchronising.  This is the entry point the multi-GPU driver uses
+ * with device buffers owned by its RCCL communicator.
+ */
+int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
+                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                      double *d_rgb_out, void *hip_stream);
+
+/*
+ * Multi-GPU tile partition: the image is cut into tile_w x tile_h tiles
+ * numbered row-major; this call renders tiles first_tile, first_tile+stride,
+ * ... (n_my_tiles of them) into the compact buffer
+ * d_rgb_out[k][tile_h][tile_w][3]; pixels of edge tiles that fall outside the
+ * image are written as 0.  Asynchronous on `hip_stream` like rtc_render_device.
+ */
+int rtc_render_tiles_device(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
+                            uint32_t tile_w, uint32_t tile_h, uint32_t first_tile,
+                            uint32_t tile_stride, uint32_t n_my_tiles,
+                            double *d_rgb_out, void *hip_stream);
+
+/* Waits for the work enqueued on the handle's own stream. */
+int rtc_scene_synchronize(rtc_scene *scene);
+
+/* Counters of the last render that was enqueued on this handle (synchronises). */
+int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
+
+/* Thread-local, static storage; "" when the last call on this thread succeeded. */
+const char *rtc_last_error(void);
+/* "NotInvertible", "OutOfMemory", ... (Zig error-name style, cf. lib.zig:226-227). */
+const char *rtc_status_name(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTC_H */

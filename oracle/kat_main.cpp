@@ -1,0 +1,690 @@
+// kat_main.cpp — pins the CPU oracle (rtc_oracle.hpp) to the reference's own
+// known-answer tests.  TEST INFRASTRUCTURE.
+//
+// Every numeric KAT the reference's inline `test` blocks hold for the hot path
+//  is restated here against the oracle, in f64.  The
+// reference runs most of them in f32 with tolerance 1e-5; expected values are
+// the reference's literals and the tolerance is the reference's 1e-5, with ONE
+// exception noted at the case (cylinder.zig:175: the literals 6.80800/7.08869
+// are f32 round-off; f64 gives the book's 6.80798/7.08872).
+//
+// Output: one line per case, "KAT <file>:<line> <name> PASS|FAIL [detail]";
+// exit status 1 if any case failed.  tests/test_oracle_kats.py parses it.
+#include <cstdio>
+#include <string>
+
+#include "rtc_oracle.hpp"
+
+using namespace orc;
+
+static int g_failed = 0, g_total = 0;
+
+static void report(const char* where, const std::string& name, bool ok, const std::string& detail = "") {
+  ++g_total;
+  if (!ok) ++g_failed;
+  std::printf("KAT %s %s %s%s%s\n", where, name.c_str(), ok ? "PASS" : "FAIL", detail.empty() ? "" : " ",
+              detail.c_str());
+}
+static std::string fmt(Tuple t) {
+  char b[160];
+  std::snprintf(b, sizeof b, "(%.8g,%.8g,%.8g,%.8g)", t.x, t.y, t.z, t.w);
+  return b;
+}
+static std::string fmt(Color c) {
+  char b[160];
+  std::snprintf(b, sizeof b, "(%.8g,%.8g,%.8g)", c.r, c.g, c.b);
+  return b;
+}
+// tol == 0 demands exact equality (the reference uses expectEqual there).
+static bool within(double a, double b, double tol) { return std::fabs(a - b) <= tol; }
+static void expectTuple(const char* where, const std::string& name, Tuple got, Tuple want, double tol = 1e-5) {
+  const bool ok = within(got.x, want.x, tol) && within(got.y, want.y, tol) && within(got.z, want.z, tol) &&
+                  within(got.w, want.w, tol);
+  report(where, name, ok, "got " + fmt(got) + " want " + fmt(want));
+}
+static void expectColor(const char* where, const std::string& name, Color got, Color want, double tol = 1e-5) {
+  const bool ok = within(got.r, want.r, tol) && within(got.g, want.g, tol) && within(got.b, want.b, tol);
+  report(where, name, ok, "got " + fmt(got) + " want " + fmt(want));
+}
+static void expectNear(const char* where, const std::string& name, double got, double want, double tol = 1e-5) {
+  char b[96];
+  std::snprintf(b, sizeof b, "got %.10g want %.10g", got, want);
+  report(where, name, std::fabs(got - want) <= tol, b);
+}
+static void expectTrue(const char* where, const std::string& name, bool v) { report(where, name, v); }
+
+static const double PI = 3.14159265358979323846;
+static const double RS2 = 1.0 / std::sqrt(2.0);
+
+static Matrix M(std::initializer_list<double> v) { return Matrix::make(v); }
+
+// ------------------------------------------------------------------------------------------
+static void tupleKats() {  // tuple.zig:146-216
+  const Tuple a = vec3(1, 2, 3), b = vec3(2, 3, 4);
+  expectNear("tuple.zig:187", "dot", dot(a, b), 20.0);
+  expectTuple("tuple.zig:193", "cross_ab", cross(a, b), vec3(-1, 2, -1));
+  expectTuple("tuple.zig:194", "cross_ba", cross(b, a), vec3(1, -2, 1));
+  expectNear("tuple.zig:175", "magnitude", magnitude(vec3(1, 2, 3)), std::sqrt(14.0));
+  expectTuple("tuple.zig:181", "normalize", normalized(vec3(1, 2, 3)), vec3(0.26726, 0.53452, 0.80178));
+  expectTuple("tuple.zig:203", "reflect_45", reflect(vec3(1, -1, 0), vec3(0, 1, 0)), vec3(1, 1, 0));
+  expectTuple("tuple.zig:209", "reflect_slanted", reflect(vec3(0, -1, 0), vec3(RS2, RS2, 0)), vec3(1, 0, 0));
+}
+
+static void matrixKats() {  // matrix.zig:330-683
+  const Matrix a = M({1, 2, 3, 4, 5, 6, 7, 8, 9, 8, 7, 6, 5, 4, 3, 2});
+  const Matrix b = M({-2, 1, 2, 3, 3, 2, 1, -1, 4, 3, 6, 5, 1, 2, 7, 8});
+  const Matrix axb = M({20, 22, 50, 48, 44, 54, 114, 108, 40, 58, 110, 102, 16, 26, 46, 42});
+  expectTrue("matrix.zig:352", "mul", a.mul(b).approxEqual(axb));
+  const Matrix a2 = M({1, 2, 3, 4, 2, 4, 4, 2, 8, 6, 4, 1, 0, 0, 0, 1});
+  expectTuple("matrix.zig:378", "tupleMul", a2.tupleMul(Tuple{1, 2, 3, 1}), Tuple{18, 24, 33, 1});
+  const Matrix t = M({0, 9, 3, 0, 9, 8, 0, 8, 1, 8, 5, 3, 0, 0, 5, 8});
+  expectTrue("matrix.zig:395", "transpose", t.transpose().approxEqual(M({0, 9, 1, 0, 9, 8, 8, 0, 3, 0, 5, 5, 0, 8, 3, 8})));
+  const double m3[3][3] = {{1, 2, 6}, {-5, 8, -4}, {2, 6, 4}};
+  expectNear("matrix.zig:437", "det3", det3(m3), -196.0);
+  const Matrix d4 = M({-2, -8, 3, 5, -3, 1, 7, 3, 1, 2, -9, 6, -6, 7, 7, -9});
+  expectNear("matrix.zig:446", "cofactor00", d4.cofactor(0, 0), 690.0);
+  expectNear("matrix.zig:447", "cofactor01", d4.cofactor(0, 1), 447.0);
+  expectNear("matrix.zig:448", "cofactor02", d4.cofactor(0, 2), 210.0);
+  expectNear("matrix.zig:449", "cofactor03", d4.cofactor(0, 3), 51.0);
+  expectNear("matrix.zig:450", "det4", d4.det(), -4071.0);
+  const Matrix ia = M({8, -5, 9, 2, 7, 5, 6, 1, -6, 0, 9, 6, -3, 0, -9, -4});
+  expectTrue("matrix.zig:468", "inverse_a",
+             ia.inverse().approxEqual(M({-0.15385, -0.15385, -0.28205, -0.53846, -0.07692, 0.12308, 0.02564, 0.03077,
+                                         0.35897, 0.35897, 0.43590, 0.92308, -0.69231, -0.69231, -0.76923, -1.92308})));
+  const Matrix ib = M({9, 3, 0, 9, -5, -2, -6, -3, -4, 9, 6, 4, -7, 6, 6, 2});
+  expectTrue("matrix.zig:484", "inverse_b",
+             ib.inverse().approxEqual(M({-0.04074, -0.07778, 0.14444, -0.22222, -0.07778, 0.03333, 0.36667, -0.33333,
+                                         -0.02901, -0.14630, -0.10926, 0.12963, 0.17778, 0.06667, -0.26667, 0.33333})));
+  const Matrix c = M({3, -9, 7, 3, 3, -8, 2, -9, -4, 4, 4, 1, -6, 5, -1, 1});
+  const Matrix d = M({8, 2, 2, 2, 3, -1, 7, 0, 7, 0, 5, 4, 6, -2, 0, 5});
+  expectTrue("matrix.zig:500", "mul_by_inverse", c.mul(d).mul(d.inverse()).approxEqual(c));
+  bool threw = false;
+  try {
+    M({-4, 2, -2, -3, 9, 6, 2, 6, 0, -5, 1, -5, 0, 0, 0, 0}).inverse();
+  } catch (const std::exception&) {
+    threw = true;
+  }
+  expectTrue("matrix.zig:204", "not_invertible", threw);
+
+  const Matrix I = Matrix::identity();
+  Matrix tr = I.translate(5, -3, 2);
+  expectTuple("matrix.zig:507", "translate", tr.tupleMul(point(-3, 4, 5)), point(2, 1, 7));
+  expectTuple("matrix.zig:510", "translate_inv", tr.inverse().tupleMul(point(-3, 4, 5)), point(-8, 7, 3));
+  expectTuple("matrix.zig:513", "translate_vec", tr.inverse().tupleMul(vec3(3, 4, 5)), vec3(3, 4, 5));
+  tr = I.scale(2, 3, 4);
+  expectTuple("matrix.zig:518", "scale_pt", tr.tupleMul(point(-4, 6, 8)), point(-8, 18, 32));
+  expectTuple("matrix.zig:523", "scale_inv", tr.inverse().tupleMul(vec3(-4, 6, 8)), vec3(-2, 2, 2));
+  expectTuple("matrix.zig:531", "rotx_half", I.rotateX(PI / 4).tupleMul(point(0, 1, 0)), point(0, RS2, RS2));
+  expectTuple("matrix.zig:535", "rotx_full", I.rotateX(PI / 4).rotateX(PI / 4).tupleMul(point(0, 1, 0)), point(0, 0, 1));
+  expectTuple("matrix.zig:538", "rotx_inv", I.rotateX(PI / 4).inverse().tupleMul(point(0, 1, 0)), point(0, RS2, -RS2));
+  expectTuple("matrix.zig:543", "roty_half", I.rotateY(PI / 4).tupleMul(point(0, 0, 1)), point(RS2, 0, RS2));
+  expectTuple("matrix.zig:547", "roty_full", I.rotateY(PI / 4).rotateY(PI / 4).tupleMul(point(0, 0, 1)), point(1, 0, 0));
+  expectTuple("matrix.zig:551", "rotz_half", I.rotateZ(PI / 4).tupleMul(point(0, 1, 0)), point(-RS2, RS2, 0));
+  expectTuple("matrix.zig:555", "rotz_full", I.rotateZ(PI / 4).rotateZ(PI / 4).tupleMul(point(0, 1, 0)), point(-1, 0, 0));
+  const Tuple p = point(2, 3, 4);
+  expectTuple("matrix.zig:560", "shear_xy", I.shear(1, 0, 0, 0, 0, 0).tupleMul(p), point(5, 3, 4));
+  expectTuple("matrix.zig:563", "shear_xz", I.shear(0, 1, 0, 0, 0, 0).tupleMul(p), point(6, 3, 4));
+  expectTuple("matrix.zig:566", "shear_yx", I.shear(0, 0, 1, 0, 0, 0).tupleMul(p), point(2, 5, 4));
+  expectTuple("matrix.zig:569", "shear_yz", I.shear(0, 0, 0, 1, 0, 0).tupleMul(p), point(2, 7, 4));
+  expectTuple("matrix.zig:572", "shear_zx", I.shear(0, 0, 0, 0, 1, 0).tupleMul(p), point(2, 3, 6));
+  expectTuple("matrix.zig:575", "shear_zy", I.shear(0, 0, 0, 0, 0, 1).tupleMul(p), point(2, 3, 7));
+  expectTuple("matrix.zig:581", "chained", I.rotateX(PI / 2).scale(5, 5, 5).translate(10, 5, 7).tupleMul(point(1, 0, 1)),
+              point(15, 0, 7));
+
+  expectTrue("matrix.zig:590", "view_default", Matrix::viewTransform(point(0, 0, 0), point(0, 0, -1), vec3(0, 1, 0)).approxEqual(I));
+  expectTrue("matrix.zig:602", "view_positive_z",
+             Matrix::viewTransform(point(0, 0, 0), point(0, 0, 1), vec3(0, 1, 0)).approxEqual(I.scale(-1, 1, -1)));
+  expectTrue("matrix.zig:614", "view_moves_world",
+             Matrix::viewTransform(point(0, 0, 8), point(0, 0, 0), vec3(0, 1, 0)).approxEqual(I.translate(0, 0, -8)));
+  expectTrue("matrix.zig:633", "view_arbitrary",
+             Matrix::viewTransform(point(1, 3, 2), point(4, -2, 8), vec3(1, 1, 0))
+                 .approxEqual(M({-0.50709, 0.50709, 0.67612, -2.36643, 0.76772, 0.60609, 0.12122, -2.82843, -0.35857,
+                                 0.59761, -0.71714, 0.00000, 0.00000, 0.00000, 0.00000, 1.00000})));
+}
+
+static void rayKats() {  // ray.zig:37-64
+  const Ray r{point(2, 3, 4), vec3(1, 0, 0)};
+  expectTuple("ray.zig:45", "position_0", r.position(0), point(2, 3, 4));
+  expectTuple("ray.zig:46", "position_1", r.position(1), point(3, 3, 4));
+  expectTuple("ray.zig:47", "position_m1", r.position(-1), point(1, 3, 4));
+  expectTuple("ray.zig:48", "position_2.5", r.position(2.5), point(4.5, 3, 4));
+  const Ray r2{point(1, 2, 3), vec3(0, 1, 0)};
+  const Ray t = r2.transform(Matrix::identity().translate(3, 4, 5));
+  expectTuple("ray.zig:55", "translate_origin", t.origin, point(4, 6, 8));
+  expectTuple("ray.zig:56", "translate_dir", t.direction, vec3(0, 1, 0));
+  const Ray s = r2.transform(Matrix::identity().scale(2, 3, 4));
+  expectTuple("ray.zig:61", "scale_origin", s.origin, point(2, 6, 12));
+  expectTuple("ray.zig:62", "scale_dir", s.direction, vec3(0, 3, 0));
+}
+
+// ------------------------------------------------------------------------------------------
+static void expectTs(const char* where, const std::string& name, const Intersections& xs, std::initializer_list<double> ts,
+                     double tol = 1e-5) {
+  bool ok = xs.size() == ts.size();
+  std::string detail = "n=" + std::to_string(xs.size());
+  size_t i = 0;
+  for (double t : ts) {
+    if (ok) ok = std::fabs(xs[i].t - t) <= tol;
+    ++i;
+  }
+  for (const auto& x : xs) detail += " " + std::to_string(x.t);
+  report(where, name, ok, detail);
+}
+
+static void sphereKats() {  // sphere.zig:67-184
+  Shape s = Shape::make(SPHERE);
+  expectTs("sphere.zig:71", "through_center", s.intersect({point(0, 0, -5), vec3(0, 0, 1)}), {4.0, 6.0});
+  expectTs("sphere.zig:87", "tangent", s.intersect({point(0, 1, -5), vec3(0, 0, 1)}), {5.0, 5.0});
+  expectTs("sphere.zig:103", "miss", s.intersect({point(0, 2, -5), vec3(0, 0, 1)}), {});
+  expectTs("sphere.zig:112", "inside", s.intersect({point(0, 0, 0), vec3(0, 0, 1)}), {-1.0, 1.0});
+  expectTs("sphere.zig:128", "behind", s.intersect({point(0, 0, 5), vec3(0, 0, 1)}), {-6.0, -4.0});
+  Shape s2 = Shape::make(SPHERE);
+  s2.setTransform(Matrix::identity().scale(2, 2, 2));
+  expectTs("sphere.zig:144", "scaled", s2.intersect({point(0, 0, -5), vec3(0, 0, 1)}), {3.0, 7.0});
+  Shape s3 = Shape::make(SPHERE);
+  s3.setTransform(Matrix::identity().translate(5, 0, 0));
+  expectTs("sphere.zig:161", "translated_miss", s3.intersect({point(0, 0, -5), vec3(0, 0, 1)}), {});
+  Shape n1 = Shape::make(SPHERE);
+  n1.setTransform(Matrix::identity().translate(0, 1, 0));
+  expectTuple("sphere.zig:173", "normal_translated", n1.normalAt(point(0, 1.70711, -0.70711), {}), vec3(0, 0.70711, -0.70711));
+  Shape n2 = Shape::make(SPHERE);
+  n2.setTransform(Matrix::identity().rotateZ(PI / 5.0).scale(1, 0.5, 1));
+  expectTuple("sphere.zig:179", "normal_transformed", n2.normalAt(point(0, RS2, -RS2), {}), vec3(0, 0.97014, -0.24254));
+}
+
+static void planeKats() {  // plane.zig:58-107
+  Shape p = Shape::make(PLANE);
+  expectTs("plane.zig:62", "parallel", p.intersect({point(0, 10, 0), vec3(0, 0, 1)}), {});
+  expectTs("plane.zig:70", "coplanar", p.intersect({point(0, 0, 0), vec3(0, 0, 1)}), {});
+  expectTs("plane.zig:78", "from_above", p.intersect({point(0, 1, 0), vec3(0, -1, 0)}), {1.0});
+  expectTs("plane.zig:88", "from_below", p.intersect({point(0, -1, 0), vec3(0, 1, 0)}), {1.0});
+  expectTuple("plane.zig:100", "normal_a", p.normalAt(point(0, 0, 0), {}), vec3(0, 1, 0));
+  expectTuple("plane.zig:101", "normal_b", p.normalAt(point(10, 0, -10), {}), vec3(0, 1, 0));
+  expectTuple("plane.zig:102", "normal_c", p.normalAt(point(-5, 0, 150), {}), vec3(0, 1, 0));
+}
+
+static void cubeKats() {  // cube.zig:126-209
+  Shape c = Shape::make(CUBE);
+  struct Hit { Tuple o, d; double t1, t2; };
+  const Hit hits[] = {{point(5, 0.5, 0), vec3(-1, 0, 0), 4, 6},  {point(-5, 0.5, 0), vec3(1, 0, 0), 4, 6},
+                      {point(0.5, 5, 0), vec3(0, -1, 0), 4, 6},  {point(0.5, -5, 0), vec3(0, 1, 0), 4, 6},
+                      {point(0.5, 0, -5), vec3(0, 0, 1), 4, 6},  {point(0, 0.5, 0), vec3(0, 0, 1), -1, 1}};
+  int i = 0;
+  for (const Hit& h : hits) expectTs("cube.zig:129", "hit_" + std::to_string(i++), c.intersect({h.o, h.d}), {h.t1, h.t2});
+  const Ray misses[] = {{point(-2, 0, 0), vec3(0.2673, 0.5345, 0.8018)}, {point(0, -2, 0), vec3(0.8018, 0.2673, 0.5345)},
+                        {point(0, 0, -2), vec3(0.5345, 0.8018, 0.2673)}, {point(2, 0, 2), vec3(0, 0, -1)},
+                        {point(0, 2, 2), vec3(0, -1, 0)},                {point(2, 2, 0), vec3(-1, 0, 0)}};
+  i = 0;
+  for (const Ray& r : misses) expectTs("cube.zig:167", "miss_" + std::to_string(i++), c.intersect(r), {});
+  struct N { Tuple p, n; };
+  const N normals[] = {{point(1, 0.5, -0.8), vec3(1, 0, 0)},  {point(-1, -0.2, 0.9), vec3(-1, 0, 0)},
+                       {point(-0.4, 1, -0.1), vec3(0, 1, 0)}, {point(0.3, -1, -0.7), vec3(0, -1, 0)},
+                       {point(-0.6, 0.3, 1), vec3(0, 0, 1)},  {point(0.4, 0.4, -1), vec3(0, 0, -1)},
+                       {point(1, 1, 1), vec3(1, 0, 0)},       {point(-1, -1, -1), vec3(-1, 0, 0)}};
+  i = 0;
+  for (const N& n : normals) expectTuple("cube.zig:198", "normal_" + std::to_string(i++), c.normalAt(n.p, {}), n.n);
+}
+
+static void cylinderKats() {  // cylinder.zig:136-332
+  Shape cyl = Shape::make(CYLINDER);
+  const Ray misses[] = {{point(1, 0, 0), vec3(0, 1, 0)}, {point(0, 0, 0), vec3(0, 1, 0)}, {point(0, 0, -5), vec3(1, 1, 1)}};
+  int i = 0;
+  for (const Ray& r : misses)
+    expectTs("cylinder.zig:136", "miss_" + std::to_string(i++), cyl.intersect({r.origin, normalized(r.direction)}), {});
+  expectTs("cylinder.zig:169", "tangent", cyl.intersect({point(1, 0, -5), normalized(vec3(0, 0, 1))}), {5.0, 5.0});
+  expectTs("cylinder.zig:172", "through", cyl.intersect({point(0, 0, -5), normalized(vec3(0, 0, 1))}), {4.0, 6.0});
+  expectTs("cylinder.zig:175", "skewed", cyl.intersect({point(0.5, 0, -5), normalized(vec3(0.1, 1, 1))}), {6.80798, 7.08872},
+           1e-4);  // reference literals 6.80800 / 7.08869 are the f32 results; book (f64): 6.80798 / 7.08872
+  struct N { Tuple p, n; };
+  const N normals[] = {{point(1, 0, 0), vec3(1, 0, 0)}, {point(0, 5, -1), vec3(0, 0, -1)},
+                       {point(0, -2, 1), vec3(0, 0, 1)}, {point(-1, 1, 0), vec3(-1, 0, 0)}};
+  i = 0;
+  for (const N& n : normals) expectTuple("cylinder.zig:187", "normal_" + std::to_string(i++), cyl.normalAt(n.p, {}), n.n);
+  expectTrue("cylinder.zig:205", "default_min_max", cyl.ymin == -INF && cyl.ymax == INF);
+
+  Shape tc = Shape::make(CYLINDER);
+  tc.ymin = 1.0;
+  tc.ymax = 2.0;
+  struct C { Tuple o, d; size_t count; };
+  const C trunc[] = {{point(0, 1.5, 0), vec3(0.1, 1, 0), 0}, {point(0, 3, -5), vec3(0, 0, 1), 0},
+                     {point(0, 0, -5), vec3(0, 0, 1), 0},    {point(0, 2, -5), vec3(0, 0, 1), 0},
+                     {point(0, 1, -5), vec3(0, 0, 1), 0},    {point(0, 1.5, -2), vec3(0, 0, 1), 2}};
+  i = 0;
+  for (const C& c : trunc)
+    expectTrue("cylinder.zig:228", "truncated_" + std::to_string(i++), tc.intersect({c.o, normalized(c.d)}).size() == c.count);
+  Shape cc = tc;
+  cc.closed = true;
+  const C caps[] = {{point(0, 3, 0), vec3(0, -1, 0), 2},  {point(0, 3, -2), vec3(0, -1, 2), 2},
+                    {point(0, 4, -2), vec3(0, -1, 1), 2}, {point(0, 0, -2), vec3(0, 1, 2), 2},
+                    {point(0, -1, -2), vec3(0, 1, 1), 2}};
+  i = 0;
+  for (const C& c : caps)
+    expectTrue("cylinder.zig:271", "closed_caps_" + std::to_string(i++), cc.intersect({c.o, normalized(c.d)}).size() == c.count);
+  const N capn[] = {{point(0, 1, 0), vec3(0, -1, 0)},   {point(0.5, 1, 0), vec3(0, -1, 0)}, {point(0, 1, 0.5), vec3(0, -1, 0)},
+                    {point(0, 2, 0), vec3(0, 1, 0)},    {point(0.5, 2, 0), vec3(0, 1, 0)},  {point(0, 2, 0.5), vec3(0, 1, 0)}};
+  i = 0;
+  for (const N& n : capn) expectTuple("cylinder.zig:308", "cap_normal_" + std::to_string(i++), cc.normalAt(n.p, {}), n.n);
+}
+
+static void triangleKats() {  // triangle.zig:83-196, 289-342
+  const Shape t = Shape::triangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0));
+  expectTuple("triangle.zig:94", "e1", t.e1, vec3(-1, -1, 0));
+  expectTuple("triangle.zig:95", "e2", t.e2, vec3(1, -1, 0));
+  expectTuple("triangle.zig:96", "normal", t.normal, vec3(0, 0, -1));
+  expectTuple("triangle.zig:107", "normalAt", t.normalAt(point(-0.5, 0.75, 0), {}), t.normal);
+  expectTs("triangle.zig:118", "parallel", t.intersect({point(0, -1, -2), vec3(0, 1, 0)}), {});
+  expectTs("triangle.zig:133", "miss_p1p3", t.intersect({point(1, 1, -2), vec3(0, 0, 1)}), {});
+  expectTs("triangle.zig:148", "miss_p1p2", t.intersect({point(-1, 1, -2), vec3(0, 0, 1)}), {});
+  expectTs("triangle.zig:163", "miss_p2p3", t.intersect({point(0, -1, -2), vec3(0, 0, 1)}), {});
+  expectTs("triangle.zig:178", "strike", t.intersect({point(0, 0.5, -2), vec3(0, 0, 1)}), {2.0}, 0.0);
+  const Shape st = Shape::smoothTriangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0), vec3(0, 1, 0), vec3(-1, 0, 0),
+                                         vec3(1, 0, 0));
+  const Intersections xs = st.intersect({point(-0.2, 0.3, -2), vec3(0, 0, 1)});
+  expectTrue("triangle.zig:305", "smooth_hit", xs.size() == 1);
+  if (xs.size() == 1) {
+    expectNear("triangle.zig:315", "smooth_u", xs[0].u, 0.45);
+    expectNear("triangle.zig:316", "smooth_v", xs[0].v, 0.25);
+  }
+  Intersection i{1.0, &st, 0.45, 0.25};
+  expectTuple("triangle.zig:323", "smooth_normal", st.normalAt(point(0, 0, 0), i), vec3(-0.5547, 0.83205, 0));
+  Intersections one{i};
+  const PreComputations comps = PreComputations::make(i, {point(-0.2, 0.3, -2), vec3(0, 0, 1)}, one);
+  expectTuple("triangle.zig:341", "smooth_prepared_normal", comps.normal, vec3(-0.5547, 0.83205, 0));
+}
+
+static Shape groupOf(std::vector<Shape> kids, Tuple mn, Tuple mx) {
+  Shape g = Shape::make(GROUP);
+  g.children = std::move(kids);
+  g.bmin = mn;
+  g.bmax = mx;
+  return g;
+}
+
+static void groupAndBoxKats() {  // group.zig:163-223, bounding_box.zig:254-360
+  expectTs("group.zig:163", "empty_group", Shape::make(GROUP).intersect({point(0, 0, 0), vec3(0, 0, 1)}), {});
+  Shape s1 = Shape::make(SPHERE);
+  Shape s2 = Shape::make(SPHERE);
+  s2.setTransform(Matrix::identity().translate(0, 0, -3));
+  Shape s3 = Shape::make(SPHERE);
+  s3.setTransform(Matrix::identity().translate(5, 0, 0));
+  // box = merge of the three children's parent-space bounds (group.zig:75-78)
+  const Shape g = groupOf({s1, s2, s3}, point(-1, -1, -4), point(6, 1, 1));
+  const Intersections xs = g.intersect({point(0, 0, -5), vec3(0, 0, 1)});
+  bool ok = xs.size() == 4;
+  if (ok) ok = xs[0].object->id == s2.id && xs[1].object->id == s2.id && xs[2].object->id == s1.id && xs[3].object->id == s1.id;
+  expectTrue("group.zig:175", "nonempty_group_order", ok);
+  // transformed group: group scale(2) pushed onto child translate(5,0,0) (group.zig:201-216)
+  Shape ts = Shape::make(SPHERE);
+  ts.setTransform(Matrix::identity().scale(2, 2, 2).mul(Matrix::identity().translate(5, 0, 0)));
+  const Shape tg = groupOf({ts}, point(8, -2, -2), point(12, 2, 2));
+  expectTrue("group.zig:201", "transformed_group", tg.intersect({point(10, 0, -10), vec3(0, 0, 1)}).size() == 2);
+
+  auto boxHit = [](Tuple mn, Tuple mx, Tuple o, Tuple d) {
+    Shape b = Shape::make(BOUNDING_BOX);
+    b.bmin = mn;
+    b.bmax = mx;
+    return !b.intersect({o, normalized(d)}).empty();
+  };
+  struct B { Tuple o, d; bool r; };
+  const B unit[] = {{point(5, 0.5, 0), vec3(-1, 0, 0), true},  {point(-5, 0.5, 0), vec3(1, 0, 0), true},
+                    {point(0.5, -5, 0), vec3(0, -1, 0), true}, {point(0.5, -5, 0), vec3(0, 1, 0), true},
+                    {point(0.5, 0, 5), vec3(0, 0, -1), true},  {point(0.5, 0, -5), vec3(0, 0, 1), true},
+                    {point(0, 0.5, 0), vec3(0, 0, 1), true},   {point(-2, 0, 0), vec3(2, 4, 6), false},
+                    {point(0, -2, 0), vec3(6, 2, 4), false},   {point(0, 0, -2), vec3(4, 6, 2), false},
+                    {point(2, 0, 2), vec3(0, 0, -1), false},   {point(0, 2, 2), vec3(0, -1, 0), false},
+                    {point(2, 2, 0), vec3(-1, 0, 0), false}};
+  int i = 0;
+  for (const B& b : unit)
+    expectTrue("bounding_box.zig:283", "aabb_unit_" + std::to_string(i++),
+               boxHit(point(-1, -1, -1), point(1, 1, 1), b.o, b.d) == b.r);
+  const B nc[] = {{point(15, 1, 2), vec3(-1, 0, 0), true}, {point(-5, -1, 4), vec3(1, 0, 0), true},
+                  {point(7, 6, 5), vec3(0, -1, 0), true},  {point(9, -5, 6), vec3(0, 1, 0), true},
+                  {point(8, 2, 12), vec3(0, 0, -1), true}, {point(6, 0, -5), vec3(0, 0, 1), true},
+                  {point(8, 1, 3.5), vec3(0, 0, 1), true}, {point(9, -1, -8), vec3(2, 4, 6), false},
+                  {point(8, 3, -4), vec3(6, 2, 4), false}, {point(9, -1, -2), vec3(4, 6, 2), false},
+                  {point(4, 0, 9), vec3(0, 0, -1), false}, {point(8, 6, -1), vec3(0, -1, 0), false},
+                  {point(12, 5, 4), vec3(-1, 0, 0), false}};
+  i = 0;
+  for (const B& b : nc)
+    expectTrue("bounding_box.zig:343", "aabb_noncubic_" + std::to_string(i++),
+               boxHit(point(5, -2, 0), point(11, 4, 7), b.o, b.d) == b.r);
+}
+
+static void nestedGroupKats() {  // shape.zig:560-617 (transforms pushed to the leaf)
+  // g1.rotateY(pi/2) o g2.scale(2,2,2) o s.translate(5,0,0)
+  Shape s = Shape::make(SPHERE);
+  s.setTransform(Matrix::identity().rotateY(PI / 2).mul(Matrix::identity().scale(2, 2, 2).mul(Matrix::identity().translate(5, 0, 0))));
+  expectTuple("shape.zig:560", "world_to_object", s.worldToObject(point(-2, 0, -10)), point(0, 0, -1));
+  Shape s2 = Shape::make(SPHERE);
+  s2.setTransform(Matrix::identity().rotateY(PI / 2).mul(Matrix::identity().scale(1, 2, 3).mul(Matrix::identity().translate(5, 0, 0))));
+  const double r3 = 1.0 / std::sqrt(3.0);
+  expectTuple("shape.zig:582", "normal_to_world", s2.normalToWorld(vec3(r3, r3, r3)), vec3(0.28571, 0.42857, -0.85714));
+  expectTuple("shape.zig:605", "normal_on_child", s2.normalAt(point(1.7321, 1.1547, -5.5774), {}),
+              vec3(0.2857, 0.42854, -0.85716));
+}
+
+static void refractionIndexKats() {  // shape.zig:520-558
+  Shape a = Shape::glassSphere();
+  a.setTransform(Matrix::identity().scale(2, 2, 2));
+  a.material.refractive_index = 1.5;
+  Shape b = Shape::glassSphere();
+  b.setTransform(Matrix::identity().translate(0, 0, -0.25));
+  b.material.refractive_index = 2.0;
+  Shape c = Shape::glassSphere();
+  c.setTransform(Matrix::identity().translate(0, 0, 0.25));
+  c.material.refractive_index = 2.5;
+  const Ray r{point(0, 0, -4), vec3(0, 0, 1)};
+  const Intersections xs{{2.0, &a}, {2.75, &b}, {3.25, &c}, {4.75, &b}, {5.25, &c}, {6.0, &a}};
+  const double want[6][2] = {{1.0, 1.5}, {1.5, 2.0}, {2.0, 2.5}, {2.5, 2.5}, {2.5, 1.5}, {1.5, 1.0}};
+  for (int i = 0; i < 6; ++i) {
+    const PreComputations comps = PreComputations::make(xs[i], r, xs);
+    report("shape.zig:551", "n1_n2_" + std::to_string(i), comps.n1 == want[i][0] && comps.n2 == want[i][1]);
+  }
+  // hit(): shape.zig:464-518
+  Shape s = Shape::make(SPHERE);
+  Intersections h1{{1, &s}, {2, &s}};
+  expectTrue("shape.zig:467", "hit_all_positive", hit(h1) == 0);
+  Intersections h2{{-1, &s}, {1, &s}};
+  expectTrue("shape.zig:480", "hit_some_negative", hit(h2) == 1);
+  Intersections h3{{-2, &s}, {-1, &s}};
+  expectTrue("shape.zig:493", "hit_all_negative", hit(h3) == -1);
+  Intersections h4{{5, &s}, {7, &s}, {-3, &s}, {2, &s}};
+  sortIntersections(h4);
+  expectTrue("shape.zig:504", "hit_lowest_nonnegative", hit(h4) >= 0 && h4[hit(h4)].t == 2.0);
+}
+
+static void materialKats() {  // material.zig:78-163
+  Material m;
+  const Shape obj = Shape::make(SPHERE);
+  const Tuple position = point(0, 0, 0);
+  expectColor("material.zig:83", "eye_between", m.lighting({point(0, 0, -10), {1, 1, 1}}, &obj, position, vec3(0, 0, -1), vec3(0, 0, -1), false), {1.9, 1.9, 1.9});
+  expectColor("material.zig:93", "eye_offset_45", m.lighting({point(0, 0, -10), {1, 1, 1}}, &obj, position, vec3(0, RS2, -RS2), vec3(0, 0, -1), false), {1.0, 1.0, 1.0});
+  expectColor("material.zig:103", "light_offset_45", m.lighting({point(0, 10, -10), {1, 1, 1}}, &obj, position, vec3(0, 0, -1), vec3(0, 0, -1), false), {0.7364, 0.7364, 0.7364});
+  expectColor("material.zig:113", "eye_in_reflection", m.lighting({point(0, 10, -10), {1, 1, 1}}, &obj, position, vec3(0, -RS2, -RS2), vec3(0, 0, -1), false), {1.63639, 1.63639, 1.63639});
+  expectColor("material.zig:123", "light_behind", m.lighting({point(0, 0, 10), {1, 1, 1}}, &obj, position, vec3(0, 0, -1), vec3(0, 0, -1), false), {0.1, 0.1, 0.1});
+  expectColor("material.zig:133", "in_shadow", m.lighting({point(0, 0, -10), {1, 1, 1}}, &obj, position, vec3(0, 0, -1), vec3(0, 0, -1), true), {0.1, 0.1, 0.1});
+  // Lighting with pattern (material.zig:140-163)
+  Pattern white, black;
+  white.rgb = {1, 1, 1};
+  black.rgb = {0, 0, 0};
+  Material pm;
+  pm.pattern.kind = PAT_STRIPES;
+  pm.pattern.a = &white;
+  pm.pattern.b = &black;
+  pm.ambient = 1.0;
+  pm.diffuse = 0.0;
+  pm.specular = 0.0;
+  const Light l{point(0, 0, -10), {1, 1, 1}};
+  expectColor("material.zig:160", "stripes_c1", pm.lighting(l, &obj, point(0.9, 0, 0), vec3(0, 0, -1), vec3(0, 0, -1), false), {1, 1, 1}, 0.0);
+  expectColor("material.zig:161", "stripes_c2", pm.lighting(l, &obj, point(1.1, 0, 0), vec3(0, 0, -1), vec3(0, 0, -1), false), {0, 0, 0}, 0.0);
+}
+
+static void patternKats() {  // pattern.zig:152-177, checkers.zig:33-54, stripes.zig:37-53, solid.zig:28-39
+  Pattern white, black;
+  white.rgb = {1, 1, 1};
+  black.rgb = {0, 0, 0};
+  const Color W{1, 1, 1}, B{0, 0, 0};
+  Pattern st;
+  st.kind = PAT_STRIPES;
+  st.a = &white;
+  st.b = &black;
+  struct P { double x; Color c; };
+  const P sp[] = {{0.0, W}, {0.9, W}, {1.0, B}, {-0.1, B}, {-1.0, B}, {-1.1, W}};
+  int i = 0;
+  for (const P& p : sp) expectColor("stripes.zig:47", "stripes_" + std::to_string(i++), st.patternAt(point(p.x, 0, 0)), p.c, 0.0);
+  Pattern ck;
+  ck.kind = PAT_CHECKERS;
+  ck.a = &white;
+  ck.b = &black;
+  struct Q { Tuple p; Color c; };
+  const Q cp[] = {{point(0, 0, 0), W},    {point(0.99, 0, 0), W}, {point(1.01, 0, 0), B}, {point(0, 0.99, 0), W},
+                  {point(0, 1.01, 0), B}, {point(0, 0, 0.99), W}, {point(0, 0, 1.01), B}};
+  i = 0;
+  for (const Q& q : cp) expectColor("checkers.zig:43", "checkers_" + std::to_string(i++), ck.patternAt(q.p), q.c, 0.0);
+  expectColor("solid.zig:34", "solid", white.patternAt(point(3, 4, 5)), W, 0.0);
+  // object + pattern transforms compose (pattern.zig:152-177)
+  Pattern tp;
+  tp.kind = PAT_TEST;
+  Shape s = Shape::make(SPHERE);
+  s.setTransform(Matrix::identity().scale(2, 2, 2));
+  expectColor("pattern.zig:157", "object_transform", tp.patternAt(s.worldToObject(point(2, 3, 4))), {1, 1.5, 2});
+  Pattern tp2 = tp;
+  tp2.setTransform(Matrix::identity().scale(2, 2, 2));
+  const Shape s0 = Shape::make(SPHERE);
+  expectColor("pattern.zig:165", "pattern_transform", tp2.patternAt(s0.worldToObject(point(2, 3, 4))), {1, 1.5, 2});
+  Pattern tp3 = tp;
+  tp3.setTransform(Matrix::identity().translate(0.5, 1, 1.5));
+  expectColor("pattern.zig:174", "both_transforms", tp3.patternAt(s.worldToObject(point(2.5, 3, 3.5))), {0.75, 0.5, 0.25});
+  // gradient.zig, rings.zig, blend.zig
+  Pattern gr;
+  gr.kind = PAT_GRADIENT;
+  gr.a = &white;
+  gr.b = &black;
+  expectColor("gradient.zig:75", "gradient_0.25", gr.patternAt(point(0.25, 0, 0)), {0.75, 0.75, 0.75});
+  expectColor("gradient.zig:77", "gradient_0.5", gr.patternAt(point(0.5, 0, 0)), {0.5, 0.5, 0.5});
+  Pattern rg;
+  rg.kind = PAT_RINGS;
+  rg.a = &white;
+  rg.b = &black;
+  expectColor("rings.zig:45", "rings_x1", rg.patternAt(point(1, 0, 0)), B, 0.0);
+  expectColor("rings.zig:47", "rings_diag", rg.patternAt(point(0.708, 0, 0.708)), B, 0.0);
+}
+
+static void worldKats() {  // world.zig:293-892
+  const World w = World::defaultWorld();
+  expectTs("world.zig:293", "world_intersect", w.intersect({point(0, 0, -5), vec3(0, 0, 1)}), {4.0, 4.5, 5.5, 6.0});
+  {
+    const Shape shape = Shape::make(SPHERE);
+    const Intersection i{4.0, &shape};
+    const PreComputations c = PreComputations::make(i, {point(0, 0, -5), vec3(0, 0, 1)}, {i});
+    expectTuple("world.zig:324", "comps_point", c.point, point(0, 0, -1));
+    expectTuple("world.zig:325", "comps_eyev", c.eyev, vec3(0, 0, -1));
+    expectTuple("world.zig:326", "comps_normal", c.normal, vec3(0, 0, -1));
+    expectTrue("world.zig:327", "comps_outside", !c.inside);
+    const Intersection i2{1.0, &shape};
+    const PreComputations c2 = PreComputations::make(i2, {point(0, 0, 0), vec3(0, 0, 1)}, {i2});
+    expectTuple("world.zig:341", "comps_inside_point", c2.point, point(0, 0, 1));
+    expectTuple("world.zig:343", "comps_inside_normal", c2.normal, vec3(0, 0, -1));
+    expectTrue("world.zig:344", "comps_inside", c2.inside);
+    Shape sh = Shape::make(SPHERE);
+    sh.setTransform(Matrix::identity().translate(0, 0, 1));
+    const Intersection i3{5.0, &sh};
+    const PreComputations c3 = PreComputations::make(i3, {point(0, 0, -5), vec3(0, 0, 1)}, {i3});
+    expectTrue("world.zig:358", "over_point", c3.over_point.z < -1e-5 / 2.0 && c3.point.z > c3.over_point.z);
+    Shape gs = Shape::glassSphere();
+    gs.setTransform(Matrix::identity().translate(0, 0, 1));
+    const Intersection i4{5.0, &gs};
+    const PreComputations c4 = PreComputations::make(i4, {point(0, 0, -5), vec3(0, 0, 1)}, {i4});
+    expectTrue("world.zig:374", "under_point", c4.under_point.z > 1e-5 / 2.0 && c4.point.z < c4.under_point.z);
+  }
+  {  // Shading, world.zig:379-443
+    const Intersection i{4.0, &w.objects[0]};
+    const PreComputations c = PreComputations::make(i, {point(0, 0, -5), vec3(0, 0, 1)}, {i});
+    expectColor("world.zig:394", "shade_outside", w.shadeHit(c, 3), {0.38066, 0.47583, 0.2855});
+    World w2 = World::defaultWorld();
+    w2.lights[0] = {point(0, 0.25, 0), {1, 1, 1}};
+    const Intersection i2{0.5, &w2.objects[1]};
+    const PreComputations c2 = PreComputations::make(i2, {point(0, 0, 0), vec3(0, 0, 1)}, {i2});
+    expectColor("world.zig:414", "shade_inside", w2.shadeHit(c2, 3), {0.90498, 0.90498, 0.90498});
+    World w3;
+    w3.lights.push_back({point(0, 0, -10), {1, 1, 1}});
+    w3.objects.push_back(Shape::make(SPHERE));
+    Shape s2 = Shape::make(SPHERE);
+    s2.setTransform(Matrix::identity().translate(0, 0, 10));
+    w3.objects.push_back(s2);
+    const Intersection i3{4.0, &w3.objects[1]};
+    const PreComputations c3 = PreComputations::make(i3, {point(0, 0, 5), vec3(0, 0, 1)}, {i3});
+    expectColor("world.zig:440", "shade_in_shadow", w3.shadeHit(c3, 3), {0.1, 0.1, 0.1});
+  }
+  {  // Coloring, world.zig:445-491
+    expectColor("world.zig:456", "color_miss", w.colorAt({point(0, 0, -5), vec3(0, 1, 0)}, 3), {0, 0, 0}, 0.0);
+    expectColor("world.zig:467", "color_hit", w.colorAt({point(0, 0, -5), vec3(0, 0, 1)}, 3), {0.38066, 0.47583, 0.2855});
+    World w2 = World::defaultWorld();
+    w2.objects[0].material.ambient = 1.0;
+    w2.objects[1].material.ambient = 1.0;
+    expectColor("world.zig:487", "color_behind_ray", w2.colorAt({point(0, 0, 0.75), vec3(0, 0, -1)}, 3),
+                w2.objects[1].material.pattern.rgb);
+  }
+  {  // isShadowed, world.zig:493-525
+    World w2 = World::defaultWorld();
+    const Light& l = w2.lights[0];
+    expectTrue("world.zig:500", "shadow_collinear_none", !w2.isShadowed(point(0, 10, 0), l));
+    expectTrue("world.zig:503", "shadow_object_between", w2.isShadowed(point(10, -10, 10), l));
+    expectTrue("world.zig:506", "shadow_behind_light", !w2.isShadowed(point(-20, 20, -20), l));
+    expectTrue("world.zig:509", "shadow_behind_point", !w2.isShadowed(point(-2, 2, -2), l));
+    const Tuple p = point(0, 0, 0);
+    w2.objects[0].casts_shadow = false;
+    w2.objects[1].casts_shadow = true;
+    expectTrue("world.zig:516", "shadow_optout_outer", w2.isShadowed(p, l));
+    w2.objects[0].casts_shadow = true;
+    w2.objects[1].casts_shadow = false;
+    expectTrue("world.zig:520", "shadow_optout_inner", w2.isShadowed(p, l));
+    w2.objects[0].casts_shadow = false;
+    w2.objects[1].casts_shadow = false;
+    expectTrue("world.zig:524", "shadow_optout_both", !w2.isShadowed(p, l));
+  }
+  const double S2 = std::sqrt(2.0);
+  {  // Reflections, world.zig:527-679
+    const Shape plane = Shape::make(PLANE);
+    const Intersection i{S2, &plane};
+    const PreComputations c = PreComputations::make(i, {point(0, 1, -1), vec3(0, -RS2, RS2)}, {i});
+    expectTuple("world.zig:542", "reflectv", c.reflectv, vec3(0, RS2, RS2));
+    World w1 = World::defaultWorld();
+    w1.objects[1].material.ambient = 1.0;  // (the reference omits this; result is black either way: reflective == 0)
+    const Intersection i1{1.0, &w1.objects[1]};
+    const PreComputations c1 = PreComputations::make(i1, {point(0, 1, 0), vec3(0, 0, 1)}, {i1});
+    expectColor("world.zig:560", "reflected_nonreflective", w1.reflectedColor(c1, 3), {0, 0, 0}, 0.0);
+
+    World w2 = World::defaultWorld();
+    Shape shape = Shape::make(PLANE);
+    shape.material.reflective = 0.5;
+    shape.setTransform(Matrix::identity().translate(0, -1, 0));
+    w2.objects.push_back(shape);
+    const Ray r{point(0, 0, -3), vec3(0, -RS2, RS2)};
+    const Intersection i2{S2, &w2.objects[2]};
+    const PreComputations c2 = PreComputations::make(i2, r, {i2});
+    expectColor("world.zig:584", "reflected_color", w2.reflectedColor(c2, 3), {0.19033, 0.23791, 0.14275});
+    expectColor("world.zig:607", "shade_with_reflection", w2.shadeHit(c2, 3), {0.87676, 0.92434, 0.82917});
+    expectColor("world.zig:676", "reflected_at_depth_0", w2.reflectedColor(c2, 0), {0, 0, 0}, 0.0);
+
+    World w3;  // mutually reflective planes terminate, world.zig:633-654
+    w3.lights.push_back({point(0, 0, 0), {1, 1, 1}});
+    Shape lower = Shape::make(PLANE);
+    lower.material.reflective = 1.0;
+    lower.setTransform(Matrix::identity().translate(0, -1, 0));
+    Shape upper = Shape::make(PLANE);
+    upper.material.reflective = 1.0;
+    upper.setTransform(Matrix::identity().translate(0, 1, 0));
+    w3.objects.push_back(lower);
+    w3.objects.push_back(upper);
+    const Color cc = w3.colorAt({point(0, 0, 0), vec3(0, 1, 0)}, 3);
+    expectTrue("world.zig:653", "parallel_mirrors_terminate", std::isfinite(cc.r));
+  }
+  {  // Refraction base cases / TIR, world.zig:681-749
+    World w1 = World::defaultWorld();
+    const Shape& shape = w1.objects[0];
+    const Intersections xs{{4.0, &shape}, {6.0, &shape}};
+    const PreComputations c = PreComputations::make(xs[0], {point(0, 0, -5), vec3(0, 0, 1)}, xs);
+    expectColor("world.zig:699", "refracted_opaque", w1.refractedColor(c, 3), {0, 0, 0}, 0.0);
+    World w2 = World::defaultWorld();
+    w2.objects[0].material.transparency = 1.0;
+    w2.objects[0].material.refractive_index = 1.5;
+    const Intersections xs2{{4.0, &w2.objects[0]}, {6.0, &w2.objects[0]}};
+    const PreComputations c2 = PreComputations::make(xs2[0], {point(0, 0, -5), vec3(0, 0, 1)}, xs2);
+    expectColor("world.zig:721", "refracted_depth_0", w2.refractedColor(c2, 0), {0, 0, 0}, 0.0);
+    const Intersections xs3{{-RS2, &w2.objects[0]}, {RS2, &w2.objects[0]}};
+    const PreComputations c3 = PreComputations::make(xs3[1], {point(0, 0, RS2), vec3(0, 1, 0)}, xs3);
+    expectColor("world.zig:746", "total_internal_reflection", w2.refractedColor(c3, 5), {0, 0, 0}, 0.0);
+  }
+  {  // Recursive refraction, world.zig:751-807
+    World w1 = World::defaultWorld();
+    w1.objects[0].material.ambient = 1.0;
+    w1.objects[0].material.pattern.kind = PAT_TEST;
+    w1.objects[1].material.transparency = 1.0;
+    w1.objects[1].material.refractive_index = 1.5;
+    const Shape* a = &w1.objects[0];
+    const Shape* b = &w1.objects[1];
+    const Intersections xs{{-0.9899, a}, {-0.4899, b}, {0.4899, b}, {0.9899, a}};
+    const PreComputations c = PreComputations::make(xs[2], {point(0, 0, 0.1), vec3(0, 1, 0)}, xs);
+    expectColor("world.zig:776", "refracted_color", w1.refractedColor(c, 5), {0, 0.99887, 0.04721});
+
+    World w2 = World::defaultWorld();
+    Shape floor = Shape::make(PLANE);
+    floor.setTransform(Matrix::identity().translate(0, -1, 0));
+    floor.material.transparency = 0.5;
+    floor.material.refractive_index = 1.5;
+    Shape ball = Shape::make(SPHERE);
+    ball.setTransform(Matrix::identity().translate(0, -3.5, -0.5));
+    ball.material.pattern.rgb = {1, 0, 0};
+    ball.material.ambient = 0.5;
+    w2.objects.push_back(floor);
+    w2.objects.push_back(ball);
+    const Intersections xs2{{S2, &w2.objects[2]}};
+    const PreComputations c2 = PreComputations::make(xs2[0], {point(0, 0, -3), vec3(0, -RS2, RS2)}, xs2);
+    expectColor("world.zig:805", "shade_transparent", w2.shadeHit(c2, 5), {0.93642, 0.68642, 0.68642});
+  }
+  {  // Schlick, world.zig:809-892
+    const Shape gs = Shape::glassSphere();
+    const Intersections xs{{-RS2, &gs}, {RS2, &gs}};
+    expectNear("world.zig:825", "schlick_tir", PreComputations::make(xs[1], {point(0, 0, RS2), vec3(0, 1, 0)}, xs).schlick(), 1.0, 0.0);
+    const Intersections xs2{{-1.0, &gs}, {1.0, &gs}};
+    expectNear("world.zig:841", "schlick_perpendicular", PreComputations::make(xs2[1], {point(0, 0, 0), vec3(0, 1, 0)}, xs2).schlick(), 0.04);
+    const Intersections xs3{{1.8589, &gs}};
+    expectNear("world.zig:856", "schlick_grazing", PreComputations::make(xs3[0], {point(0, 0.99, -2), vec3(0, 0, 1)}, xs3).schlick(), 0.48873);
+    World w2 = World::defaultWorld();
+    Shape floor = Shape::make(PLANE);
+    floor.setTransform(Matrix::identity().translate(0, -1, 0));
+    floor.material.reflective = 0.5;
+    floor.material.transparency = 0.5;
+    floor.material.refractive_index = 1.5;
+    Shape ball = Shape::make(SPHERE);
+    ball.setTransform(Matrix::identity().translate(0, -3.5, -0.5));
+    ball.material.pattern.rgb = {1, 0, 0};
+    ball.material.ambient = 0.5;
+    w2.objects.push_back(floor);
+    w2.objects.push_back(ball);
+    const Intersections xs4{{S2, &w2.objects[2]}};
+    const PreComputations c4 = PreComputations::make(xs4[0], {point(0, 0, -3), vec3(0, -RS2, RS2)}, xs4);
+    expectColor("world.zig:890", "shade_schlick", w2.shadeHit(c4, 5), {0.93391, 0.69643, 0.69243});
+  }
+}
+
+static void cameraKats() {  // camera.zig:129-187
+  expectNear("camera.zig:133", "pixel_size_landscape", Camera::make(200, 125, PI / 2).pixel_size, 0.01);
+  expectNear("camera.zig:139", "pixel_size_portrait", Camera::make(125, 200, PI / 2).pixel_size, 0.01);
+  Camera c = Camera::make(201, 101, PI / 2);
+  Ray r = c.rayForPixel(100, 50);
+  expectTuple("camera.zig:148", "ray_center_origin", r.origin, point(0, 0, 0));
+  expectTuple("camera.zig:149", "ray_center_dir", r.direction, vec3(0, 0, -1));
+  r = c.rayForPixel(0, 0);
+  expectTuple("camera.zig:156", "ray_corner_dir", r.direction, vec3(0.66519, 0.33259, -0.66851));
+  c.setTransform(Matrix::identity().translate(0, -2, 5).rotateY(PI / 4));
+  r = c.rayForPixel(100, 50);
+  expectTuple("camera.zig:165", "ray_transformed_origin", r.origin, point(0, 2, -5));
+  expectTuple("camera.zig:166", "ray_transformed_dir", r.direction, vec3(RS2, 0, -RS2));
+  // Rendering, camera.zig:171-187
+  const World w = World::defaultWorld();
+  Camera rc = Camera::make(11, 11, PI / 2);
+  rc.setTransform(Matrix::viewTransform(point(0, 0, -5), point(0, 0, 0), vec3(0, 1, 0)));
+  expectColor("camera.zig:186", "render_center_pixel", w.colorAt(rc.rayForPixel(5, 5), 5), {0.38066, 0.47583, 0.2855});
+}
+
+int main() {
+  tupleKats();
+  matrixKats();
+  rayKats();
+  sphereKats();
+  planeKats();
+  cubeKats();
+  cylinderKats();
+  triangleKats();
+  groupAndBoxKats();
+  nestedGroupKats();
+  refractionIndexKats();
+  materialKats();
+  patternKats();
+  worldKats();
+  cameraKats();
+  std::printf("KAT-SUMMARY total=%d failed=%d\n", g_total, g_failed);
+  return g_failed ? 1 : 0;
+}

@@ -1,0 +1,285 @@
+"""ray-tracer-challenge_amd — MI355X-native render path for SinclaM/ray-tracer-challenge.
+
+Python is only the harness language here (tests, bench, multi-GPU driver): this
+module is a ctypes binding of the two product libraries
+
+  lib/librtc_hip.so   HIP kernels behind the C ABI of include/rtc.h
+                      (replaces Camera.render, reference src/raytracer/camera.zig:80-125)
+  lib/librtc_host.so  C++ host side: scene JSON / OBJ loaders, Camera/World/Canvas
+                      mirror (reference src/parsing/*.zig, src/raytracer/canvas.zig)
+
+There is no CPU implementation of the render path in this package: `GpuScene`
+needs the HIP library and a GPU, and raises `RtcError` otherwise.  The package
+directory name contains a hyphen, so import it with
+`importlib.import_module("ray-tracer-challenge_amd")`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+REPO_ROOT = os.path.dirname(_HERE)
+SCENE_DIR = os.path.join(REPO_ROOT, "tests", "golden", "scenes")
+DATA_DIR = os.path.join(REPO_ROOT, "tests", "golden", "data")
+
+RTC_CHILD_NODE_BIT = 0x80000000
+RTC_MAT_STRIDE = 7
+REFERENCE_DEPTH = 5  # camera.zig:118
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class RtcError(RuntimeError):
+    """An rtc_status != RTC_OK; `.name` is the Zig-style error name."""
+
+    def __init__(self, name, message):
+        super().__init__(message or name)
+        self.name = name
+
+
+class SceneDesc(C.Structure):
+    """struct rtc_scene_desc (include/rtc.h)."""
+
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("n_xforms", C.c_uint32), ("xf_inv", _dp), ("xf_inv_t", _dp),
+        ("n_leaves", C.c_uint32), ("leaf_kind", _u8p), ("leaf_xform", _u32p), ("leaf_material", _u32p),
+        ("leaf_shadow", _u8p), ("leaf_id", _u32p), ("leaf_geom", _u32p),
+        ("n_cyls", C.c_uint32), ("cyl_min", _dp), ("cyl_max", _dp), ("cyl_closed", _u8p),
+        ("n_tris", C.c_uint32), ("tri_p1", _dp), ("tri_e1", _dp), ("tri_e2", _dp),
+        ("tri_n1", _dp), ("tri_n2", _dp), ("tri_n3", _dp),
+        ("n_materials", C.c_uint32), ("mat_params", _dp), ("mat_pattern", _u32p),
+        ("n_patterns", C.c_uint32), ("pat_kind", _u8p), ("pat_inv", _dp), ("pat_rgb", _dp),
+        ("pat_a", _u32p), ("pat_b", _u32p),
+        ("n_nodes", C.c_uint32), ("node_min", _dp), ("node_max", _dp), ("node_first", _u32p), ("node_count", _u32p),
+        ("n_children", C.c_uint32), ("children", _u32p),
+        ("n_roots", C.c_uint32), ("roots", _u32p),
+        ("n_lights", C.c_uint32), ("light_pos", _dp), ("light_rgb", _dp),
+    ]
+
+
+class Camera(C.Structure):
+    """struct rtc_camera (include/rtc.h)."""
+
+    _fields_ = [("hsize", C.c_uint32), ("vsize", C.c_uint32),
+                ("half_width", C.c_double), ("half_height", C.c_double), ("pixel_size", C.c_double),
+                ("inv_view", C.c_double * 16)]
+
+
+class Stats(C.Structure):
+    """struct rtc_stats (include/rtc.h)."""
+
+    _fields_ = [("primary", C.c_uint64), ("secondary", C.c_uint64), ("shadow_calls", C.c_uint64),
+                ("shadow_traced", C.c_uint64), ("overflow", C.c_uint64)]
+
+
+RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_device",
+               "rtc_render_tiles_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
+               "rtc_status_name"]
+HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
+                "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """librtc_hip.so; raises if the library has not been built (no fallback)."""
+    global _hip
+    if _hip is None:
+        path = os.path.join(LIB_DIR, "librtc_hip.so")
+        if not os.path.exists(path):
+            raise RtcError("LibraryMissing", f"{path} not built: run `make` or __graft_entry__.build()")
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib.rtc_last_error.restype = C.c_char_p
+        lib.rtc_status_name.restype = C.c_char_p
+        lib.rtc_status_name.argtypes = [C.c_int]
+        lib.rtc_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        lib.rtc_scene_destroy.argtypes = [C.c_void_p]
+        lib.rtc_scene_destroy.restype = None
+        lib.rtc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p]
+        lib.rtc_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
+        lib.rtc_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 5 + [C.c_void_p, C.c_void_p]
+        lib.rtc_scene_synchronize.argtypes = [C.c_void_p]
+        lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        _hip = lib
+    return _hip
+
+
+def host_lib():
+    """librtc_host.so (links librtc_hip.so)."""
+    global _host
+    if _host is None:
+        hip_lib()
+        path = os.path.join(LIB_DIR, "librtc_host.so")
+        if not os.path.exists(path):
+            raise RtcError("LibraryMissing", f"{path} not built: run `make` or __graft_entry__.build()")
+        lib = C.CDLL(path)
+        lib.rtch_last_error.restype = C.c_char_p
+        lib.rtch_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.rtch_scene_free.argtypes = [C.c_void_p]
+        lib.rtch_scene_free.restype = None
+        lib.rtch_scene_desc.argtypes = [C.c_void_p]
+        lib.rtch_scene_desc.restype = C.POINTER(SceneDesc)
+        lib.rtch_scene_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Camera)]
+        lib.rtch_camera_make.argtypes = [C.c_uint32, C.c_uint32, C.c_double, _dp, _dp, _dp, C.POINTER(Camera)]
+        lib.rtch_canvas_ppm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+        lib.rtch_canvas_ppm.restype = C.c_size_t
+        lib.rtch_canvas_rgba8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        lib.rtch_canvas_rgba8.restype = None
+        lib.rtch_scene_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        _host = lib
+    return _host
+
+
+def _check_host(status):
+    if status != 0:
+        msg = host_lib().rtch_last_error().decode()
+        raise RtcError(msg.split(":")[0], msg)
+
+
+def _check_hip(status):
+    if status != 0:
+        lib = hip_lib()
+        raise RtcError(lib.rtc_status_name(status).decode(), lib.rtc_last_error().decode())
+
+
+class HostScene:
+    """parseScene (reference src/parsing/scene.zig:612-661) + flattening, on the host."""
+
+    def __init__(self, scene_json, data_dir=DATA_DIR):
+        if isinstance(scene_json, str):
+            scene_json = scene_json.encode()
+        self._h = C.c_void_p()
+        _check_host(host_lib().rtch_scene_load(scene_json, data_dir.encode(), C.byref(self._h)))
+        self.desc = host_lib().rtch_scene_desc(self._h).contents
+
+    @classmethod
+    def from_file(cls, name, data_dir=DATA_DIR):
+        path = name if os.path.exists(name) else os.path.join(SCENE_DIR, name)
+        with open(path, "rb") as f:
+            return cls(f.read(), data_dir)
+
+    def camera(self, width=0, height=0):
+        cam = Camera()
+        _check_host(host_lib().rtch_scene_camera(self._h, width, height, C.byref(cam)))
+        return cam
+
+    def array(self, field, count, width=1, dtype=None):
+        """numpy view of one table of the flat description (writable: tests patch tables)."""
+        ptr = getattr(self.desc, field)
+        n = count * width
+        if n == 0:
+            return np.zeros((0,), dtype=dtype)
+        arr = np.ctypeslib.as_array(ptr, shape=(n,))
+        return arr.reshape(count, width) if width > 1 else arr
+
+    def close(self):
+        if self._h:
+            host_lib().rtch_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_camera(hsize, vsize, fov, frm, to, up):
+    """Camera.new + setTransform(viewTransform(from,to,up)) (camera.zig:33-61, matrix.zig:54-67)."""
+    cam = Camera()
+    arr = lambda v: (C.c_double * 3)(*v)
+    _check_host(host_lib().rtch_camera_make(hsize, vsize, fov, arr(frm), arr(to), arr(up), C.byref(cam)))
+    return cam
+
+
+class GpuScene:
+    """rtc_scene: the flat scene resident in HBM; many renders per upload."""
+
+    def __init__(self, desc):
+        self._s = C.c_void_p()
+        _check_hip(hip_lib().rtc_scene_create(C.byref(desc), C.byref(self._s)))
+
+    def render(self, cam, max_depth=REFERENCE_DEPTH, tile=None):
+        """Camera.render for the whole image or tile=(x0,y0,w,h); returns [h][w][3] f64 (host)."""
+        x0, y0, w, h = tile if tile else (0, 0, cam.hsize, cam.vsize)
+        out = np.empty((h, w, 3), dtype=np.float64)
+        _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, x0, y0, w, h, out.ctypes.data))
+        return out
+
+    def render_device(self, cam, d_out_ptr, max_depth=REFERENCE_DEPTH, tile=None, stream=None):
+        x0, y0, w, h = tile if tile else (0, 0, cam.hsize, cam.vsize)
+        _check_hip(hip_lib().rtc_render_device(self._s, C.byref(cam), max_depth, x0, y0, w, h, d_out_ptr, stream))
+
+    def render_tiles_device(self, cam, d_out_ptr, tile_w, tile_h, first_tile, tile_stride, n_my_tiles,
+                            max_depth=REFERENCE_DEPTH, stream=None):
+        _check_hip(hip_lib().rtc_render_tiles_device(self._s, C.byref(cam), max_depth, tile_w, tile_h, first_tile,
+                                                     tile_stride, n_my_tiles, d_out_ptr, stream))
+
+    def synchronize(self):
+        _check_hip(hip_lib().rtc_scene_synchronize(self._s))
+
+    def stats(self):
+        st = Stats()
+        _check_hip(hip_lib().rtc_get_stats(self._s, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def close(self):
+        if self._s:
+            hip_lib().rtc_scene_destroy(self._s)
+            self._s = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def canvas_ppm(rgb):
+    """Canvas.ppm (canvas.zig:181-254) of an [h][w][3] f64 array."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w, _ = rgb.shape
+    n = host_lib().rtch_canvas_ppm(rgb.ctypes.data, w, h, None, 0)
+    buf = C.create_string_buffer(n)
+    host_lib().rtch_canvas_ppm(rgb.ctypes.data, w, h, buf, n)
+    return buf.raw[:n].decode()
+
+
+def canvas_rgba8(rgb):
+    """RGBA8 framebuffer of lib.zig:146-153."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w, _ = rgb.shape
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    host_lib().rtch_canvas_rgba8(rgb.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
+# ---- multi-GPU tile partition: interleaved tiles, one gather, un-permute on rank 0
+def tile_grid(hsize, vsize, tile_w, tile_h):
+    return (hsize + tile_w - 1) // tile_w, (vsize + tile_h - 1) // tile_h
+
+
+def tiles_of_rank(n_tiles, rank, world):
+    """Tiles rank, rank+world, ... ; every rank renders the same COUNT (padded by wrapping) so one
+    equal-count gather suffices.  Returns (first_tile, stride, count, padded_count)."""
+    count = (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
+    padded = (n_tiles + world - 1) // world
+    return rank, world, count, padded
+
+
+def assemble_tiles(gathered, hsize, vsize, tile_w, tile_h, world):
+    """gathered: [world][padded][tile_h][tile_w][3] -> [vsize][hsize][3] canvas (row-major, canvas.zig:132)."""
+    tx, ty = tile_grid(hsize, vsize, tile_w, tile_h)
+    n_tiles = tx * ty
+    out = np.zeros((ty * tile_h, tx * tile_w, 3), dtype=gathered.dtype)
+    for t in range(n_tiles):
+        r, k = t % world, t // world
+        y, x = divmod(t, tx)
+        out[y * tile_h:(y + 1) * tile_h, x * tile_w:(x + 1) * tile_w] = gathered[r, k]
+    return out[:vsize, :hsize]

@@ -1,0 +1,495 @@
+// rtc_capi.hip — the extern "C" boundary of librtc_hip.so (include/rtc.h): validation of
+// the flat scene, upload to HBM, kernel launches.  No torch types, no CPU render path: every
+// entry point either runs the HIP kernel or fails with an rtc_status.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/rtc.h"
+#include "rtc_device.h"
+
+extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                             const uint32_t max_depth, double* __restrict__ out,
+                                             DevStats* __restrict__ stats);
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = std::string(rtc_status_name(status)) + ": " + buf;
+  return status;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      return fail(e_ == hipErrorOutOfMemory ? RTC_ERR_OUT_OF_MEMORY : RTC_ERR_NO_DEVICE,      \
+                  "%s -> %s", #expr, hipGetErrorString(e_));                                  \
+    }                                                                                         \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t upload(const std::vector<T>& v) {
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);  // never a null table
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+    if (e != hipSuccess) return e;
+    if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+};
+
+}  // namespace
+
+struct rtc_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevScene dev{};
+  DevStats* d_stats = nullptr;
+  double* d_frame = nullptr;  // staging for rtc_render (host output)
+  size_t frame_capacity = 0;  // in doubles
+  DevBuf<uint32_t> roots, kids;
+  DevBuf<uint4> leaf_meta;
+  DevBuf<double> xf, tri, trin, pat_inv, pat_rgb, node_box, light;
+  DevBuf<DevCyl> cyl;
+  DevBuf<DevMaterial> mat;
+  DevBuf<uint8_t> pat_kind;
+  DevBuf<uint2> pat_ab, node_kids;
+  uint32_t max_trav_stack = 0;
+};
+
+namespace {
+
+bool affineRow(const double* m16) {  // last row must be exactly (0,0,0,1); -0 is accepted
+  return m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0;
+}
+
+bool selectChainOnly(const rtc_scene_desc& d, uint32_t idx, int depth = 0) {
+  if (depth > 64) return false;
+  switch (d.pat_kind[idx]) {
+    case RTC_PAT_SOLID:
+    case RTC_PAT_TEST: return true;
+    case RTC_PAT_STRIPES:
+    case RTC_PAT_CHECKERS:
+    case RTC_PAT_RINGS: return selectChainOnly(d, d.pat_a[idx], depth + 1) && selectChainOnly(d, d.pat_b[idx], depth + 1);
+    default: return false;
+  }
+}
+
+// Validates the tree shape and measures the deepest traversal stack the kernel's push/pop
+// order can reach, so an overflow is reported here instead of on the device.
+int walkTree(const rtc_scene_desc& d, std::vector<uint8_t>& leaf_seen, std::vector<uint8_t>& node_seen,
+             uint32_t root_node, uint32_t& max_stack) {
+  std::vector<uint32_t> stack{root_node};
+  while (!stack.empty()) {
+    max_stack = std::max<uint32_t>(max_stack, static_cast<uint32_t>(stack.size()));
+    const uint32_t n = stack.back();
+    stack.pop_back();
+    if (n >= d.n_nodes) return fail(RTC_ERR_BAD_INDEX, "node index %u >= n_nodes %u", n, d.n_nodes);
+    if (node_seen[n]++) return fail(RTC_ERR_BAD_INDEX, "group node %u is referenced twice (not a tree)", n);
+    const uint32_t first = d.node_first[n], count = d.node_count[n];
+    if (static_cast<uint64_t>(first) + count > d.n_children)
+      return fail(RTC_ERR_BAD_INDEX, "node %u children [%u,+%u) exceed n_children %u", n, first, count, d.n_children);
+    for (uint32_t i = 0; i < count; ++i) {
+      const uint32_t c = d.children[first + i];
+      if (c & RTC_CHILD_NODE_BIT) {
+        stack.push_back(c & ~RTC_CHILD_NODE_BIT);
+      } else {
+        if (c >= d.n_leaves) return fail(RTC_ERR_BAD_INDEX, "leaf index %u >= n_leaves %u", c, d.n_leaves);
+        if (leaf_seen[c]++) return fail(RTC_ERR_BAD_INDEX, "leaf %u is referenced twice", c);
+      }
+    }
+    max_stack = std::max<uint32_t>(max_stack, static_cast<uint32_t>(stack.size()));
+  }
+  return RTC_OK;
+}
+
+int buildPixelMapRect(const rtc_camera& cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, DevPixelMap& m) {
+  if (w == 0 || h == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "empty tile %ux%u", w, h);
+  if (static_cast<uint64_t>(x0) + w > cam.hsize || static_cast<uint64_t>(y0) + h > cam.vsize)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "tile (%u,%u)+%ux%u outside the %ux%u image", x0, y0, w, h, cam.hsize,
+                cam.vsize);
+  std::memset(&m, 0, sizeof m);
+  m.mode = 0;
+  m.x0 = x0;
+  m.y0 = y0;
+  m.w = w;
+  m.h = h;
+  m.blocks_x = (w + 15) / 16;
+  m.blocks_y = (h + 15) / 16;
+  return RTC_OK;
+}
+
+int checkCamera(const rtc_camera* cam) {
+  if (!cam) return fail(RTC_ERR_INVALID_ARGUMENT, "camera is null");
+  if (cam->hsize == 0 || cam->vsize == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
+  if (!affineRow(cam->inv_view)) return fail(RTC_ERR_NOT_AFFINE, "camera inverse view last row is not (0,0,0,1)");
+  return RTC_OK;
+}
+
+DevCamera devCamera(const rtc_camera& c) {
+  DevCamera d;
+  d.half_width = c.half_width;
+  d.half_height = c.half_height;
+  d.pixel_size = c.pixel_size;
+  std::memcpy(d.inv, c.inv_view, sizeof d.inv);
+  d.hsize = c.hsize;
+  d.vsize = c.vsize;
+  return d;
+}
+
+int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t regions, uint32_t max_depth,
+           double* d_out, hipStream_t stream) {
+  if (max_depth > RTC_MAX_DEPTH)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
+  const uint64_t blocks = static_cast<uint64_t>(regions) * map.blocks_x * map.blocks_y;
+  if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "grid of %llu blocks", (unsigned long long)blocks);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
+  hipLaunchKernelGGL(rtc_render_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, s->dev, devCamera(cam),
+                     map, max_depth, d_out, s->d_stats);
+  HIP_TRY(hipGetLastError());
+  return RTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtc_last_error(void) { return g_error.c_str(); }
+
+const char* rtc_status_name(int status) {
+  switch (status) {
+    case RTC_OK: return "Ok";
+    case RTC_ERR_INVALID_ARGUMENT: return "InvalidArgument";
+    case RTC_ERR_OUT_OF_MEMORY: return "OutOfMemory";
+    case RTC_ERR_NOT_INVERTIBLE: return "NotInvertible";
+    case RTC_ERR_UNSUPPORTED: return "Unsupported";
+    case RTC_ERR_BAD_INDEX: return "BadIndex";
+    case RTC_ERR_NO_DEVICE: return "NoDevice";
+    case RTC_ERR_NOT_AFFINE: return "NotAffine";
+    case RTC_ERR_OVERFLOW: return "StackOverflow";
+    default: return "Unknown";
+  }
+}
+
+int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
+  g_error.clear();
+  if (!desc || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  const rtc_scene_desc& d = *desc;
+  if (d.abi_version != RTC_ABI_VERSION)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "abi_version %u, library speaks %u", d.abi_version, RTC_ABI_VERSION);
+
+  // ---- validate (host only; nothing touches the GPU until the scene is known to be sound)
+  for (uint32_t i = 0; i < d.n_xforms; ++i)
+    if (!affineRow(d.xf_inv + 16ull * i)) return fail(RTC_ERR_NOT_AFFINE, "xform %u: last row is not (0,0,0,1)", i);
+  for (uint32_t i = 0; i < d.n_patterns; ++i) {
+    if (!affineRow(d.pat_inv + 16ull * i)) return fail(RTC_ERR_NOT_AFFINE, "pattern %u: last row is not (0,0,0,1)", i);
+    const uint8_t k = d.pat_kind[i];
+    if (k == RTC_PAT_PERTURB || k == RTC_PAT_TEXTURE_MAP || k > RTC_PAT_TEST)
+      return fail(RTC_ERR_UNSUPPORTED, "pattern %u: kind %u is not implemented by this kernel", i, k);
+    if (d.pat_a[i] >= d.n_patterns || d.pat_b[i] >= d.n_patterns)
+      return fail(RTC_ERR_BAD_INDEX, "pattern %u: sub-pattern index out of range", i);
+  }
+  for (uint32_t i = 0; i < d.n_patterns; ++i) {
+    const uint8_t k = d.pat_kind[i];
+    if (k == RTC_PAT_GRADIENT || k == RTC_PAT_RADIAL_GRADIENT || k == RTC_PAT_BLEND) {
+      if (!selectChainOnly(d, d.pat_a[i]) || !selectChainOnly(d, d.pat_b[i]))
+        return fail(RTC_ERR_UNSUPPORTED, "pattern %u: a gradient/blend nested inside a gradient/blend", i);
+    }
+  }
+  for (uint32_t i = 0; i < d.n_materials; ++i)
+    if (d.mat_pattern[i] >= d.n_patterns) return fail(RTC_ERR_BAD_INDEX, "material %u: pattern index out of range", i);
+  std::unordered_set<uint32_t> ids;
+  for (uint32_t i = 0; i < d.n_leaves; ++i) {
+    const uint8_t k = d.leaf_kind[i];
+    if (k > RTC_CONE) return fail(RTC_ERR_UNSUPPORTED, "leaf %u: kind %u is not implemented by this kernel", i, k);
+    if (d.leaf_xform[i] >= d.n_xforms) return fail(RTC_ERR_BAD_INDEX, "leaf %u: xform index out of range", i);
+    if (d.leaf_material[i] >= d.n_materials) return fail(RTC_ERR_BAD_INDEX, "leaf %u: material index out of range", i);
+    if ((k == RTC_CYLINDER || k == RTC_CONE) && d.leaf_geom[i] >= d.n_cyls)
+      return fail(RTC_ERR_BAD_INDEX, "leaf %u: cylinder index out of range", i);
+    if ((k == RTC_TRIANGLE || k == RTC_SMOOTH_TRIANGLE) && d.leaf_geom[i] >= d.n_tris)
+      return fail(RTC_ERR_BAD_INDEX, "leaf %u: triangle index out of range", i);
+    if (!ids.insert(d.leaf_id[i]).second)
+      return fail(RTC_ERR_UNSUPPORTED, "leaf %u: Shape.id %u appears on more than one leaf", i, d.leaf_id[i]);
+  }
+  std::vector<uint8_t> leaf_seen(d.n_leaves, 0), node_seen(d.n_nodes, 0);
+  uint32_t max_stack = 0;
+  for (uint32_t i = 0; i < d.n_roots; ++i) {
+    const uint32_t r = d.roots[i];
+    if (r & RTC_CHILD_NODE_BIT) {
+      const int st = walkTree(d, leaf_seen, node_seen, r & ~RTC_CHILD_NODE_BIT, max_stack);
+      if (st != RTC_OK) return st;
+    } else {
+      if (r >= d.n_leaves) return fail(RTC_ERR_BAD_INDEX, "root %u: leaf index out of range", i);
+      if (leaf_seen[r]++) return fail(RTC_ERR_BAD_INDEX, "leaf %u is referenced twice", r);
+    }
+  }
+  if (max_stack > RTC_TRAV_STACK)
+    return fail(RTC_ERR_OVERFLOW, "group tree needs a traversal stack of %u entries, kernel has %d", max_stack, RTC_TRAV_STACK);
+
+  // ---- device tables.  Leaves are re-indexed to depth-first order: the leaf index IS the
+  // equal-t tie-break (see ClosestVisitor), whatever order the caller's arrays are in.
+  std::vector<uint32_t> dfs_of(d.n_leaves, RTC_NO_LEAF);
+  {
+    uint32_t next = 0;
+    std::vector<uint32_t> st;
+    for (uint32_t i = 0; i < d.n_roots; ++i) {
+      // explicit pre-order walk, children in list order
+      std::vector<std::pair<uint32_t, uint32_t>> frames;  // (node, next child)
+      const uint32_t r = d.roots[i];
+      if (!(r & RTC_CHILD_NODE_BIT)) {
+        dfs_of[r] = next++;
+        continue;
+      }
+      frames.push_back({r & ~RTC_CHILD_NODE_BIT, 0});
+      while (!frames.empty()) {
+        auto& f = frames.back();
+        if (f.second >= d.node_count[f.first]) {
+          frames.pop_back();
+          continue;
+        }
+        const uint32_t c = d.children[d.node_first[f.first] + f.second++];
+        if (c & RTC_CHILD_NODE_BIT) {
+          frames.push_back({c & ~RTC_CHILD_NODE_BIT, 0});
+        } else {
+          dfs_of[c] = next++;
+        }
+      }
+    }
+    // leaves not reachable from any root keep RTC_NO_LEAF and are dropped
+  }
+  uint32_t n_live = 0;
+  for (uint32_t v : dfs_of) n_live += (v != RTC_NO_LEAF);
+
+  std::vector<uint4> leaf_meta(n_live);
+  for (uint32_t i = 0; i < d.n_leaves; ++i) {
+    if (dfs_of[i] == RTC_NO_LEAF) continue;
+    uint4 m;
+    m.x = static_cast<uint32_t>(d.leaf_kind[i]) | (d.leaf_shadow[i] ? 0x100u : 0u);
+    m.y = d.leaf_xform[i];
+    m.z = d.leaf_material[i];
+    m.w = d.leaf_geom[i];
+    leaf_meta[dfs_of[i]] = m;
+  }
+  auto remap = [&](uint32_t ref) { return (ref & RTC_CHILD_NODE_BIT) ? ref : dfs_of[ref]; };
+  std::vector<uint32_t> roots(d.n_roots), kids(d.n_children);
+  for (uint32_t i = 0; i < d.n_roots; ++i) roots[i] = remap(d.roots[i]);
+  for (uint32_t i = 0; i < d.n_children; ++i) {
+    const uint32_t c = d.children[i];
+    kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
+  }
+  auto rows12 = [](const double* src, uint32_t n) {
+    std::vector<double> v(12ull * n);
+    for (uint32_t i = 0; i < n; ++i) std::memcpy(&v[12ull * i], src + 16ull * i, 12 * sizeof(double));
+    return v;
+  };
+  std::vector<double> xf = rows12(d.xf_inv, d.n_xforms);
+  std::vector<double> pat_inv = rows12(d.pat_inv, d.n_patterns);
+  std::vector<DevCyl> cyl(d.n_cyls);
+  for (uint32_t i = 0; i < d.n_cyls; ++i) cyl[i] = {d.cyl_min[i], d.cyl_max[i], d.cyl_closed[i] ? 1u : 0u, 0u};
+  std::vector<double> tri(9ull * d.n_tris), trin(9ull * d.n_tris);
+  for (uint32_t i = 0; i < d.n_tris; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      tri[9ull * i + k] = d.tri_p1[3ull * i + k];
+      tri[9ull * i + 3 + k] = d.tri_e1[3ull * i + k];
+      tri[9ull * i + 6 + k] = d.tri_e2[3ull * i + k];
+      trin[9ull * i + k] = d.tri_n1[3ull * i + k];
+      trin[9ull * i + 3 + k] = d.tri_n2[3ull * i + k];
+      trin[9ull * i + 6 + k] = d.tri_n3[3ull * i + k];
+    }
+  }
+  std::vector<DevMaterial> mat(d.n_materials);
+  for (uint32_t i = 0; i < d.n_materials; ++i) {
+    const double* p = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * i;
+    mat[i] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], d.mat_pattern[i], 0u};
+  }
+  std::vector<uint8_t> pat_kind(d.pat_kind, d.pat_kind + d.n_patterns);
+  std::vector<double> pat_rgb(d.pat_rgb, d.pat_rgb + 3ull * d.n_patterns);
+  std::vector<uint2> pat_ab(d.n_patterns), node_kids(d.n_nodes);
+  for (uint32_t i = 0; i < d.n_patterns; ++i) pat_ab[i] = {d.pat_a[i], d.pat_b[i]};
+  std::vector<double> node_box(6ull * d.n_nodes);
+  for (uint32_t i = 0; i < d.n_nodes; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      node_box[6ull * i + k] = d.node_min[3ull * i + k];
+      node_box[6ull * i + 3 + k] = d.node_max[3ull * i + k];
+    }
+    node_kids[i] = {d.node_first[i], d.node_count[i]};
+  }
+  std::vector<double> light(6ull * d.n_lights);
+  for (uint32_t i = 0; i < d.n_lights; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      light[6ull * i + k] = d.light_pos[3ull * i + k];
+      light[6ull * i + 3 + k] = d.light_rgb[3ull * i + k];
+    }
+  }
+
+  // ---- upload
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+    return fail(RTC_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+  auto s = new (std::nothrow) rtc_scene();
+  if (!s) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation");
+  struct Guard {
+    rtc_scene* s;
+    ~Guard() {
+      if (s) rtc_scene_destroy(s);
+    }
+  } guard{s};
+  HIP_TRY(hipGetDevice(&s->device));
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(s->roots.upload(roots));
+  HIP_TRY(s->kids.upload(kids));
+  HIP_TRY(s->leaf_meta.upload(leaf_meta));
+  HIP_TRY(s->xf.upload(xf));
+  HIP_TRY(s->cyl.upload(cyl));
+  HIP_TRY(s->tri.upload(tri));
+  HIP_TRY(s->trin.upload(trin));
+  HIP_TRY(s->mat.upload(mat));
+  HIP_TRY(s->pat_kind.upload(pat_kind));
+  HIP_TRY(s->pat_inv.upload(pat_inv));
+  HIP_TRY(s->pat_rgb.upload(pat_rgb));
+  HIP_TRY(s->pat_ab.upload(pat_ab));
+  HIP_TRY(s->node_box.upload(node_box));
+  HIP_TRY(s->node_kids.upload(node_kids));
+  HIP_TRY(s->light.upload(light));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DevStats)));
+  HIP_TRY(hipMemset(s->d_stats, 0, sizeof(DevStats)));
+  s->max_trav_stack = max_stack;
+  DevScene& D = s->dev;
+  D.roots = s->roots.p;
+  D.leaf_meta = s->leaf_meta.p;
+  D.xf = s->xf.p;
+  D.cyl = s->cyl.p;
+  D.tri = s->tri.p;
+  D.trin = s->trin.p;
+  D.mat = s->mat.p;
+  D.pat_kind = s->pat_kind.p;
+  D.pat_inv = s->pat_inv.p;
+  D.pat_rgb = s->pat_rgb.p;
+  D.pat_ab = s->pat_ab.p;
+  D.node_box = s->node_box.p;
+  D.node_kids = s->node_kids.p;
+  D.kids = s->kids.p;
+  D.light = s->light.p;
+  D.n_roots = d.n_roots;
+  D.n_leaves = n_live;
+  D.n_nodes = d.n_nodes;
+  D.n_lights = d.n_lights;
+  guard.s = nullptr;
+  *out = s;
+  return RTC_OK;
+}
+
+void rtc_scene_destroy(rtc_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) {
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipStreamDestroy(s->stream);
+  }
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  if (s->d_frame) (void)hipFree(s->d_frame);
+  delete s;
+}
+
+int rtc_render_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w,
+                      uint32_t h, double* d_rgb_out, void* hip_stream) {
+  g_error.clear();
+  if (!s || !d_rgb_out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  int st = checkCamera(cam);
+  if (st != RTC_OK) return st;
+  DevPixelMap map;
+  st = buildPixelMapRect(*cam, x0, y0, w, h, map);
+  if (st != RTC_OK) return st;
+  return launch(s, *cam, map, 1, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+}
+
+int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t tile_w, uint32_t tile_h,
+                            uint32_t first_tile, uint32_t tile_stride, uint32_t n_my_tiles, double* d_rgb_out,
+                            void* hip_stream) {
+  g_error.clear();
+  if (!s || !d_rgb_out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  int st = checkCamera(cam);
+  if (st != RTC_OK) return st;
+  if (tile_w == 0 || tile_h == 0 || tile_stride == 0 || n_my_tiles == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "tile %ux%u stride %u count %u", tile_w, tile_h, tile_stride, n_my_tiles);
+  DevPixelMap map;
+  std::memset(&map, 0, sizeof map);
+  map.mode = 1;
+  map.tile_w = tile_w;
+  map.tile_h = tile_h;
+  map.first_tile = first_tile;
+  map.tile_stride = tile_stride;
+  map.n_my_tiles = n_my_tiles;
+  map.tiles_x = (cam->hsize + tile_w - 1) / tile_w;
+  const uint32_t tiles_y = (cam->vsize + tile_h - 1) / tile_h;
+  const uint64_t last = static_cast<uint64_t>(first_tile) + static_cast<uint64_t>(n_my_tiles - 1) * tile_stride;
+  if (last >= static_cast<uint64_t>(map.tiles_x) * tiles_y)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "tile %llu outside the %ux%u tiling", (unsigned long long)last, map.tiles_x, tiles_y);
+  map.blocks_x = (tile_w + 15) / 16;
+  map.blocks_y = (tile_h + 15) / 16;
+  return launch(s, *cam, map, n_my_tiles, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+}
+
+int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+               double* rgb_out) {
+  g_error.clear();
+  if (!s || !rgb_out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t need = 3ull * w * h;
+  HIP_TRY(hipSetDevice(s->device));
+  if (need > s->frame_capacity) {
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    s->d_frame = nullptr;
+    s->frame_capacity = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), std::max<size_t>(need, 1) * sizeof(double)));
+    s->frame_capacity = need;
+  }
+  const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
+  if (st != RTC_OK) return st;
+  HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, need * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTC_OK;
+}
+
+int rtc_scene_synchronize(rtc_scene* s) {
+  g_error.clear();
+  if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTC_OK;
+}
+
+int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
+  g_error.clear();
+  if (!s || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  DevStats h;
+  HIP_TRY(hipMemcpy(&h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  out->primary = h.primary;
+  out->secondary = h.secondary;
+  out->shadow_calls = h.shadow_calls;
+  out->shadow_traced = h.shadow_traced;
+  out->overflow = h.overflow;
+  return RTC_OK;
+}
+
+}  // extern "C"

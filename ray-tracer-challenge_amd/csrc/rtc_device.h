@@ -1,0 +1,83 @@
+// rtc_device.h — device-side scene layout shared by rtc_kernels.hip (kernels)
+// and rtc_capi.hip (upload).  gfx950 only.
+//
+// HBM layout (everything read-only during a render, uploaded once per scene):
+//
+//   roots[]      u32      World.objects in order; high bit = group node
+//   leaf_meta[]  uint4    {kind | casts_shadow<<8, xform, material, geom} per leaf, leaf index =
+//                         position in the reference's depth-first order (the equal-t tie-break)
+//   xf[]         12 f64   rows 0..2 of Shape._inverse_transform (row 3 is (0,0,0,1): validated at
+//                         create).  The inverse-transpose used by normalToWorld (shape.zig:139) is
+//                         the same 3x3 read column-wise, so it is not stored.
+//   cyl[]        {min,max,closed}
+//   tri[]        9 f64    p1,e1,e2 packed per triangle (AoS: a BVH leaf visit is a per-lane
+//                         gather, one 72-byte record beats nine SoA lines)
+//   trin[]       9 f64    n1,n2,n3 (flat triangles: n1 = stored face normal)
+//   mat[]        8 f64    ambient,diffuse,specular,shininess,reflective,transparency,ior,pattern
+//   pat_*        pattern table
+//   node_box[]   6 f64    Group._bbox min,max; node_kids[] {first,count}; kids[] u32
+//   light[]      6 f64    position, intensity
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RTC_NODE_BIT 0x80000000u
+#define RTC_NO_LEAF 0xFFFFFFFFu
+
+// per-lane traversal stack (node indices) and secondary-ray stack capacities
+#define RTC_TRAV_STACK 64
+#define RTC_MAX_DEPTH 16
+#define RTC_RAY_STACK (RTC_MAX_DEPTH + 2)
+
+struct DevMaterial {
+  double ambient, diffuse, specular, shininess, reflective, transparency, ior;
+  uint32_t pattern;
+  uint32_t pad;
+};
+
+struct DevCyl {
+  double ymin, ymax;
+  uint32_t closed;
+  uint32_t pad;
+};
+
+struct DevScene {
+  const uint32_t* __restrict__ roots;
+  const uint4* __restrict__ leaf_meta;
+  const double* __restrict__ xf;        // [n_xforms][12]
+  const DevCyl* __restrict__ cyl;
+  const double* __restrict__ tri;       // [n_tris][9]
+  const double* __restrict__ trin;      // [n_tris][9]
+  const DevMaterial* __restrict__ mat;
+  const uint8_t* __restrict__ pat_kind;
+  const double* __restrict__ pat_inv;   // [n_patterns][12]
+  const double* __restrict__ pat_rgb;   // [n_patterns][3]
+  const uint2* __restrict__ pat_ab;     // sub-pattern indices
+  const double* __restrict__ node_box;  // [n_nodes][6]
+  const uint2* __restrict__ node_kids;  // {first, count}
+  const uint32_t* __restrict__ kids;
+  const double* __restrict__ light;     // [n_lights][6]
+  uint32_t n_roots, n_leaves, n_nodes, n_lights;
+};
+
+struct DevCamera {
+  double half_width, half_height, pixel_size;
+  double inv[12];  // rows 0..2 of Camera._inverse_transform
+  uint32_t hsize, vsize;
+};
+
+// How work-groups map to pixels and where results go.
+//   mode 0: rectangle [x0,x0+w) x [y0,y0+h) -> out[(y-y0)*w + (x-x0)]
+//   mode 1: interleaved tiles (multi-GPU): tile k = first_tile + i*tile_stride of a tile_w x tile_h
+//           tiling of the image -> out[(i*tile_h + ly)*tile_w + lx]
+struct DevPixelMap {
+  uint32_t mode;
+  uint32_t x0, y0, w, h;
+  uint32_t tile_w, tile_h, first_tile, tile_stride, n_my_tiles;
+  uint32_t tiles_x;           // tiles per image row (mode 1)
+  uint32_t blocks_x, blocks_y;  // 16x16-pixel blocks per rectangle / per tile
+};
+
+struct DevStats {  // accumulated with one atomic per wave
+  unsigned long long primary, secondary, shadow_calls, shadow_traced, overflow;
+};

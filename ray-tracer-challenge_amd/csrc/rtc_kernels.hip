@@ -1,0 +1,830 @@
+// rtc_kernels.hip — the per-pixel hot path of SinclaM/ray-tracer-challenge as ONE
+// hand-written FP64 megakernel for gfx950 (MI355X, wave64).
+//
+// Replaces, per pixel (all file:line citations are into /root/reference/src/raytracer):
+//   Camera.rayForPixel                      camera.zig:64-76
+//   World.colorAt                           world.zig:111-121
+//   World.intersect + sort + hit            world.zig:71-83, shapes/shape.zig:64-80
+//   Shape.intersect (per-leaf ray xform)    shapes/shape.zig:313-335
+//   Sphere/Plane/Cube/Cylinder/Cone/Triangle/SmoothTriangle.localIntersect
+//   Group.localIntersect + BoundingBox      shapes/group.zig:39-62, bounding_box.zig:112-165
+//   PreComputations.new / schlick           world.zig:212-289
+//   World.shadeHit / isShadowed             world.zig:86-154
+//   Material.lighting, Pattern.patternAt    material.zig:40-74, patterns/*.zig
+//   World.reflectedColor / refractedColor   world.zig:157-189
+//
+// Design (MI355X-first, not a translation of the reference's control flow):
+//   * one lane = one pixel; the reflection/refraction recursion is an explicit per-lane
+//     stack of (ray, weight, remaining) entries, colour accumulated top-down;
+//   * the reference builds, sorts and scans a heap-allocated list of ALL intersections for
+//     every ray (and again for every shadow ray).  Here the three things that list is used
+//     for are computed by streaming reductions over exactly the same candidate set:
+//       - the hit   = min over entries with t >= 0 of (t, depth-first leaf index),
+//       - shadowed  = exists entry with 0 <= t < distance on a shadow-casting leaf,
+//       - n1 / n2   = refractive index of the "open" leaf whose last entry before the hit
+//                     comes latest (see behind_visitor), which is what the containers walk
+//                     of world.zig:229-255 evaluates to;
+//   * top-level World.objects are walked by a wave-uniform loop (leaf records come in through
+//     scalar loads); groups are walked by a per-lane stack traversal of the reference's own
+//     group tree with the reference's own boxes and slab test, so the candidate set is the
+//     reference's;
+//   * arithmetic is FP64 in the reference's evaluation order and this file is compiled with
+//     -ffp-contract=off (the reference's Zig float mode is strict: no FMA contraction), so
+//     every t, point and normal is bit-identical to the CPU restatement; only pow() (specular,
+//     schlick) may differ in the last ulp.  No MFMA: nothing here is a dense contraction.
+#include "rtc_device.h"
+
+namespace {
+
+constexpr double kInf = __builtin_huge_val();
+
+struct Ray {
+  double ox, oy, oz, dx, dy, dz;
+};
+
+// Zig @max/@min return the non-NaN operand (IEEE maxNum/minNum) == v_max_f64/v_min_f64.
+__device__ __forceinline__ double zmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double zmin(double a, double b) { return __builtin_fmin(a, b); }
+
+// Matrix.tupleMul (matrix.zig:124-140) on rows 0..2 of an affine matrix: a row dot is
+// ((m0*x + m1*y) + m2*z) + m3*w; w == 1 for points (m3*1 is exact) and w == 0 for vectors
+// (the term is an exact +0 and is dropped).
+__device__ __forceinline__ double row_pt(const double* __restrict__ m, double x, double y, double z) {
+  return ((m[0] * x + m[1] * y) + m[2] * z) + m[3];
+}
+__device__ __forceinline__ double row_vec(const double* __restrict__ m, double x, double y, double z) {
+  return (m[0] * x + m[1] * y) + m[2] * z;
+}
+
+// Ray.transform (ray.zig:30-32)
+__device__ __forceinline__ Ray xform_ray(const double* __restrict__ m, const Ray& r) {
+  Ray o;
+  o.ox = row_pt(m + 0, r.ox, r.oy, r.oz);
+  o.oy = row_pt(m + 4, r.ox, r.oy, r.oz);
+  o.oz = row_pt(m + 8, r.ox, r.oy, r.oz);
+  o.dx = row_vec(m + 0, r.dx, r.dy, r.dz);
+  o.dy = row_vec(m + 4, r.dx, r.dy, r.dz);
+  o.dz = row_vec(m + 8, r.dx, r.dy, r.dz);
+  return o;
+}
+
+// cube.zig:24-47 / bounding_box.zig:112-137
+__device__ __forceinline__ void check_axis(double origin, double direction, double mn, double mx, double& tmin,
+                                           double& tmax) {
+  const double tmin_numerator = mn - origin;
+  const double tmax_numerator = mx - origin;
+  if (__builtin_fabs(direction) >= 1e-5) {
+    tmin = tmin_numerator / direction;
+    tmax = tmax_numerator / direction;
+  } else {
+    tmin = tmin_numerator * kInf;
+    tmax = tmax_numerator * kInf;
+  }
+  if (tmin > tmax) {
+    const double save = tmax;
+    tmax = tmin;
+    tmin = save;
+  }
+}
+
+// cube.zig:49-79 / bounding_box.zig:139-165; returns false on a miss (tmin > tmax).
+__device__ __forceinline__ bool slab(const Ray& r, double mnx, double mny, double mnz, double mxx, double mxy,
+                                     double mxz, double& tmin, double& tmax) {
+  double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+  check_axis(r.ox, r.dx, mnx, mxx, xtmin, xtmax);
+  check_axis(r.oy, r.dy, mny, mxy, ytmin, ytmax);
+  check_axis(r.oz, r.dz, mnz, mxz, ztmin, ztmax);
+  tmin = zmax(xtmin, zmax(ytmin, ztmin));
+  tmax = zmin(xtmax, zmin(ytmax, ztmax));
+  return !(tmin > tmax);
+}
+
+// Emits the entries a leaf's localIntersect appends, in the reference's order, as f(t, u, v).
+// `r` is the ray in the leaf's object space.
+template <class F>
+__device__ __forceinline__ void leaf_entries(const DevScene& S, uint32_t kind, uint32_t geom, const Ray& r, F&& f) {
+  switch (kind) {
+    case 0: {  // sphere.zig:24-46
+      const double a = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
+      const double b = 2.0 * ((r.ox * r.dx + r.oy * r.dy) + r.oz * r.dz);
+      const double c = ((r.ox * r.ox + r.oy * r.oy) + r.oz * r.oz) - 1.0;
+      const double discriminant = b * b - 4.0 * a * c;
+      if (discriminant >= 0.0) {
+        const double sq = __builtin_sqrt(discriminant);
+        double t1 = (-b - sq) / (2.0 * a);
+        double t2 = (-b + sq) / (2.0 * a);
+        if (t2 < t1) {  // sortIntersections on two entries
+          const double s = t1;
+          t1 = t2;
+          t2 = s;
+        }
+        f(t1, 0.0, 0.0);
+        f(t2, 0.0, 0.0);
+      }
+      break;
+    }
+    case 1: {  // plane.zig:25-36
+      if (__builtin_fabs(r.dy) > 1e-5) f(-r.oy / r.dy, 0.0, 0.0);
+      break;
+    }
+    case 2: {  // cube.zig:49-79
+      double tmin, tmax;
+      if (slab(r, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax)) {
+        f(tmin, 0.0, 0.0);
+        f(tmax, 0.0, 0.0);
+      }
+      break;
+    }
+    case 3: {  // cylinder.zig:53-98
+      const DevCyl cy = S.cyl[geom];
+      const double a = r.dx * r.dx + r.dz * r.dz;
+      bool walls_done = false, caps = true;
+      if (__builtin_fabs(a) < 1e-5) {
+        walls_done = true;  // parallel to the axis: caps only
+      }
+      if (!walls_done) {
+        const double b = 2.0 * r.ox * r.dx + 2.0 * r.oz * r.dz;
+        const double c = (r.ox * r.ox + r.oz * r.oz) - 1.0;
+        const double discriminant = b * b - 4.0 * a * c;
+        if (discriminant < 0.0) {
+          caps = false;  // early return before intersectCaps
+        } else {
+          const double sq = __builtin_sqrt(discriminant);
+          double t0 = (-b - sq) / (2.0 * a);
+          double t1 = (-b + sq) / (2.0 * a);
+          if (t0 > t1) {
+            const double s = t0;
+            t0 = t1;
+            t1 = s;
+          }
+          const double y0 = r.oy + t0 * r.dy;
+          if (cy.ymin < y0 && y0 < cy.ymax) f(t0, 0.0, 0.0);
+          const double y1 = r.oy + t1 * r.dy;
+          if (cy.ymin < y1 && y1 < cy.ymax) f(t1, 0.0, 0.0);
+        }
+      }
+      if (caps && cy.closed && !(__builtin_fabs(r.dy) < 1e-5)) {  // cylinder.zig:37-51
+        double t = (cy.ymin - r.oy) / r.dy;
+        double x = r.ox + t * r.dx, z = r.oz + t * r.dz;
+        if (x * x + z * z <= 1.0) f(t, 0.0, 0.0);
+        t = (cy.ymax - r.oy) / r.dy;
+        x = r.ox + t * r.dx;
+        z = r.oz + t * r.dz;
+        if (x * x + z * z <= 1.0) f(t, 0.0, 0.0);
+      }
+      break;
+    }
+    case 6: {  // cone.zig:52-113
+      const DevCyl cy = S.cyl[geom];
+      const double tol = 1e-4;
+      const double a = (r.dx * r.dx - r.dy * r.dy) + r.dz * r.dz;
+      const double b = (2.0 * r.ox * r.dx - 2.0 * r.oy * r.dy) + 2.0 * r.oz * r.dz;
+      bool caps = true;
+      if (__builtin_fabs(a) < tol && __builtin_fabs(b) < tol) {
+        // misses the surface; caps only
+      } else {
+        const double c = (r.ox * r.ox - r.oy * r.oy) + r.oz * r.oz;
+        if (__builtin_fabs(a) < tol) {
+          f(-c / (2.0 * b), 0.0, 0.0);
+        } else {
+          const double discriminant = b * b - 4.0 * a * c;
+          if (discriminant < 0.0) {
+            caps = false;
+          } else {
+            const double sq = __builtin_sqrt(discriminant);
+            double t0 = (-b - sq) / (2.0 * a);
+            double t1 = (-b + sq) / (2.0 * a);
+            if (t0 > t1) {
+              const double s = t0;
+              t0 = t1;
+              t1 = s;
+            }
+            const double y0 = r.oy + t0 * r.dy;
+            if (cy.ymin < y0 && y0 < cy.ymax) f(t0, 0.0, 0.0);
+            const double y1 = r.oy + t1 * r.dy;
+            if (cy.ymin < y1 && y1 < cy.ymax) f(t1, 0.0, 0.0);
+          }
+        }
+      }
+      if (caps && cy.closed && !(__builtin_fabs(r.dy) < tol)) {  // cone.zig:36-50
+        double t = (cy.ymin - r.oy) / r.dy;
+        double x = r.ox + t * r.dx, z = r.oz + t * r.dz;
+        if (x * x + z * z <= cy.ymin * cy.ymin) f(t, 0.0, 0.0);
+        t = (cy.ymax - r.oy) / r.dy;
+        x = r.ox + t * r.dx;
+        z = r.oz + t * r.dz;
+        if (x * x + z * z <= cy.ymax * cy.ymax) f(t, 0.0, 0.0);
+      }
+      break;
+    }
+    default: {  // 4 triangle.zig:29-63, 5 triangle.zig:225-259 (Moller-Trumbore, left-handed cross)
+      const double* __restrict__ T = S.tri + 9ull * geom;
+      const double p1x = T[0], p1y = T[1], p1z = T[2];
+      const double e1x = T[3], e1y = T[4], e1z = T[5];
+      const double e2x = T[6], e2y = T[7], e2z = T[8];
+      // dir_cross_e2 = direction.cross(e2)  (tuple.zig:128)
+      const double cx = r.dy * e2z - r.dz * e2y;
+      const double cy = r.dz * e2x - r.dx * e2z;
+      const double cz = r.dx * e2y - r.dy * e2x;
+      const double det = (e1x * cx + e1y * cy) + e1z * cz;
+      if (__builtin_fabs(det) < 1e-5) break;
+      const double ff = 1.0 / det;
+      const double qx = r.ox - p1x, qy = r.oy - p1y, qz = r.oz - p1z;  // p1_to_origin
+      const double u = ff * ((qx * cx + qy * cy) + qz * cz);
+      if (u < 0.0 || u > 1.0) break;
+      // p1_to_origin.cross(e1)
+      const double ox = qy * e1z - qz * e1y;
+      const double oy = qz * e1x - qx * e1z;
+      const double oz = qx * e1y - qy * e1x;
+      const double v = ff * ((r.dx * ox + r.dy * oy) + r.dz * oz);
+      if (v < 0.0 || (u + v) > 1.0) break;
+      const double t = ff * ((e2x * ox + e2y * oy) + e2z * oz);
+      f(t, u, v);
+      break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Candidate enumeration: World.intersect (world.zig:71-83) + Group.localIntersect
+// (group.zig:39-62) without materialising the list.  The visitor sees every entry the
+// reference would have appended: vis.entry(leaf, meta, t, u, v); vis.cull(tmin, tmax) may
+// skip a group whose box interval cannot contribute; vis.done() stops early.
+// Box-interval culling is conservative by kBoxSlack: a box's [tmin,tmax] and a leaf's t are
+// computed by different roundings, so "entirely behind / beyond" is only trusted with slack.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double box_slack(double t) { return 1e-4 + 1e-6 * __builtin_fabs(t); }
+
+template <class V>
+__device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, const Ray& ray, uint32_t& cur_xf,
+                                           Ray& lr, V& vis) {
+  const uint4 meta = S.leaf_meta[leaf];
+  if (meta.y != cur_xf) {  // Shape.intersect: ray.transform(_inverse_transform), shape.zig:314-318
+    lr = xform_ray(S.xf + 12ull * meta.y, ray);
+    cur_xf = meta.y;
+  }
+  leaf_entries(S, meta.x & 0xFFu, meta.w, lr, [&](double t, double u, double v) { vis.entry(leaf, meta, t, u, v); });
+}
+
+template <class V>
+__device__ __forceinline__ void trace(const DevScene& S, const Ray& ray, V& vis, unsigned& overflow) {
+  uint32_t cur_xf = 0xFFFFFFFFu;
+  Ray lr = ray;
+  for (uint32_t ri = 0; ri < S.n_roots; ++ri) {  // wave-uniform loop over World.objects
+    if (vis.done()) break;
+    const uint32_t ref = S.roots[ri];
+    if (!(ref & RTC_NODE_BIT)) {
+      visit_leaf(S, ref, ray, cur_xf, lr, vis);
+      continue;
+    }
+    uint32_t stack[RTC_TRAV_STACK];
+    int sp = 0;
+    stack[sp++] = ref & ~RTC_NODE_BIT;
+    while (sp > 0 && !vis.done()) {
+      const uint32_t n = stack[--sp];
+      const double* __restrict__ B = S.node_box + 6ull * n;
+      double tmin, tmax;
+      // Group._bbox.intersect (group.zig:46-50): the ray is NOT transformed (identity).
+      if (!slab(ray, B[0], B[1], B[2], B[3], B[4], B[5], tmin, tmax)) continue;
+      if (vis.cull(tmin, tmax)) continue;
+      const uint2 k = S.node_kids[n];
+      for (uint32_t i = 0; i < k.y; ++i) {
+        const uint32_t c = S.kids[k.x + i];
+        if (c & RTC_NODE_BIT) {
+          if (sp < RTC_TRAV_STACK) {
+            stack[sp++] = c & ~RTC_NODE_BIT;
+          } else {
+            overflow = 1u;
+          }
+        } else {
+          visit_leaf(S, c, ray, cur_xf, lr, vis);
+        }
+      }
+    }
+  }
+}
+
+// hit(): first entry with t >= 0 of the stably sorted list (shape.zig:71-80) ==
+// lexicographic min of (t, depth-first leaf index) over entries with t >= 0.
+struct ClosestVisitor {
+  double t = kInf;
+  uint32_t leaf = RTC_NO_LEAF;
+  double u = 0.0, v = 0.0;
+  __device__ __forceinline__ void entry(uint32_t l, const uint4&, double et, double eu, double ev) {
+    if (et >= 0.0 && (et < t || (et == t && l < leaf))) {
+      t = et;
+      leaf = l;
+      u = eu;
+      v = ev;
+    }
+  }
+  __device__ __forceinline__ bool cull(double tmin, double tmax) const {
+    return tmax < -box_slack(tmax) || tmin > t + box_slack(t);
+  }
+  __device__ __forceinline__ bool done() const { return false; }
+};
+
+// isShadowed (world.zig:126-154): any entry with 0 <= t < distance on a casts_shadow leaf.
+struct ShadowVisitor {
+  double distance;
+  bool shadowed = false;
+  __device__ __forceinline__ void entry(uint32_t, const uint4& meta, double et, double, double) {
+    if (et >= 0.0 && et < distance && ((meta.x >> 8) & 1u)) shadowed = true;
+  }
+  __device__ __forceinline__ bool cull(double tmin, double tmax) const {
+    return tmax < -box_slack(tmax) || tmin > distance + box_slack(distance);
+  }
+  __device__ __forceinline__ bool done() const { return shadowed; }
+};
+
+// The containers walk of PreComputations.new (world.zig:229-255), as a reduction.
+// Entries before the hit in the sorted list are exactly those with t < 0.  A leaf with an
+// odd number of them is still in `containers` when the hit is reached, at the position of
+// its LAST such entry (its final toggle is an append), so
+//   n1 = ior of the open leaf whose last t<0 entry is latest in (t, leaf order), else 1;
+//   n2 = ior of the hit leaf if it was not open (it gets appended), else ior of the latest
+//        open leaf other than the hit leaf, else 1 (or the hit leaf again if it has a second
+//        entry at exactly t_hit: the reference does not `break` on an empty list).
+// Identity is the leaf index; rtc_scene_create rejects scenes whose leaves share a Shape.id.
+struct BehindVisitor {
+  uint32_t hit_leaf;
+  double hit_t;
+  // running state of the leaf currently being visited (entries of one leaf arrive together)
+  uint32_t cur = RTC_NO_LEAF;
+  uint32_t cur_cnt = 0;
+  double cur_last = -kInf;
+  uint32_t cur_mat = 0;
+  // results
+  double best_t = -kInf, best_excl_t = -kInf;
+  uint32_t best_leaf = RTC_NO_LEAF, best_excl_leaf = RTC_NO_LEAF;
+  uint32_t best_mat = 0, best_excl_mat = 0;
+  bool hit_open = false;
+  uint32_t hit_dups = 0;
+
+  __device__ __forceinline__ void flush() {
+    if (cur != RTC_NO_LEAF && (cur_cnt & 1u)) {
+      if (cur_last > best_t || (cur_last == best_t && (best_leaf == RTC_NO_LEAF || cur > best_leaf))) {
+        best_t = cur_last;
+        best_leaf = cur;
+        best_mat = cur_mat;
+      }
+      if (cur == hit_leaf) {
+        hit_open = true;
+      } else if (cur_last > best_excl_t ||
+                 (cur_last == best_excl_t && (best_excl_leaf == RTC_NO_LEAF || cur > best_excl_leaf))) {
+        best_excl_t = cur_last;
+        best_excl_leaf = cur;
+        best_excl_mat = cur_mat;
+      }
+    }
+    cur = RTC_NO_LEAF;
+    cur_cnt = 0;
+    cur_last = -kInf;
+  }
+  __device__ __forceinline__ void entry(uint32_t l, const uint4& meta, double et, double, double) {
+    if (l != cur) {
+      flush();
+      cur = l;
+      cur_mat = meta.z;
+    }
+    if (et < 0.0) {
+      cur_cnt++;
+      cur_last = zmax(cur_last, et);
+    } else if (l == hit_leaf && et == hit_t) {
+      hit_dups++;
+    }
+  }
+  __device__ __forceinline__ bool cull(double tmin, double) const { return tmin > box_slack(tmin); }
+  __device__ __forceinline__ bool done() const { return false; }
+};
+
+// ------------------------------------------------------------------------------------------
+// Patterns (patterns/pattern.zig:112-131).  Zig @mod for floats (LLVM backend): r = fmod(x,y);
+// x < 0 ? fmod(r + y, y) : r.  With y == 2 fmod is exact: x - 2*trunc(x/2).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fmod2(double x) { return x - 2.0 * __builtin_trunc(x / 2.0); }
+__device__ __forceinline__ double zig_mod2(double x) {
+  const double a = fmod2(x);
+  return (x < 0.0) ? fmod2(a + 2.0) : a;
+}
+
+struct Rgb {
+  double r, g, b;
+};
+
+// Follows a chain of "selecting" patterns (stripes / checkers / rings) down to a solid or
+// test pattern.  Sub-patterns are evaluated at the OBJECT-space point with their own inverse
+// (stripes.zig:27-33).  Returns false if the chain ends in a mixing pattern (idx then names it).
+__device__ __forceinline__ bool pattern_chain(const DevScene& S, uint32_t& idx, double ox, double oy, double oz,
+                                              Rgb& out) {
+  for (int guard = 0; guard < 64; ++guard) {
+    const uint32_t kind = S.pat_kind[idx];
+    if (kind == 0) {  // solid.zig:20-24
+      const double* __restrict__ c = S.pat_rgb + 3ull * idx;
+      out = {c[0], c[1], c[2]};
+      return true;
+    }
+    const double* __restrict__ m = S.pat_inv + 12ull * idx;
+    const double px = row_pt(m + 0, ox, oy, oz);
+    const double py = row_pt(m + 4, ox, oy, oz);
+    const double pz = row_pt(m + 8, ox, oy, oz);
+    const uint2 ab = S.pat_ab[idx];
+    if (kind == 9) {  // TestPattern, pattern.zig:144-148
+      out = {px, py, pz};
+      return true;
+    } else if (kind == 1) {  // stripes.zig:27-33
+      idx = (zig_mod2(px) < 1.0) ? ab.x : ab.y;
+    } else if (kind == 5) {  // checkers.zig:23-29
+      idx = (zig_mod2((__builtin_floor(px) + __builtin_floor(py)) + __builtin_floor(pz)) < 1.0) ? ab.x : ab.y;
+    } else if (kind == 2) {  // rings.zig:27-33
+      idx = (zig_mod2(__builtin_floor(__builtin_sqrt(px * px + pz * pz))) < 1.0) ? ab.x : ab.y;
+    } else {
+      return false;  // gradient / radial gradient / blend: needs both children
+    }
+  }
+  out = {0.0, 0.0, 0.0};
+  return true;
+}
+
+// Pattern.patternAt for the whole table.  Mixing patterns (gradient.zig, blend.zig) may sit
+// anywhere in a select-chain but their own children must be select-chains (validated at create).
+__device__ __forceinline__ Rgb pattern_at(const DevScene& S, uint32_t idx, double ox, double oy, double oz) {
+  Rgb out;
+  if (pattern_chain(S, idx, ox, oy, oz, out)) return out;
+  const uint32_t kind = S.pat_kind[idx];
+  const double* __restrict__ m = S.pat_inv + 12ull * idx;
+  const double px = row_pt(m + 0, ox, oy, oz);
+  const double pz = row_pt(m + 8, ox, oy, oz);
+  const uint2 ab = S.pat_ab[idx];
+  uint32_t ia = ab.x, ib = ab.y;
+  Rgb ca{0, 0, 0}, cb{0, 0, 0};
+  pattern_chain(S, ia, ox, oy, oz, ca);
+  pattern_chain(S, ib, ox, oy, oz, cb);
+  if (kind == 6) {  // blend.zig:21-24
+    return {(ca.r + cb.r) * 0.5, (ca.g + cb.g) * 0.5, (ca.b + cb.b) * 0.5};
+  }
+  double fpart;
+  if (kind == 3) {  // gradient.zig:27-32
+    fpart = px - __builtin_floor(px);
+  } else {  // radial gradient, gradient.zig:49-55
+    const double mag = __builtin_sqrt(px * px + pz * pz);
+    fpart = mag - __builtin_floor(mag);
+  }
+  return {ca.r + (cb.r - ca.r) * fpart, ca.g + (cb.g - ca.g) * fpart, ca.b + (cb.b - ca.b) * fpart};
+}
+
+// One pending secondary ray of the colorAt recursion (world.zig:157-189): the colour it
+// returns is multiplied by `weight` on its way up to the pixel.
+struct Pending {
+  Ray ray;
+  double weight;
+  uint32_t remaining;
+};
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
+  unsigned long long s = v;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// The megakernel.  256 threads = 4 waves; each wave owns an 8x8-pixel tile of a 16x16 block,
+// so the 64 lanes of a wave start from neighbouring primary rays.
+// ------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                  double* __restrict__ out, DevStats* __restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
+  const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
+
+  uint32_t px, py;        // image pixel
+  size_t out_index;       // position in `out` (pixels)
+  bool in_buffer, in_image;
+  {
+    const uint32_t per_region = map.blocks_x * map.blocks_y;
+    const uint32_t region = blockIdx.x / per_region;
+    const uint32_t b = blockIdx.x - region * per_region;
+    const uint32_t bx = b % map.blocks_x, by = b / map.blocks_x;
+    const uint32_t rx = bx * 16u + lx, ry = by * 16u + ly;  // position inside the rectangle / tile
+    if (map.mode == 0u) {
+      in_buffer = rx < map.w && ry < map.h;
+      px = map.x0 + rx;
+      py = map.y0 + ry;
+      out_index = static_cast<size_t>(ry) * map.w + rx;
+    } else {
+      const uint32_t tile = map.first_tile + region * map.tile_stride;
+      const uint32_t tx = tile % map.tiles_x, ty = tile / map.tiles_x;
+      in_buffer = rx < map.tile_w && ry < map.tile_h;
+      px = tx * map.tile_w + rx;
+      py = ty * map.tile_h + ry;
+      out_index = (static_cast<size_t>(region) * map.tile_h + ry) * map.tile_w + rx;
+    }
+    in_image = in_buffer && px < cam.hsize && py < cam.vsize;
+  }
+
+  double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
+  unsigned n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0;
+
+  Pending stack[RTC_RAY_STACK];
+  int sp = 0;
+
+  if (in_image) {
+    // Camera.rayForPixel, camera.zig:64-76
+    const double xoffset = (static_cast<double>(px) + 0.5) * cam.pixel_size;
+    const double yoffset = (static_cast<double>(py) + 0.5) * cam.pixel_size;
+    const double world_x = cam.half_width - xoffset;
+    const double world_y = cam.half_height - yoffset;
+    const double pix_x = row_pt(cam.inv + 0, world_x, world_y, -1.0);
+    const double pix_y = row_pt(cam.inv + 4, world_x, world_y, -1.0);
+    const double pix_z = row_pt(cam.inv + 8, world_x, world_y, -1.0);
+    Pending p;
+    p.ray.ox = row_pt(cam.inv + 0, 0.0, 0.0, 0.0);
+    p.ray.oy = row_pt(cam.inv + 4, 0.0, 0.0, 0.0);
+    p.ray.oz = row_pt(cam.inv + 8, 0.0, 0.0, 0.0);
+    double dx = pix_x - p.ray.ox, dy = pix_y - p.ray.oy, dz = pix_z - p.ray.oz;
+    const double mag = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);  // Tuple.normalized, tuple.zig:109-116
+    if (mag != 0.0) {
+      dx = dx / mag;
+      dy = dy / mag;
+      dz = dz / mag;
+    }
+    p.ray.dx = dx;
+    p.ray.dy = dy;
+    p.ray.dz = dz;
+    p.weight = 1.0;
+    p.remaining = max_depth;
+    stack[sp++] = p;
+  }
+
+  while (sp > 0) {
+    const Pending cur = stack[--sp];
+    const Ray& ray = cur.ray;
+
+    // ---- World.colorAt: intersect + hit (world.zig:111-115)
+    ClosestVisitor hv;
+    trace(S, ray, hv, overflow);
+    if (hv.leaf == RTC_NO_LEAF) continue;  // black
+
+    // ---- PreComputations.new (world.zig:212-227)
+    const uint4 meta = S.leaf_meta[hv.leaf];
+    const uint32_t kind = meta.x & 0xFFu;
+    const double* __restrict__ M = S.xf + 12ull * meta.y;
+    const DevMaterial mat = S.mat[meta.z];
+    const double t = hv.t;
+    const double ptx = ray.ox + ray.dx * t, pty = ray.oy + ray.dy * t, ptz = ray.oz + ray.dz * t;  // ray.position
+    const double ex = -ray.dx, ey = -ray.dy, ez = -ray.dz;                                          // eyev
+    // Shape.normalAt (shape.zig:338-350): local point, local normal, normalToWorld
+    const double lpx = row_pt(M + 0, ptx, pty, ptz);
+    const double lpy = row_pt(M + 4, ptx, pty, ptz);
+    const double lpz = row_pt(M + 8, ptx, pty, ptz);
+    double lnx, lny, lnz;
+    switch (kind) {
+      case 0:  // sphere.zig:48-53
+        lnx = lpx;
+        lny = lpy;
+        lnz = lpz;
+        break;
+      case 1:  // plane.zig:38-43
+        lnx = 0.0;
+        lny = 1.0;
+        lnz = 0.0;
+        break;
+      case 2: {  // cube.zig:81-97
+        const double ax = __builtin_fabs(lpx), ay = __builtin_fabs(lpy), az = __builtin_fabs(lpz);
+        const double maxc = zmax(ax, zmax(ay, az));
+        lnx = lny = lnz = 0.0;
+        if (maxc == ax) {
+          lnx = lpx;
+        } else if (maxc == ay) {
+          lny = lpy;
+        } else {
+          lnz = lpz;
+        }
+        break;
+      }
+      case 3: {  // cylinder.zig:100-112
+        const DevCyl cy = S.cyl[meta.w];
+        const double dist = lpx * lpx + lpz * lpz;
+        if (dist < 1.0 && lpy >= cy.ymax - 1e-5) {
+          lnx = 0.0; lny = 1.0; lnz = 0.0;
+        } else if (dist < 1.0 && lpy <= cy.ymin + 1e-5) {
+          lnx = 0.0; lny = -1.0; lnz = 0.0;
+        } else {
+          lnx = lpx; lny = 0.0; lnz = lpz;
+        }
+        break;
+      }
+      case 6: {  // cone.zig:115-132
+        const DevCyl cy = S.cyl[meta.w];
+        const double dist = lpx * lpx + lpz * lpz;
+        if (dist < cy.ymax * cy.ymax && lpy >= cy.ymax - 1e-4) {
+          lnx = 0.0; lny = 1.0; lnz = 0.0;
+        } else if (dist < cy.ymin * cy.ymin && lpy <= cy.ymin + 1e-4) {
+          lnx = 0.0; lny = -1.0; lnz = 0.0;
+        } else {
+          const double sgn = lpy > 0.0 ? 1.0 : (lpy < 0.0 ? -1.0 : lpy);  // std.math.sign
+          lnx = lpx;
+          lny = -sgn * __builtin_sqrt(lpx * lpx + lpz * lpz);
+          lnz = lpz;
+        }
+        break;
+      }
+      case 4: {  // triangle.zig:65-70: the stored face normal
+        const double* __restrict__ N = S.trin + 9ull * meta.w;
+        lnx = N[0]; lny = N[1]; lnz = N[2];
+        break;
+      }
+      default: {  // smooth triangle, triangle.zig:261-265: n2*u + n3*v + n1*(1-u-v)
+        const double* __restrict__ N = S.trin + 9ull * meta.w;
+        const double w1 = (1.0 - hv.u) - hv.v;
+        lnx = (N[3] * hv.u + N[6] * hv.v) + N[0] * w1;
+        lny = (N[4] * hv.u + N[7] * hv.v) + N[1] * w1;
+        lnz = (N[5] * hv.u + N[8] * hv.v) + N[2] * w1;
+        break;
+      }
+    }
+    // normalToWorld (shape.zig:139-145): rows of inverse-transpose == columns of the inverse
+    double nx = (M[0] * lnx + M[4] * lny) + M[8] * lnz;
+    double ny = (M[1] * lnx + M[5] * lny) + M[9] * lnz;
+    double nz = (M[2] * lnx + M[6] * lny) + M[10] * lnz;
+    {
+      const double mag = __builtin_sqrt((nx * nx + ny * ny) + nz * nz);
+      if (mag != 0.0) {
+        nx = nx / mag;
+        ny = ny / mag;
+        nz = nz / mag;
+      }
+    }
+    if (((nx * ex + ny * ey) + nz * ez) < 0.0) {  // inside: world.zig:218-221
+      nx = -nx;
+      ny = -ny;
+      nz = -nz;
+    }
+    const double eps = 1e-5;
+    const double ovx = ptx + nx * eps, ovy = pty + ny * eps, ovz = ptz + nz * eps;  // over_point
+    const double unx = ptx - nx * eps, uny = pty - ny * eps, unz = ptz - nz * eps;  // under_point
+
+    // ---- World.shadeHit, lights loop (world.zig:89-96)
+    double sr = 0.0, sg = 0.0, sb = 0.0;
+    {
+      // Pattern.patternAtShape (pattern.zig:128-131) at over_point; same for every light
+      const double opx = row_pt(M + 0, ovx, ovy, ovz);
+      const double opy = row_pt(M + 4, ovx, ovy, ovz);
+      const double opz = row_pt(M + 8, ovx, ovy, ovz);
+      const Rgb color = pattern_at(S, mat.pattern, opx, opy, opz);
+      // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
+      // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
+      const bool shadow_matters = !(mat.diffuse == 0.0 && mat.specular == 0.0);
+      for (uint32_t li = 0; li < S.n_lights; ++li) {
+        const double* __restrict__ L = S.light + 6ull * li;
+        n_shadow_calls++;
+        // isShadowed (world.zig:127-131) and lighting's point_to_light (material.zig:51) share this
+        const double vx = L[0] - ovx, vy = L[1] - ovy, vz = L[2] - ovz;
+        const double distance = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);
+        double lvx = vx, lvy = vy, lvz = vz;
+        if (distance != 0.0) {
+          lvx = vx / distance;
+          lvy = vy / distance;
+          lvz = vz / distance;
+        }
+        bool shadowed = false;
+        if (shadow_matters) {
+          n_shadow_traced++;
+          ShadowVisitor sv;
+          sv.distance = distance;
+          Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
+          trace(S, sray, sv, overflow);
+          shadowed = sv.shadowed;
+        }
+        // Material.lighting (material.zig:40-74)
+        const double er = color.r * L[3], eg = color.g * L[4], eb = color.b * L[5];  // effective_color
+        double lr_ = er * mat.ambient, lg_ = eg * mat.ambient, lb_ = eb * mat.ambient;
+        if (!shadowed) {
+          double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
+          const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
+          if (light_dot_normal >= 0.0) {
+            const double kd = mat.diffuse * light_dot_normal;
+            dr = er * kd;
+            dg = eg * kd;
+            db = eb * kd;
+            const double two_dot = 2.0 * light_dot_normal;  // point_to_light.reflect(normal)
+            const double rx = lvx - nx * two_dot, ry = lvy - ny * two_dot, rz = lvz - nz * two_dot;
+            const double reflect_dot_eye = ((-rx) * ex + (-ry) * ey) + (-rz) * ez;
+            if (reflect_dot_eye > 0.0) {
+              const double ks = mat.specular * pow(reflect_dot_eye, mat.shininess);
+              pr = L[3] * ks;
+              pg = L[4] * ks;
+              pb = L[5] * ks;
+            }
+          }
+          lr_ = (lr_ + dr) + pr;
+          lg_ = (lg_ + dg) + pg;
+          lb_ = (lb_ + db) + pb;
+        }
+        sr = sr + lr_;
+        sg = sg + lg_;
+        sb = sb + lb_;
+      }
+    }
+    acc_r += cur.weight * sr;
+    acc_g += cur.weight * sg;
+    acc_b += cur.weight * sb;
+
+    // ---- reflectedColor / refractedColor / schlick (world.zig:98-107, 157-189, 272-289)
+    if (cur.remaining == 0u) continue;
+    const bool do_reflect = !(mat.reflective == 0.0);
+    const bool transparent = !(mat.transparency == 0.0);
+    if (!do_reflect && !transparent) continue;
+
+    const double cos_i = (ex * nx + ey * ny) + ez * nz;  // eyev.dot(normal)
+    double w_reflect = mat.reflective, w_refract = mat.transparency;
+    bool do_refract = false;
+    double n_ratio = 1.0, sin2_t = 0.0;
+    if (transparent) {
+      BehindVisitor bv;
+      bv.hit_leaf = hv.leaf;
+      bv.hit_t = t;
+      trace(S, ray, bv, overflow);
+      bv.flush();
+      double n1 = 1.0, n2 = 1.0;
+      if (bv.best_leaf != RTC_NO_LEAF) n1 = S.mat[bv.best_mat].ior;
+      if (!bv.hit_open) {
+        n2 = mat.ior;
+      } else if (bv.best_excl_leaf != RTC_NO_LEAF) {
+        n2 = S.mat[bv.best_excl_mat].ior;
+      } else if (bv.hit_dups >= 2u) {
+        n2 = mat.ior;
+      }
+      n_ratio = n1 / n2;
+      sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
+      do_refract = !(sin2_t > 1.0);
+      if (mat.reflective > 0.0 && mat.transparency > 0.0) {  // schlick, world.zig:272-289
+        double reflectance;
+        double c = cos_i;
+        bool tir = false;
+        if (n1 > n2) {
+          const double nr = n1 / n2;
+          const double s2 = nr * nr * (1.0 - c * c);
+          if (s2 > 1.0) {
+            tir = true;
+          } else {
+            c = __builtin_sqrt(1.0 - s2);
+          }
+        }
+        if (tir) {
+          reflectance = 1.0;
+        } else {
+          const double frac = (n1 - n2) / (n1 + n2);
+          const double r0 = frac * frac;
+          reflectance = r0 + (1.0 - r0) * pow(1.0 - c, 5.0);
+        }
+        w_reflect = mat.reflective * reflectance;
+        w_refract = mat.transparency * (1.0 - reflectance);
+      }
+    }
+    if (do_refract && sp < RTC_RAY_STACK) {
+      const double cos_t = __builtin_sqrt(1.0 - sin2_t);
+      const double k = n_ratio * cos_i - cos_t;
+      Pending p;
+      p.ray = {unx, uny, unz, nx * k - ex * n_ratio, ny * k - ey * n_ratio, nz * k - ez * n_ratio};
+      p.weight = cur.weight * w_refract;
+      p.remaining = cur.remaining - 1u;
+      stack[sp++] = p;
+      n_secondary++;
+    }
+    if (do_reflect && sp < RTC_RAY_STACK) {
+      const double two_dot = 2.0 * ((ray.dx * nx + ray.dy * ny) + ray.dz * nz);  // direction.reflect(normal)
+      Pending p;
+      p.ray = {ovx, ovy, ovz, ray.dx - nx * two_dot, ray.dy - ny * two_dot, ray.dz - nz * two_dot};
+      p.weight = cur.weight * w_reflect;
+      p.remaining = cur.remaining - 1u;
+      stack[sp++] = p;
+      n_secondary++;
+    }
+  }
+
+  if (in_buffer) {
+    double* __restrict__ o = out + 3 * out_index;
+    o[0] = acc_r;
+    o[1] = acc_g;
+    o[2] = acc_b;
+  }
+
+  // one atomic per counter per wave
+  const unsigned long long s_pri = wave_sum(in_image ? 1u : 0u);
+  const unsigned long long s_sec = wave_sum(n_secondary);
+  const unsigned long long s_shc = wave_sum(n_shadow_calls);
+  const unsigned long long s_sht = wave_sum(n_shadow_traced);
+  const unsigned long long s_ovf = wave_sum(overflow);
+  if (lane == 0u) {
+    atomicAdd(&stats->primary, s_pri);
+    atomicAdd(&stats->secondary, s_sec);
+    atomicAdd(&stats->shadow_calls, s_shc);
+    atomicAdd(&stats->shadow_traced, s_sht);
+    if (s_ovf) atomicAdd(&stats->overflow, s_ovf);
+  }
+}

@@ -1,0 +1,145 @@
+// rtc_scene.cpp — Shape tree construction (transform push-down, AABB re-boxing,
+// divide(8) BVH build).  Restates, in order, shapes/shape.zig:286-399,
+// shapes/group.zig:75-135 and the per-kind bounds() functions.
+#include "rtc_scene.hpp"
+
+#include <atomic>
+
+namespace rtc {
+
+size_t nextShapeId() {
+  // shape.zig:123-130 keeps a non-atomic static; the loader is single-threaded
+  // there.  An atomic costs nothing and keeps ids unique if callers use threads.
+  static std::atomic<size_t> id{0};
+  return id.fetch_add(1);
+}
+
+BoundingBox Shape::bounds() const {
+  BoundingBox box;
+  switch (kind) {
+    case ShapeKind::Sphere:     // sphere.zig:55-63
+    case ShapeKind::Cube:       // cube.zig:99-107
+    case ShapeKind::TestShape:  // shape.zig:429-437
+      box.min = Tuple::point(-1.0, -1.0, -1.0);
+      box.max = Tuple::point(1.0, 1.0, 1.0);
+      break;
+    case ShapeKind::Plane:  // plane.zig:45-53
+      box.min = Tuple::point(-kInf, 0.0, -kInf);
+      box.max = Tuple::point(kInf, 0.0, kInf);
+      break;
+    case ShapeKind::Cylinder:  // cylinder.zig:114-120
+      box.min = Tuple::point(-1.0, ymin, -1.0);
+      box.max = Tuple::point(1.0, ymax, 1.0);
+      break;
+    case ShapeKind::Cone: {  // cone.zig:134-142
+      const double limit = std::fmax(std::fabs(ymin), std::fabs(ymax));
+      box.min = Tuple::point(-limit, ymin, -limit);
+      box.max = Tuple::point(limit, ymax, limit);
+      break;
+    }
+    case ShapeKind::Triangle:        // triangle.zig:72-79
+    case ShapeKind::SmoothTriangle:  // triangle.zig:267-274
+      box.add(p1);
+      box.add(p2);
+      box.add(p3);
+      break;
+    case ShapeKind::Group:  // group.zig:81-83
+      box = bbox;
+      break;
+  }
+  return box;
+}
+
+void Shape::setTransform(const Matrix4& m) {
+  if (kind == ShapeKind::Group) {
+    // Groups pass the transformation on to their children and re-box themselves
+    // with the AABB of their transformed AABB (shape.zig:288-296).
+    for (Shape& child : children) child.setTransform(m.mul(child.transform));
+    bbox = bbox.transform(m);
+    (void)nextShapeId();  // the replacement bbox Shape consumes an id (bounding_box.zig:59)
+  } else {
+    transform = m;
+    inverse = m.inverse();  // throws Error("NotInvertible")
+    inverse_transpose = inverse.transpose();
+  }
+}
+
+void Shape::addChild(Shape child) {
+  bbox.merge(child.parentSpaceBounds());
+  children.push_back(std::move(child));
+}
+
+std::pair<std::vector<Shape>, std::vector<Shape>> Shape::partitionChildren() {
+  std::vector<Shape> left, right, keep;
+  const auto halves = bbox.split();
+  for (Shape& child : children) {
+    const BoundingBox cb = child.parentSpaceBounds();
+    if (halves.first.containsBox(cb)) {
+      left.push_back(std::move(child));
+    } else if (halves.second.containsBox(cb)) {
+      right.push_back(std::move(child));
+    } else {
+      keep.push_back(std::move(child));
+    }
+  }
+  children = std::move(keep);
+  return {std::move(left), std::move(right)};
+}
+
+void Shape::makeSubgroup(std::vector<Shape> list) {
+  Shape sub = Shape::group();
+  for (Shape& c : list) sub.addChild(std::move(c));
+  addChild(std::move(sub));
+}
+
+void Shape::divide(size_t threshold) {
+  if (kind != ShapeKind::Group) return;
+  if (children.size() >= threshold) {
+    auto parts = partitionChildren();
+    if (!parts.first.empty()) makeSubgroup(std::move(parts.first));
+    if (!parts.second.empty()) makeSubgroup(std::move(parts.second));
+  }
+  for (Shape& child : children) child.divide(threshold);
+}
+
+size_t Shape::leafCount() const {
+  if (kind != ShapeKind::Group) return 1;
+  size_t n = 0;
+  for (const Shape& c : children) n += c.leafCount();
+  return n;
+}
+
+World World::defaultWorld() {
+  World w;
+  Shape s1 = Shape::sphere();
+  s1.material.pattern = Pattern::solid({0.8, 1.0, 0.6});
+  s1.material.diffuse = 0.7;
+  s1.material.specular = 0.2;
+  Shape s2 = Shape::sphere();
+  s2.setTransform(Matrix4::identity().scale(0.5, 0.5, 0.5));
+  w.objects.push_back(std::move(s1));
+  w.objects.push_back(std::move(s2));
+  w.lights.push_back({Tuple::point(-10.0, 10.0, -10.0), {1.0, 1.0, 1.0}});
+  return w;
+}
+
+Camera Camera::create(size_t hsize, size_t vsize, double fov) {  // camera.zig:33-52
+  Camera c;
+  const double half_view = std::tan(fov / 2.0);
+  const double aspect = static_cast<double>(hsize) / static_cast<double>(vsize);
+  double half_width = half_view * aspect;
+  double half_height = half_view;
+  if (aspect >= 1.0) {
+    half_width = half_view;
+    half_height = half_view / aspect;
+  }
+  c.hsize = hsize;
+  c.vsize = vsize;
+  c.fov = fov;
+  c.half_width = half_width;
+  c.half_height = half_height;
+  c.pixel_size = (half_width * 2.0) / static_cast<double>(hsize);
+  return c;
+}
+
+}  // namespace rtc

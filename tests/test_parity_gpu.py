@@ -1,0 +1,169 @@
+"""Parity of the HIP render path against the CPU oracle, through the C ABI (include/rtc.h).
+
+Tolerance: BASELINE.json's north_star — per-channel |delta colour| < 1e-5 (f64).  The kernel keeps
+the reference's evaluation order with FMA contraction off, so geometry is bit-identical and only
+pow() (specular, schlick) can differ in the last ulps; the measured max delta is printed.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+# (scene, width, height, depth): sizes the oracle finishes in seconds
+CASES = [
+    ("fresnel.json", 300, 300, 5),                      # BASELINE configs[0]
+    ("cover.json", 192, 108, 5),                        # configs[1] at 1/10 scale
+    ("cover.json", 160, 200, 5),                        # aspect < 1 branch of Camera.new
+    ("reflection_and_refraction.json", 192, 108, 8),    # configs[2]: depth 8 extension
+    ("reflection_and_refraction.json", 96, 54, 5),
+    ("teapot.json", 192, 108, 5),                       # configs[3]: OBJ triangles + BVH
+    ("dragons.json", 192, 108, 5),                      # configs[4]: smooth triangles, nested groups
+    ("cubes.json", 150, 75, 5),
+    ("cylinders.json", 160, 80, 5),
+    ("groups.json", 150, 50, 5),                        # cones + cylinder in divided groups
+    ("cover.json", 33, 17, 0),                          # depth 0: no secondary rays at all
+    ("fresnel.json", 17, 33, 1),
+]
+
+
+def _both(rtc, scene, w, h, depth, tile=None):
+    hs = rtc.HostScene.from_file(scene)
+    cam = hs.camera(w, h)
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(cam, depth, tile)
+    stats = gpu.stats()
+    want, counters = ob.OracleScene(hs.desc).render(cam, depth, tile)
+    return got, want, stats, counters
+
+
+@pytest.mark.parametrize("scene,w,h,depth", CASES)
+def test_scene_parity(rtc, scene, w, h, depth):
+    got, want, stats, counters = _both(rtc, scene, w, h, depth)
+    delta = np.abs(got - want)
+    worst = np.unravel_index(np.argmax(delta), delta.shape)
+    print(f"{scene} {w}x{h} d{depth}: max|delta|={delta.max():.3e} at {worst}, "
+          f"bit-identical pixels={np.mean(np.all(got == want, axis=2)) * 100:.2f}%")
+    assert np.isfinite(got).all()
+    assert delta.max() < TOL, (scene, delta.max(), worst, got[worst[:2]], want[worst[:2]])
+    # ray counters are deterministic per scene/res/depth and must agree exactly
+    assert stats["overflow"] == 0
+    assert stats["primary"] == counters["primary"] == w * h
+    assert stats["secondary"] == counters["secondary"]
+    assert stats["shadow_calls"] == counters["shadow"]
+    assert stats["shadow_traced"] <= stats["shadow_calls"]
+
+
+def test_tile_render_matches_full_frame(rtc):
+    hs = rtc.HostScene.from_file("cover.json")
+    cam = hs.camera(120, 90)
+    gpu = rtc.GpuScene(hs.desc)
+    full = gpu.render(cam, 5)
+    for tile in [(0, 0, 120, 90), (7, 3, 50, 41), (119, 89, 1, 1), (0, 80, 120, 10)]:
+        x0, y0, w, h = tile
+        part = gpu.render(cam, 5, tile)
+        assert np.array_equal(part, full[y0:y0 + h, x0:x0 + w]), tile
+
+
+def test_interleaved_tiles_reassemble(rtc):
+    """The multi-GPU partition on one GPU: render each rank's tiles, un-permute."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file("fresnel.json")
+    cam = hs.camera(100, 70)
+    gpu = rtc.GpuScene(hs.desc)
+    full = gpu.render(cam, 5)
+    tw, th, world = 32, 16, 3
+    tx, ty = rtc.tile_grid(cam.hsize, cam.vsize, tw, th)
+    n_tiles = tx * ty
+    padded = (n_tiles + world - 1) // world
+    gathered = np.zeros((world, padded, th, tw, 3))
+    for rank in range(world):
+        first, stride, count, _ = rtc.tiles_of_rank(n_tiles, rank, world)
+        buf = torch.zeros((padded, th, tw, 3), dtype=torch.float64, device="cuda")
+        gpu.render_tiles_device(cam, buf.data_ptr(), tw, th, first, stride, count, 5,
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        gathered[rank] = buf.cpu().numpy()
+    img = rtc.assemble_tiles(gathered, cam.hsize, cam.vsize, tw, th, world)
+    assert np.array_equal(img, full)
+
+
+def test_repeat_renders_are_deterministic(rtc):
+    hs = rtc.HostScene.from_file("reflection_and_refraction.json")
+    cam = hs.camera(96, 54)
+    gpu = rtc.GpuScene(hs.desc)
+    a = gpu.render(cam, 5)
+    b = gpu.render(cam, 5)
+    assert np.array_equal(a, b)
+
+
+def test_default_world_kat_through_the_abi(rtc):
+    """camera.zig:171-187: default world, 11x11, fov pi/2, from (0,0,-5): pixel (5,5) = (0.38066, 0.47583, 0.2855)."""
+    scene = """{"camera":{"width":11,"height":11,"field-of-view":1.5707963267948966,"from":[0,0,-5],"to":[0,0,0],"up":[0,1,0]},
+      "lights":[{"point-light":{"position":[-10,10,-10],"intensity":[1,1,1]}}],
+      "objects":[{"type":{"sphere":{}},"material":{"pattern":{"type":{"solid":[0.8,1.0,0.6]}},"diffuse":0.7,"specular":0.2}},
+                 {"type":{"sphere":{}},"transform":[{"scale":[0.5,0.5,0.5]}]}]}"""
+    hs = rtc.HostScene(scene)
+    img = rtc.GpuScene(hs.desc).render(hs.camera(), 5)
+    assert np.allclose(img[5, 5], [0.38066, 0.47583, 0.2855], atol=1e-5)
+
+
+def test_test_pattern_refraction_kat(rtc):
+    """world.zig:751-778 geometry through the ABI, GPU vs oracle (TestPattern, nested glass)."""
+    scene = """{"camera":{"width":40,"height":40,"field-of-view":0.8,"from":[0,0,-3],"to":[0,0,0],"up":[0,1,0]},
+      "lights":[{"point-light":{"position":[-10,10,-10],"intensity":[1,1,1]}}],
+      "objects":[{"type":{"sphere":{}},"material":{"pattern":{"type":{"solid":[0.8,1.0,0.6]}},"ambient":1.0,"diffuse":0.7,"specular":0.2,
+                   "transparency":0.9,"refractive-index":1.3,"reflective":0.3}},
+                 {"type":{"sphere":{}},"transform":[{"scale":[0.5,0.5,0.5]}],"material":{"transparency":1.0,"refractive-index":1.5}},
+                 {"type":{"cube":{}},"transform":[{"scale":[0.2,0.2,0.2]},{"translate":[0.1,0,0]}],"material":{"transparency":0.5,"reflective":0.5,"refractive-index":2.0}}]}"""
+    hs = rtc.HostScene(scene)
+    # make the outer sphere's pattern the reference's TestPattern (colour = pattern-space point)
+    kinds = hs.array("pat_kind", hs.desc.n_patterns)
+    mats = hs.array("mat_pattern", hs.desc.n_materials)
+    kinds[mats[hs.array("leaf_material", hs.desc.n_leaves)[0]]] = 9
+    cam = hs.camera()
+    got = rtc.GpuScene(hs.desc).render(cam, 5)
+    want, _ = ob.OracleScene(hs.desc).render(cam, 5)
+    assert np.abs(got - want).max() < TOL
+
+
+def test_full_size_cover_properties(rtc):
+    """BASELINE configs[1] at full size (1920x1080): size-independent properties + a sampled oracle check."""
+    hs = rtc.HostScene.from_file("cover.json")
+    cam = hs.camera(1920, 1080)
+    gpu = rtc.GpuScene(hs.desc)
+    full = gpu.render(cam, 5)
+    st = gpu.stats()
+    assert st["primary"] == 1920 * 1080 and st["overflow"] == 0
+    assert np.isfinite(full).all() and full.min() >= 0.0
+    # idempotence
+    assert np.array_equal(full, gpu.render(cam, 5))
+    # tiles of the frame equal the frame (pixels are independent: camera.zig:116-121)
+    for tile in [(640, 360, 333, 211), (0, 1079, 1920, 1)]:
+        x0, y0, w, h = tile
+        assert np.array_equal(gpu.render(cam, 5, tile), full[y0:y0 + h, x0:x0 + w])
+    # depth linearity: depth 0 equals the surface term only, and is <= full colour where all weights >= 0
+    d0 = gpu.render(cam, 0)
+    assert gpu.stats()["secondary"] == 0
+    assert (full - d0 >= -1e-12).all()
+    # every 40th row against the oracle
+    want, _ = ob.OracleScene(hs.desc).render(cam, 5, row_step=40)
+    rows = np.arange(0, 1080, 40)
+    assert np.abs(full[rows] - want[rows]).max() < TOL
+
+
+def test_errors_through_the_abi(rtc):
+    hs = rtc.HostScene.from_file("fresnel.json")
+    gpu = rtc.GpuScene(hs.desc)
+    cam = hs.camera(64, 64)
+    with pytest.raises(rtc.RtcError) as e:
+        gpu.render(cam, 5, (60, 0, 10, 10))   # tile outside the image
+    assert e.value.name == "InvalidArgument"
+    with pytest.raises(rtc.RtcError) as e:
+        gpu.render(cam, 99)                    # deeper than the per-lane ray stack
+    assert e.value.name == "InvalidArgument"
