@@ -67,15 +67,20 @@ def cpu_baseline(rtc, hs, cam, depth, target_seconds=12.0):
     per_row = cal / rows_cal
     rows_target = max(rows_cal, min(cam.vsize, int(target_seconds / max(per_row, 1e-9))))
     step = max(1, cam.vsize // rows_target)
-    t0 = time.perf_counter()
-    _, c = osc.render(cam, depth, row_step=step, threads=cores)
-    dt = time.perf_counter() - t0
     rows = (cam.vsize + step - 1) // step
+    times = []
+    spent = 0.0
+    while len(times) < 3 or (spent < target_seconds and len(times) < 9):   # median of >= 3 passes
+        t0 = time.perf_counter()
+        _, c = osc.render(cam, depth, row_step=step, threads=cores)
+        times.append(time.perf_counter() - t0)
+        spent += times[-1]
+    dt = sorted(times)[len(times) // 2]
     rays = c["primary"] + c["secondary"]
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "sample": f"every {step}th row ({rows} of {cam.vsize} rows) of the same frame, {dt:.2f} s, "
-                  f"{cores} threads, one job per row",
+        "sample": f"every {step}th row ({rows} of {cam.vsize} rows) of the same frame, median of {len(times)} "
+                  f"passes of {dt:.2f} s, {cores} threads, one job per row (camera.zig:88-97)",
         "ms_per_frame_extrapolated": dt * 1e3 * cam.vsize / rows,
     }
 
@@ -113,7 +118,10 @@ def main():
     cam = hs.camera(args.width, args.height)
     W, H = cam.hsize, cam.vsize
     gpu = rtc.GpuScene(hs.desc)                      # scene uploaded to HBM once (outside the timed region)
-    stream = torch.cuda.current_stream()
+    # A non-default torch stream: the C ABI treats a NULL stream as "the handle's own stream", and
+    # torch's default stream IS the NULL stream; HIP events must sit on the stream the kernel runs on.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
     if world == 1:

@@ -16,6 +16,9 @@
 extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                              const uint32_t max_depth, double* __restrict__ out,
                                              DevStats* __restrict__ stats);
+extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                      const uint32_t max_depth, double* __restrict__ out,
+                                                      DevStats* __restrict__ stats);
 
 namespace {
 
@@ -65,6 +68,7 @@ struct rtc_scene {
   double* d_frame = nullptr;  // staging for rtc_render (host output)
   size_t frame_capacity = 0;  // in doubles
   DevBuf<uint32_t> roots, kids;
+  DevBuf<RootRec> root_recs;
   DevBuf<uint4> leaf_meta;
   DevBuf<double> xf, tri, trin, pat_inv, pat_rgb, node_box, light;
   DevBuf<DevCyl> cyl;
@@ -75,6 +79,119 @@ struct rtc_scene {
 };
 
 namespace {
+
+// ---- conservative world-space bounding spheres for the root-loop rejection test ----------------
+// These only ever REMOVE work whose result is provably "no entry"; they are computed in plain double
+// arithmetic with an inflated radius, never feed a colour, and so need not follow reference rounding.
+struct Sphere {
+  double cx = 0, cy = 0, cz = 0, r = INFINITY;
+  bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
+};
+
+// Forward transform (object -> world) = inverse of the stored affine inverse; false if singular.
+bool forwardOf(const double* inv16, double M[12]) {
+  const double a = inv16[0], b = inv16[1], c = inv16[2], d = inv16[4], e = inv16[5], f = inv16[6], g = inv16[8],
+               h = inv16[9], i = inv16[10];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+  const double r[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                       (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                       (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  const double tx = inv16[3], ty = inv16[7], tz = inv16[11];
+  for (int k = 0; k < 3; ++k) {
+    M[4 * k + 0] = r[3 * k + 0];
+    M[4 * k + 1] = r[3 * k + 1];
+    M[4 * k + 2] = r[3 * k + 2];
+    M[4 * k + 3] = -(r[3 * k + 0] * tx + r[3 * k + 1] * ty + r[3 * k + 2] * tz);
+  }
+  for (int k = 0; k < 12; ++k)
+    if (!std::isfinite(M[k])) return false;
+  return true;
+}
+
+Sphere sphereOfPoints(const double (*pts)[3], int n) {
+  Sphere s;
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::fmin(mn[k], pts[i][k]);
+      mx[k] = std::fmax(mx[k], pts[i][k]);
+    }
+  s.cx = 0.5 * (mn[0] + mx[0]);
+  s.cy = 0.5 * (mn[1] + mx[1]);
+  s.cz = 0.5 * (mn[2] + mx[2]);
+  double r2 = 0;
+  for (int i = 0; i < n; ++i) {
+    const double dx = pts[i][0] - s.cx, dy = pts[i][1] - s.cy, dz = pts[i][2] - s.cz;
+    r2 = std::fmax(r2, dx * dx + dy * dy + dz * dz);
+  }
+  s.r = std::sqrt(r2);
+  return s;
+}
+
+// Object-space box [lo,hi] pushed through M; any convex shape inside the box is inside the sphere.
+Sphere sphereOfBox(const double M[12], const double lo[3], const double hi[3]) {
+  for (int k = 0; k < 3; ++k)
+    if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return Sphere{};
+  double pts[8][3];
+  for (int c = 0; c < 8; ++c) {
+    const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+    for (int k = 0; k < 3; ++k) pts[c][k] = M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3];
+  }
+  return sphereOfPoints(pts, 8);
+}
+
+Sphere leafSphere(const rtc_scene_desc& d, uint32_t leaf) {
+  double M[12];
+  if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[leaf], M)) return Sphere{};
+  const uint32_t g = d.leaf_geom[leaf];
+  switch (d.leaf_kind[leaf]) {
+    case RTC_SPHERE: {
+      // |M3 u| <= ||M3||_F for unit u
+      double fro = 0;
+      for (int k = 0; k < 3; ++k) fro += M[4 * k] * M[4 * k] + M[4 * k + 1] * M[4 * k + 1] + M[4 * k + 2] * M[4 * k + 2];
+      Sphere s;
+      s.cx = M[3];
+      s.cy = M[7];
+      s.cz = M[11];
+      s.r = std::sqrt(fro);
+      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+      const Sphere box = sphereOfBox(M, lo, hi);  // also valid; keep the tighter one
+      return (box.finite() && box.r < s.r) ? box : s;
+    }
+    case RTC_CUBE: {
+      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+      return sphereOfBox(M, lo, hi);
+    }
+    case RTC_CYLINDER: {
+      const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
+      return sphereOfBox(M, lo, hi);
+    }
+    case RTC_CONE: {
+      const double lim = std::fmax(std::fabs(d.cyl_min[g]), std::fabs(d.cyl_max[g]));
+      const double lo[3] = {-lim, d.cyl_min[g], -lim}, hi[3] = {lim, d.cyl_max[g], lim};
+      return sphereOfBox(M, lo, hi);
+    }
+    case RTC_TRIANGLE:
+    case RTC_SMOOTH_TRIANGLE: {
+      double pts[3][3];
+      for (int v = 0; v < 3; ++v) {
+        double p[3];
+        for (int k = 0; k < 3; ++k)
+          p[k] = d.tri_p1[3ull * g + k] + (v == 1 ? d.tri_e1[3ull * g + k] : 0.0) + (v == 2 ? d.tri_e2[3ull * g + k] : 0.0);
+        for (int k = 0; k < 3; ++k) pts[v][k] = M[4 * k] * p[0] + M[4 * k + 1] * p[1] + M[4 * k + 2] * p[2] + M[4 * k + 3];
+      }
+      return sphereOfPoints(pts, 3);
+    }
+    default: return Sphere{};  // planes are unbounded
+  }
+}
+
+Sphere inflate(Sphere s) {
+  if (!s.finite()) return Sphere{};
+  s.r = s.r * (1.0 + 1e-6) + 1e-9;
+  return s;
+}
 
 bool affineRow(const double* m16) {  // last row must be exactly (0,0,0,1); -0 is accepted
   return m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0;
@@ -162,8 +279,13 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t
   if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "grid of %llu blocks", (unsigned long long)blocks);
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
-  hipLaunchKernelGGL(rtc_render_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, s->dev, devCamera(cam),
-                     map, max_depth, d_out, s->d_stats);
+  if (s->dev.n_roots <= RTC_LDS_ROOTS) {
+    hipLaunchKernelGGL(rtc_render_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, s->dev,
+                       devCamera(cam), map, max_depth, d_out, s->d_stats);
+  } else {
+    hipLaunchKernelGGL(rtc_render_kernel_bigworld, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, s->dev,
+                       devCamera(cam), map, max_depth, d_out, s->d_stats);
+  }
   HIP_TRY(hipGetLastError());
   return RTC_OK;
 }
@@ -296,6 +418,43 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     const uint32_t c = d.children[i];
     kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
   }
+  std::vector<RootRec> root_recs(d.n_roots);
+  for (uint32_t i = 0; i < d.n_roots; ++i) {
+    RootRec& R = root_recs[i];
+    std::memset(&R, 0, sizeof R);
+    const uint32_t ref = d.roots[i];
+    Sphere sp;
+    if (ref & RTC_CHILD_NODE_BIT) {
+      const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
+      R.kind_flags = RTC_ROOT_IS_GROUP;
+      R.index = n;
+      // every entry of the group lies on a line that passes the group's own box test
+      const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
+      const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
+      const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
+    } else {
+      const uint8_t k = d.leaf_kind[ref];
+      const uint32_t g = d.leaf_geom[ref];
+      std::memcpy(R.inv, d.xf_inv + 16ull * d.leaf_xform[ref], sizeof R.inv);
+      R.kind_flags = static_cast<uint32_t>(k) | (d.leaf_shadow[ref] ? 0x100u : 0u);
+      if (k == RTC_CYLINDER || k == RTC_CONE) {
+        R.ymin = d.cyl_min[g];
+        R.ymax = d.cyl_max[g];
+        if (d.cyl_closed[g]) R.kind_flags |= 0x200u;
+      }
+      R.index = dfs_of[ref];
+      R.material = d.leaf_material[ref];
+      R.geom = (k == RTC_TRIANGLE || k == RTC_SMOOTH_TRIANGLE) ? g : 0u;
+      sp = leafSphere(d, ref);
+    }
+    sp = inflate(sp);
+    R.cx = sp.finite() ? sp.cx : 0.0;
+    R.cy = sp.finite() ? sp.cy : 0.0;
+    R.cz = sp.finite() ? sp.cz : 0.0;
+    R.r = sp.finite() ? sp.r : INFINITY;
+    R.r2 = sp.finite() ? sp.r * sp.r : INFINITY;
+  }
   auto rows12 = [](const double* src, uint32_t n) {
     std::vector<double> v(12ull * n);
     for (uint32_t i = 0; i < n; ++i) std::memcpy(&v[12ull * i], src + 16ull * i, 12 * sizeof(double));
@@ -356,6 +515,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipGetDevice(&s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(s->roots.upload(roots));
+  HIP_TRY(s->root_recs.upload(root_recs));
   HIP_TRY(s->kids.upload(kids));
   HIP_TRY(s->leaf_meta.upload(leaf_meta));
   HIP_TRY(s->xf.upload(xf));
@@ -374,6 +534,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipMemset(s->d_stats, 0, sizeof(DevStats)));
   s->max_trav_stack = max_stack;
   DevScene& D = s->dev;
+  D.root_recs = s->root_recs.p;
   D.roots = s->roots.p;
   D.leaf_meta = s->leaf_meta.p;
   D.xf = s->xf.p;

@@ -41,7 +41,23 @@ struct DevCyl {
   uint32_t pad;
 };
 
+// One record per World.objects entry, flattened so the wave-uniform root loop needs no dependent
+// loads: staged once per work-group into LDS (160 B each).  `r2 == +inf` means "no finite bound".
+struct RootRec {
+  double inv[12];        // rows 0..2 of the leaf's inverse (unused for groups)
+  double cx, cy, cz;     // conservative world-space bounding sphere of everything under this root
+  double r, r2;
+  double ymin, ymax;     // cylinder / cone
+  uint32_t kind_flags;   // kind | casts_shadow<<8 | closed<<9 | is_group<<15
+  uint32_t index;        // leaf index (depth-first) or group node index
+  uint32_t material;
+  uint32_t geom;
+};
+#define RTC_ROOT_IS_GROUP 0x8000u
+#define RTC_LDS_ROOTS 160   // roots staged in LDS (25 KB); larger worlds read the table from memory
+
 struct DevScene {
+  const RootRec* __restrict__ root_recs;
   const uint32_t* __restrict__ roots;
   const uint4* __restrict__ leaf_meta;
   const double* __restrict__ xf;        // [n_xforms][12]

@@ -101,8 +101,14 @@ __device__ __forceinline__ bool slab(const Ray& r, double mnx, double mny, doubl
 
 // Emits the entries a leaf's localIntersect appends, in the reference's order, as f(t, u, v).
 // `r` is the ray in the leaf's object space.
+struct CylParams {
+  double ymin, ymax;
+  bool closed;
+};
+
 template <class F>
-__device__ __forceinline__ void leaf_entries(const DevScene& S, uint32_t kind, uint32_t geom, const Ray& r, F&& f) {
+__device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy, const double* __restrict__ T,
+                                             const Ray& r, F&& f) {
   switch (kind) {
     case 0: {  // sphere.zig:24-46
       const double a = (r.dx * r.dx + r.dy * r.dy) + r.dz * r.dz;
@@ -136,7 +142,6 @@ __device__ __forceinline__ void leaf_entries(const DevScene& S, uint32_t kind, u
       break;
     }
     case 3: {  // cylinder.zig:53-98
-      const DevCyl cy = S.cyl[geom];
       const double a = r.dx * r.dx + r.dz * r.dz;
       bool walls_done = false, caps = true;
       if (__builtin_fabs(a) < 1e-5) {
@@ -175,7 +180,6 @@ __device__ __forceinline__ void leaf_entries(const DevScene& S, uint32_t kind, u
       break;
     }
     case 6: {  // cone.zig:52-113
-      const DevCyl cy = S.cyl[geom];
       const double tol = 1e-4;
       const double a = (r.dx * r.dx - r.dy * r.dy) + r.dz * r.dz;
       const double b = (2.0 * r.ox * r.dx - 2.0 * r.oy * r.dy) + 2.0 * r.oz * r.dz;
@@ -218,7 +222,6 @@ __device__ __forceinline__ void leaf_entries(const DevScene& S, uint32_t kind, u
       break;
     }
     default: {  // 4 triangle.zig:29-63, 5 triangle.zig:225-259 (Moller-Trumbore, left-handed cross)
-      const double* __restrict__ T = S.tri + 9ull * geom;
       const double p1x = T[0], p1y = T[1], p1z = T[2];
       const double e1x = T[3], e1y = T[4], e1z = T[5];
       const double e2x = T[6], e2y = T[7], e2z = T[8];
@@ -263,23 +266,65 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
     lr = xform_ray(S.xf + 12ull * meta.y, ray);
     cur_xf = meta.y;
   }
-  leaf_entries(S, meta.x & 0xFFu, meta.w, lr, [&](double t, double u, double v) { vis.entry(leaf, meta, t, u, v); });
+  const uint32_t kind = meta.x & 0xFFu;
+  CylParams cy{0.0, 0.0, false};
+  if (kind == 3u || kind == 6u) {
+    const DevCyl c = S.cyl[meta.w];
+    cy = {c.ymin, c.ymax, c.closed != 0u};
+  }
+  leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr,
+               [&](double t, double u, double v) { vis.entry(leaf, (meta.x >> 8) & 1u, meta.z, t, u, v); });
 }
 
+// Conservative bounding-sphere rejection for one World.objects entry.  Everything under the root lies
+// inside the sphere (radius inflated at upload), so if the LINE misses the sphere the root contributes
+// no entry at all; the visitor may additionally discard roots that cannot matter to it (entirely
+// behind the origin, entirely beyond its t range).  Tolerances are ~1e4 ulps of the terms involved.
 template <class V>
-__device__ __forceinline__ void trace(const DevScene& S, const Ray& ray, V& vis, unsigned& overflow) {
-  uint32_t cur_xf = 0xFFFFFFFFu;
-  Ray lr = ray;
+__device__ __forceinline__ bool root_culled(const RootRec& R, const Ray& ray, double a, const V& vis) {
+  if (!(R.r2 < kInf)) return false;
+  const double ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
+  const double b = (ocx * ray.dx + ocy * ray.dy) + ocz * ray.dz;
+  const double oc2 = (ocx * ocx + ocy * ocy) + ocz * ocz;
+  const double c = oc2 - R.r2;
+  const double bb = b * b;
+  const double disc = bb - a * c;
+  if (disc < -1e-12 * (bb + a * oc2)) return true;  // the line misses the sphere
+  if (c > 0.0) {                                    // origin outside the sphere
+    if (b < 0.0) return V::kFrontOnly;              // sphere entirely at t < 0
+    // sphere entirely at t > 0, nearest point at t_near = (b - sqrt(disc)) / a
+    if (V::kBehindOnly) return true;
+    const double lim = vis.t_limit();               // entries with t > lim are irrelevant
+    if (lim < kInf) {
+      const double x = b - lim * a;                 // t_near > lim  <=>  x > 0 && x^2 > disc
+      if (x > 0.0 && x * x > disc * (1.0 + 1e-9) + 1e-12 * bb) return true;
+    }
+  }
+  return false;
+}
+
+template <bool LDS, class V>
+__device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs, const Ray& ray, V& vis,
+                                      unsigned& overflow) {
+  const double a = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz;
   for (uint32_t ri = 0; ri < S.n_roots; ++ri) {  // wave-uniform loop over World.objects
     if (vis.done()) break;
-    const uint32_t ref = S.roots[ri];
-    if (!(ref & RTC_NODE_BIT)) {
-      visit_leaf(S, ref, ray, cur_xf, lr, vis);
+    const RootRec& R = recs[ri];
+    if (root_culled(R, ray, a, vis)) continue;
+    const uint32_t kf = R.kind_flags;
+    if (!(kf & RTC_ROOT_IS_GROUP)) {
+      const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
+      const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
+      const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
+      leaf_entries(kf & 0xFFu, cy, S.tri + 9ull * R.geom, lr,
+                   [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
       continue;
     }
+    uint32_t cur_xf = 0xFFFFFFFFu;
+    Ray lr = ray;
     uint32_t stack[RTC_TRAV_STACK];
     int sp = 0;
-    stack[sp++] = ref & ~RTC_NODE_BIT;
+    stack[sp++] = R.index;
     while (sp > 0 && !vis.done()) {
       const uint32_t n = stack[--sp];
       const double* __restrict__ B = S.node_box + 6ull * n;
@@ -310,7 +355,10 @@ struct ClosestVisitor {
   double t = kInf;
   uint32_t leaf = RTC_NO_LEAF;
   double u = 0.0, v = 0.0;
-  __device__ __forceinline__ void entry(uint32_t l, const uint4&, double et, double eu, double ev) {
+  static constexpr bool kFrontOnly = true;    // entries with t < 0 never matter
+  static constexpr bool kBehindOnly = false;
+  __device__ __forceinline__ double t_limit() const { return t; }
+  __device__ __forceinline__ void entry(uint32_t l, uint32_t, uint32_t, double et, double eu, double ev) {
     if (et >= 0.0 && (et < t || (et == t && l < leaf))) {
       t = et;
       leaf = l;
@@ -328,8 +376,11 @@ struct ClosestVisitor {
 struct ShadowVisitor {
   double distance;
   bool shadowed = false;
-  __device__ __forceinline__ void entry(uint32_t, const uint4& meta, double et, double, double) {
-    if (et >= 0.0 && et < distance && ((meta.x >> 8) & 1u)) shadowed = true;
+  static constexpr bool kFrontOnly = true;
+  static constexpr bool kBehindOnly = false;
+  __device__ __forceinline__ double t_limit() const { return distance; }
+  __device__ __forceinline__ void entry(uint32_t, uint32_t casts_shadow, uint32_t, double et, double, double) {
+    if (et >= 0.0 && et < distance && casts_shadow) shadowed = true;
   }
   __device__ __forceinline__ bool cull(double tmin, double tmax) const {
     return tmax < -box_slack(tmax) || tmin > distance + box_slack(distance);
@@ -381,11 +432,14 @@ struct BehindVisitor {
     cur_cnt = 0;
     cur_last = -kInf;
   }
-  __device__ __forceinline__ void entry(uint32_t l, const uint4& meta, double et, double, double) {
+  static constexpr bool kFrontOnly = false;
+  static constexpr bool kBehindOnly = true;   // only entries with t < 0 (and the hit leaf's own) matter
+  __device__ __forceinline__ double t_limit() const { return kInf; }
+  __device__ __forceinline__ void entry(uint32_t l, uint32_t, uint32_t material, double et, double, double) {
     if (l != cur) {
       flush();
       cur = l;
-      cur_mat = meta.z;
+      cur_mat = material;
     }
     if (et < 0.0) {
       cur_cnt++;
@@ -493,9 +547,22 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // The megakernel.  256 threads = 4 waves; each wave owns an 8x8-pixel tile of a 16x16 block,
 // so the 64 lanes of a wave start from neighbouring primary rays.
 // ------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
-rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
-                  double* __restrict__ out, DevStats* __restrict__ stats) {
+template <bool LDS>
+__device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
+                                            const uint32_t max_depth, double* __restrict__ out,
+                                            DevStats* __restrict__ stats) {
+  // World.objects table: staged once per work-group into LDS so the per-ray root loop has no
+  // dependent (pointer-chasing) loads; worlds with more than RTC_LDS_ROOTS entries read it from memory.
+  __shared__ RootRec lds_roots[LDS ? RTC_LDS_ROOTS : 1];
+  const RootRec* __restrict__ recs = S.root_recs;
+  if (LDS) {
+    const uint32_t n_words = S.n_roots * (sizeof(RootRec) / 8u);
+    const double* __restrict__ src = reinterpret_cast<const double*>(S.root_recs);
+    double* dst = reinterpret_cast<double*>(lds_roots);
+    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    recs = lds_roots;
+  }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
@@ -566,7 +633,7 @@ rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, 
 
     // ---- World.colorAt: intersect + hit (world.zig:111-115)
     ClosestVisitor hv;
-    trace(S, ray, hv, overflow);
+    trace<LDS>(S, recs, ray, hv, overflow);
     if (hv.leaf == RTC_NO_LEAF) continue;  // black
 
     // ---- PreComputations.new (world.zig:212-227)
@@ -697,7 +764,7 @@ rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, 
           ShadowVisitor sv;
           sv.distance = distance;
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
-          trace(S, sray, sv, overflow);
+          trace<LDS>(S, recs, sray, sv, overflow);
           shadowed = sv.shadowed;
         }
         // Material.lighting (material.zig:40-74)
@@ -748,7 +815,7 @@ rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, 
       BehindVisitor bv;
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
-      trace(S, ray, bv, overflow);
+      trace<LDS>(S, recs, ray, bv, overflow);
       bv.flush();
       double n1 = 1.0, n2 = 1.0;
       if (bv.best_leaf != RTC_NO_LEAF) n1 = S.mat[bv.best_mat].ior;
@@ -827,4 +894,17 @@ rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, 
     atomicAdd(&stats->shadow_traced, s_sht);
     if (s_ovf) atomicAdd(&stats->overflow, s_ovf);
   }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                  double* __restrict__ out, DevStats* __restrict__ stats) {
+  render_body<true>(S, cam, map, max_depth, out, stats);
+}
+
+// Same kernel for worlds whose World.objects table does not fit the LDS staging area.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                           double* __restrict__ out, DevStats* __restrict__ stats) {
+  render_body<false>(S, cam, map, max_depth, out, stats);
 }
