@@ -69,6 +69,7 @@ struct rtc_scene {
   size_t frame_capacity = 0;  // in doubles
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
+  DevBuf<RootCull> root_cull;
   DevBuf<uint4> leaf_meta;
   DevBuf<double> xf, tri, trin, pat_inv, pat_rgb, node_box, light;
   DevBuf<DevCyl> cyl;
@@ -76,6 +77,7 @@ struct rtc_scene {
   DevBuf<uint8_t> pat_kind;
   DevBuf<uint2> pat_ab, node_kids;
   uint32_t max_trav_stack = 0;
+  uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
 };
 
 namespace {
@@ -248,8 +250,9 @@ int buildPixelMapRect(const rtc_camera& cam, uint32_t x0, uint32_t y0, uint32_t 
   m.y0 = y0;
   m.w = w;
   m.h = h;
-  m.blocks_x = (w + 15) / 16;
-  m.blocks_y = (h + 15) / 16;
+  m.chunks_x = (w + 7) / 8;
+  m.chunks_per_region = m.chunks_x * ((h + 7) / 8);
+  m.n_chunks = m.chunks_per_region;
   return RTC_OK;
 }
 
@@ -271,20 +274,24 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
-int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t regions, uint32_t max_depth,
-           double* d_out, hipStream_t stream) {
+int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, double* d_out,
+           hipStream_t stream) {
   if (max_depth > RTC_MAX_DEPTH)
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
-  const uint64_t blocks = static_cast<uint64_t>(regions) * map.blocks_x * map.blocks_y;
-  if (blocks == 0 || blocks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "grid of %llu blocks", (unsigned long long)blocks);
+  if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
   HIP_TRY(hipSetDevice(s->device));
+  const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS;
+  // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
+  // chunks to hand out, 4 waves each); the waves pull chunks until the counter runs out.
+  const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+  const uint32_t blocks = std::max(1u, std::min(resident, (map.n_chunks + 3u) / 4u));
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
-  if (s->dev.n_roots <= RTC_LDS_ROOTS) {
-    hipLaunchKernelGGL(rtc_render_kernel, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, s->dev,
-                       devCamera(cam), map, max_depth, d_out, s->d_stats);
+  if (lds) {
+    hipLaunchKernelGGL(rtc_render_kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth,
+                       d_out, s->d_stats);
   } else {
-    hipLaunchKernelGGL(rtc_render_kernel_bigworld, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, stream, s->dev,
-                       devCamera(cam), map, max_depth, d_out, s->d_stats);
+    hipLaunchKernelGGL(rtc_render_kernel_bigworld, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map,
+                       max_depth, d_out, s->d_stats);
   }
   HIP_TRY(hipGetLastError());
   return RTC_OK;
@@ -419,6 +426,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
   }
   std::vector<RootRec> root_recs(d.n_roots);
+  // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
+  std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0, 0.0, 0.0, -INFINITY});
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     RootRec& R = root_recs[i];
     std::memset(&R, 0, sizeof R);
@@ -449,11 +458,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       sp = leafSphere(d, ref);
     }
     sp = inflate(sp);
-    R.cx = sp.finite() ? sp.cx : 0.0;
-    R.cy = sp.finite() ? sp.cy : 0.0;
-    R.cz = sp.finite() ? sp.cz : 0.0;
-    R.r = sp.finite() ? sp.r : INFINITY;
-    R.r2 = sp.finite() ? sp.r * sp.r : INFINITY;
+    RootCull& C = root_cull[i];
+    C.cx = sp.finite() ? sp.cx : 0.0;
+    C.cy = sp.finite() ? sp.cy : 0.0;
+    C.cz = sp.finite() ? sp.cz : 0.0;
+    C.r2 = sp.finite() ? sp.r * sp.r : INFINITY;
   }
   auto rows12 = [](const double* src, uint32_t n) {
     std::vector<double> v(12ull * n);
@@ -516,6 +525,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(s->roots.upload(roots));
   HIP_TRY(s->root_recs.upload(root_recs));
+  HIP_TRY(s->root_cull.upload(root_cull));
   HIP_TRY(s->kids.upload(kids));
   HIP_TRY(s->leaf_meta.upload(leaf_meta));
   HIP_TRY(s->xf.upload(xf));
@@ -533,8 +543,19 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, sizeof(DevStats)));
   s->max_trav_stack = max_stack;
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
+    int nb = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel, 256, 0));
+    s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel_bigworld, 256, 0));
+    s->blocks_per_cu_big = static_cast<uint32_t>(std::max(nb, 1));
+  }
   DevScene& D = s->dev;
   D.root_recs = s->root_recs.p;
+  D.root_cull = s->root_cull.p;
   D.roots = s->roots.p;
   D.leaf_meta = s->leaf_meta.p;
   D.xf = s->xf.p;
@@ -580,7 +601,7 @@ int rtc_render_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, u
   DevPixelMap map;
   st = buildPixelMapRect(*cam, x0, y0, w, h, map);
   if (st != RTC_OK) return st;
-  return launch(s, *cam, map, 1, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+  return launch(s, *cam, map, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
 }
 
 int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t tile_w, uint32_t tile_h,
@@ -605,9 +626,12 @@ int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_de
   const uint64_t last = static_cast<uint64_t>(first_tile) + static_cast<uint64_t>(n_my_tiles - 1) * tile_stride;
   if (last >= static_cast<uint64_t>(map.tiles_x) * tiles_y)
     return fail(RTC_ERR_INVALID_ARGUMENT, "tile %llu outside the %ux%u tiling", (unsigned long long)last, map.tiles_x, tiles_y);
-  map.blocks_x = (tile_w + 15) / 16;
-  map.blocks_y = (tile_h + 15) / 16;
-  return launch(s, *cam, map, n_my_tiles, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+  map.chunks_x = (tile_w + 7) / 8;
+  map.chunks_per_region = map.chunks_x * ((tile_h + 7) / 8);
+  const uint64_t total_chunks = static_cast<uint64_t>(map.chunks_per_region) * n_my_tiles;
+  if (total_chunks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "%llu chunks", (unsigned long long)total_chunks);
+  map.n_chunks = static_cast<uint32_t>(total_chunks);
+  return launch(s, *cam, map, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
 }
 
 int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
@@ -650,6 +674,11 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   out->shadow_calls = h.shadow_calls;
   out->shadow_traced = h.shadow_traced;
   out->overflow = h.overflow;
+  if (getenv("RTC_PROFILE_DUMP")) {  // diagnostic builds (-DRTC_PROFILE) only
+    std::fprintf(stderr, "rtc prof:");
+    for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", h.prof[i]);
+    std::fprintf(stderr, "\n");
+  }
   return RTC_OK;
 }
 

@@ -25,8 +25,12 @@
 #define RTC_NO_LEAF 0xFFFFFFFFu
 
 // per-lane traversal stack (node indices) and secondary-ray stack capacities
+#ifndef RTC_TRAV_STACK
 #define RTC_TRAV_STACK 64
+#endif
+#ifndef RTC_MAX_DEPTH
 #define RTC_MAX_DEPTH 16
+#endif
 #define RTC_RAY_STACK (RTC_MAX_DEPTH + 2)
 
 struct DevMaterial {
@@ -42,22 +46,27 @@ struct DevCyl {
 };
 
 // One record per World.objects entry, flattened so the wave-uniform root loop needs no dependent
-// loads: staged once per work-group into LDS (160 B each).  `r2 == +inf` means "no finite bound".
+// (pointer-chasing) loads.  Split in two tables, both staged once per work-group into LDS:
+//   RootCull  32 B  conservative world-space bounding sphere (r2 == +inf: no finite bound)
+//   RootRec  144 B  what the exact test needs
+struct RootCull {
+  double cx, cy, cz, r2;
+};
 struct RootRec {
   double inv[12];        // rows 0..2 of the leaf's inverse (unused for groups)
-  double cx, cy, cz;     // conservative world-space bounding sphere of everything under this root
-  double r, r2;
   double ymin, ymax;     // cylinder / cone
   uint32_t kind_flags;   // kind | casts_shadow<<8 | closed<<9 | is_group<<15
   uint32_t index;        // leaf index (depth-first) or group node index
   uint32_t material;
   uint32_t geom;
+  double pad_[2];        // 144-byte stride: per-lane LDS reads of different records spread over the banks
 };
 #define RTC_ROOT_IS_GROUP 0x8000u
-#define RTC_LDS_ROOTS 160   // roots staged in LDS (25 KB); larger worlds read the table from memory
+#define RTC_LDS_ROOTS 192   // roots staged in LDS (30 KB); larger worlds read the tables from memory
 
 struct DevScene {
   const RootRec* __restrict__ root_recs;
+  const RootCull* __restrict__ root_cull;
   const uint32_t* __restrict__ roots;
   const uint4* __restrict__ leaf_meta;
   const double* __restrict__ xf;        // [n_xforms][12]
@@ -82,18 +91,24 @@ struct DevCamera {
   uint32_t hsize, vsize;
 };
 
-// How work-groups map to pixels and where results go.
+// How pixels are enumerated and where results go.  Work is handed out in 8x8-pixel CHUNKS, numbered
+// 0..n_chunks-1 and pulled by the persistent waves from DevStats::next_chunk.
 //   mode 0: rectangle [x0,x0+w) x [y0,y0+h) -> out[(y-y0)*w + (x-x0)]
-//   mode 1: interleaved tiles (multi-GPU): tile k = first_tile + i*tile_stride of a tile_w x tile_h
-//           tiling of the image -> out[(i*tile_h + ly)*tile_w + lx]
+//   mode 1: interleaved tiles (multi-GPU): region i is tile first_tile + i*tile_stride of a
+//           tile_w x tile_h tiling of the image -> out[(i*tile_h + ly)*tile_w + lx]
 struct DevPixelMap {
   uint32_t mode;
   uint32_t x0, y0, w, h;
   uint32_t tile_w, tile_h, first_tile, tile_stride, n_my_tiles;
-  uint32_t tiles_x;           // tiles per image row (mode 1)
-  uint32_t blocks_x, blocks_y;  // 16x16-pixel blocks per rectangle / per tile
+  uint32_t tiles_x;             // tiles per image row (mode 1)
+  uint32_t chunks_x;            // chunks per row of the rectangle / of one tile
+  uint32_t chunks_per_region;   // chunks in the rectangle / in one tile
+  uint32_t n_chunks;            // total
 };
 
-struct DevStats {  // accumulated with one atomic per wave
+struct DevStats {  // zeroed before every launch; counters get one atomic per wave
   unsigned long long primary, secondary, shadow_calls, shadow_traced, overflow;
+  unsigned int next_chunk;  // work counter of the persistent waves
+  unsigned int pad;
+  unsigned long long prof[8];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
 };

@@ -34,6 +34,25 @@
 //     schlick) may differ in the last ulp.  No MFMA: nothing here is a dense contraction.
 #include "rtc_device.h"
 
+// Diagnostic build only (-DRTC_PROFILE): wave time per section of the main loop, from s_memtime stamps,
+// summed into DevStats::prof.  Never defined in the shipped library; numbers from such a build are
+// shares, not run times (MI355X guide, "In-kernel stamps").
+#ifdef RTC_PROFILE
+#define RTC_STAMP(sec)                                                     \
+  do {                                                                     \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();          \
+    prof_acc[prof_sec] += now_ - prof_t;                                   \
+    prof_t = now_;                                                         \
+    prof_sec = (sec);                                                      \
+  } while (0)
+#else
+#define RTC_STAMP(sec) do { } while (0)
+#endif
+
+#ifndef RTC_LB2
+#define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
+#endif
+
 namespace {
 
 constexpr double kInf = __builtin_huge_val();
@@ -280,51 +299,67 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
 // inside the sphere (radius inflated at upload), so if the LINE misses the sphere the root contributes
 // no entry at all; the visitor may additionally discard roots that cannot matter to it (entirely
 // behind the origin, entirely beyond its t range).  Tolerances are ~1e4 ulps of the terms involved.
+// Branch-free on purpose: phase 1 of trace() is a straight-line stream of LDS reads and DP math.
+// r2 == +inf (no finite bound) falls out as "keep" (c = -inf, disc = +inf) and the table padding
+// r2 == -inf as "cull" (disc = -inf) without special cases; NaNs compare false, i.e. keep.
 template <class V>
-__device__ __forceinline__ bool root_culled(const RootRec& R, const Ray& ray, double a, const V& vis) {
-  if (!(R.r2 < kInf)) return false;
+__device__ __forceinline__ bool root_culled(const RootCull& R, const Ray& ray, double a, double lim) {
   const double ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
   const double b = (ocx * ray.dx + ocy * ray.dy) + ocz * ray.dz;
   const double oc2 = (ocx * ocx + ocy * ocy) + ocz * ocz;
   const double c = oc2 - R.r2;
   const double bb = b * b;
   const double disc = bb - a * c;
-  if (disc < -1e-12 * (bb + a * oc2)) return true;  // the line misses the sphere
-  if (c > 0.0) {                                    // origin outside the sphere
-    if (b < 0.0) return V::kFrontOnly;              // sphere entirely at t < 0
-    // sphere entirely at t > 0, nearest point at t_near = (b - sqrt(disc)) / a
-    if (V::kBehindOnly) return true;
-    const double lim = vis.t_limit();               // entries with t > lim are irrelevant
-    if (lim < kInf) {
-      const double x = b - lim * a;                 // t_near > lim  <=>  x > 0 && x^2 > disc
-      if (x > 0.0 && x * x > disc * (1.0 + 1e-9) + 1e-12 * bb) return true;
-    }
-  }
-  return false;
+  const bool miss = disc < -1e-12 * (bb + a * oc2);  // the line misses the sphere
+  const bool outside = c > 0.0;                       // origin outside the sphere
+  const bool behind = outside & (b < 0.0);            // ... which lies entirely at t < 0
+  const bool front = outside & !(b < 0.0);            // ... entirely at t > 0, nearest point at
+  const double x = b - lim * a;                       //   t_near = (b - sqrt(disc)) / a;  t_near > lim <=> x > 0 && x^2 > disc
+  const bool beyond = front & (x > 0.0) & (x * x > disc * (1.0 + 1e-9) + 1e-12 * bb);
+  return miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly) | (beyond & !V::kBehindOnly);
 }
 
-template <bool LDS, class V>
-__device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs, const Ray& ray, V& vis,
-                                      unsigned& overflow) {
+// World.intersect's loop over World.objects (world.zig:74), two-phase so that no load depends on a
+// previous one and no lane waits for roots only its neighbours need:
+//   phase 1 streams the 32-byte bounding spheres of up to 64 roots (wave-uniform addresses) and
+//           leaves one survivor bit per root in a per-lane mask;
+//   phase 2 lets every lane walk the set bits of ITS OWN mask and run the exact reference test on
+//           the 144-byte-strided root records (per-lane LDS addresses; the stride spreads the banks).
+// Rays of one wave are a mix of pixels and bounces after a few iterations, so the union of the lanes'
+// survivors is most of the world while each lane's own list is 2-4 roots long.
+template <class V>
+__device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
+                                      const RootCull* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow) {
   const double a = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz;
-  for (uint32_t ri = 0; ri < S.n_roots; ++ri) {  // wave-uniform loop over World.objects
-    if (vis.done()) break;
-    const RootRec& R = recs[ri];
-    if (root_culled(R, ray, a, vis)) continue;
-    const uint32_t kf = R.kind_flags;
-    if (!(kf & RTC_ROOT_IS_GROUP)) {
-      const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
-      const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
-      const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
-      leaf_entries(kf & 0xFFu, cy, S.tri + 9ull * R.geom, lr,
-                   [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
-      continue;
+  for (uint32_t base = 0; base < S.n_roots; base += 64u) {
+    const uint32_t n = min(64u, S.n_roots - base);
+    unsigned long long mine = 0ull;
+    const double lim = vis.t_limit();
+    // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
+    for (uint32_t i = 0; i < n; i += 4u) {
+      const RootCull c0 = cull[base + i], c1 = cull[base + i + 1u], c2 = cull[base + i + 2u], c3 = cull[base + i + 3u];
+      const unsigned long long k0 = !root_culled<V>(c0, ray, a, lim), k1 = !root_culled<V>(c1, ray, a, lim);
+      const unsigned long long k2 = !root_culled<V>(c2, ray, a, lim), k3 = !root_culled<V>(c3, ray, a, lim);
+      mine |= (k0 | (k1 << 1) | (k2 << 2) | (k3 << 3)) << i;
     }
-    uint32_t cur_xf = 0xFFFFFFFFu;
-    Ray lr = ray;
-    uint32_t stack[RTC_TRAV_STACK];
-    int sp = 0;
-    stack[sp++] = R.index;
+    while (mine != 0ull && !vis.done()) {
+      const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mine));
+      mine &= mine - 1ull;
+      const RootRec& R = recs[base + bit];
+      const uint32_t kf = R.kind_flags;
+      if (!(kf & RTC_ROOT_IS_GROUP)) {
+        const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
+        const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
+        const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
+        leaf_entries(kf & 0xFFu, cy, S.tri + 9ull * R.geom, lr,
+                     [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
+        continue;
+      }
+      uint32_t cur_xf = 0xFFFFFFFFu;
+      Ray lr = ray;
+      uint32_t stack[RTC_TRAV_STACK];
+      int sp = 0;
+      stack[sp++] = R.index;
     while (sp > 0 && !vis.done()) {
       const uint32_t n = stack[--sp];
       const double* __restrict__ B = S.node_box + 6ull * n;
@@ -346,6 +381,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         }
       }
     }
+    }  // while (mine)
   }
 }
 
@@ -544,97 +580,175 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-// The megakernel.  256 threads = 4 waves; each wave owns an 8x8-pixel tile of a 16x16 block,
-// so the 64 lanes of a wave start from neighbouring primary rays.
+// The megakernel: persistent waves.  The launch has only as many work-groups as the chip holds;
+// every wave pulls 8x8-pixel chunks from one atomic counter and deals their pixels to whichever of
+// its lanes have run out of rays, so a lane that finishes a cheap pixel (one plane hit) immediately
+// starts another while its neighbours are still inside a glass sphere's ray tree.  Per iteration
+// each lane handles ONE ray: closest-hit trace, shading with its shadow traces, spawn of the
+// reflection / refraction children (one continues in registers, the other goes to the lane's stack).
+// Exit: the counter runs past n_chunks (`drained`) and no lane holds a ray; every wave reaches it.
 // ------------------------------------------------------------------------------------------
 template <bool LDS>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats) {
-  // World.objects table: staged once per work-group into LDS so the per-ray root loop has no
-  // dependent (pointer-chasing) loads; worlds with more than RTC_LDS_ROOTS entries read it from memory.
-  __shared__ RootRec lds_roots[LDS ? RTC_LDS_ROOTS : 1];
+  // World.objects tables: staged once per work-group into LDS so the per-ray root loop has no
+  // dependent (pointer-chasing) loads; worlds with more than RTC_LDS_ROOTS entries read them from memory.
+  __shared__ RootRec lds_recs[LDS ? RTC_LDS_ROOTS : 1];
+  __shared__ RootCull lds_cull[LDS ? RTC_LDS_ROOTS : 1];
   const RootRec* __restrict__ recs = S.root_recs;
+  const RootCull* __restrict__ cull = S.root_cull;
   if (LDS) {
-    const uint32_t n_words = S.n_roots * (sizeof(RootRec) / 8u);
-    const double* __restrict__ src = reinterpret_cast<const double*>(S.root_recs);
-    double* dst = reinterpret_cast<double*>(lds_roots);
-    for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+    {
+      const uint32_t n_words = S.n_roots * (sizeof(RootRec) / 8u);
+      const double* __restrict__ src = reinterpret_cast<const double*>(S.root_recs);
+      double* dst = reinterpret_cast<double*>(lds_recs);
+      for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+    }
+    {
+      const uint32_t n_words = ((S.n_roots + 3u) & ~3u) * (sizeof(RootCull) / 8u);
+      const double* __restrict__ src = reinterpret_cast<const double*>(S.root_cull);
+      double* dst = reinterpret_cast<double*>(lds_cull);
+      for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
-    recs = lds_roots;
+    recs = lds_recs;
+    cull = lds_cull;
   }
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  const uint32_t lx = ((wave & 1u) << 3) | (lane & 7u);
-  const uint32_t ly = ((wave >> 1) << 3) | (lane >> 3);
+  const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-  uint32_t px, py;        // image pixel
-  size_t out_index;       // position in `out` (pixels)
-  bool in_buffer, in_image;
-  {
-    const uint32_t per_region = map.blocks_x * map.blocks_y;
-    const uint32_t region = blockIdx.x / per_region;
-    const uint32_t b = blockIdx.x - region * per_region;
-    const uint32_t bx = b % map.blocks_x, by = b / map.blocks_x;
-    const uint32_t rx = bx * 16u + lx, ry = by * 16u + ly;  // position inside the rectangle / tile
-    if (map.mode == 0u) {
-      in_buffer = rx < map.w && ry < map.h;
-      px = map.x0 + rx;
-      py = map.y0 + ry;
-      out_index = static_cast<size_t>(ry) * map.w + rx;
-    } else {
-      const uint32_t tile = map.first_tile + region * map.tile_stride;
-      const uint32_t tx = tile % map.tiles_x, ty = tile / map.tiles_x;
-      in_buffer = rx < map.tile_w && ry < map.tile_h;
-      px = tx * map.tile_w + rx;
-      py = ty * map.tile_h + ry;
-      out_index = (static_cast<size_t>(region) * map.tile_h + ry) * map.tile_w + rx;
-    }
-    in_image = in_buffer && px < cam.hsize && py < cam.vsize;
-  }
+  // wave-uniform chunk cursor
+  uint32_t chunk = 0u, chunk_pos = 64u;
+  bool drained = false;
 
+  // per-lane pixel and ray state
+  bool has_pixel = false, have_cur = false;
+  size_t out_index = 0;
   double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
-  unsigned n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0;
-
+  unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0;
+  Pending cur;
+  cur.ray = {0, 0, 0, 0, 0, 0};
+  cur.weight = 0.0;
+  cur.remaining = 0u;
   Pending stack[RTC_RAY_STACK];
   int sp = 0;
 
-  if (in_image) {
-    // Camera.rayForPixel, camera.zig:64-76
-    const double xoffset = (static_cast<double>(px) + 0.5) * cam.pixel_size;
-    const double yoffset = (static_cast<double>(py) + 0.5) * cam.pixel_size;
-    const double world_x = cam.half_width - xoffset;
-    const double world_y = cam.half_height - yoffset;
-    const double pix_x = row_pt(cam.inv + 0, world_x, world_y, -1.0);
-    const double pix_y = row_pt(cam.inv + 4, world_x, world_y, -1.0);
-    const double pix_z = row_pt(cam.inv + 8, world_x, world_y, -1.0);
-    Pending p;
-    p.ray.ox = row_pt(cam.inv + 0, 0.0, 0.0, 0.0);
-    p.ray.oy = row_pt(cam.inv + 4, 0.0, 0.0, 0.0);
-    p.ray.oz = row_pt(cam.inv + 8, 0.0, 0.0, 0.0);
-    double dx = pix_x - p.ray.ox, dy = pix_y - p.ray.oy, dz = pix_z - p.ray.oz;
-    const double mag = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);  // Tuple.normalized, tuple.zig:109-116
-    if (mag != 0.0) {
-      dx = dx / mag;
-      dy = dy / mag;
-      dz = dz / mag;
+#ifdef RTC_PROFILE
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+  unsigned prof_sec = 0;
+  unsigned long long prof_iters = 0;
+#endif
+  for (;;) {
+    RTC_STAMP(0);
+    // ---- 1. a lane without a ray pops its stack; an empty stack means its pixel is finished
+    if (!have_cur) {
+      if (sp > 0) {
+        cur = stack[--sp];
+        have_cur = true;
+      } else if (has_pixel) {
+        double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
+        o[0] = acc_r;
+        o[1] = acc_g;
+        o[2] = acc_b;
+        has_pixel = false;
+      }
     }
-    p.ray.dx = dx;
-    p.ray.dy = dy;
-    p.ray.dz = dz;
-    p.weight = 1.0;
-    p.remaining = max_depth;
-    stack[sp++] = p;
-  }
-
-  while (sp > 0) {
-    const Pending cur = stack[--sp];
-    const Ray& ray = cur.ray;
+    // ---- 2. deal new pixels to the lanes that want one
+    bool want = !have_cur;
+    unsigned long long wmask = __ballot(want);
+    while (wmask) {
+      if (chunk_pos >= 64u) {
+        if (drained) break;
+        uint32_t c = 0u;
+        if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= map.n_chunks) {
+          drained = true;
+          break;
+        }
+        chunk = c;
+        chunk_pos = 0u;
+      }
+      const uint32_t avail = 64u - chunk_pos;
+      const uint32_t rank = static_cast<uint32_t>(__builtin_popcountll(wmask & lanes_below));
+      if (want && rank < avail) {
+        const uint32_t k = chunk_pos + rank;  // pixel k of the 8x8 chunk
+        const uint32_t region = chunk / map.chunks_per_region;
+        const uint32_t cr = chunk - region * map.chunks_per_region;
+        const uint32_t rx = (cr % map.chunks_x) * 8u + (k & 7u);
+        const uint32_t ry = (cr / map.chunks_x) * 8u + (k >> 3);
+        uint32_t px, py;
+        bool in_buffer;
+        size_t oi;
+        if (map.mode == 0u) {
+          in_buffer = rx < map.w && ry < map.h;
+          px = map.x0 + rx;
+          py = map.y0 + ry;
+          oi = static_cast<size_t>(ry) * map.w + rx;
+        } else {
+          const uint32_t tile = map.first_tile + region * map.tile_stride;
+          const uint32_t tx = tile % map.tiles_x, ty = tile / map.tiles_x;
+          in_buffer = rx < map.tile_w && ry < map.tile_h;
+          px = tx * map.tile_w + rx;
+          py = ty * map.tile_h + ry;
+          oi = (static_cast<size_t>(region) * map.tile_h + ry) * map.tile_w + rx;
+        }
+        if (in_buffer && px < cam.hsize && py < cam.vsize) {
+          // Camera.rayForPixel, camera.zig:64-76
+          const double xoffset = (static_cast<double>(px) + 0.5) * cam.pixel_size;
+          const double yoffset = (static_cast<double>(py) + 0.5) * cam.pixel_size;
+          const double world_x = cam.half_width - xoffset;
+          const double world_y = cam.half_height - yoffset;
+          const double pix_x = row_pt(cam.inv + 0, world_x, world_y, -1.0);
+          const double pix_y = row_pt(cam.inv + 4, world_x, world_y, -1.0);
+          const double pix_z = row_pt(cam.inv + 8, world_x, world_y, -1.0);
+          cur.ray.ox = row_pt(cam.inv + 0, 0.0, 0.0, 0.0);
+          cur.ray.oy = row_pt(cam.inv + 4, 0.0, 0.0, 0.0);
+          cur.ray.oz = row_pt(cam.inv + 8, 0.0, 0.0, 0.0);
+          double dx = pix_x - cur.ray.ox, dy = pix_y - cur.ray.oy, dz = pix_z - cur.ray.oz;
+          const double mag = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);  // Tuple.normalized, tuple.zig:109-116
+          if (mag != 0.0) {
+            dx = dx / mag;
+            dy = dy / mag;
+            dz = dz / mag;
+          }
+          cur.ray.dx = dx;
+          cur.ray.dy = dy;
+          cur.ray.dz = dz;
+          cur.weight = 1.0;
+          cur.remaining = max_depth;
+          have_cur = true;
+          has_pixel = true;
+          want = false;
+          out_index = oi;
+          acc_r = acc_g = acc_b = 0.0;
+          n_primary++;
+        } else if (in_buffer) {  // padding of an edge tile: defined as 0
+          double* __restrict__ o = out + 3 * oi;
+          o[0] = 0.0;
+          o[1] = 0.0;
+          o[2] = 0.0;
+        }
+      }
+      chunk_pos += min(avail, static_cast<uint32_t>(__builtin_popcountll(wmask)));
+      wmask = __ballot(want);
+    }
+    if (!__any(have_cur)) break;
+    if (!have_cur) continue;
+    have_cur = false;  // `cur` is consumed; a spawned child may refill it below
+    const Ray ray = cur.ray;
 
     // ---- World.colorAt: intersect + hit (world.zig:111-115)
+    RTC_STAMP(1);
+#ifdef RTC_PROFILE
+    prof_iters += 1ull;
+#endif
     ClosestVisitor hv;
-    trace<LDS>(S, recs, ray, hv, overflow);
-    if (hv.leaf == RTC_NO_LEAF) continue;  // black
+    trace(S, recs, cull, ray, hv, overflow);
+    RTC_STAMP(2);
+    if (hv.leaf == RTC_NO_LEAF) continue;  // black (world.zig:119)
 
     // ---- PreComputations.new (world.zig:212-227)
     const uint4 meta = S.leaf_meta[hv.leaf];
@@ -764,7 +878,9 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           ShadowVisitor sv;
           sv.distance = distance;
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
-          trace<LDS>(S, recs, sray, sv, overflow);
+          RTC_STAMP(3);
+          trace(S, recs, cull, sray, sv, overflow);
+          RTC_STAMP(4);
           shadowed = sv.shadowed;
         }
         // Material.lighting (material.zig:40-74)
@@ -801,6 +917,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     acc_g += cur.weight * sg;
     acc_b += cur.weight * sb;
 
+    RTC_STAMP(6);
     // ---- reflectedColor / refractedColor / schlick (world.zig:98-107, 157-189, 272-289)
     if (cur.remaining == 0u) continue;
     const bool do_reflect = !(mat.reflective == 0.0);
@@ -812,10 +929,12 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     bool do_refract = false;
     double n_ratio = 1.0, sin2_t = 0.0;
     if (transparent) {
+      RTC_STAMP(5);
       BehindVisitor bv;
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
-      trace<LDS>(S, recs, ray, bv, overflow);
+      trace(S, recs, cull, ray, bv, overflow);
+      RTC_STAMP(6);
       bv.flush();
       double n1 = 1.0, n2 = 1.0;
       if (bv.best_leaf != RTC_NO_LEAF) n1 = S.mat[bv.best_mat].ior;
@@ -853,36 +972,46 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         w_refract = mat.transparency * (1.0 - reflectance);
       }
     }
-    if (do_refract && sp < RTC_RAY_STACK) {
+    Pending child;
+    child.remaining = cur.remaining - 1u;
+    if (do_reflect) {
+      const double two_dot = 2.0 * ((ray.dx * nx + ray.dy * ny) + ray.dz * nz);  // direction.reflect(normal)
+      child.ray = {ovx, ovy, ovz, ray.dx - nx * two_dot, ray.dy - ny * two_dot, ray.dz - nz * two_dot};
+      child.weight = cur.weight * w_reflect;
+      n_secondary++;
+    }
+    if (do_refract) {
       const double cos_t = __builtin_sqrt(1.0 - sin2_t);
       const double k = n_ratio * cos_i - cos_t;
       Pending p;
       p.ray = {unx, uny, unz, nx * k - ex * n_ratio, ny * k - ey * n_ratio, nz * k - ez * n_ratio};
       p.weight = cur.weight * w_refract;
       p.remaining = cur.remaining - 1u;
-      stack[sp++] = p;
       n_secondary++;
+      if (do_reflect) {  // both children: the reflection continues in registers, the refraction waits
+        if (sp < RTC_RAY_STACK) {
+          stack[sp++] = p;
+        } else {
+          overflow = 1u;
+        }
+      } else {
+        child = p;
+      }
     }
-    if (do_reflect && sp < RTC_RAY_STACK) {
-      const double two_dot = 2.0 * ((ray.dx * nx + ray.dy * ny) + ray.dz * nz);  // direction.reflect(normal)
-      Pending p;
-      p.ray = {ovx, ovy, ovz, ray.dx - nx * two_dot, ray.dy - ny * two_dot, ray.dz - nz * two_dot};
-      p.weight = cur.weight * w_reflect;
-      p.remaining = cur.remaining - 1u;
-      stack[sp++] = p;
-      n_secondary++;
+    if (do_reflect || do_refract) {
+      cur = child;
+      have_cur = true;
     }
   }
 
-  if (in_buffer) {
-    double* __restrict__ o = out + 3 * out_index;
-    o[0] = acc_r;
-    o[1] = acc_g;
-    o[2] = acc_b;
-  }
-
+#ifdef RTC_PROFILE
+  RTC_STAMP(7);
+  prof_acc[7] = prof_iters;  // slot 7 reports main-loop iterations (wave-level), not cycles
+  if (lane == 0u)
+    for (int i = 0; i < 8; ++i) atomicAdd(&stats->prof[i], prof_acc[i]);
+#endif
   // one atomic per counter per wave
-  const unsigned long long s_pri = wave_sum(in_image ? 1u : 0u);
+  const unsigned long long s_pri = wave_sum(n_primary);
   const unsigned long long s_sec = wave_sum(n_secondary);
   const unsigned long long s_shc = wave_sum(n_shadow_calls);
   const unsigned long long s_sht = wave_sum(n_shadow_traced);
@@ -896,14 +1025,14 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   }
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                   double* __restrict__ out, DevStats* __restrict__ stats) {
   render_body<true>(S, cam, map, max_depth, out, stats);
 }
 
 // Same kernel for worlds whose World.objects table does not fit the LDS staging area.
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                            double* __restrict__ out, DevStats* __restrict__ stats) {
   render_body<false>(S, cam, map, max_depth, out, stats);
