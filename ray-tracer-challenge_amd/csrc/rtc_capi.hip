@@ -71,11 +71,11 @@ struct rtc_scene {
   DevBuf<RootRec> root_recs;
   DevBuf<RootCull> root_cull;
   DevBuf<uint4> leaf_meta;
-  DevBuf<double> xf, tri, trin, pat_inv, pat_rgb, node_box, light;
+  DevBuf<double> xf, tri, trin, node_box, light;
+  DevBuf<DevPattern> pat;
   DevBuf<DevCyl> cyl;
   DevBuf<DevMaterial> mat;
-  DevBuf<uint8_t> pat_kind;
-  DevBuf<uint2> pat_ab, node_kids;
+  DevBuf<uint2> node_kids;
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
 };
@@ -280,7 +280,8 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
   HIP_TRY(hipSetDevice(s->device));
-  const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS;
+  const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
+                   s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
   // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
   // chunks to hand out, 4 waves each); the waves pull chunks until the counter runs out.
   const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
@@ -470,7 +471,15 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     return v;
   };
   std::vector<double> xf = rows12(d.xf_inv, d.n_xforms);
-  std::vector<double> pat_inv = rows12(d.pat_inv, d.n_patterns);
+  std::vector<DevPattern> pat(d.n_patterns);
+  for (uint32_t i = 0; i < d.n_patterns; ++i) {
+    std::memset(&pat[i], 0, sizeof(DevPattern));
+    std::memcpy(pat[i].inv, d.pat_inv + 16ull * i, sizeof pat[i].inv);
+    for (int k = 0; k < 3; ++k) pat[i].rgb[k] = d.pat_rgb[3ull * i + k];
+    pat[i].kind = d.pat_kind[i];
+    pat[i].a = d.pat_a[i];
+    pat[i].b = d.pat_b[i];
+  }
   std::vector<DevCyl> cyl(d.n_cyls);
   for (uint32_t i = 0; i < d.n_cyls; ++i) cyl[i] = {d.cyl_min[i], d.cyl_max[i], d.cyl_closed[i] ? 1u : 0u, 0u};
   std::vector<double> tri(9ull * d.n_tris), trin(9ull * d.n_tris);
@@ -489,10 +498,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     const double* p = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * i;
     mat[i] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], d.mat_pattern[i], 0u};
   }
-  std::vector<uint8_t> pat_kind(d.pat_kind, d.pat_kind + d.n_patterns);
-  std::vector<double> pat_rgb(d.pat_rgb, d.pat_rgb + 3ull * d.n_patterns);
-  std::vector<uint2> pat_ab(d.n_patterns), node_kids(d.n_nodes);
-  for (uint32_t i = 0; i < d.n_patterns; ++i) pat_ab[i] = {d.pat_a[i], d.pat_b[i]};
+  std::vector<uint2> node_kids(d.n_nodes);
   std::vector<double> node_box(6ull * d.n_nodes);
   for (uint32_t i = 0; i < d.n_nodes; ++i) {
     for (int k = 0; k < 3; ++k) {
@@ -533,10 +539,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->tri.upload(tri));
   HIP_TRY(s->trin.upload(trin));
   HIP_TRY(s->mat.upload(mat));
-  HIP_TRY(s->pat_kind.upload(pat_kind));
-  HIP_TRY(s->pat_inv.upload(pat_inv));
-  HIP_TRY(s->pat_rgb.upload(pat_rgb));
-  HIP_TRY(s->pat_ab.upload(pat_ab));
+  HIP_TRY(s->pat.upload(pat));
   HIP_TRY(s->node_box.upload(node_box));
   HIP_TRY(s->node_kids.upload(node_kids));
   HIP_TRY(s->light.upload(light));
@@ -563,10 +566,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.tri = s->tri.p;
   D.trin = s->trin.p;
   D.mat = s->mat.p;
-  D.pat_kind = s->pat_kind.p;
-  D.pat_inv = s->pat_inv.p;
-  D.pat_rgb = s->pat_rgb.p;
-  D.pat_ab = s->pat_ab.p;
+  D.pat = s->pat.p;
   D.node_box = s->node_box.p;
   D.node_kids = s->node_kids.p;
   D.kids = s->kids.p;
@@ -575,6 +575,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.n_leaves = n_live;
   D.n_nodes = d.n_nodes;
   D.n_lights = d.n_lights;
+  D.n_materials = d.n_materials;
+  D.n_patterns = d.n_patterns;
   guard.s = nullptr;
   *out = s;
   return RTC_OK;

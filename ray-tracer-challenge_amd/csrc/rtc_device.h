@@ -14,7 +14,7 @@
 //                         gather, one 72-byte record beats nine SoA lines)
 //   trin[]       9 f64    n1,n2,n3 (flat triangles: n1 = stored face normal)
 //   mat[]        8 f64    ambient,diffuse,specular,shininess,reflective,transparency,ior,pattern
-//   pat_*        pattern table
+//   pat[]        DevPattern, 144 B
 //   node_box[]   6 f64    Group._bbox min,max; node_kids[] {first,count}; kids[] u32
 //   light[]      6 f64    position, intensity
 #pragma once
@@ -62,7 +62,19 @@ struct RootRec {
   double pad_[2];        // 144-byte stride: per-lane LDS reads of different records spread over the banks
 };
 #define RTC_ROOT_IS_GROUP 0x8000u
-#define RTC_LDS_ROOTS 192   // roots staged in LDS (30 KB); larger worlds read the tables from memory
+// Small-world limits: scenes within all four get their tables staged in LDS (34 KB per work-group);
+// anything larger runs the same kernel reading the tables from memory.
+#define RTC_LDS_ROOTS 128
+#define RTC_LDS_MATERIALS 64
+#define RTC_LDS_PATTERNS 48
+#define RTC_LDS_LIGHTS 16
+
+struct DevPattern {      // 144 B
+  double inv[12];        // rows 0..2 of Pattern._inverse_transform
+  double rgb[3];         // solid colour
+  uint32_t kind, a, b;   // RTC_PAT_*, sub-pattern indices
+  uint32_t pad_[3];
+};
 
 struct DevScene {
   const RootRec* __restrict__ root_recs;
@@ -74,15 +86,12 @@ struct DevScene {
   const double* __restrict__ tri;       // [n_tris][9]
   const double* __restrict__ trin;      // [n_tris][9]
   const DevMaterial* __restrict__ mat;
-  const uint8_t* __restrict__ pat_kind;
-  const double* __restrict__ pat_inv;   // [n_patterns][12]
-  const double* __restrict__ pat_rgb;   // [n_patterns][3]
-  const uint2* __restrict__ pat_ab;     // sub-pattern indices
+  const DevPattern* __restrict__ pat;
   const double* __restrict__ node_box;  // [n_nodes][6]
   const uint2* __restrict__ node_kids;  // {first, count}
   const uint32_t* __restrict__ kids;
   const double* __restrict__ light;     // [n_lights][6]
-  uint32_t n_roots, n_leaves, n_nodes, n_lights;
+  uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
 };
 
 struct DevCamera {

@@ -351,10 +351,12 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
         const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
         const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
+        vis.set_root(base + bit);
         leaf_entries(kf & 0xFFu, cy, S.tri + 9ull * R.geom, lr,
                      [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
         continue;
       }
+      vis.set_root(RTC_NO_LEAF);
       uint32_t cur_xf = 0xFFFFFFFFu;
       Ray lr = ray;
       uint32_t stack[RTC_TRAV_STACK];
@@ -390,7 +392,10 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
 struct ClosestVisitor {
   double t = kInf;
   uint32_t leaf = RTC_NO_LEAF;
+  uint32_t root = RTC_NO_LEAF;      // World.objects index when the hit leaf IS a top-level object
+  uint32_t cur_root = RTC_NO_LEAF;
   double u = 0.0, v = 0.0;
+  __device__ __forceinline__ void set_root(uint32_t r) { cur_root = r; }
   static constexpr bool kFrontOnly = true;    // entries with t < 0 never matter
   static constexpr bool kBehindOnly = false;
   __device__ __forceinline__ double t_limit() const { return t; }
@@ -398,6 +403,7 @@ struct ClosestVisitor {
     if (et >= 0.0 && (et < t || (et == t && l < leaf))) {
       t = et;
       leaf = l;
+      root = cur_root;
       u = eu;
       v = ev;
     }
@@ -412,6 +418,7 @@ struct ClosestVisitor {
 struct ShadowVisitor {
   double distance;
   bool shadowed = false;
+  __device__ __forceinline__ void set_root(uint32_t) {}
   static constexpr bool kFrontOnly = true;
   static constexpr bool kBehindOnly = false;
   __device__ __forceinline__ double t_limit() const { return distance; }
@@ -447,6 +454,7 @@ struct BehindVisitor {
   uint32_t best_mat = 0, best_excl_mat = 0;
   bool hit_open = false;
   uint32_t hit_dups = 0;
+  __device__ __forceinline__ void set_root(uint32_t) {}
 
   __device__ __forceinline__ void flush() {
     if (cur != RTC_NO_LEAF && (cur_cnt & 1u)) {
@@ -505,20 +513,20 @@ struct Rgb {
 // Follows a chain of "selecting" patterns (stripes / checkers / rings) down to a solid or
 // test pattern.  Sub-patterns are evaluated at the OBJECT-space point with their own inverse
 // (stripes.zig:27-33).  Returns false if the chain ends in a mixing pattern (idx then names it).
-__device__ __forceinline__ bool pattern_chain(const DevScene& S, uint32_t& idx, double ox, double oy, double oz,
-                                              Rgb& out) {
+__device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat, uint32_t& idx, double ox, double oy,
+                                              double oz, Rgb& out) {
   for (int guard = 0; guard < 64; ++guard) {
-    const uint32_t kind = S.pat_kind[idx];
+    const DevPattern& P = pat[idx];
+    const uint32_t kind = P.kind;
     if (kind == 0) {  // solid.zig:20-24
-      const double* __restrict__ c = S.pat_rgb + 3ull * idx;
-      out = {c[0], c[1], c[2]};
+      out = {P.rgb[0], P.rgb[1], P.rgb[2]};
       return true;
     }
-    const double* __restrict__ m = S.pat_inv + 12ull * idx;
+    const double* __restrict__ m = P.inv;
     const double px = row_pt(m + 0, ox, oy, oz);
     const double py = row_pt(m + 4, ox, oy, oz);
     const double pz = row_pt(m + 8, ox, oy, oz);
-    const uint2 ab = S.pat_ab[idx];
+    const uint2 ab{P.a, P.b};
     if (kind == 9) {  // TestPattern, pattern.zig:144-148
       out = {px, py, pz};
       return true;
@@ -538,18 +546,19 @@ __device__ __forceinline__ bool pattern_chain(const DevScene& S, uint32_t& idx, 
 
 // Pattern.patternAt for the whole table.  Mixing patterns (gradient.zig, blend.zig) may sit
 // anywhere in a select-chain but their own children must be select-chains (validated at create).
-__device__ __forceinline__ Rgb pattern_at(const DevScene& S, uint32_t idx, double ox, double oy, double oz) {
+__device__ __forceinline__ Rgb pattern_at(const DevPattern* __restrict__ pat, uint32_t idx, double ox, double oy,
+                                          double oz) {
   Rgb out;
-  if (pattern_chain(S, idx, ox, oy, oz, out)) return out;
-  const uint32_t kind = S.pat_kind[idx];
-  const double* __restrict__ m = S.pat_inv + 12ull * idx;
+  if (pattern_chain(pat, idx, ox, oy, oz, out)) return out;
+  const DevPattern& P = pat[idx];
+  const uint32_t kind = P.kind;
+  const double* __restrict__ m = P.inv;
   const double px = row_pt(m + 0, ox, oy, oz);
   const double pz = row_pt(m + 8, ox, oy, oz);
-  const uint2 ab = S.pat_ab[idx];
-  uint32_t ia = ab.x, ib = ab.y;
+  uint32_t ia = P.a, ib = P.b;
   Rgb ca{0, 0, 0}, cb{0, 0, 0};
-  pattern_chain(S, ia, ox, oy, oz, ca);
-  pattern_chain(S, ib, ox, oy, oz, cb);
+  pattern_chain(pat, ia, ox, oy, oz, ca);
+  pattern_chain(pat, ib, ox, oy, oz, cb);
   if (kind == 6) {  // blend.zig:21-24
     return {(ca.r + cb.r) * 0.5, (ca.g + cb.g) * 0.5, (ca.b + cb.b) * 0.5};
   }
@@ -592,34 +601,44 @@ template <bool LDS>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats) {
-  // World.objects tables: staged once per work-group into LDS so the per-ray root loop has no
-  // dependent (pointer-chasing) loads; worlds with more than RTC_LDS_ROOTS entries read them from memory.
+  // Small-world tables (World.objects records + bounding spheres, materials, patterns, lights):
+  // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
+  // chases pointers through memory.  Larger worlds run the same code on the tables in memory.
   __shared__ RootRec lds_recs[LDS ? RTC_LDS_ROOTS : 1];
   __shared__ RootCull lds_cull[LDS ? RTC_LDS_ROOTS : 1];
+  __shared__ DevMaterial lds_mat[LDS ? RTC_LDS_MATERIALS : 1];
+  __shared__ DevPattern lds_pat[LDS ? RTC_LDS_PATTERNS : 1];
+  __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCull* __restrict__ cull = S.root_cull;
+  const DevMaterial* __restrict__ mats = S.mat;
+  const DevPattern* __restrict__ pats = S.pat;
+  const double* __restrict__ lights = S.light;
   if (LDS) {
-    {
-      const uint32_t n_words = S.n_roots * (sizeof(RootRec) / 8u);
-      const double* __restrict__ src = reinterpret_cast<const double*>(S.root_recs);
-      double* dst = reinterpret_cast<double*>(lds_recs);
+    auto stage = [&](void* dst_, const void* src_, uint32_t n_words) {
+      const double* __restrict__ src = reinterpret_cast<const double*>(src_);
+      double* dst = reinterpret_cast<double*>(dst_);
       for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
-    }
-    {
-      const uint32_t n_words = ((S.n_roots + 3u) & ~3u) * (sizeof(RootCull) / 8u);
-      const double* __restrict__ src = reinterpret_cast<const double*>(S.root_cull);
-      double* dst = reinterpret_cast<double*>(lds_cull);
-      for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
-    }
+    };
+    stage(lds_recs, S.root_recs, S.n_roots * (sizeof(RootRec) / 8u));
+    stage(lds_cull, S.root_cull, ((S.n_roots + 3u) & ~3u) * (sizeof(RootCull) / 8u));
+    stage(lds_mat, S.mat, S.n_materials * (sizeof(DevMaterial) / 8u));
+    stage(lds_pat, S.pat, S.n_patterns * (sizeof(DevPattern) / 8u));
+    stage(lds_light, S.light, S.n_lights * 6u);
     __syncthreads();
     recs = lds_recs;
     cull = lds_cull;
+    mats = lds_mat;
+    pats = lds_pat;
+    lights = lds_light;
   }
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
   // wave-uniform chunk cursor
-  uint32_t chunk = 0u, chunk_pos = 64u;
+  uint32_t chunk_pos = 64u;
+  uint32_t chunk_rx0 = 0u, chunk_ry0 = 0u, chunk_px0 = 0u, chunk_py0 = 0u, chunk_w = 0u, chunk_h = 0u;
+  size_t chunk_out0 = 0;
   bool drained = false;
 
   // per-lane pixel and ray state
@@ -668,33 +687,37 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           drained = true;
           break;
         }
-        chunk = c;
         chunk_pos = 0u;
+        // wave-uniform placement of the chunk, once per fetch (scalar unit)
+        const uint32_t region = c / map.chunks_per_region;
+        const uint32_t cr = c - region * map.chunks_per_region;
+        const uint32_t ccy = cr / map.chunks_x;
+        chunk_rx0 = (cr - ccy * map.chunks_x) * 8u;
+        chunk_ry0 = ccy * 8u;
+        if (map.mode == 0u) {
+          chunk_px0 = map.x0;
+          chunk_py0 = map.y0;
+          chunk_w = map.w;
+          chunk_h = map.h;
+          chunk_out0 = 0;
+        } else {
+          const uint32_t tile = map.first_tile + region * map.tile_stride;
+          const uint32_t ty = tile / map.tiles_x;
+          chunk_px0 = (tile - ty * map.tiles_x) * map.tile_w;
+          chunk_py0 = ty * map.tile_h;
+          chunk_w = map.tile_w;
+          chunk_h = map.tile_h;
+          chunk_out0 = static_cast<size_t>(region) * map.tile_h * map.tile_w;
+        }
       }
       const uint32_t avail = 64u - chunk_pos;
       const uint32_t rank = static_cast<uint32_t>(__builtin_popcountll(wmask & lanes_below));
       if (want && rank < avail) {
         const uint32_t k = chunk_pos + rank;  // pixel k of the 8x8 chunk
-        const uint32_t region = chunk / map.chunks_per_region;
-        const uint32_t cr = chunk - region * map.chunks_per_region;
-        const uint32_t rx = (cr % map.chunks_x) * 8u + (k & 7u);
-        const uint32_t ry = (cr / map.chunks_x) * 8u + (k >> 3);
-        uint32_t px, py;
-        bool in_buffer;
-        size_t oi;
-        if (map.mode == 0u) {
-          in_buffer = rx < map.w && ry < map.h;
-          px = map.x0 + rx;
-          py = map.y0 + ry;
-          oi = static_cast<size_t>(ry) * map.w + rx;
-        } else {
-          const uint32_t tile = map.first_tile + region * map.tile_stride;
-          const uint32_t tx = tile % map.tiles_x, ty = tile / map.tiles_x;
-          in_buffer = rx < map.tile_w && ry < map.tile_h;
-          px = tx * map.tile_w + rx;
-          py = ty * map.tile_h + ry;
-          oi = (static_cast<size_t>(region) * map.tile_h + ry) * map.tile_w + rx;
-        }
+        const uint32_t rx = chunk_rx0 + (k & 7u), ry = chunk_ry0 + (k >> 3);
+        const bool in_buffer = rx < chunk_w && ry < chunk_h;
+        const uint32_t px = chunk_px0 + rx, py = chunk_py0 + ry;
+        const size_t oi = chunk_out0 + static_cast<size_t>(ry) * chunk_w + rx;
         if (in_buffer && px < cam.hsize && py < cam.vsize) {
           // Camera.rayForPixel, camera.zig:64-76
           const double xoffset = (static_cast<double>(px) + 0.5) * cam.pixel_size;
@@ -751,10 +774,31 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (hv.leaf == RTC_NO_LEAF) continue;  // black (world.zig:119)
 
     // ---- PreComputations.new (world.zig:212-227)
-    const uint4 meta = S.leaf_meta[hv.leaf];
-    const uint32_t kind = meta.x & 0xFFu;
-    const double* __restrict__ M = S.xf + 12ull * meta.y;
-    const DevMaterial mat = S.mat[meta.z];
+    // the hit Shape: its record sits in the (LDS) root table when it is a top-level object,
+    // otherwise it is a leaf inside a group and comes from the leaf tables in memory
+    uint32_t kind, geom, mat_index;
+    double M[12];
+    DevCyl hcy{0.0, 0.0, 0u, 0u};
+    if (hv.root != RTC_NO_LEAF) {
+      const RootRec& R = recs[hv.root];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) M[i] = R.inv[i];
+      kind = R.kind_flags & 0xFFu;
+      geom = R.geom;
+      mat_index = R.material;
+      hcy.ymin = R.ymin;
+      hcy.ymax = R.ymax;
+    } else {
+      const uint4 meta = S.leaf_meta[hv.leaf];
+      const double* __restrict__ X = S.xf + 12ull * meta.y;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) M[i] = X[i];
+      kind = meta.x & 0xFFu;
+      geom = meta.w;
+      mat_index = meta.z;
+      if (kind == 3u || kind == 6u) hcy = S.cyl[geom];
+    }
+    const DevMaterial mat = mats[mat_index];
     const double t = hv.t;
     const double ptx = ray.ox + ray.dx * t, pty = ray.oy + ray.dy * t, ptz = ray.oz + ray.dz * t;  // ray.position
     const double ex = -ray.dx, ey = -ray.dy, ez = -ray.dz;                                          // eyev
@@ -788,7 +832,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         break;
       }
       case 3: {  // cylinder.zig:100-112
-        const DevCyl cy = S.cyl[meta.w];
+        const DevCyl cy = hcy;
         const double dist = lpx * lpx + lpz * lpz;
         if (dist < 1.0 && lpy >= cy.ymax - 1e-5) {
           lnx = 0.0; lny = 1.0; lnz = 0.0;
@@ -800,7 +844,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         break;
       }
       case 6: {  // cone.zig:115-132
-        const DevCyl cy = S.cyl[meta.w];
+        const DevCyl cy = hcy;
         const double dist = lpx * lpx + lpz * lpz;
         if (dist < cy.ymax * cy.ymax && lpy >= cy.ymax - 1e-4) {
           lnx = 0.0; lny = 1.0; lnz = 0.0;
@@ -815,12 +859,12 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         break;
       }
       case 4: {  // triangle.zig:65-70: the stored face normal
-        const double* __restrict__ N = S.trin + 9ull * meta.w;
+        const double* __restrict__ N = S.trin + 9ull * geom;
         lnx = N[0]; lny = N[1]; lnz = N[2];
         break;
       }
       default: {  // smooth triangle, triangle.zig:261-265: n2*u + n3*v + n1*(1-u-v)
-        const double* __restrict__ N = S.trin + 9ull * meta.w;
+        const double* __restrict__ N = S.trin + 9ull * geom;
         const double w1 = (1.0 - hv.u) - hv.v;
         lnx = (N[3] * hv.u + N[6] * hv.v) + N[0] * w1;
         lny = (N[4] * hv.u + N[7] * hv.v) + N[1] * w1;
@@ -856,12 +900,12 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       const double opx = row_pt(M + 0, ovx, ovy, ovz);
       const double opy = row_pt(M + 4, ovx, ovy, ovz);
       const double opz = row_pt(M + 8, ovx, ovy, ovz);
-      const Rgb color = pattern_at(S, mat.pattern, opx, opy, opz);
+      const Rgb color = pattern_at(pats, mat.pattern, opx, opy, opz);
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
       // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
       const bool shadow_matters = !(mat.diffuse == 0.0 && mat.specular == 0.0);
       for (uint32_t li = 0; li < S.n_lights; ++li) {
-        const double* __restrict__ L = S.light + 6ull * li;
+        const double* __restrict__ L = lights + 6ull * li;
         n_shadow_calls++;
         // isShadowed (world.zig:127-131) and lighting's point_to_light (material.zig:51) share this
         const double vx = L[0] - ovx, vy = L[1] - ovy, vz = L[2] - ovz;
@@ -937,11 +981,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       RTC_STAMP(6);
       bv.flush();
       double n1 = 1.0, n2 = 1.0;
-      if (bv.best_leaf != RTC_NO_LEAF) n1 = S.mat[bv.best_mat].ior;
+      if (bv.best_leaf != RTC_NO_LEAF) n1 = mats[bv.best_mat].ior;
       if (!bv.hit_open) {
         n2 = mat.ior;
       } else if (bv.best_excl_leaf != RTC_NO_LEAF) {
-        n2 = S.mat[bv.best_excl_mat].ior;
+        n2 = mats[bv.best_excl_mat].ior;
       } else if (bv.hit_dups >= 2u) {
         n2 = mat.ior;
       }
