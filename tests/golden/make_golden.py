@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: small f64 canvases + ray counters of every config scene, rendered by
+the CPU oracle (oracle/, pinned to the reference's KATs).  The reference itself cannot produce these
+(Zig, no toolchain here; it commits no golden images either), so the vectors are ORACLE outputs; they
+guard the oracle against regressions on the CPU and give the GPU box fixed expected values.
+
+    python tests/golden/make_golden.py          # rewrites the .npz files
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+# (scene, width, height, depth)
+CASES = [
+    ("fresnel.json", 60, 60, 5),
+    ("cover.json", 96, 54, 5),
+    ("reflection_and_refraction.json", 96, 54, 5),
+    ("reflection_and_refraction.json", 48, 27, 8),
+    ("teapot.json", 96, 54, 5),
+    ("dragons.json", 96, 54, 5),
+    ("cubes.json", 60, 30, 5),
+    ("cylinders.json", 80, 40, 5),
+    ("groups.json", 60, 20, 5),
+]
+
+
+def name_of(scene, w, h, depth):
+    return f"{scene.replace('.json', '')}_{w}x{h}_d{depth}.npz"
+
+
+def main():
+    rtc = importlib.import_module("ray-tracer-challenge_amd")
+    import oracle_binding as ob
+    for scene, w, h, depth in CASES:
+        hs = rtc.HostScene.from_file(scene)
+        cam = hs.camera(w, h)
+        img, counters = ob.OracleScene(hs.desc).render(cam, depth)
+        np.savez_compressed(os.path.join(HERE, name_of(scene, w, h, depth)), image=img,
+                            counters=np.array([counters[k] for k in ob.COUNTER_NAMES], dtype=np.int64))
+        print(scene, w, h, depth, counters)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Each rank renders ITS interleaved tiles (with the CPU
+oracle standing in for the kernel — this test is about the partition, the single gather and the
+un-permute on rank 0, exactly the helpers bench.py uses), rank 0 gathers and reassembles, and the result
+must equal the full frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+TILE_W, TILE_H = 32, 16
+W, H = 70, 50
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_path):
+    import importlib
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import oracle_binding as ob
+    rtc = importlib.import_module("ray-tracer-challenge_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs = rtc.HostScene.from_file("fresnel.json")
+    cam = hs.camera(W, H)
+    osc = ob.OracleScene(hs.desc)
+    tx, ty = rtc.tile_grid(W, H, TILE_W, TILE_H)
+    n_tiles = tx * ty
+    first, stride, count, padded = rtc.tiles_of_rank(n_tiles, rank, world)
+    buf = torch.zeros((padded, TILE_H, TILE_W, 3), dtype=torch.float64)
+    for i in range(count):
+        t = first + i * stride
+        x0, y0 = (t % tx) * TILE_W, (t // tx) * TILE_H
+        w, h = min(TILE_W, W - x0), min(TILE_H, H - y0)
+        img, _ = osc.render(cam, 5, (x0, y0, w, h), threads=1)
+        buf[i, :h, :w] = torch.from_numpy(img)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)          # the ONE collective of the path
+    if rank == 0:
+        g = torch.stack(gathered).numpy()
+        canvas = rtc.assemble_tiles(g, W, H, TILE_W, TILE_H, world)
+        full, _ = osc.render(cam, 5, threads=1)
+        np.save(out_path, np.abs(canvas - full).max())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_partition_gather_reassemble(tmp_path, world):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "delta.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert float(np.load(out)) == 0.0
+
+
+def test_tiles_of_rank_cover_every_tile_once(rtc):
+    for n_tiles in [1, 7, 510, 2040]:
+        for world in [1, 2, 3, 8]:
+            seen = []
+            for r in range(world):
+                first, stride, count, padded = rtc.tiles_of_rank(n_tiles, r, world)
+                assert count <= padded == (n_tiles + world - 1) // world
+                seen += [first + i * stride for i in range(count)]
+            assert sorted(seen) == list(range(n_tiles))

@@ -167,3 +167,68 @@ def test_errors_through_the_abi(rtc):
     with pytest.raises(rtc.RtcError) as e:
         gpu.render(cam, 99)                    # deeper than the per-lane ray stack
     assert e.value.name == "InvalidArgument"
+
+
+# ---------------------------------------------------------------- committed golden vectors
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden"))
+from make_golden import CASES as GOLDEN_CASES, name_of as golden_name  # noqa: E402
+
+
+@pytest.mark.parametrize("scene,w,h,depth", GOLDEN_CASES)
+def test_gpu_matches_golden(rtc, scene, w, h, depth):
+    g = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", golden_name(scene, w, h, depth)))
+    hs = rtc.HostScene.from_file(scene)
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(hs.camera(w, h), depth)
+    assert np.abs(got - g["image"]).max() < TOL
+    st = gpu.stats()
+    assert [st["primary"], st["secondary"], st["shadow_calls"]] == g["counters"][:3].tolist()
+
+
+def _many_objects_scene(n):
+    """n top-level objects (> RTC_LDS_ROOTS = 128): exercises the table-in-memory kernel variant."""
+    import json
+    import math
+    objs = [{"type": {"plane": {}}, "material": {"pattern": {"type": {"checkers": [
+        {"type": {"solid": [0.2, 0.2, 0.2]}}, {"type": {"solid": [0.9, 0.9, 0.9]}}]}}, "reflective": 0.2}}]
+    for i in range(n):
+        a = 2.399963 * i
+        r = 0.35 * math.sqrt(i + 1)
+        kind = [{"sphere": {}}, {"cube": {}}, {"cylinder": {"min": -1, "max": 1, "closed": True}}][i % 3]
+        objs.append({"type": kind,
+                     "transform": [{"scale": [0.25, 0.25, 0.25]}, {"rotate-y": 0.1 * i},
+                                   {"translate": [r * math.cos(a), 0.25 + 0.02 * (i % 7), r * math.sin(a)]}],
+                     "material": {"pattern": {"type": {"solid": [(i % 5) / 5.0, (i % 3) / 3.0, (i % 7) / 7.0]}},
+                                  "reflective": 0.3 if i % 4 == 0 else 0.0,
+                                  "transparency": 0.6 if i % 9 == 0 else 0.0, "refractive-index": 1.4}})
+    return json.dumps({"camera": {"width": 160, "height": 90, "field-of-view": 0.9, "from": [0, 4, -9], "to": [0, 0, 0],
+                                  "up": [0, 1, 0]},
+                       "lights": [{"point-light": {"position": [-6, 9, -6], "intensity": [1, 1, 1]}},
+                                  {"point-light": {"position": [7, 6, -2], "intensity": [0.3, 0.3, 0.3]}}],
+                       "objects": objs})
+
+
+@pytest.mark.parametrize("n", [100, 200])
+def test_many_top_level_objects(rtc, n):
+    hs = rtc.HostScene(_many_objects_scene(n))
+    assert hs.desc.n_roots == n + 1
+    cam = hs.camera()
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(cam, 5)
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    assert np.abs(got - want).max() < TOL
+    st = gpu.stats()
+    assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0
+
+
+def test_host_library_render_entry(rtc):
+    """Camera.render(world) through the C++ host mirror (librtc_host -> librtc_hip), not the Python binding."""
+    hs = rtc.HostScene.from_file("fresnel.json")
+    out = np.empty((40, 40, 3))
+    st = rtc.host_lib().rtch_scene_render(hs._h, 40, 40, 5, out.ctypes.data)
+    assert st == 0, rtc.host_lib().rtch_last_error()
+    want, _ = ob.OracleScene(hs.desc).render(hs.camera(40, 40), 5)
+    assert np.abs(out - want).max() < TOL
