@@ -33,13 +33,34 @@ FP64_VECTOR_PEAK_TF = 78.6   # half the 157.3 TF FP32 vector peak of the same gu
 TILE = 64
 
 
-def algorithmic_bytes(desc, stats, width, height):
-    """24*W*H framebuffer bytes + per ray the scene bytes the REFERENCE traversal touches.
-    For scenes without groups every ray (incl. every isShadowed ray) transforms into all n leaves:
-    128 B (one 4x4 f64 inverse) per leaf per ray.  (Group scenes add 56 B per node visit and 72 B per
-    triangle test; those counts come from the oracle and are only filled in when it ran.)"""
+def algorithmic_bytes(desc, width, height):
+    """Compulsory HBM bytes of one frame: the W*H*3 f64 canvas written once plus every scene table read
+    once (DESIGN.md "Algorithmic bytes").  Everything else the reference's traversal touches per ray is
+    re-use of those tables: for cover.json 19 leaves x 128 B per ray out of a ~10 KB scene that the
+    kernel keeps in LDS."""
+    scene = (desc.n_xforms * 96 + desc.n_leaves * 16 + desc.n_tris * 144 + desc.n_nodes * 56 + desc.n_children * 4 +
+             desc.n_materials * 64 + desc.n_patterns * 144 + desc.n_lights * 48 + desc.n_roots * 176)
+    return 24 * width * height + scene
+
+
+def scene_bytes_touched(desc, stats):
+    """SURVEY 8(d) per-ray figure for scenes without groups: every ray (incl. every isShadowed ray) of the
+    REFERENCE traversal reads every leaf's 128-B inverse.  Cache-level re-use, not HBM traffic."""
     rays = stats["primary"] + stats["secondary"] + stats["shadow_calls"]
-    return 24 * width * height + 128 * desc.n_leaves * rays if desc.n_nodes == 0 else None
+    return 128 * desc.n_leaves * rays if desc.n_nodes == 0 else None
+
+
+def measured_traffic(scene, width, height, depth):
+    """HBM bytes per launch from the PMC passes of the latest committed profile (FETCH_SIZE x2 as the
+    MI355X guide prescribes for gfx950, WRITE_SIZE exact), if that profile is of this workload."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except OSError:
+        return None
+    if [t.get("scene"), t.get("width"), t.get("height"), t.get("depth")] != [scene, width, height, depth]:
+        return None
+    return 2 * 1024 * t["fetch_size_kb"] + 1024 * t["write_size_kb"]
 
 
 def algorithmic_flops(desc, hs, stats):
@@ -218,24 +239,26 @@ def main():
                        "mrays_per_s_incl_shadow": (rays + stats["shadow_calls"]) * args.steps / elapsed / 1e6},
         }
         if world == 1:
-            ab = algorithmic_bytes(hs.desc, stats, W, H)
+            ab = algorithmic_bytes(hs.desc, W, H)
             fl = algorithmic_flops(hs.desc, hs, stats)
-            if ab is not None:
-                result["roofline"] = {
-                    "bound": "hbm", "achieved": ab / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ab / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                    "kernel": "rtc_render_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
-                    "note": "algorithmic bytes follow SURVEY 8(d) (reference traversal: every ray reads every "
-                            "leaf's 128-B inverse); the scene is ~10 KB and stays in the scalar cache/L2, so the "
-                            "compulsory HBM traffic is the 24*W*H framebuffer write; the binding limit is the FP64 "
-                            "vector rate, see roofline_valu",
-                }
+            gbs = ab / (kernel_ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": measured_traffic(args.scene, W, H, args.depth),
+                "kernel": "rtc_render_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
+                "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
+                "note": "HBM is NOT what binds this kernel: the compulsory traffic is the canvas (24*W*H B) plus "
+                        "a few KB of scene tables that live in LDS; the binding limit is FP64 vector issue, see "
+                        "roofline_valu.  `traffic` is FETCH_SIZE*2 + WRITE_SIZE of profiles/ (separate PMC passes).",
+            }
+            if fl is not None:
+                tf = fl / (kernel_ms * 1e-3) / 1e12
                 result["roofline_valu"] = {
-                    "bound": "valu_fp64", "achieved": fl / (kernel_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": fl / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,
-                    "algorithmic_flops": fl,
-                    "note": "peak counts an FMA as 2 flops; the path runs with FMA contraction OFF to round like "
-                            "the reference, so separate mul/add can reach at most half of it",
+                    "bound": "valu_fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": tf / FP64_VECTOR_PEAK_TF, "algorithmic_flops": fl,
+                    "note": "flops of the REFERENCE algorithm (SURVEY 8(d) table: every ray tests every leaf); the "
+                            "kernel skips most of them by bounding-sphere rejection.  Peak counts an FMA as 2 "
+                            "flops; the path runs with FMA contraction OFF to round like the reference.",
                 }
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)
