@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-path", action="store_true",
+                    help="run the multi-GPU code path (tiles + gather + un-permute) even with one rank")
+    ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
     args = ap.parse_args()
 
     import numpy as np
@@ -131,8 +134,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.tile_path:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:   # single-process rehearsal of the tile path
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     hs = rtc.HostScene.from_file(args.scene)
@@ -145,7 +150,7 @@ def main():
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
-    if world == 1:
+    if world == 1 and not args.tile_path:
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
 
         def step(i):
@@ -198,8 +203,6 @@ def main():
     for i in range(args.steps):
         kernel_ev[i][0].record(stream)
         step(i)
-        if world > 1:
-            pass
         kernel_ev[i][1].record(stream)
     finish()
     barrier()
@@ -217,6 +220,13 @@ def main():
         stats = dict(zip(["primary", "secondary", "shadow_calls", "shadow_traced"], [int(x) for x in v.tolist()]))
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev]))   # HIP events on the launch stream
 
+    if args.check and rank == 0:
+        ref = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+        gpu.render_device(cam, ref.data_ptr(), args.depth, None, sptr)
+        torch.cuda.synchronize()
+        if not torch.equal(ref, canvas):
+            raise SystemExit("tile path result differs from the plain render")
+        print("check ok: assembled canvas == plain render", file=sys.stderr)
     if rank == 0:
         rays = stats["primary"] + stats["secondary"]
         ms_per_step = elapsed * 1e3 / args.steps
@@ -238,7 +248,7 @@ def main():
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
                        "mrays_per_s_incl_shadow": (rays + stats["shadow_calls"]) * args.steps / elapsed / 1e6},
         }
-        if world == 1:
+        if world == 1 and not args.tile_path:
             ab = algorithmic_bytes(hs.desc, W, H)
             fl = algorithmic_flops(hs.desc, hs, stats)
             gbs = ab / (kernel_ms * 1e-3) / 1e9
