@@ -275,7 +275,7 @@ DevCamera devCamera(const rtc_camera& c) {
 }
 
 int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, double* d_out,
-           hipStream_t stream) {
+           size_t out_pixels, hipStream_t stream) {
   if (max_depth > RTC_MAX_DEPTH)
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
@@ -287,6 +287,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t
   const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   const uint32_t blocks = std::max(1u, std::min(resident, (map.n_chunks + 3u) / 4u));
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
+  HIP_TRY(hipMemsetAsync(&s->d_stats->prof_t0, 0xFF, sizeof(unsigned long long), stream));
+  // the kernel ADDS each lane's share of a pixel (shares of one ray tree may finish in several lanes)
+  HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
   if (lds) {
     hipLaunchKernelGGL(rtc_render_kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth,
                        d_out, s->d_stats);
@@ -603,7 +606,8 @@ int rtc_render_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, u
   DevPixelMap map;
   st = buildPixelMapRect(*cam, x0, y0, w, h, map);
   if (st != RTC_OK) return st;
-  return launch(s, *cam, map, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+  return launch(s, *cam, map, max_depth, d_rgb_out, static_cast<size_t>(w) * h,
+                hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
 }
 
 int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t tile_w, uint32_t tile_h,
@@ -633,7 +637,8 @@ int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_de
   const uint64_t total_chunks = static_cast<uint64_t>(map.chunks_per_region) * n_my_tiles;
   if (total_chunks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "%llu chunks", (unsigned long long)total_chunks);
   map.n_chunks = static_cast<uint32_t>(total_chunks);
-  return launch(s, *cam, map, max_depth, d_rgb_out, hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+  return launch(s, *cam, map, max_depth, d_rgb_out, static_cast<size_t>(n_my_tiles) * tile_w * tile_h,
+                hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
 }
 
 int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
@@ -679,7 +684,8 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   if (getenv("RTC_PROFILE_DUMP")) {  // diagnostic builds (-DRTC_PROFILE) only
     std::fprintf(stderr, "rtc prof:");
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", h.prof[i]);
-    std::fprintf(stderr, "\n");
+    std::fprintf(stderr, " | wave lifetime min %llu max %llu sum %llu | stolen %u\n", h.prof_t0, h.prof_t1, h.prof_busy,
+                 h.stolen);
   }
   return RTC_OK;
 }

@@ -118,6 +118,7 @@ struct DevPixelMap {
 struct DevStats {  // zeroed before every launch; counters get one atomic per wave
   unsigned long long primary, secondary, shadow_calls, shadow_traced, overflow;
   unsigned int next_chunk;  // work counter of the persistent waves
-  unsigned int pad;
+  unsigned int stolen;      // rays handed from one lane to another (diagnostic)
   unsigned long long prof[8];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
+  unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
 };

@@ -580,6 +580,12 @@ struct Pending {
   uint32_t remaining;
 };
 
+// One ray in flight between two lanes of a wave, with the canvas pixel its colour is added to.
+struct Mail {
+  Pending p;
+  size_t out_index;
+};
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   unsigned long long s = v;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -609,6 +615,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   __shared__ DevMaterial lds_mat[LDS ? RTC_LDS_MATERIALS : 1];
   __shared__ DevPattern lds_pat[LDS ? RTC_LDS_PATTERNS : 1];
   __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
+  __shared__ Mail lds_mail[4][64];  // per wave: rays handed from busy lanes to idle ones
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCull* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -645,36 +652,73 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   bool has_pixel = false, have_cur = false;
   size_t out_index = 0;
   double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
-  unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0;
+  unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
   cur.ray = {0, 0, 0, 0, 0, 0};
   cur.weight = 0.0;
   cur.remaining = 0u;
+  // The lane's pending refraction siblings: a deque.  The lane itself pops the newest entry (depth
+  // first); an idle neighbour may take the OLDEST one (the largest sub-tree) through the mailbox.
   Pending stack[RTC_RAY_STACK];
-  int sp = 0;
+  int sp = 0, base = 0;
+  Mail* const mailbox = lds_mail[threadIdx.x >> 6];
 
 #ifdef RTC_PROFILE
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long prof_start = prof_t;
   unsigned prof_sec = 0;
   unsigned long long prof_iters = 0;
 #endif
   for (;;) {
     RTC_STAMP(0);
-    // ---- 1. a lane without a ray pops its stack; an empty stack means its pixel is finished
+    // ---- 1. a lane without a ray pops its stack; an empty stack means its share of the pixel is done.
+    // Shares of one pixel may finish in several lanes (step 2a), so they are ADDED to the zeroed canvas.
     if (!have_cur) {
-      if (sp > 0) {
+      if (sp > base) {
         cur = stack[--sp];
         have_cur = true;
-      } else if (has_pixel) {
-        double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
-        o[0] = acc_r;
-        o[1] = acc_g;
-        o[2] = acc_b;
-        has_pixel = false;
+      } else {
+        sp = base = 0;
+        if (has_pixel) {
+          double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
+          atomicAdd(o + 0, acc_r);
+          atomicAdd(o + 1, acc_g);
+          atomicAdd(o + 2, acc_b);
+          has_pixel = false;
+        }
       }
     }
-    // ---- 2. deal new pixels to the lanes that want one
+    // ---- 2a. work sharing inside the wave: an idle lane takes the oldest pending ray (the root of the
+    // largest unexplored sub-tree) of a busy lane.  Without this a pixel whose ray tree has 2^(depth+1)-1
+    // nodes occupies ONE lane for that many iterations.
+    {
+      const bool idle = !have_cur;
+      const bool donor = have_cur && sp > base;
+      const unsigned long long imask = __ballot(idle), dmask = __ballot(donor);
+      if (imask != 0ull && dmask != 0ull) {
+        const uint32_t pairs = min(static_cast<uint32_t>(__builtin_popcountll(imask)),
+                                   static_cast<uint32_t>(__builtin_popcountll(dmask)));
+        const uint32_t irank = static_cast<uint32_t>(__builtin_popcountll(imask & lanes_below));
+        const uint32_t drank = static_cast<uint32_t>(__builtin_popcountll(dmask & lanes_below));
+        if (donor && drank < pairs) {
+          mailbox[drank].p = stack[base++];
+          mailbox[drank].out_index = out_index;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (idle && irank < pairs) {
+          cur = mailbox[irank].p;
+          out_index = mailbox[irank].out_index;
+          have_cur = true;
+          has_pixel = true;
+          acc_r = acc_g = acc_b = 0.0;
+          n_stolen++;
+        }
+      }
+    }
+    // ---- 2b. deal new pixels to the lanes that still want one
     bool want = !have_cur;
     unsigned long long wmask = __ballot(want);
     while (wmask) {
@@ -748,12 +792,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           out_index = oi;
           acc_r = acc_g = acc_b = 0.0;
           n_primary++;
-        } else if (in_buffer) {  // padding of an edge tile: defined as 0
-          double* __restrict__ o = out + 3 * oi;
-          o[0] = 0.0;
-          o[1] = 0.0;
-          o[2] = 0.0;
-        }
+        }  // pixels of an edge tile outside the image stay 0 (the canvas is zeroed before the launch)
       }
       chunk_pos += min(avail, static_cast<uint32_t>(__builtin_popcountll(wmask)));
       wmask = __ballot(want);
@@ -761,6 +800,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (!__any(have_cur)) break;
     if (!have_cur) continue;
     have_cur = false;  // `cur` is consumed; a spawned child may refill it below
+    cur.remaining = min(cur.remaining, max_depth);  // termination never depends on a value read back from memory
     const Ray ray = cur.ray;
 
     // ---- World.colorAt: intersect + hit (world.zig:111-115)
@@ -916,8 +956,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           lvy = vy / distance;
           lvz = vz / distance;
         }
+        // With light_dot_normal < 0 (light behind the surface) lighting() returns `ambient` shadowed
+        // or not (material.zig:62-73): that shadow ray cannot change the result either.
+        const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
         bool shadowed = false;
-        if (shadow_matters) {
+        if (shadow_matters && light_dot_normal >= 0.0) {
           n_shadow_traced++;
           ShadowVisitor sv;
           sv.distance = distance;
@@ -932,7 +975,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         double lr_ = er * mat.ambient, lg_ = eg * mat.ambient, lb_ = eb * mat.ambient;
         if (!shadowed) {
           double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
-          const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
           if (light_dot_normal >= 0.0) {
             const double kd = mat.diffuse * light_dot_normal;
             dr = er * kd;
@@ -1051,8 +1093,12 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 #ifdef RTC_PROFILE
   RTC_STAMP(7);
   prof_acc[7] = prof_iters;  // slot 7 reports main-loop iterations (wave-level), not cycles
-  if (lane == 0u)
+  if (lane == 0u) {
     for (int i = 0; i < 8; ++i) atomicAdd(&stats->prof[i], prof_acc[i]);
+    atomicMin(&stats->prof_t0, prof_t - prof_start);  // shortest / longest wave lifetime (s_memtime is
+    atomicMax(&stats->prof_t1, prof_t - prof_start);  // per-XCD: only differences within a wave are meaningful)
+    atomicAdd(&stats->prof_busy, prof_t - prof_start);
+  }
 #endif
   // one atomic per counter per wave
   const unsigned long long s_pri = wave_sum(n_primary);
@@ -1067,6 +1113,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     atomicAdd(&stats->shadow_traced, s_sht);
     if (s_ovf) atomicAdd(&stats->overflow, s_ovf);
   }
+  const unsigned long long s_stolen = wave_sum(n_stolen);
+  if (lane == 0u && s_stolen) atomicAdd(&stats->stolen, static_cast<unsigned int>(s_stolen));
 }
 
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)

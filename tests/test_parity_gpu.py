@@ -14,6 +14,9 @@ import oracle_binding as ob
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+# Two renders of the same frame agree to the last bits, not bitwise: a pixel whose ray tree is shared
+# between lanes is the SUM of the lanes' shares in completion order (f64 atomic adds).
+REPEAT_TOL = 1e-13
 
 # (scene, width, height, depth): sizes the oracle finishes in seconds
 CASES = [
@@ -67,7 +70,7 @@ def test_tile_render_matches_full_frame(rtc):
     for tile in [(0, 0, 120, 90), (7, 3, 50, 41), (119, 89, 1, 1), (0, 80, 120, 10)]:
         x0, y0, w, h = tile
         part = gpu.render(cam, 5, tile)
-        assert np.array_equal(part, full[y0:y0 + h, x0:x0 + w]), tile
+        assert np.abs(part - full[y0:y0 + h, x0:x0 + w]).max() < REPEAT_TOL, tile
 
 
 def test_interleaved_tiles_reassemble(rtc):
@@ -90,16 +93,21 @@ def test_interleaved_tiles_reassemble(rtc):
         torch.cuda.synchronize()
         gathered[rank] = buf.cpu().numpy()
     img = rtc.assemble_tiles(gathered, cam.hsize, cam.vsize, tw, th, world)
-    assert np.array_equal(img, full)
+    assert np.abs(img - full).max() < REPEAT_TOL
 
 
-def test_repeat_renders_are_deterministic(rtc):
+def test_repeat_renders_agree(rtc):
     hs = rtc.HostScene.from_file("reflection_and_refraction.json")
     cam = hs.camera(96, 54)
     gpu = rtc.GpuScene(hs.desc)
     a = gpu.render(cam, 5)
     b = gpu.render(cam, 5)
-    assert np.array_equal(a, b)
+    assert np.abs(a - b).max() < REPEAT_TOL
+    # a scene whose ray trees never branch (no transparent material) has nothing to share: bitwise equal
+    hs2 = rtc.HostScene.from_file("cubes.json")
+    gpu2 = rtc.GpuScene(hs2.desc)
+    cam2 = hs2.camera(120, 60)
+    assert np.array_equal(gpu2.render(cam2, 5), gpu2.render(cam2, 5))
 
 
 def test_default_world_kat_through_the_abi(rtc):
@@ -142,11 +150,11 @@ def test_full_size_cover_properties(rtc):
     assert st["primary"] == 1920 * 1080 and st["overflow"] == 0
     assert np.isfinite(full).all() and full.min() >= 0.0
     # idempotence
-    assert np.array_equal(full, gpu.render(cam, 5))
+    assert np.abs(full - gpu.render(cam, 5)).max() < REPEAT_TOL
     # tiles of the frame equal the frame (pixels are independent: camera.zig:116-121)
     for tile in [(640, 360, 333, 211), (0, 1079, 1920, 1)]:
         x0, y0, w, h = tile
-        assert np.array_equal(gpu.render(cam, 5, tile), full[y0:y0 + h, x0:x0 + w])
+        assert np.abs(gpu.render(cam, 5, tile) - full[y0:y0 + h, x0:x0 + w]).max() < REPEAT_TOL
     # depth linearity: depth 0 equals the surface term only, and is <= full colour where all weights >= 0
     d0 = gpu.render(cam, 0)
     assert gpu.stats()["secondary"] == 0
