@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <unordered_set>
@@ -60,6 +61,12 @@ struct DevBuf {
 
 }  // namespace
 
+// conservative world-space bounding sphere (see leafSphere below)
+struct Sphere {
+  double cx = 0, cy = 0, cz = 0, r = INFINITY;
+  bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
+};
+
 struct rtc_scene {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -78,6 +85,13 @@ struct rtc_scene {
   DevBuf<uint2> node_kids;
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
+  // heavy-first scheduling hint (see DevPixelMap::order)
+  std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
+  bool branching_everywhere = false;  // such a root without a finite bound
+  std::vector<uint32_t> h_order;
+  uint32_t* d_order = nullptr;
+  size_t order_capacity = 0;
+  std::vector<double> order_key;   // camera + map the cached order was built for
 };
 
 namespace {
@@ -85,11 +99,6 @@ namespace {
 // ---- conservative world-space bounding spheres for the root-loop rejection test ----------------
 // These only ever REMOVE work whose result is provably "no entry"; they are computed in plain double
 // arithmetic with an inflated radius, never feed a colour, and so need not follow reference rounding.
-struct Sphere {
-  double cx = 0, cy = 0, cz = 0, r = INFINITY;
-  bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
-};
-
 // Forward transform (object -> world) = inverse of the stored affine inverse; false if singular.
 bool forwardOf(const double* inv16, double M[12]) {
   const double a = inv16[0], b = inv16[1], c = inv16[2], d = inv16[4], e = inv16[5], f = inv16[6], g = inv16[8],
@@ -274,12 +283,88 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
-int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, double* d_out,
+// Heavy-first chunk order (DevPixelMap::order): chunks whose pixels may look straight at an object with a
+// branching material come first.  A heuristic on the host, cached per (camera, map); never affects results.
+int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_t stream) {
+  map.order = nullptr;
+  if (s->branching.empty() || s->branching_everywhere || map.n_chunks < 64) return RTC_OK;
+  std::vector<double> key{static_cast<double>(cam.hsize), static_cast<double>(cam.vsize), cam.half_width, cam.half_height,
+                          cam.pixel_size};
+  key.insert(key.end(), cam.inv_view, cam.inv_view + 16);
+  const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
+  for (size_t i = 0; i < offsetof(DevPixelMap, order) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
+  if (key == s->order_key && s->d_order) {
+    map.order = s->d_order;
+    return RTC_OK;
+  }
+  // forward view matrix (world -> camera)
+  double V[12];
+  if (!forwardOf(cam.inv_view, V)) return RTC_OK;
+  struct Box { double x0, x1, y0, y1; };  // pixel-space boxes of the branching objects
+  std::vector<Box> boxes;
+  for (const Sphere& sp : s->branching) {
+    const double X = V[0] * sp.cx + V[1] * sp.cy + V[2] * sp.cz + V[3];
+    const double Y = V[4] * sp.cx + V[5] * sp.cy + V[6] * sp.cz + V[7];
+    const double Z = V[8] * sp.cx + V[9] * sp.cy + V[10] * sp.cz + V[11];
+    const double depth = -Z;  // the camera looks down -z (camera.zig:70)
+    if (depth <= sp.r * 1.05) {
+      if (depth > -sp.r) return RTC_OK;  // the camera is inside / next to it: no useful order
+      continue;                           // entirely behind the camera
+    }
+    const double wx = X / depth, wy = Y / depth;
+    const double rho = sp.r / (depth - sp.r) * (1.0 + std::fmax(std::fabs(wx), std::fabs(wy))) * 1.25;
+    // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
+    boxes.push_back({(cam.half_width - (wx + rho)) / cam.pixel_size - 0.5, (cam.half_width - (wx - rho)) / cam.pixel_size - 0.5,
+                     (cam.half_height - (wy + rho)) / cam.pixel_size - 0.5, (cam.half_height - (wy - rho)) / cam.pixel_size - 0.5});
+  }
+  if (boxes.empty()) return RTC_OK;
+  std::vector<uint32_t>& order = s->h_order;
+  order.clear();
+  order.reserve(map.n_chunks);
+  std::vector<uint32_t> light;
+  light.reserve(map.n_chunks);
+  for (uint32_t c = 0; c < map.n_chunks; ++c) {
+    const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
+    const uint32_t ccy = cr / map.chunks_x;
+    double px0 = (cr - ccy * map.chunks_x) * 8.0, py0 = ccy * 8.0;
+    if (map.mode == 0u) {
+      px0 += map.x0;
+      py0 += map.y0;
+    } else {
+      const uint32_t tile = map.first_tile + region * map.tile_stride, ty = tile / map.tiles_x;
+      px0 += static_cast<double>(tile - ty * map.tiles_x) * map.tile_w;
+      py0 += static_cast<double>(ty) * map.tile_h;
+    }
+    bool heavy = false;
+    for (const Box& b : boxes) heavy = heavy || (px0 + 8.0 >= b.x0 && px0 <= b.x1 && py0 + 8.0 >= b.y0 && py0 <= b.y1);
+    (heavy ? order : light).push_back(c);
+  }
+  if (order.empty() || light.empty()) return RTC_OK;  // nothing to reorder
+  order.insert(order.end(), light.begin(), light.end());
+  if (order.size() > s->order_capacity) {
+    if (s->d_order) (void)hipFree(s->d_order);
+    s->d_order = nullptr;
+    s->order_capacity = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_order), order.size() * sizeof(uint32_t)));
+    s->order_capacity = order.size();
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  s->order_key = key;
+  map.order = s->d_order;
+  return RTC_OK;
+}
+
+int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
            size_t out_pixels, hipStream_t stream) {
+  DevPixelMap map = map_in;
   if (max_depth > RTC_MAX_DEPTH)
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
   HIP_TRY(hipSetDevice(s->device));
+  {
+    const int st = chunkOrder(s, cam, map, stream);
+    if (st != RTC_OK) return st;
+  }
   const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
   // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
@@ -429,6 +514,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     const uint32_t c = d.children[i];
     kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
   }
+  std::vector<Sphere> branching_spheres;
+  bool branching_everywhere = false;
   std::vector<RootRec> root_recs(d.n_roots);
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
   std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0, 0.0, 0.0, -INFINITY});
@@ -462,6 +549,26 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       sp = leafSphere(d, ref);
     }
     sp = inflate(sp);
+    {
+      // does anything under this root branch the ray tree (reflective AND transparent, world.zig:101-102)?
+      bool branches = false;
+      std::vector<uint32_t> todo{ref};
+      while (!todo.empty() && !branches) {
+        const uint32_t r = todo.back();
+        todo.pop_back();
+        if (r & RTC_CHILD_NODE_BIT) {
+          const uint32_t n = r & ~RTC_CHILD_NODE_BIT;
+          for (uint32_t k = 0; k < d.node_count[n]; ++k) todo.push_back(d.children[d.node_first[n] + k]);
+        } else {
+          const double* mp = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * d.leaf_material[r];
+          branches = mp[4] != 0.0 && mp[5] != 0.0;
+        }
+      }
+      if (branches) {
+        if (sp.finite()) branching_spheres.push_back(sp);
+        else branching_everywhere = true;
+      }
+    }
     RootCull& C = root_cull[i];
     C.cx = sp.finite() ? sp.cx : 0.0;
     C.cy = sp.finite() ? sp.cy : 0.0;
@@ -549,6 +656,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, sizeof(DevStats)));
   s->max_trav_stack = max_stack;
+  s->branching = branching_spheres;
+  s->branching_everywhere = branching_everywhere;
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -594,6 +703,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   }
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
+  if (s->d_order) (void)hipFree(s->d_order);
   delete s;
 }
 

@@ -113,6 +113,11 @@ struct DevPixelMap {
   uint32_t chunks_x;            // chunks per row of the rectangle / of one tile
   uint32_t chunks_per_region;   // chunks in the rectangle / in one tile
   uint32_t n_chunks;            // total
+  // Optional processing order (a permutation of 0..n_chunks-1): chunks that look at objects whose
+  // material branches the ray tree (reflective AND transparent) are handed out first, so the longest
+  // jobs start at t = 0 instead of becoming the tail of the launch.  Scheduling only: results do not
+  // depend on it.
+  const uint32_t* __restrict__ order;
 };
 
 struct DevStats {  // zeroed before every launch; counters get one atomic per wave

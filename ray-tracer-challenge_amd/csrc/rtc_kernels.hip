@@ -732,6 +732,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           break;
         }
         chunk_pos = 0u;
+        if (map.order != nullptr) c = map.order[c];
         // wave-uniform placement of the chunk, once per fetch (scalar unit)
         const uint32_t region = c / map.chunks_per_region;
         const uint32_t cr = c - region * map.chunks_per_region;
