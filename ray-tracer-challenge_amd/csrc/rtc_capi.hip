@@ -158,14 +158,37 @@ Sphere leafSphere(const rtc_scene_desc& d, uint32_t leaf) {
   const uint32_t g = d.leaf_geom[leaf];
   switch (d.leaf_kind[leaf]) {
     case RTC_SPHERE: {
-      // |M3 u| <= ||M3||_F for unit u
+      // radius = largest singular value of the 3x3 part = sqrt(largest eigenvalue of A = M3^T M3),
+      // from the closed-form (trigonometric) eigenvalues of a symmetric 3x3 matrix, with a margin;
+      // the Frobenius norm is an always-valid upper bound and caps it.
       double fro = 0;
       for (int k = 0; k < 3; ++k) fro += M[4 * k] * M[4 * k] + M[4 * k + 1] * M[4 * k + 1] + M[4 * k + 2] * M[4 * k + 2];
+      double A[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = M[i] * M[j] + M[4 + i] * M[4 + j] + M[8 + i] * M[8 + j];
+      double r2 = fro;
+      {
+        const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+        const double p2 = (A[0][0] - q) * (A[0][0] - q) + (A[1][1] - q) * (A[1][1] - q) + (A[2][2] - q) * (A[2][2] - q) + 2.0 * p1;
+        double lmax = q;
+        if (p2 > 0.0) {
+          const double pp = std::sqrt(p2 / 6.0);
+          double B[3][3];
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) B[i][j] = (A[i][j] - (i == j ? q : 0.0)) / pp;
+          const double detB = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                              B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+          const double rr = std::fmax(-1.0, std::fmin(1.0, detB / 2.0));
+          lmax = q + 2.0 * pp * std::cos(std::acos(rr) / 3.0);
+        }
+        if (std::isfinite(lmax) && lmax > 0.0) r2 = std::fmin(r2, lmax * (1.0 + 1e-6));
+      }
       Sphere s;
       s.cx = M[3];
       s.cy = M[7];
       s.cz = M[11];
-      s.r = std::sqrt(fro);
+      s.r = std::sqrt(r2);
       const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
       const Sphere box = sphereOfBox(M, lo, hi);  // also valid; keep the tighter one
       return (box.finite() && box.r < s.r) ? box : s;
@@ -287,6 +310,8 @@ DevCamera devCamera(const rtc_camera& c) {
 // branching material come first.  A heuristic on the host, cached per (camera, map); never affects results.
 int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_t stream) {
   map.order = nullptr;
+  map.n_units = map.n_chunks;
+  if (map.n_chunks >= 0x10000000u) return RTC_OK;  // chunk index must fit the 28-bit unit encoding
   if (s->branching.empty() || s->branching_everywhere || map.n_chunks < 64) return RTC_OK;
   std::vector<double> key{static_cast<double>(cam.hsize), static_cast<double>(cam.vsize), cam.half_width, cam.half_height,
                           cam.pixel_size};
@@ -295,6 +320,7 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   for (size_t i = 0; i < offsetof(DevPixelMap, order) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
   if (key == s->order_key && s->d_order) {
     map.order = s->d_order;
+    map.n_units = static_cast<uint32_t>(s->h_order.size());
     return RTC_OK;
   }
   // forward view matrix (world -> camera)
@@ -311,11 +337,20 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
       if (depth > -sp.r) return RTC_OK;  // the camera is inside / next to it: no useful order
       continue;                           // entirely behind the camera
     }
-    const double wx = X / depth, wy = Y / depth;
-    const double rho = sp.r / (depth - sp.r) * (1.0 + std::fmax(std::fabs(wx), std::fabs(wy))) * 1.25;
+    // silhouette of the sphere on the image plane z = -1: per axis the interval tan(theta -+ alpha)
+    auto extent = [&](double c, double& lo, double& hi) {
+      const double theta = std::atan2(c, depth);
+      const double alpha = std::asin(std::fmin(1.0, sp.r / std::sqrt(c * c + depth * depth)));
+      if (theta + alpha >= 1.5 || theta - alpha <= -1.5) return false;
+      lo = std::tan(theta - alpha);
+      hi = std::tan(theta + alpha);
+      return true;
+    };
+    double wx0, wx1, wy0, wy1;
+    if (!extent(X, wx0, wx1) || !extent(Y, wy0, wy1)) return RTC_OK;
     // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
-    boxes.push_back({(cam.half_width - (wx + rho)) / cam.pixel_size - 0.5, (cam.half_width - (wx - rho)) / cam.pixel_size - 0.5,
-                     (cam.half_height - (wy + rho)) / cam.pixel_size - 0.5, (cam.half_height - (wy - rho)) / cam.pixel_size - 0.5});
+    boxes.push_back({(cam.half_width - wx1) / cam.pixel_size - 1.5, (cam.half_width - wx0) / cam.pixel_size + 0.5,
+                     (cam.half_height - wy1) / cam.pixel_size - 1.5, (cam.half_height - wy0) / cam.pixel_size + 0.5});
   }
   if (boxes.empty()) return RTC_OK;
   std::vector<uint32_t>& order = s->h_order;
@@ -340,7 +375,22 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
     (heavy ? order : light).push_back(c);
   }
   if (order.empty() || light.empty()) return RTC_OK;  // nothing to reorder
-  order.insert(order.end(), light.begin(), light.end());
+  if (order.size() * 4 > map.n_chunks) {
+    // branching objects fill much of the view: plain heavy-first, whole chunks
+    order.insert(order.end(), light.begin(), light.end());
+  } else {
+    // heavy chunks as 8 row-units each, interleaved 1:1 with light chunks until either runs out
+    std::vector<uint32_t> heavy;
+    heavy.swap(order);
+    order.reserve(heavy.size() * 8 + light.size());
+    size_t li = 0;
+    for (uint32_t c : heavy)
+      for (uint32_t row = 0; row < 8; ++row) {
+        order.push_back(0x80000000u | (row << 28) | c);
+        if (li < light.size()) order.push_back(light[li++]);
+      }
+    for (; li < light.size(); ++li) order.push_back(light[li]);
+  }
   if (order.size() > s->order_capacity) {
     if (s->d_order) (void)hipFree(s->d_order);
     s->d_order = nullptr;
@@ -351,6 +401,7 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   HIP_TRY(hipMemcpyAsync(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   s->order_key = key;
   map.order = s->d_order;
+  map.n_units = static_cast<uint32_t>(order.size());
   return RTC_OK;
 }
 

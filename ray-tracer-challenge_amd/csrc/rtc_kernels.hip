@@ -643,7 +643,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
   // wave-uniform chunk cursor
-  uint32_t chunk_pos = 64u;
+  uint32_t chunk_pos = 64u, chunk_end = 64u;
   uint32_t chunk_rx0 = 0u, chunk_ry0 = 0u, chunk_px0 = 0u, chunk_py0 = 0u, chunk_w = 0u, chunk_h = 0u;
   size_t chunk_out0 = 0;
   bool drained = false;
@@ -722,17 +722,26 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     bool want = !have_cur;
     unsigned long long wmask = __ballot(want);
     while (wmask) {
-      if (chunk_pos >= 64u) {
+      if (chunk_pos >= chunk_end) {
         if (drained) break;
         uint32_t c = 0u;
         if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
         c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= map.n_chunks) {
+        if (c >= map.n_units) {
           drained = true;
           break;
         }
         chunk_pos = 0u;
-        if (map.order != nullptr) c = map.order[c];
+        chunk_end = 64u;
+        if (map.order != nullptr) {
+          // a unit of the schedule: a whole chunk, or (bit 31) one 8-pixel row of a heavy chunk
+          const uint32_t unit = map.order[c];
+          c = unit & 0x0FFFFFFFu;
+          if (unit & 0x80000000u) {
+            chunk_pos = ((unit >> 28) & 7u) * 8u;
+            chunk_end = chunk_pos + 8u;
+          }
+        }
         // wave-uniform placement of the chunk, once per fetch (scalar unit)
         const uint32_t region = c / map.chunks_per_region;
         const uint32_t cr = c - region * map.chunks_per_region;
@@ -755,7 +764,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           chunk_out0 = static_cast<size_t>(region) * map.tile_h * map.tile_w;
         }
       }
-      const uint32_t avail = 64u - chunk_pos;
+      const uint32_t avail = chunk_end - chunk_pos;
       const uint32_t rank = static_cast<uint32_t>(__builtin_popcountll(wmask & lanes_below));
       if (want && rank < avail) {
         const uint32_t k = chunk_pos + rank;  // pixel k of the 8x8 chunk

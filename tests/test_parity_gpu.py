@@ -104,9 +104,9 @@ def test_repeat_renders_agree(rtc):
     b = gpu.render(cam, 5)
     assert np.abs(a - b).max() < REPEAT_TOL
     # a scene whose ray trees never branch (no transparent material) has nothing to share: bitwise equal
-    hs2 = rtc.HostScene.from_file("cubes.json")
+    hs2 = rtc.HostScene.from_file("groups.json")
     gpu2 = rtc.GpuScene(hs2.desc)
-    cam2 = hs2.camera(120, 60)
+    cam2 = hs2.camera(150, 50)
     assert np.array_equal(gpu2.render(cam2, 5), gpu2.render(cam2, 5))
 
 
