@@ -114,12 +114,10 @@ struct DevPixelMap {
   uint32_t chunks_per_region;   // chunks in the rectangle / in one tile
   uint32_t n_chunks;            // total
   uint32_t n_units;             // entries the work counter runs over: n_chunks, or the length of `order`
-  // Optional schedule.  Each entry is a chunk (bits 0..27) or, with bit 31 set, ONE 8-pixel row (bits
-  // 28..30) of a chunk.  Chunks that look at objects whose material branches the ray tree (reflective
-  // AND transparent) are cut into rows and dealt one row per wave at the start of the launch, each
-  // followed by ordinary chunks: every wave gets a few deep ray trees early and many cheap pixels whose
-  // lanes, once idle, take over parts of those trees (work sharing).  Scheduling only: results do not
-  // depend on it.
+  // Optional schedule: a permutation of the chunks (an entry may also name ONE 8-pixel row of a chunk:
+  // bit 31 set, row in bits 28..30).  Chunks that look at objects whose material branches the ray tree
+  // (reflective AND transparent) are handed out first, so the longest jobs start at t = 0 instead of
+  // becoming the tail of the launch.  Scheduling only: results do not depend on it.
   const uint32_t* __restrict__ order;
 };
 
