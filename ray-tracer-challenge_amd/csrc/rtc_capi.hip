@@ -557,7 +557,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   bool branching_everywhere = false;
   std::vector<RootRec> root_recs(d.n_roots);
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
-  std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0, 0.0, 0.0, -INFINITY});
+  std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  float cull_cmax = 0.0f;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     RootRec& R = root_recs[i];
     std::memset(&R, 0, sizeof R);
@@ -609,10 +610,23 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       }
     }
     RootCull& C = root_cull[i];
-    C.cx = sp.finite() ? sp.cx : 0.0;
-    C.cy = sp.finite() ? sp.cy : 0.0;
-    C.cz = sp.finite() ? sp.cz : 0.0;
-    C.r2 = sp.finite() ? sp.r * sp.r : INFINITY;
+    if (sp.finite()) {
+      // FP32 copy: centre to nearest (its rounding is covered by the kernel's margin, which scales with
+      // max|c|), r^2 rounded UP after a further 1e-5 relative inflation
+      C.cx = static_cast<float>(sp.cx);
+      C.cy = static_cast<float>(sp.cy);
+      C.cz = static_cast<float>(sp.cz);
+      const double r2 = sp.r * sp.r * (1.0 + 1e-5);
+      float r2f = static_cast<float>(r2);
+      if (static_cast<double>(r2f) < r2) r2f = std::nextafterf(r2f, INFINITY);
+      C.r2 = r2f;
+      const float cm = static_cast<float>(std::sqrt(sp.cx * sp.cx + sp.cy * sp.cy + sp.cz * sp.cz) * (1.0 + 1e-6));
+      cull_cmax = std::fmax(cull_cmax, std::isfinite(cm) ? cm : 0.0f);
+      if (!std::isfinite(C.cx) || !std::isfinite(C.cy) || !std::isfinite(C.cz) || !std::isfinite(C.r2) || !std::isfinite(cm))
+        C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};  // out of FP32 range: no bound
+    } else {
+      C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};
+    }
   }
   auto rows12 = [](const double* src, uint32_t n) {
     std::vector<double> v(12ull * n);
@@ -728,6 +742,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.n_lights = d.n_lights;
   D.n_materials = d.n_materials;
   D.n_patterns = d.n_patterns;
+  D.cull_cmax = cull_cmax;
   guard.s = nullptr;
   *out = s;
   return RTC_OK;

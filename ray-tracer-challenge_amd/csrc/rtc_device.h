@@ -47,10 +47,10 @@ struct DevCyl {
 
 // One record per World.objects entry, flattened so the wave-uniform root loop needs no dependent
 // (pointer-chasing) loads.  Split in two tables, both staged once per work-group into LDS:
-//   RootCull  32 B  conservative world-space bounding sphere (r2 == +inf: no finite bound)
+//   RootCull  16 B  conservative world-space bounding sphere in FP32 (r2 == +inf: no finite bound)
 //   RootRec  144 B  what the exact test needs
 struct RootCull {
-  double cx, cy, cz, r2;
+  float cx, cy, cz, r2;  // centre rounded to nearest, r2 rounded UP; phase 1 of the root loop is FP32
 };
 struct RootRec {
   double inv[12];        // rows 0..2 of the leaf's inverse (unused for groups)
@@ -92,6 +92,7 @@ struct DevScene {
   const uint32_t* __restrict__ kids;
   const double* __restrict__ light;     // [n_lights][6]
   uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
+  float cull_cmax;  // max over bounded roots of |centre|: scale of the FP32 rounding margin
 };
 
 struct DevCamera {

@@ -295,33 +295,55 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
                [&](double t, double u, double v) { vis.entry(leaf, (meta.x >> 8) & 1u, meta.z, t, u, v); });
 }
 
-// Conservative bounding-sphere rejection for one World.objects entry.  Everything under the root lies
-// inside the sphere (radius inflated at upload), so if the LINE misses the sphere the root contributes
-// no entry at all; the visitor may additionally discard roots that cannot matter to it (entirely
-// behind the origin, entirely beyond its t range).  Tolerances are ~1e4 ulps of the terms involved.
-// Branch-free on purpose: phase 1 of trace() is a straight-line stream of LDS reads and DP math.
-// r2 == +inf (no finite bound) falls out as "keep" (c = -inf, disc = +inf) and the table padding
-// r2 == -inf as "cull" (disc = -inf) without special cases; NaNs compare false, i.e. keep.
+// Conservative bounding-sphere rejection for one World.objects entry, in FP32.
+// Everything under the root lies inside the sphere (radius inflated and rounded up at upload), so if the
+// LINE misses the sphere the root contributes no entry at all; the visitor may additionally discard
+// roots entirely behind the origin (closest hit, shadows) or entirely in front of it (containers pass).
+// FP32 is safe here because the test only ever REMOVES work and every comparison carries a margin T that
+// dominates the rounding of its operands: with S = |o| + max|c| the coordinates entering oc = c - o are
+// off by <= 1.2e-7 * S each, which perturbs b^2 - a*c and a*(oc^2 - r^2) by less than
+// 8e-6 * a * (oc^2 + S^2) = T  (>= 4e-6 * a * (|oc| + S)^2).  Far from the origin T grows and the test
+// merely rejects less.  Branch-free on purpose: phase 1 is a straight-line stream of LDS reads and
+// FP32 math (half the issue cost of FP64).  r2 == +inf (no finite bound) falls out as "keep", the table
+// padding r2 == -inf as "cull", NaNs compare false, i.e. keep.
+struct RayF {
+  float ox, oy, oz, dx, dy, dz, a, s2;
+};
+
+__device__ __forceinline__ RayF ray_f32(const Ray& r, float cmax) {
+  RayF f;
+  f.ox = static_cast<float>(r.ox);
+  f.oy = static_cast<float>(r.oy);
+  f.oz = static_cast<float>(r.oz);
+  f.dx = static_cast<float>(r.dx);
+  f.dy = static_cast<float>(r.dy);
+  f.dz = static_cast<float>(r.dz);
+  f.a = f.dx * f.dx + f.dy * f.dy + f.dz * f.dz;
+  const float s = __builtin_sqrtf(f.ox * f.ox + f.oy * f.oy + f.oz * f.oz) + cmax;
+  f.s2 = s * s;
+  return f;
+}
+
 template <class V>
-__device__ __forceinline__ bool root_culled(const RootCull& R, const Ray& ray, double a, double lim) {
-  const double ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
-  const double b = (ocx * ray.dx + ocy * ray.dy) + ocz * ray.dz;
-  const double oc2 = (ocx * ocx + ocy * ocy) + ocz * ocz;
-  const double c = oc2 - R.r2;
-  const double bb = b * b;
-  const double disc = bb - a * c;
-  const bool miss = disc < -1e-12 * (bb + a * oc2);  // the line misses the sphere
-  const bool outside = c > 0.0;                       // origin outside the sphere
-  const bool behind = outside & (b < 0.0);            // ... which lies entirely at t < 0
-  const bool front = outside & !(b < 0.0);            // ... entirely at t > 0, nearest point at
-  const double x = b - lim * a;                       //   t_near = (b - sqrt(disc)) / a;  t_near > lim <=> x > 0 && x^2 > disc
-  const bool beyond = front & (x > 0.0) & (x * x > disc * (1.0 + 1e-9) + 1e-12 * bb);
-  return miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly) | (beyond & !V::kBehindOnly);
+__device__ __forceinline__ bool root_culled(const RootCull& R, const RayF& ray) {
+  const float ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
+  const float b = ocx * ray.dx + ocy * ray.dy + ocz * ray.dz;
+  const float oc2 = ocx * ocx + ocy * ocy + ocz * ocz;
+  const float T = 8e-6f * ray.a * (oc2 + ray.s2);
+  const float c = oc2 - R.r2;
+  const float bb = b * b;
+  const float disc = bb - ray.a * c;
+  const bool miss = disc < -T;                          // the line misses the sphere
+  const bool outside = ray.a * c > T;                   // origin outside the sphere
+  const bool sided = outside & (bb > T);                // ... and the sphere clearly on one side of it
+  const bool behind = sided & (b < 0.0f);               // entirely at t < 0
+  const bool front = sided & (b > 0.0f);                // entirely at t > 0
+  return miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly);
 }
 
 // World.intersect's loop over World.objects (world.zig:74), two-phase so that no load depends on a
 // previous one and no lane waits for roots only its neighbours need:
-//   phase 1 streams the 32-byte bounding spheres of up to 64 roots (wave-uniform addresses) and
+//   phase 1 streams the 16-byte FP32 bounding spheres of up to 64 roots (wave-uniform addresses) and
 //           leaves one survivor bit per root in a per-lane mask;
 //   phase 2 lets every lane walk the set bits of ITS OWN mask and run the exact reference test on
 //           the 144-byte-strided root records (per-lane LDS addresses; the stride spreads the banks).
@@ -330,16 +352,15 @@ __device__ __forceinline__ bool root_culled(const RootCull& R, const Ray& ray, d
 template <class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
                                       const RootCull* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow) {
-  const double a = (ray.dx * ray.dx + ray.dy * ray.dy) + ray.dz * ray.dz;
+  const RayF rf = ray_f32(ray, S.cull_cmax);
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
     unsigned long long mine = 0ull;
-    const double lim = vis.t_limit();
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
     for (uint32_t i = 0; i < n; i += 4u) {
       const RootCull c0 = cull[base + i], c1 = cull[base + i + 1u], c2 = cull[base + i + 2u], c3 = cull[base + i + 3u];
-      const unsigned long long k0 = !root_culled<V>(c0, ray, a, lim), k1 = !root_culled<V>(c1, ray, a, lim);
-      const unsigned long long k2 = !root_culled<V>(c2, ray, a, lim), k3 = !root_culled<V>(c3, ray, a, lim);
+      const unsigned long long k0 = !root_culled<V>(c0, rf), k1 = !root_culled<V>(c1, rf);
+      const unsigned long long k2 = !root_culled<V>(c2, rf), k3 = !root_culled<V>(c3, rf);
       mine |= (k0 | (k1 << 1) | (k2 << 2) | (k3 << 3)) << i;
     }
     while (mine != 0ull && !vis.done()) {
