@@ -838,7 +838,7 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   if (!s || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipDeviceSynchronize());
-  DevStats h;
+  static DevStats h;  // large in diagnostic layouts: keep it off the stack
   HIP_TRY(hipMemcpy(&h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
   out->primary = h.primary;
   out->secondary = h.secondary;
@@ -848,8 +848,17 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   if (getenv("RTC_PROFILE_DUMP")) {  // diagnostic builds (-DRTC_PROFILE) only
     std::fprintf(stderr, "rtc prof:");
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", h.prof[i]);
-    std::fprintf(stderr, " | wave lifetime min %llu max %llu sum %llu | stolen %u\n", h.prof_t0, h.prof_t1, h.prof_busy,
-                 h.stolen);
+    std::fprintf(stderr, " | wave lifetime min %llu max %llu (last unit %llu) sum %llu | stolen %u\n", h.prof_t0,
+                 h.prof_t1 >> 24, h.prof_t1 & 0xFFFFFFull, h.prof_busy, h.stolen);
+    if (const char* path = getenv("RTC_PROFILE_LOG")) {
+      if (FILE* f = std::fopen(path, "w")) {
+        for (int i = 0; i < 4096; ++i)
+          if (h.prof_log[i][0])
+            std::fprintf(f, "%d %llu %llu %llu %llu %llu\n", i, h.prof_log[i][0], h.prof_log[i][1], h.prof_log[i][2],
+                         h.prof_log[i][3] >> 32, h.prof_log[i][3] & 0xFFFFFFFFull);
+        std::fclose(f);
+      }
+    }
   }
   return RTC_OK;
 }

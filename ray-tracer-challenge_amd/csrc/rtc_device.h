@@ -128,4 +128,5 @@ struct DevStats {  // zeroed before every launch; counters get one atomic per wa
   unsigned int stolen;      // rays handed from one lane to another (diagnostic)
   unsigned long long prof[8];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
+  unsigned long long prof_log[4096][4];            // per wave: lifetime, iterations, units, first<<32|last unit
 };

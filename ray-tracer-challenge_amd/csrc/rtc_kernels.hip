@@ -689,7 +689,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   unsigned long long prof_t = __builtin_amdgcn_s_memtime();
   const unsigned long long prof_start = prof_t;
   unsigned prof_sec = 0;
-  unsigned long long prof_iters = 0;
+  unsigned long long prof_iters = 0, prof_units = 0;
+  unsigned prof_last_unit = 0, prof_first_unit = 0;
 #endif
   for (;;) {
     RTC_STAMP(0);
@@ -754,6 +755,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         }
         chunk_pos = 0u;
         chunk_end = 64u;
+#ifdef RTC_PROFILE
+        prof_last_unit = c;
+        if (prof_units == 0ull) prof_first_unit = c;
+        prof_units += 1ull;
+#endif
         if (map.order != nullptr) {
           // a unit of the schedule: a whole chunk, or (bit 31) one 8-pixel row of a heavy chunk
           const uint32_t unit = map.order[c];
@@ -1127,8 +1133,13 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   if (lane == 0u) {
     for (int i = 0; i < 8; ++i) atomicAdd(&stats->prof[i], prof_acc[i]);
     atomicMin(&stats->prof_t0, prof_t - prof_start);  // shortest / longest wave lifetime (s_memtime is
-    atomicMax(&stats->prof_t1, prof_t - prof_start);  // per-XCD: only differences within a wave are meaningful)
+    atomicMax(&stats->prof_t1, ((prof_t - prof_start) << 24) | (prof_last_unit & 0xFFFFFFull));  // longest wave + its last unit
     atomicAdd(&stats->prof_busy, prof_t - prof_start);
+    const unsigned wid = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 4095u;
+    stats->prof_log[wid][0] = prof_t - prof_start;
+    stats->prof_log[wid][1] = prof_iters;
+    stats->prof_log[wid][2] = prof_units;
+    stats->prof_log[wid][3] = (static_cast<unsigned long long>(prof_first_unit) << 32) | prof_last_unit;
   }
 #endif
   // one atomic per counter per wave
