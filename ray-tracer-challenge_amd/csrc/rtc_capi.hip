@@ -86,6 +86,8 @@ struct rtc_scene {
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
   // heavy-first scheduling hint (see DevPixelMap::order)
+  std::vector<Sphere> occupied;    // bounding spheres of every bounded root
+  bool unbounded_nonplane = false; // a root other than a plane without a finite bound (cannot be projected)
   std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
   bool branching_everywhere = false;  // such a root without a finite bound
   std::vector<uint32_t> h_order;
@@ -312,12 +314,15 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   map.order = nullptr;
   map.n_units = map.n_chunks;
   if (map.n_chunks >= 0x10000000u) return RTC_OK;  // chunk index must fit the 28-bit unit encoding
-  if (s->branching.empty() || s->branching_everywhere || map.n_chunks < 64) return RTC_OK;
+  if (map.n_chunks < 64) return RTC_OK;
+  const bool rank_heavy = !s->branching.empty() && !s->branching_everywhere;
+  const bool rank_trivial = !s->occupied.empty() && !s->unbounded_nonplane;
+  if (!rank_heavy && !rank_trivial) return RTC_OK;
   std::vector<double> key{static_cast<double>(cam.hsize), static_cast<double>(cam.vsize), cam.half_width, cam.half_height,
                           cam.pixel_size};
   key.insert(key.end(), cam.inv_view, cam.inv_view + 16);
   const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
-  for (size_t i = 0; i < offsetof(DevPixelMap, order) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
+  for (size_t i = 0; i < offsetof(DevPixelMap, n_units) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
   if (key == s->order_key && s->d_order) {
     map.order = s->d_order;
     map.n_units = static_cast<uint32_t>(s->h_order.size());
@@ -326,38 +331,46 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   // forward view matrix (world -> camera)
   double V[12];
   if (!forwardOf(cam.inv_view, V)) return RTC_OK;
-  struct Box { double x0, x1, y0, y1; };  // pixel-space boxes of the branching objects
-  std::vector<Box> boxes;
-  for (const Sphere& sp : s->branching) {
-    const double X = V[0] * sp.cx + V[1] * sp.cy + V[2] * sp.cz + V[3];
-    const double Y = V[4] * sp.cx + V[5] * sp.cy + V[6] * sp.cz + V[7];
-    const double Z = V[8] * sp.cx + V[9] * sp.cy + V[10] * sp.cz + V[11];
-    const double depth = -Z;  // the camera looks down -z (camera.zig:70)
-    if (depth <= sp.r * 1.05) {
-      if (depth > -sp.r) return RTC_OK;  // the camera is inside / next to it: no useful order
-      continue;                           // entirely behind the camera
+  struct Box { double x0, x1, y0, y1; };  // pixel-space boxes of projected bounding spheres
+  // false: the sphere cannot be projected (camera inside / next to it): give up on that ranking
+  auto project = [&](const std::vector<Sphere>& spheres, std::vector<Box>& boxes) {
+    for (const Sphere& sp : spheres) {
+      const double X = V[0] * sp.cx + V[1] * sp.cy + V[2] * sp.cz + V[3];
+      const double Y = V[4] * sp.cx + V[5] * sp.cy + V[6] * sp.cz + V[7];
+      const double Z = V[8] * sp.cx + V[9] * sp.cy + V[10] * sp.cz + V[11];
+      const double depth = -Z;  // the camera looks down -z (camera.zig:70)
+      if (depth <= sp.r * 1.05) {
+        if (depth > -sp.r) return false;
+        continue;  // entirely behind the camera
+      }
+      // silhouette of the sphere on the image plane z = -1: per axis the interval tan(theta -+ alpha)
+      auto extent = [&](double c, double& lo, double& hi) {
+        const double theta = std::atan2(c, depth);
+        const double alpha = std::asin(std::fmin(1.0, sp.r / std::sqrt(c * c + depth * depth)));
+        if (theta + alpha >= 1.5 || theta - alpha <= -1.5) return false;
+        lo = std::tan(theta - alpha);
+        hi = std::tan(theta + alpha);
+        return true;
+      };
+      double wx0, wx1, wy0, wy1;
+      if (!extent(X, wx0, wx1) || !extent(Y, wy0, wy1)) return false;
+      // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
+      boxes.push_back({(cam.half_width - wx1) / cam.pixel_size - 1.5, (cam.half_width - wx0) / cam.pixel_size + 0.5,
+                       (cam.half_height - wy1) / cam.pixel_size - 1.5, (cam.half_height - wy0) / cam.pixel_size + 0.5});
     }
-    // silhouette of the sphere on the image plane z = -1: per axis the interval tan(theta -+ alpha)
-    auto extent = [&](double c, double& lo, double& hi) {
-      const double theta = std::atan2(c, depth);
-      const double alpha = std::asin(std::fmin(1.0, sp.r / std::sqrt(c * c + depth * depth)));
-      if (theta + alpha >= 1.5 || theta - alpha <= -1.5) return false;
-      lo = std::tan(theta - alpha);
-      hi = std::tan(theta + alpha);
-      return true;
-    };
-    double wx0, wx1, wy0, wy1;
-    if (!extent(X, wx0, wx1) || !extent(Y, wy0, wy1)) return RTC_OK;
-    // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
-    boxes.push_back({(cam.half_width - wx1) / cam.pixel_size - 1.5, (cam.half_width - wx0) / cam.pixel_size + 0.5,
-                     (cam.half_height - wy1) / cam.pixel_size - 1.5, (cam.half_height - wy0) / cam.pixel_size + 0.5});
-  }
-  if (boxes.empty()) return RTC_OK;
+    return true;
+  };
+  std::vector<Box> heavy_boxes, any_boxes;
+  const bool have_heavy = rank_heavy && project(s->branching, heavy_boxes) && !heavy_boxes.empty();
+  const bool have_any = rank_trivial && project(s->occupied, any_boxes);
+  if (!have_heavy && !have_any) return RTC_OK;
+  // Longest-job-first: [chunks looking at a branching material][chunks looking at any bounded object]
+  // [chunks that can only see unbounded planes or nothing: one or two rays per pixel].  The launch ends
+  // when the LAST unit handed out is finished, so the cheapest work goes last.
   std::vector<uint32_t>& order = s->h_order;
   order.clear();
   order.reserve(map.n_chunks);
-  std::vector<uint32_t> light;
-  light.reserve(map.n_chunks);
+  std::vector<uint32_t> medium, trivial;
   for (uint32_t c = 0; c < map.n_chunks; ++c) {
     const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
     const uint32_t ccy = cr / map.chunks_x;
@@ -370,15 +383,24 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
       px0 += static_cast<double>(tile - ty * map.tiles_x) * map.tile_w;
       py0 += static_cast<double>(ty) * map.tile_h;
     }
-    bool heavy = false;
-    for (const Box& b : boxes) heavy = heavy || (px0 + 8.0 >= b.x0 && px0 <= b.x1 && py0 + 8.0 >= b.y0 && py0 <= b.y1);
-    (heavy ? order : light).push_back(c);
+    auto overlaps = [&](const std::vector<Box>& boxes) {
+      for (const Box& b : boxes)
+        if (px0 + 8.0 >= b.x0 && px0 <= b.x1 && py0 + 8.0 >= b.y0 && py0 <= b.y1) return true;
+      return false;
+    };
+    if (have_heavy && overlaps(heavy_boxes)) {
+      order.push_back(c);
+    } else if (!have_any || overlaps(any_boxes)) {
+      medium.push_back(c);
+    } else {
+      trivial.push_back(c);
+    }
   }
-  if (order.empty() || light.empty()) return RTC_OK;  // nothing to reorder
-  // Whole chunks, heavy first.  (Cutting heavy chunks into 8-pixel rows dealt one per wave balances
-  // better but was measured 15 % SLOWER on cover.json: every wave then pays the transparent-hit code
-  // paths in every iteration.  Coherent waves beat balanced waves with this kernel.)
-  order.insert(order.end(), light.begin(), light.end());
+  if (order.size() + trivial.size() == 0 || order.size() == map.n_chunks || medium.size() == map.n_chunks) return RTC_OK;
+  if (getenv("RTC_PROFILE_DUMP"))
+    std::fprintf(stderr, "rtc schedule: %zu heavy, %zu medium, %zu trivial chunks\n", order.size(), medium.size(), trivial.size());
+  order.insert(order.end(), medium.begin(), medium.end());
+  order.insert(order.end(), trivial.begin(), trivial.end());
   if (order.size() > s->order_capacity) {
     if (s->d_order) (void)hipFree(s->d_order);
     s->d_order = nullptr;
@@ -553,8 +575,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     const uint32_t c = d.children[i];
     kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
   }
-  std::vector<Sphere> branching_spheres;
-  bool branching_everywhere = false;
+  std::vector<Sphere> branching_spheres, occupied_spheres;
+  bool branching_everywhere = false, unbounded_nonplane = false;
   std::vector<RootRec> root_recs(d.n_roots);
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
   std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
@@ -607,6 +629,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       if (branches) {
         if (sp.finite()) branching_spheres.push_back(sp);
         else branching_everywhere = true;
+      }
+      if (sp.finite()) {
+        occupied_spheres.push_back(sp);
+      } else if ((ref & RTC_CHILD_NODE_BIT) || d.leaf_kind[ref] != RTC_PLANE) {
+        unbounded_nonplane = true;
       }
     }
     RootCull& C = root_cull[i];
@@ -711,6 +738,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   s->max_trav_stack = max_stack;
   s->branching = branching_spheres;
   s->branching_everywhere = branching_everywhere;
+  s->occupied = occupied_spheres;
+  s->unbounded_nonplane = unbounded_nonplane;
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));

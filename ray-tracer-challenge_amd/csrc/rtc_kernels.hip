@@ -757,7 +757,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         chunk_end = 64u;
 #ifdef RTC_PROFILE
         prof_last_unit = c;
-        if (prof_units == 0ull) prof_first_unit = c;
+        prof_first_unit = static_cast<unsigned>((__builtin_amdgcn_s_memtime() - prof_start) >> 8);  // time of the last fetch
         prof_units += 1ull;
 #endif
         if (map.order != nullptr) {
