@@ -93,7 +93,15 @@ struct rtc_scene {
   std::vector<uint32_t> h_order;
   uint32_t* d_order = nullptr;
   size_t order_capacity = 0;
-  std::vector<double> order_key;   // camera + map the cached order was built for
+  std::vector<double> order_key;   // camera + map the cached (heuristic) order was built for
+  // measured-cost feedback: per-chunk ray counts of the previous launch with the same pixel map
+  uint32_t* d_cost = nullptr;
+  size_t cost_capacity = 0;
+  std::vector<uint32_t> cost_key;  // pixel map the costs / the cost-sorted order belong to
+  std::vector<uint32_t> h_cost;
+  uint64_t launches_with_key = 0;
+  bool order_from_cost = false;
+  hipStream_t last_stream = nullptr;
 };
 
 namespace {
@@ -423,8 +431,58 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
   HIP_TRY(hipSetDevice(s->device));
   {
-    const int st = chunkOrder(s, cam, map, stream);
-    if (st != RTC_OK) return st;
+    // Schedule.  First launch with a pixel map: the geometric heuristic of chunkOrder().  From the second
+    // launch on: longest job first by the MEASURED per-chunk ray counts of the previous frame (refreshed on
+    // launch 2 and then every 64 launches: one stream sync, a 4-byte-per-chunk copy and a sort).  Frames
+    // of an interactive session (lib.zig's move/rotateCamera) change little from one to the next.
+    const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
+    std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
+    if (mkey != s->cost_key) {
+      s->cost_key = mkey;
+      s->launches_with_key = 0;
+      s->order_from_cost = false;
+    }
+    if (map.n_chunks > s->cost_capacity) {
+      if (s->d_cost) (void)hipFree(s->d_cost);
+      s->d_cost = nullptr;
+      s->cost_capacity = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+      s->cost_capacity = map.n_chunks;
+      s->launches_with_key = 0;
+    }
+    const bool refresh = map.n_chunks >= 64 && map.n_chunks < 0x10000000u &&
+                         (s->launches_with_key == 1 || (s->launches_with_key > 1 && s->launches_with_key % 64 == 0));
+    if (refresh) {
+      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      s->h_cost.resize(map.n_chunks);
+      HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      std::vector<uint32_t>& order = s->h_order;
+      order.resize(map.n_chunks);
+      for (uint32_t i = 0; i < map.n_chunks; ++i) order[i] = i;
+      const std::vector<uint32_t>& cost = s->h_cost;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+      if (order.size() > s->order_capacity) {
+        if (s->d_order) (void)hipFree(s->d_order);
+        s->d_order = nullptr;
+        s->order_capacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_order), order.size() * sizeof(uint32_t)));
+        s->order_capacity = order.size();
+      }
+      HIP_TRY(hipMemcpyAsync(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+      s->order_from_cost = true;
+      s->order_key.clear();  // the heuristic cache no longer describes d_order
+    }
+    if (s->order_from_cost) {
+      map.order = s->d_order;
+      map.n_units = map.n_chunks;
+    } else {
+      const int st = chunkOrder(s, cam, map, stream);
+      if (st != RTC_OK) return st;
+    }
+    map.cost = s->d_cost;
+    HIP_TRY(hipMemsetAsync(s->d_cost, 0, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), stream));
+    s->launches_with_key++;
+    s->last_stream = stream;
   }
   const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
@@ -787,6 +845,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->d_order) (void)hipFree(s->d_order);
+  if (s->d_cost) (void)hipFree(s->d_cost);
   delete s;
 }
 

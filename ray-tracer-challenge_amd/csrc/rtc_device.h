@@ -120,6 +120,9 @@ struct DevPixelMap {
   // (reflective AND transparent) are handed out first, so the longest jobs start at t = 0 instead of
   // becoming the tail of the launch.  Scheduling only: results do not depend on it.
   const uint32_t* __restrict__ order;
+  // Optional per-chunk cost output (rays traced for the chunk's pixels), zeroed before the launch; the
+  // host sorts the next frame's schedule by it (longest job first).
+  uint32_t* __restrict__ cost;
 };
 
 struct DevStats {  // zeroed before every launch; counters get one atomic per wave

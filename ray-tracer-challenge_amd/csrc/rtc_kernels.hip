@@ -605,6 +605,8 @@ struct Pending {
 struct Mail {
   Pending p;
   size_t out_index;
+  uint32_t chunk;  // chunk the pixel belongs to (per-chunk cost feedback)
+  uint32_t pad_;
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
@@ -664,7 +666,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
   // wave-uniform chunk cursor
-  uint32_t chunk_pos = 64u, chunk_end = 64u;
+  uint32_t chunk_pos = 64u, chunk_end = 64u, cur_chunk = 0u;
   uint32_t chunk_rx0 = 0u, chunk_ry0 = 0u, chunk_px0 = 0u, chunk_py0 = 0u, chunk_w = 0u, chunk_h = 0u;
   size_t chunk_out0 = 0;
   bool drained = false;
@@ -672,6 +674,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // per-lane pixel and ray state
   bool has_pixel = false, have_cur = false;
   size_t out_index = 0;
+  uint32_t my_chunk = 0u, share_rays = 0u;  // cost feedback: rays this lane spent on its share of the pixel
   double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
@@ -707,6 +710,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           atomicAdd(o + 0, acc_r);
           atomicAdd(o + 1, acc_g);
           atomicAdd(o + 2, acc_b);
+          if (map.cost != nullptr) atomicAdd(map.cost + my_chunk, share_rays);
+          share_rays = 0u;
           has_pixel = false;
         }
       }
@@ -726,6 +731,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (donor && drank < pairs) {
           mailbox[drank].p = stack[base++];
           mailbox[drank].out_index = out_index;
+          mailbox[drank].chunk = my_chunk;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -733,6 +739,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (idle && irank < pairs) {
           cur = mailbox[irank].p;
           out_index = mailbox[irank].out_index;
+          my_chunk = mailbox[irank].chunk;
           have_cur = true;
           has_pixel = true;
           acc_r = acc_g = acc_b = 0.0;
@@ -769,6 +776,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             chunk_end = chunk_pos + 8u;
           }
         }
+        cur_chunk = c;
         // wave-uniform placement of the chunk, once per fetch (scalar unit)
         const uint32_t region = c / map.chunks_per_region;
         const uint32_t cr = c - region * map.chunks_per_region;
@@ -827,6 +835,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           has_pixel = true;
           want = false;
           out_index = oi;
+          my_chunk = cur_chunk;
           acc_r = acc_g = acc_b = 0.0;
           n_primary++;
         }  // pixels of an edge tile outside the image stay 0 (the canvas is zeroed before the launch)
@@ -837,6 +846,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (!__any(have_cur)) break;
     if (!have_cur) continue;
     have_cur = false;  // `cur` is consumed; a spawned child may refill it below
+    share_rays++;
     cur.remaining = min(cur.remaining, max_depth);  // termination never depends on a value read back from memory
     const Ray ray = cur.ray;
 
