@@ -938,6 +938,8 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", h.prof[i]);
     std::fprintf(stderr, " | wave lifetime min %llu max %llu (last unit %llu) sum %llu | stolen %u\n", h.prof_t0,
                  h.prof_t1 >> 24, h.prof_t1 & 0xFFFFFFull, h.prof_busy, h.stolen);
+    std::fprintf(stderr, "rtc traces (invocations, lanes): closest %llu %llu | shadow %llu %llu | behind %llu %llu\n", h.prof2[0],
+                 h.prof2[1], h.prof2[2], h.prof2[3], h.prof2[4], h.prof2[5]);
     if (const char* path = getenv("RTC_PROFILE_LOG")) {
       if (FILE* f = std::fopen(path, "w")) {
         for (int i = 0; i < 4096; ++i)

@@ -130,6 +130,7 @@ struct DevStats {  // zeroed before every launch; counters get one atomic per wa
   unsigned int next_chunk;  // work counter of the persistent waves
   unsigned int stolen;      // rays handed from one lane to another (diagnostic)
   unsigned long long prof[8];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
+  unsigned long long prof2[8];  // trace invocations (wave level) and active lanes: closest, shadow, behind
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
   unsigned long long prof_log[4096][4];            // per wave: lifetime, iterations, units, first<<32|last unit
 };

@@ -45,8 +45,14 @@
     prof_t = now_;                                                         \
     prof_sec = (sec);                                                      \
   } while (0)
+#define RTC_COUNT(slot)                                                                 \
+  do {                                                                                  \
+    prof2[slot] += 1ull;                                                                \
+    prof2[(slot) + 1] += static_cast<unsigned long long>(__builtin_popcountll(__ballot(true))); \
+  } while (0)
 #else
 #define RTC_STAMP(sec) do { } while (0)
+#define RTC_COUNT(slot) do { } while (0)
 #endif
 
 #ifndef RTC_LB2
@@ -160,6 +166,7 @@ __device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy,
       }
       break;
     }
+#ifndef RTC_EXP_SMALL
     case 3: {  // cylinder.zig:53-98
       const double a = r.dx * r.dx + r.dz * r.dz;
       bool walls_done = false, caps = true;
@@ -240,7 +247,11 @@ __device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy,
       }
       break;
     }
+#endif
     default: {  // 4 triangle.zig:29-63, 5 triangle.zig:225-259 (Moller-Trumbore, left-handed cross)
+#ifdef RTC_EXP_SMALL
+      break;
+#endif
       const double p1x = T[0], p1y = T[1], p1z = T[2];
       const double e1x = T[3], e1y = T[4], e1z = T[5];
       const double e2x = T[6], e2y = T[7], e2z = T[8];
@@ -378,6 +389,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         continue;
       }
       vis.set_root(RTC_NO_LEAF);
+#ifdef RTC_EXP_SMALL
+      continue;
+#endif
       uint32_t cur_xf = 0xFFFFFFFFu;
       Ray lr = ray;
       uint32_t stack[RTC_TRAV_STACK];
@@ -693,6 +707,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   const unsigned long long prof_start = prof_t;
   unsigned prof_sec = 0;
   unsigned long long prof_iters = 0, prof_units = 0;
+  unsigned long long prof2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned prof_last_unit = 0, prof_first_unit = 0;
 #endif
   for (;;) {
@@ -707,10 +722,18 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sp = base = 0;
         if (has_pixel) {
           double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
+#ifdef RTC_EXP_STORE  // timing experiment only (wrong for shared pixels)
+          o[0] = acc_r;
+          o[1] = acc_g;
+          o[2] = acc_b;
+#else
           atomicAdd(o + 0, acc_r);
           atomicAdd(o + 1, acc_g);
           atomicAdd(o + 2, acc_b);
+#endif
+#ifndef RTC_EXP_NOCOST
           if (map.cost != nullptr) atomicAdd(map.cost + my_chunk, share_rays);
+#endif
           share_rays = 0u;
           has_pixel = false;
         }
@@ -856,6 +879,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     prof_iters += 1ull;
 #endif
     ClosestVisitor hv;
+    RTC_COUNT(0);
     trace(S, recs, cull, ray, hv, overflow);
     RTC_STAMP(2);
     if (hv.leaf == RTC_NO_LEAF) continue;  // black (world.zig:119)
@@ -1013,6 +1037,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           sv.distance = distance;
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
           RTC_STAMP(3);
+          RTC_COUNT(2);
           trace(S, recs, cull, sray, sv, overflow);
           RTC_STAMP(4);
           shadowed = sv.shadowed;
@@ -1066,6 +1091,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       BehindVisitor bv;
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
+      RTC_COUNT(4);
       trace(S, recs, cull, ray, bv, overflow);
       RTC_STAMP(6);
       bv.flush();
@@ -1145,6 +1171,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     atomicMin(&stats->prof_t0, prof_t - prof_start);  // shortest / longest wave lifetime (s_memtime is
     atomicMax(&stats->prof_t1, ((prof_t - prof_start) << 24) | (prof_last_unit & 0xFFFFFFull));  // longest wave + its last unit
     atomicAdd(&stats->prof_busy, prof_t - prof_start);
+    for (int i = 0; i < 8; ++i) atomicAdd(&stats->prof2[i], prof2[i]);
     const unsigned wid = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 4095u;
     stats->prof_log[wid][0] = prof_t - prof_start;
     stats->prof_log[wid][1] = prof_iters;
