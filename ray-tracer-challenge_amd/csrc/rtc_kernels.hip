@@ -318,7 +318,7 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
 // FP32 math (half the issue cost of FP64).  r2 == +inf (no finite bound) falls out as "keep", the table
 // padding r2 == -inf as "cull", NaNs compare false, i.e. keep.
 struct RayF {
-  float ox, oy, oz, dx, dy, dz, a, s2;
+  float ox, oy, oz, dx, dy, dz, a, s2, t_scale;
 };
 
 __device__ __forceinline__ RayF ray_f32(const Ray& r, float cmax) {
@@ -332,21 +332,23 @@ __device__ __forceinline__ RayF ray_f32(const Ray& r, float cmax) {
   f.a = f.dx * f.dx + f.dy * f.dy + f.dz * f.dz;
   const float s = __builtin_sqrtf(f.ox * f.ox + f.oy * f.oy + f.oz * f.oz) + cmax;
   f.s2 = s * s;
+  f.t_scale = 8e-6f * f.a;
   return f;
 }
 
 template <class V>
 __device__ __forceinline__ bool root_culled(const RootCull& R, const RayF& ray) {
+  // explicit FMAs: this file is compiled with contraction off for the FP64 path, but nothing here has
+  // to round like the reference
   const float ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
-  const float b = ocx * ray.dx + ocy * ray.dy + ocz * ray.dz;
-  const float oc2 = ocx * ocx + ocy * ocy + ocz * ocz;
-  const float T = 8e-6f * ray.a * (oc2 + ray.s2);
-  const float c = oc2 - R.r2;
+  const float b = __builtin_fmaf(ocx, ray.dx, __builtin_fmaf(ocy, ray.dy, ocz * ray.dz));
+  const float oc2 = __builtin_fmaf(ocx, ocx, __builtin_fmaf(ocy, ocy, ocz * ocz));
+  const float T = ray.t_scale * (oc2 + ray.s2);       // 8e-6 * a * (oc^2 + S^2)
+  const float ac = ray.a * (oc2 - R.r2);
   const float bb = b * b;
-  const float disc = bb - ray.a * c;
+  const float disc = bb - ac;
   const bool miss = disc < -T;                          // the line misses the sphere
-  const bool outside = ray.a * c > T;                   // origin outside the sphere
-  const bool sided = outside & (bb > T);                // ... and the sphere clearly on one side of it
+  const bool sided = (ac > T) & (bb > T);               // origin outside, sphere clearly on one side of it
   const bool behind = sided & (b < 0.0f);               // entirely at t < 0
   const bool front = sided & (b > 0.0f);                // entirely at t > 0
   return miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly);
