@@ -83,6 +83,8 @@ struct rtc_scene {
   DevBuf<DevCyl> cyl;
   DevBuf<DevMaterial> mat;
   DevBuf<uint2> node_kids;
+  DevBuf<BvhNode> bvh;
+  DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent;
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
   // heavy-first scheduling hint (see DevPixelMap::order)
@@ -236,6 +238,249 @@ Sphere inflate(Sphere s) {
   s.r = s.r * (1.0 + 1e-6) + 1e-9;
   return s;
 }
+
+
+// ---- candidate BVH (BvhNode, rtc_device.h) ------------------------------------------------------
+struct Aabb {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  void add(const double p[3]) {
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::fmin(lo[k], p[k]);
+      hi[k] = std::fmax(hi[k], p[k]);
+    }
+  }
+  void merge(const Aabb& o) {
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::fmin(lo[k], o.lo[k]);
+      hi[k] = std::fmax(hi[k], o.hi[k]);
+    }
+  }
+  bool finite() const {
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) return false;
+    return true;
+  }
+  double area() const {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+const float kHuge = 3.0e38f;  // "unbounded" in an FP32 box
+
+// World-space box of one leaf: the object-space box of the shape pushed through the forward transform.
+Aabb leafWorldBox(const rtc_scene_desc& d, uint32_t leaf) {
+  Aabb box;
+  double M[12];
+  if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[leaf], M)) return Aabb{};
+  auto addObjectBox = [&](const double lo[3], const double hi[3]) {
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
+        box = Aabb{};
+        return;
+      }
+    for (int c = 0; c < 8; ++c) {
+      const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+      double p[3];
+      for (int k = 0; k < 3; ++k) p[k] = M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3];
+      box.add(p);
+    }
+  };
+  const uint32_t g = d.leaf_geom[leaf];
+  switch (d.leaf_kind[leaf]) {
+    case RTC_SPHERE:
+    case RTC_CUBE: {
+      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+      addObjectBox(lo, hi);
+      break;
+    }
+    case RTC_CYLINDER: {
+      const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
+      addObjectBox(lo, hi);
+      break;
+    }
+    case RTC_CONE: {
+      const double lim = std::fmax(std::fabs(d.cyl_min[g]), std::fabs(d.cyl_max[g]));
+      const double lo[3] = {-lim, d.cyl_min[g], -lim}, hi[3] = {lim, d.cyl_max[g], lim};
+      addObjectBox(lo, hi);
+      break;
+    }
+    case RTC_TRIANGLE:
+    case RTC_SMOOTH_TRIANGLE:
+      for (int v = 0; v < 3; ++v) {
+        double q[3], p[3];
+        for (int k = 0; k < 3; ++k)
+          q[k] = d.tri_p1[3ull * g + k] + (v == 1 ? d.tri_e1[3ull * g + k] : 0.0) + (v == 2 ? d.tri_e2[3ull * g + k] : 0.0);
+        for (int k = 0; k < 3; ++k) p[k] = M[4 * k] * q[0] + M[4 * k + 1] * q[1] + M[4 * k + 2] * q[2] + M[4 * k + 3];
+        box.add(p);
+      }
+      break;
+    default: break;  // planes are unbounded
+  }
+  return box;
+}
+
+struct BvhPrim {
+  Aabb box;        // may be non-finite: treated as unbounded
+  double c[3];     // centroid (0 for unbounded)
+  uint32_t leaf;   // depth-first leaf index
+};
+
+struct BvhBuilder {
+  std::vector<BvhNode>& nodes;
+  std::vector<uint32_t>& leaves;
+  std::vector<BvhPrim> prims;
+  float mag = 0.0f;
+
+  static float down(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+  }
+  static float up(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
+    return f;
+  }
+  void storeBox(const Aabb& b, float lo[3], float hi[3]) {
+    if (!b.finite()) {
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = -kHuge;
+        hi[k] = kHuge;
+      }
+      return;
+    }
+    for (int k = 0; k < 3; ++k) {
+      // rounded outward plus a relative cushion; the kernel adds the ray-dependent part of the margin
+      const double pad = 1e-6 * (std::fabs(b.lo[k]) + std::fabs(b.hi[k])) + 1e-30;
+      lo[k] = down(b.lo[k] - pad);
+      hi[k] = up(b.hi[k] + pad);
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
+        lo[k] = -kHuge;
+        hi[k] = kHuge;
+      } else {
+        mag = std::fmax(mag, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
+      }
+    }
+  }
+  Aabb boundsOf(size_t first, size_t count) const {
+    Aabb b;
+    bool unbounded = false;
+    for (size_t i = first; i < first + count; ++i) {
+      if (!prims[i].box.finite()) unbounded = true;
+      else b.merge(prims[i].box);
+    }
+    if (unbounded) {
+      for (int k = 0; k < 3; ++k) {
+        b.lo[k] = -INFINITY;
+        b.hi[k] = INFINITY;
+      }
+    }
+    return b;
+  }
+  // returns the child reference for prims[first, first+count)
+  uint32_t build(size_t first, size_t count) {
+    if (count <= 4) {
+      const uint32_t at = static_cast<uint32_t>(leaves.size());
+      for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
+      return RTC_NODE_BIT | (at << 3) | static_cast<uint32_t>(count - 1);
+    }
+    // centroid bounds -> split axis; 16-bin SAH along it
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = first; i < first + count; ++i)
+      for (int k = 0; k < 3; ++k) {
+        clo[k] = std::fmin(clo[k], prims[i].c[k]);
+        chi[k] = std::fmax(chi[k], prims[i].c[k]);
+      }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+      if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    size_t mid = first + count / 2;
+    const double extent = chi[axis] - clo[axis];
+    bool split_done = false;
+    if (extent > 0.0 && std::isfinite(extent)) {
+      constexpr int kBins = 16;
+      Aabb bin_box[kBins];
+      size_t bin_n[kBins] = {};
+      auto binOf = [&](const BvhPrim& p) {
+        int b = static_cast<int>((p.c[axis] - clo[axis]) / extent * kBins);
+        return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+      };
+      for (size_t i = first; i < first + count; ++i) {
+        const int b = binOf(prims[i]);
+        bin_n[b]++;
+        if (prims[i].box.finite()) bin_box[b].merge(prims[i].box);
+      }
+      double right_area[kBins];
+      size_t right_n[kBins];
+      Aabb acc;
+      size_t n = 0;
+      for (int b = kBins - 1; b > 0; --b) {
+        acc.merge(bin_box[b]);
+        n += bin_n[b];
+        right_area[b] = acc.finite() ? acc.area() : 0.0;
+        right_n[b] = n;
+      }
+      acc = Aabb{};
+      n = 0;
+      double best = INFINITY;
+      int best_b = -1;
+      for (int b = 0; b < kBins - 1; ++b) {
+        acc.merge(bin_box[b]);
+        n += bin_n[b];
+        if (n == 0 || right_n[b + 1] == 0) continue;
+        const double cost = (acc.finite() ? acc.area() : 0.0) * n + right_area[b + 1] * right_n[b + 1];
+        if (cost < best) {
+          best = cost;
+          best_b = b;
+        }
+      }
+      if (best_b >= 0) {
+        auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
+                                 [&](const BvhPrim& p) { return binOf(p) <= best_b; });
+        mid = static_cast<size_t>(it - prims.begin());
+        split_done = mid > first && mid < first + count;
+      }
+    }
+    if (!split_done) {
+      mid = first + count / 2;
+      std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                       [&](const BvhPrim& a, const BvhPrim& b) { return a.c[axis] < b.c[axis]; });
+    }
+    const uint32_t me = static_cast<uint32_t>(nodes.size());
+    nodes.emplace_back();
+    const Aabb b0 = boundsOf(first, mid - first), b1 = boundsOf(mid, first + count - mid);
+    const uint32_t c0 = build(first, mid - first);
+    const uint32_t c1 = build(mid, first + count - mid);
+    BvhNode& N = nodes[me];
+    storeBox(b0, N.lo0, N.hi0);
+    storeBox(b1, N.lo1, N.hi1);
+    N.c0 = c0;
+    N.c1 = c1;
+    N.pad_[0] = N.pad_[1] = 0;
+    return me;
+  }
+  // root node index of a BVH over `items` (always a node, so the kernel can start from a node)
+  uint32_t buildRoot(std::vector<BvhPrim> items) {
+    prims = std::move(items);
+    const uint32_t me = static_cast<uint32_t>(nodes.size());
+    if (prims.size() > 4) return build(0, prims.size());
+    nodes.emplace_back();
+    BvhNode N;
+    std::memset(&N, 0, sizeof N);
+    for (int k = 0; k < 3; ++k) {  // empty boxes: never entered
+      N.lo0[k] = N.lo1[k] = kHuge;
+      N.hi0[k] = N.hi1[k] = -kHuge;
+    }
+    N.c0 = N.c1 = RTC_NO_LEAF;  // empty child
+    if (!prims.empty()) {
+      storeBox(boundsOf(0, prims.size()), N.lo0, N.hi0);
+      N.c0 = build(0, prims.size());
+    }
+    nodes[me] = N;
+    return me;
+  }
+};
 
 bool affineRow(const double* m16) {  // last row must be exactly (0,0,0,1); -0 is accepted
   return m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0;
@@ -633,6 +878,40 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     const uint32_t c = d.children[i];
     kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
   }
+  // reference-tree parents (for the box-chain re-check) and the candidate BVH of every group root
+  std::vector<uint32_t> leaf_parent(n_live, RTC_NO_LEAF), node_parent(d.n_nodes, RTC_NO_LEAF);
+  std::vector<BvhNode> bvh_nodes;
+  std::vector<uint32_t> bvh_leaves;
+  std::vector<uint32_t> bvh_root_of(d.n_roots, 0);
+  float bvh_mag = 0.0f;
+  for (uint32_t i = 0; i < d.n_roots; ++i) {
+    const uint32_t r = d.roots[i];
+    if (!(r & RTC_CHILD_NODE_BIT)) continue;
+    std::vector<BvhPrim> items;
+    std::vector<uint32_t> todo{r & ~RTC_CHILD_NODE_BIT};
+    while (!todo.empty()) {
+      const uint32_t n = todo.back();
+      todo.pop_back();
+      for (uint32_t k = 0; k < d.node_count[n]; ++k) {
+        const uint32_t c = d.children[d.node_first[n] + k];
+        if (c & RTC_CHILD_NODE_BIT) {
+          node_parent[c & ~RTC_CHILD_NODE_BIT] = n;
+          todo.push_back(c & ~RTC_CHILD_NODE_BIT);
+        } else {
+          leaf_parent[dfs_of[c]] = n;
+          BvhPrim p;
+          p.box = leafWorldBox(d, c);
+          for (int a = 0; a < 3; ++a) p.c[a] = p.box.finite() ? 0.5 * (p.box.lo[a] + p.box.hi[a]) : 0.0;
+          p.leaf = dfs_of[c];
+          items.push_back(p);
+        }
+      }
+    }
+    BvhBuilder builder{bvh_nodes, bvh_leaves};
+    bvh_root_of[i] = builder.buildRoot(std::move(items));
+    bvh_mag = std::fmax(bvh_mag, builder.mag);
+  }
+  if (bvh_leaves.size() >= (1u << 28)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the BVH leaf-range encoding", bvh_leaves.size());
   std::vector<Sphere> branching_spheres, occupied_spheres;
   bool branching_everywhere = false, unbounded_nonplane = false;
   std::vector<RootRec> root_recs(d.n_roots);
@@ -648,6 +927,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
       R.kind_flags = RTC_ROOT_IS_GROUP;
       R.index = n;
+      R.geom = bvh_root_of[i];
       // every entry of the group lies on a line that passes the group's own box test
       const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
       const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
@@ -790,6 +1070,10 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->pat.upload(pat));
   HIP_TRY(s->node_box.upload(node_box));
   HIP_TRY(s->node_kids.upload(node_kids));
+  HIP_TRY(s->bvh.upload(bvh_nodes));
+  HIP_TRY(s->bvh_leaf.upload(bvh_leaves));
+  HIP_TRY(s->leaf_parent.upload(leaf_parent));
+  HIP_TRY(s->node_parent.upload(node_parent));
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, sizeof(DevStats)));
@@ -819,6 +1103,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.trin = s->trin.p;
   D.mat = s->mat.p;
   D.pat = s->pat.p;
+  D.bvh = s->bvh.p;
+  D.bvh_leaf = s->bvh_leaf.p;
+  D.leaf_parent = s->leaf_parent.p;
+  D.node_parent = s->node_parent.p;
+  D.bvh_mag = bvh_mag;
   D.node_box = s->node_box.p;
   D.node_kids = s->node_kids.p;
   D.kids = s->kids.p;

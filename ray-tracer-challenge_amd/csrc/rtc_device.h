@@ -76,6 +76,18 @@ struct DevPattern {      // 144 B
   uint32_t pad_[3];
 };
 
+// Acceleration structure the kernel actually walks for a World.objects entry that is a Group: a binary
+// SAH BVH over the WORLD-space boxes of all leaves under that group, FP32, both child boxes in the
+// parent (one 64-byte fetch per step).  It only proposes candidates: a leaf's entries count only if the
+// ray also passes the exact reference box test of every reference Group above that leaf
+// (Group.localIntersect, group.zig:46-50), which is re-checked on the reference's own boxes.
+struct BvhNode {
+  float lo0[3], hi0[3];  // child 0
+  float lo1[3], hi1[3];  // child 1
+  uint32_t c0, c1;       // child: node index, RTC_NODE_BIT | first << 3 | (count - 1) into bvh_leaf[], or RTC_NO_LEAF (none)
+  uint32_t pad_[2];
+};
+
 struct DevScene {
   const RootRec* __restrict__ root_recs;
   const RootCull* __restrict__ root_cull;
@@ -87,12 +99,17 @@ struct DevScene {
   const double* __restrict__ trin;      // [n_tris][9]
   const DevMaterial* __restrict__ mat;
   const DevPattern* __restrict__ pat;
+  const BvhNode* __restrict__ bvh;      // all groups' BVHs; RootRec::geom = root node of a group's BVH
+  const uint32_t* __restrict__ bvh_leaf;   // leaf indices referenced by BvhNode leaf ranges
+  const uint32_t* __restrict__ leaf_parent;  // reference Group node directly above each leaf (RTC_NO_LEAF: none)
+  const uint32_t* __restrict__ node_parent;  // reference Group above each Group node (RTC_NO_LEAF: none)
   const double* __restrict__ node_box;  // [n_nodes][6]
   const uint2* __restrict__ node_kids;  // {first, count}
   const uint32_t* __restrict__ kids;
   const double* __restrict__ light;     // [n_lights][6]
   uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
   float cull_cmax;  // max over bounded roots of |centre|: scale of the FP32 rounding margin
+  float bvh_mag;    // max |coordinate| of any finite BVH box: scale of the FP32 traversal margin
 };
 
 struct DevCamera {

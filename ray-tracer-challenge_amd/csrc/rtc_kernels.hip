@@ -286,11 +286,39 @@ __device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy,
 // Box-interval culling is conservative by kBoxSlack: a box's [tmin,tmax] and a leaf's t are
 // computed by different roundings, so "entirely behind / beyond" is only trusted with slack.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double box_slack(double t) { return 1e-4 + 1e-6 * __builtin_fabs(t); }
 
+// The reference only records a leaf's entries if the ray's LINE passes the box of every Group above it
+// (Group.localIntersect, group.zig:46-50).  The kernel finds candidates through its own BVH, so before a
+// leaf may influence a visitor this chain of reference box tests is replayed, bottom-up, on the
+// reference's boxes.  Shortcut: if the candidate point o + t*d lies inside a box by a margin far above
+// rounding, the line passes through that box and every slab comparison of the reference test holds with
+// room to spare - unless a direction component is below the reference's 1e-5 "parallel" threshold, where
+// the reference test ignores the direction (bounding_box.zig:124-127); then the exact test is run.
+__device__ __forceinline__ bool chain_ok(const DevScene& S, uint32_t leaf, const Ray& ray, double t, bool degenerate) {
+  const double px = ray.ox + ray.dx * t, py = ray.oy + ray.dy * t, pz = ray.oz + ray.dz * t;
+  const double scale = zmax(zmax(__builtin_fabs(px), __builtin_fabs(py)), __builtin_fabs(pz)) +
+                       zmax(zmax(__builtin_fabs(ray.ox), __builtin_fabs(ray.oy)), __builtin_fabs(ray.oz));
+  const double m = 1e-9 * (1.0 + scale);
+  uint32_t n = S.leaf_parent[leaf];
+  while (n != RTC_NO_LEAF) {
+    const double* __restrict__ B = S.node_box + 6ull * n;
+    const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4], b5 = B[5];
+    const bool inside = !degenerate & (b0 + m <= px) & (px <= b3 - m) & (b1 + m <= py) & (py <= b4 - m) &
+                        (b2 + m <= pz) & (pz <= b5 - m);
+    if (!inside) {
+      double tmin, tmax;
+      if (!slab(ray, b0, b1, b2, b3, b4, b5, tmin, tmax)) return false;
+    }
+    n = S.node_parent[n];
+  }
+  return true;
+}
+
+// A leaf proposed by the BVH: run the exact reference test; if one of its entries could change the
+// visitor's state, replay the reference box chain, then hand the entries over.
 template <class V>
-__device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, const Ray& ray, uint32_t& cur_xf,
-                                           Ray& lr, V& vis) {
+__device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, const Ray& ray, bool degenerate,
+                                           uint32_t& cur_xf, Ray& lr, V& vis) {
   const uint4 meta = S.leaf_meta[leaf];
   if (meta.y != cur_xf) {  // Shape.intersect: ray.transform(_inverse_transform), shape.zig:314-318
     lr = xform_ray(S.xf + 12ull * meta.y, ray);
@@ -302,8 +330,79 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
     const DevCyl c = S.cyl[meta.w];
     cy = {c.ymin, c.ymax, c.closed != 0u};
   }
+  const uint32_t shadow = (meta.x >> 8) & 1u;
+  bool relevant = false;
+  double t_rel = 0.0;
+  leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr, [&](double t, double, double) {
+    if (!relevant && vis.relevant(leaf, shadow, t)) {
+      relevant = true;
+      t_rel = t;
+    }
+  });
+  if (!relevant) return;
+  if (!chain_ok(S, leaf, ray, t_rel, degenerate)) return;
   leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr,
-               [&](double t, double u, double v) { vis.entry(leaf, (meta.x >> 8) & 1u, meta.z, t, u, v); });
+               [&](double t, double u, double v) { vis.entry(leaf, shadow, meta.z, t, u, v); });
+}
+
+// Walks the candidate BVH of one group (BvhNode, rtc_device.h) with an FP32 copy of the ray.  The boxes
+// were rounded outward at upload; `delta` adds what the FP32 ray and slab arithmetic can be off by
+// (5e-7 * (|o| + largest box coordinate)), so a leaf whose exact test would produce an entry is never
+// skipped; visitors prune by t-interval with their own slack.
+template <class V>
+__device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, const Ray& ray, V& vis,
+                                             unsigned& overflow) {
+  const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
+  const float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
+  const float delta = 5e-7f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
+  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+  const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
+  // origin shifted against / along the direction: (near - on) and (far - of) grow the box by delta
+  const float onx = px ? ox + delta : ox - delta, ofx = px ? ox - delta : ox + delta;
+  const float ony = py ? oy + delta : oy - delta, ofy = py ? oy - delta : oy + delta;
+  const float onz = pz ? oz + delta : oz - delta, ofz = pz ? oz - delta : oz + delta;
+  const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
+  uint32_t cur_xf = 0xFFFFFFFFu;
+  Ray lr = ray;
+  uint32_t stack[RTC_TRAV_STACK];
+  int sp = 0;
+  stack[sp++] = root;
+  while (sp > 0 && !vis.done()) {
+    const uint32_t ref = stack[--sp];
+    if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
+      const uint32_t first = (ref & ~RTC_NODE_BIT) >> 3, count = (ref & 7u) + 1u;
+      for (uint32_t i = 0; i < count; ++i) visit_leaf(S, S.bvh_leaf[first + i], ray, degenerate, cur_xf, lr, vis);
+      continue;
+    }
+    const BvhNode& N = S.bvh[ref];
+    auto interval = [&](const float* lo, const float* hi, float& tn, float& tf) {
+      const float tnx = ((px ? lo[0] : hi[0]) - onx) * ix, tfx = ((px ? hi[0] : lo[0]) - ofx) * ix;
+      const float tny = ((py ? lo[1] : hi[1]) - ony) * iy, tfy = ((py ? hi[1] : lo[1]) - ofy) * iy;
+      const float tnz = ((pz ? lo[2] : hi[2]) - onz) * iz, tfz = ((pz ? hi[2] : lo[2]) - ofz) * iz;
+      tn = fmaxf(fmaxf(tnx, tny), tnz);  // fmaxf/fminf drop the NaN of 0 * inf (ray inside a slab, parallel to it)
+      tf = fminf(fminf(tfx, tfy), tfz);
+    };
+    float tn0, tf0, tn1, tf1;
+    interval(N.lo0, N.hi0, tn0, tf0);
+    interval(N.lo1, N.hi1, tn1, tf1);
+    const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0) & !vis.cullf(tn0, tf0);
+    const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1) & !vis.cullf(tn1, tf1);
+    if (h0 & h1) {
+      if (sp + 2 > RTC_TRAV_STACK) {
+        overflow = 1u;
+        continue;
+      }
+      const bool first0 = tn0 <= tn1;  // nearer child on top of the stack
+      stack[sp++] = first0 ? N.c1 : N.c0;
+      stack[sp++] = first0 ? N.c0 : N.c1;
+    } else if (h0 | h1) {
+      if (sp + 1 > RTC_TRAV_STACK) {
+        overflow = 1u;
+        continue;
+      }
+      stack[sp++] = h0 ? N.c0 : N.c1;
+    }
+  }
 }
 
 // Conservative bounding-sphere rejection for one World.objects entry, in FP32.
@@ -391,35 +490,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         continue;
       }
       vis.set_root(RTC_NO_LEAF);
-#ifdef RTC_EXP_SMALL
-      continue;
+#ifndef RTC_EXP_SMALL
+      traverse_bvh(S, R.geom, ray, vis, overflow);
 #endif
-      uint32_t cur_xf = 0xFFFFFFFFu;
-      Ray lr = ray;
-      uint32_t stack[RTC_TRAV_STACK];
-      int sp = 0;
-      stack[sp++] = R.index;
-    while (sp > 0 && !vis.done()) {
-      const uint32_t n = stack[--sp];
-      const double* __restrict__ B = S.node_box + 6ull * n;
-      double tmin, tmax;
-      // Group._bbox.intersect (group.zig:46-50): the ray is NOT transformed (identity).
-      if (!slab(ray, B[0], B[1], B[2], B[3], B[4], B[5], tmin, tmax)) continue;
-      if (vis.cull(tmin, tmax)) continue;
-      const uint2 k = S.node_kids[n];
-      for (uint32_t i = 0; i < k.y; ++i) {
-        const uint32_t c = S.kids[k.x + i];
-        if (c & RTC_NODE_BIT) {
-          if (sp < RTC_TRAV_STACK) {
-            stack[sp++] = c & ~RTC_NODE_BIT;
-          } else {
-            overflow = 1u;
-          }
-        } else {
-          visit_leaf(S, c, ray, cur_xf, lr, vis);
-        }
-      }
-    }
     }  // while (mine)
   }
 }
@@ -445,8 +518,12 @@ struct ClosestVisitor {
       v = ev;
     }
   }
-  __device__ __forceinline__ bool cull(double tmin, double tmax) const {
-    return tmax < -box_slack(tmax) || tmin > t + box_slack(t);
+  __device__ __forceinline__ bool relevant(uint32_t l, uint32_t, double et) const {
+    return et >= 0.0 && (et < t || (et == t && l < leaf));
+  }
+  __device__ __forceinline__ bool cullf(float tn, float tf) const {  // FP32 box interval of the candidate BVH
+    const float best = static_cast<float>(t);
+    return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > best + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(best));
   }
   __device__ __forceinline__ bool done() const { return false; }
 };
@@ -462,8 +539,12 @@ struct ShadowVisitor {
   __device__ __forceinline__ void entry(uint32_t, uint32_t casts_shadow, uint32_t, double et, double, double) {
     if (et >= 0.0 && et < distance && casts_shadow) shadowed = true;
   }
-  __device__ __forceinline__ bool cull(double tmin, double tmax) const {
-    return tmax < -box_slack(tmax) || tmin > distance + box_slack(distance);
+  __device__ __forceinline__ bool relevant(uint32_t, uint32_t casts_shadow, double et) const {
+    return et >= 0.0 && et < distance && casts_shadow;
+  }
+  __device__ __forceinline__ bool cullf(float tn, float tf) const {
+    const float lim = static_cast<float>(distance);
+    return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > lim + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(lim));
   }
   __device__ __forceinline__ bool done() const { return shadowed; }
 };
@@ -529,7 +610,10 @@ struct BehindVisitor {
       hit_dups++;
     }
   }
-  __device__ __forceinline__ bool cull(double tmin, double) const { return tmin > box_slack(tmin); }
+  __device__ __forceinline__ bool relevant(uint32_t l, uint32_t, double et) const {
+    return et < 0.0 || (l == hit_leaf && et == hit_t);
+  }
+  __device__ __forceinline__ bool cullf(float tn, float) const { return tn > 1e-4f * (1.0f + __builtin_fabsf(tn)); }
   __device__ __forceinline__ bool done() const { return false; }
 };
 
