@@ -213,11 +213,11 @@ Sphere leafSphere(const rtc_scene_desc& d, uint32_t leaf) {
       const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
       return sphereOfBox(M, lo, hi);
     }
-    case RTC_CONE: {
-      const double lim = std::fmax(std::fabs(d.cyl_min[g]), std::fabs(d.cyl_max[g]));
-      const double lo[3] = {-lim, d.cyl_min[g], -lim}, hi[3] = {lim, d.cyl_max[g], lim};
-      return sphereOfBox(M, lo, hi);
-    }
+    case RTC_CONE:
+      // NOT bounded by its truncated box: for a ray parallel to one of the cone's halves the reference
+      // appends the single surface hit t = -c / 2b WITHOUT the min < y < max filter (cone.zig:79-86),
+      // so a truncated cone can report an entry anywhere on the infinite double cone.
+      return Sphere{};
     case RTC_TRIANGLE:
     case RTC_SMOOTH_TRIANGLE: {
       double pts[3][3];
@@ -299,12 +299,8 @@ Aabb leafWorldBox(const rtc_scene_desc& d, uint32_t leaf) {
       addObjectBox(lo, hi);
       break;
     }
-    case RTC_CONE: {
-      const double lim = std::fmax(std::fabs(d.cyl_min[g]), std::fabs(d.cyl_max[g]));
-      const double lo[3] = {-lim, d.cyl_min[g], -lim}, hi[3] = {lim, d.cyl_max[g], lim};
-      addObjectBox(lo, hi);
-      break;
-    }
+    case RTC_CONE:
+      break;  // unbounded, see leafSphere(): the parallel-ray entry ignores the truncation
     case RTC_TRIANGLE:
     case RTC_SMOOTH_TRIANGLE:
       for (int v = 0; v < 3; ++v) {
@@ -910,6 +906,70 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     BvhBuilder builder{bvh_nodes, bvh_leaves};
     bvh_root_of[i] = builder.buildRoot(std::move(items));
     bvh_mag = std::fmax(bvh_mag, builder.mag);
+  }
+  if (getenv("RTC_BVH_CHECK")) {
+    // diagnostic: every leaf once, every stored child box contains the world boxes below it
+    std::vector<Aabb> world(n_live);
+    for (uint32_t c = 0; c < d.n_leaves; ++c)
+      if (dfs_of[c] != RTC_NO_LEAF) world[dfs_of[c]] = leafWorldBox(d, c);
+    std::vector<uint32_t> seen(n_live, 0);
+    size_t bad = 0;
+    for (uint32_t i = 0; i < d.n_roots; ++i) {
+      if (!(d.roots[i] & RTC_CHILD_NODE_BIT)) continue;
+      struct Item { uint32_t ref; const float* lo; const float* hi; };
+      std::vector<Item> todo;
+      const BvhNode& R0 = bvh_nodes[bvh_root_of[i]];
+      todo.push_back({R0.c0, R0.lo0, R0.hi0});
+      todo.push_back({R0.c1, R0.lo1, R0.hi1});
+      while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.ref == RTC_NO_LEAF) continue;
+        // collect leaves below it.ref
+        std::vector<uint32_t> st{it.ref};
+        while (!st.empty()) {
+          const uint32_t r = st.back();
+          st.pop_back();
+          if (r == RTC_NO_LEAF) continue;
+          if (r & RTC_NODE_BIT) {
+            const uint32_t first = (r & ~RTC_NODE_BIT) >> 3, count = (r & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+              const uint32_t leaf = bvh_leaves[first + k];
+              const Aabb& w = world[leaf];
+              if (w.finite())
+                for (int a = 0; a < 3; ++a)
+                  if (w.lo[a] < it.lo[a] || w.hi[a] > it.hi[a]) {
+                    if (bad++ < 5)
+                      std::fprintf(stderr, "rtc bvh check: leaf %u axis %d [%g,%g] outside stored box [%g,%g] (ref %08x)\n", leaf, a,
+                                   w.lo[a], w.hi[a], it.lo[a], it.hi[a], it.ref);
+                  }
+              if (!w.finite() && (it.lo[0] > -1e38f || it.hi[0] < 1e38f) && bad++ < 5)
+                std::fprintf(stderr, "rtc bvh check: unbounded leaf %u under a bounded box\n", leaf);
+            }
+          } else {
+            st.push_back(bvh_nodes[r].c0);
+            st.push_back(bvh_nodes[r].c1);
+          }
+        }
+        if (!(it.ref & RTC_NODE_BIT)) {
+          const BvhNode& N = bvh_nodes[it.ref];
+          todo.push_back({N.c0, N.lo0, N.hi0});
+          todo.push_back({N.c1, N.lo1, N.hi1});
+        } else {
+          const uint32_t first = (it.ref & ~RTC_NODE_BIT) >> 3, count = (it.ref & 7u) + 1u;
+          for (uint32_t k = 0; k < count; ++k) seen[bvh_leaves[first + k]]++;
+        }
+      }
+    }
+    size_t in_groups = 0, once = 0;
+    for (uint32_t l = 0; l < n_live; ++l) {
+      if (leaf_parent[l] != RTC_NO_LEAF) {
+        in_groups++;
+        once += seen[l] == 1;
+      }
+    }
+    std::fprintf(stderr, "rtc bvh check: %zu nodes, %zu leaves in groups, %zu seen exactly once, %zu containment violations\n",
+                 bvh_nodes.size(), in_groups, once, bad);
   }
   if (bvh_leaves.size() >= (1u << 28)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the BVH leaf-range encoding", bvh_leaves.size());
   std::vector<Sphere> branching_spheres, occupied_spheres;

@@ -340,7 +340,11 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
     }
   });
   if (!relevant) return;
+#ifdef RTC_EXP_EXACTCHAIN  // diagnostic: always run the exact reference box tests
+  if (!chain_ok(S, leaf, ray, t_rel, true)) return;
+#else
   if (!chain_ok(S, leaf, ray, t_rel, degenerate)) return;
+#endif
   leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr,
                [&](double t, double u, double v) { vis.entry(leaf, shadow, meta.z, t, u, v); });
 }
@@ -354,7 +358,11 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
                                              unsigned& overflow) {
   const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
   const float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
+#ifdef RTC_EXP_BIGDELTA
+  const float delta = 5e-2f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
+#else
   const float delta = 5e-7f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
+#endif
   const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
   const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
   // origin shifted against / along the direction: (near - on) and (far - of) grow the box by delta
@@ -385,8 +393,15 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
     float tn0, tf0, tn1, tf1;
     interval(N.lo0, N.hi0, tn0, tf0);
     interval(N.lo1, N.hi1, tn1, tf1);
+#if defined(RTC_EXP_NOBVHCULL)  // diagnostic: visit every node
+    const bool h0 = (N.c0 != RTC_NO_LEAF), h1 = (N.c1 != RTC_NO_LEAF);
+#elif defined(RTC_EXP_NOCULLF)  // diagnostic: box test only, no t-interval pruning
+    const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0);
+    const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1);
+#else
     const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0) & !vis.cullf(tn0, tf0);
     const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1) & !vis.cullf(tn1, tf1);
+#endif
     if (h0 & h1) {
       if (sp + 2 > RTC_TRAV_STACK) {
         overflow = 1u;
@@ -450,6 +465,9 @@ __device__ __forceinline__ bool root_culled(const RootCull& R, const RayF& ray) 
   const bool sided = (ac > T) & (bb > T);               // origin outside, sphere clearly on one side of it
   const bool behind = sided & (b < 0.0f);               // entirely at t < 0
   const bool front = sided & (b > 0.0f);                // entirely at t > 0
+#ifdef RTC_EXP_NOROOTCULL  // diagnostic: keep every root
+  return false;
+#endif
   return miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly);
 }
 
@@ -523,6 +541,11 @@ struct ClosestVisitor {
   }
   __device__ __forceinline__ bool cullf(float tn, float tf) const {  // FP32 box interval of the candidate BVH
     const float best = static_cast<float>(t);
+#ifdef RTC_EXP_CULL_A
+    return tf < -1e-4f * (1.0f + __builtin_fabsf(tf));
+#elif defined(RTC_EXP_CULL_B)
+    return tn > best + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(best));
+#endif
     return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > best + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(best));
   }
   __device__ __forceinline__ bool done() const { return false; }
@@ -544,6 +567,11 @@ struct ShadowVisitor {
   }
   __device__ __forceinline__ bool cullf(float tn, float tf) const {
     const float lim = static_cast<float>(distance);
+#ifdef RTC_EXP_CULL_A
+    return tf < -1e-4f * (1.0f + __builtin_fabsf(tf));
+#elif defined(RTC_EXP_CULL_B)
+    return tn > lim + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(lim));
+#endif
     return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > lim + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(lim));
   }
   __device__ __forceinline__ bool done() const { return shadowed; }

@@ -240,3 +240,94 @@ def test_host_library_render_entry(rtc):
     assert st == 0, rtc.host_lib().rtch_last_error()
     want, _ = ob.OracleScene(hs.desc).render(hs.camera(40, 40), 5)
     assert np.abs(out - want).max() < TOL
+
+
+def _random_scene(seed):
+    """Random world through the JSON loader: every in-scope primitive, nested groups (some large enough to be
+    divided), planes inside groups, glass inside glass, every pattern kind the kernel implements."""
+    import json
+    import random
+    rnd = random.Random(seed)
+
+    def solid():
+        return {"type": {"solid": [round(rnd.random(), 3) for _ in range(3)]}}
+
+    def pattern(depth=0):
+        k = rnd.choice(["solid", "solid", "stripes", "checkers", "rings", "gradient", "radial-gradient", "blend"])
+        if k == "solid" or depth >= 2:
+            return solid()
+        sub = (lambda: solid()) if k in ("gradient", "radial-gradient", "blend") else (lambda: pattern(depth + 1))
+        p = {"type": {k: [sub(), sub()]}}
+        if rnd.random() < 0.7:
+            p["transform"] = [{"scale": [rnd.uniform(0.2, 1.5)] * 3}, {"rotate-y": rnd.uniform(0, 3)}]
+        return p
+
+    def material():
+        m = {"pattern": pattern(), "ambient": rnd.uniform(0, 0.4), "diffuse": rnd.uniform(0.2, 0.9),
+             "specular": rnd.choice([0, 0.3, 0.9]), "shininess": rnd.choice([10, 200])}
+        r = rnd.random()
+        if r < 0.25:
+            m.update({"reflective": rnd.uniform(0.1, 0.9)})
+        elif r < 0.5:
+            m.update({"reflective": rnd.uniform(0.1, 0.9), "transparency": rnd.uniform(0.3, 1.0),
+                      "refractive-index": rnd.choice([1.0, 1.33, 1.5, 2.4])})
+        elif r < 0.6:
+            m.update({"transparency": rnd.uniform(0.3, 1.0), "refractive-index": 1.5})
+        return m
+
+    def transform(spread):
+        return [{"scale": [rnd.uniform(0.3, 1.2) for _ in range(3)]},
+                {"rotate-x": rnd.uniform(0, 6.28)}, {"rotate-z": rnd.uniform(0, 6.28)},
+                {"translate": [rnd.uniform(-spread, spread), rnd.uniform(0, spread), rnd.uniform(-spread, spread)]}]
+
+    def leaf(spread):
+        k = rnd.choice(["sphere", "cube", "cylinder", "cone", "triangle", "sphere", "cube"])
+        if k in ("sphere", "cube"):
+            t = {k: {}}
+        elif k == "triangle":
+            t = {"triangle": {"p1": [0, 1, 0], "p2": [-1, 0, 0.2], "p3": [1, 0, -0.3]}}
+        else:
+            lo = rnd.uniform(-1.5, -0.2)
+            t = {k: {"min": lo, "max": lo + rnd.uniform(0.5, 2.0), "closed": rnd.random() < 0.6}}
+        o = {"type": t, "transform": transform(spread), "material": material()}
+        if rnd.random() < 0.15:
+            o["casts-shadow"] = False
+        return o
+
+    def group(depth, n):
+        kids = []
+        for _ in range(n):
+            kids.append(group(depth + 1, rnd.randint(2, 5)) if depth < 2 and rnd.random() < 0.25 else leaf(3.0))
+        if depth == 0 and rnd.random() < 0.5:   # a plane inside a group: its box has infinite / NaN extents
+            kids.append({"type": {"plane": {}}, "transform": [{"translate": [0, -2.5, 0]}], "material": material()})
+        g = {"type": {"group": kids}}
+        if rnd.random() < 0.8:
+            g["transform"] = [{"rotate-y": rnd.uniform(0, 6.28)}, {"translate": [rnd.uniform(-2, 2), 0, rnd.uniform(-2, 2)]}]
+        return g
+
+    objs = [{"type": {"plane": {}}, "transform": [{"translate": [0, -3, 0]}], "material": material()},
+            # nested glass: exercises the containers walk (n1/n2)
+            {"type": {"sphere": {}}, "transform": [{"scale": [1.5, 1.5, 1.5]}, {"translate": [0, 0.5, 0]}],
+             "material": {"transparency": 0.9, "reflective": 0.4, "refractive-index": 1.5, "diffuse": 0.1}},
+            {"type": {"sphere": {}}, "transform": [{"scale": [0.7, 0.7, 0.7]}, {"translate": [0.2, 0.5, 0]}],
+             "material": {"transparency": 0.9, "reflective": 0.2, "refractive-index": 1.0003, "diffuse": 0.1}}]
+    objs += [leaf(4.0) for _ in range(rnd.randint(3, 8))]
+    objs += [group(0, rnd.randint(6, 14)) for _ in range(rnd.randint(1, 3))]
+    lights = [{"point-light": {"position": [rnd.uniform(-8, 8), rnd.uniform(4, 10), rnd.uniform(-10, -4)],
+                               "intensity": [rnd.uniform(0.3, 1.0)] * 3}} for _ in range(rnd.randint(1, 3))]
+    return json.dumps({"camera": {"width": 96, "height": 64, "field-of-view": 1.0, "from": [rnd.uniform(-3, 3), 3, -9],
+                                  "to": [0, 0.5, 0], "up": [0, 1, 0]}, "lights": lights, "objects": objs})
+
+
+@pytest.mark.parametrize("seed", list(range(1, 17)))
+def test_random_scenes(rtc, seed):
+    hs = rtc.HostScene(_random_scene(seed))
+    cam = hs.camera()
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(cam, 5)
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    delta = np.abs(got - want)
+    print(f"seed {seed}: leaves {hs.desc.n_leaves} nodes {hs.desc.n_nodes} max|delta| {delta.max():.2e}")
+    assert delta.max() < TOL, (seed, delta.max(), np.unravel_index(np.argmax(delta), delta.shape))
+    st = gpu.stats()
+    assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0

@@ -1,0 +1,17 @@
+import importlib, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+import numpy as np
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+import oracle_binding as ob
+import test_parity_gpu as t
+seeds = [int(a) for a in sys.argv[1:]] or list(range(1, 9))
+for seed in seeds:
+    hs = rtc.HostScene(t._random_scene(seed)); cam = hs.camera(); gpu = rtc.GpuScene(hs.desc); osc = ob.OracleScene(hs.desc)
+    for depth in (0, 1, 5):
+        got = gpu.render(cam, depth); want, c = osc.render(cam, depth)
+        d = np.abs(got - want).max(axis=2); bad = np.argwhere(d > 1e-5)
+        st = gpu.stats()
+        print(f"seed {seed} depth {depth}: bad pixels {len(bad)} max {d.max():.3e} sec gpu/cpu {st['secondary']}/{c['secondary']} shadow {st['shadow_calls']}/{c['shadow']}")
+        for y, x in bad[:4]:
+            print("   px", x, y, "gpu", got[y, x].round(6), "cpu", want[y, x].round(6))
