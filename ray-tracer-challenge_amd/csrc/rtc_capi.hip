@@ -720,8 +720,14 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       const int st = chunkOrder(s, cam, map, stream);
       if (st != RTC_OK) return st;
     }
-    map.cost = s->d_cost;
-    HIP_TRY(hipMemsetAsync(s->d_cost, 0, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), stream));
+    // per-chunk ray counts are collected only by the launch whose successor re-sorts the schedule
+    const uint64_t next = s->launches_with_key + 1;
+    if (next == 1 || next % 64 == 0) {
+      map.cost = s->d_cost;
+      HIP_TRY(hipMemsetAsync(s->d_cost, 0, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), stream));
+    } else {
+      map.cost = nullptr;
+    }
     s->launches_with_key++;
     s->last_stream = stream;
   }

@@ -801,6 +801,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 
   // per-lane pixel and ray state
   bool has_pixel = false, have_cur = false;
+  bool shared = false;  // part of this pixel's ray tree runs (or ran) in another lane
   size_t out_index = 0;
   uint32_t my_chunk = 0u, share_rays = 0u;  // cost feedback: rays this lane spent on its share of the pixel
   double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
@@ -827,7 +828,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   for (;;) {
     RTC_STAMP(0);
     // ---- 1. a lane without a ray pops its stack; an empty stack means its share of the pixel is done.
-    // Shares of one pixel may finish in several lanes (step 2a), so they are ADDED to the zeroed canvas.
+    // Shares of one pixel may finish in several lanes (step 2a): those are ADDED to the zeroed canvas; a
+    // pixel whose whole ray tree stayed in one lane (most of them) is stored once.
     if (!have_cur) {
       if (sp > base) {
         cur = stack[--sp];
@@ -836,18 +838,16 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sp = base = 0;
         if (has_pixel) {
           double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
-#ifdef RTC_EXP_STORE  // timing experiment only (wrong for shared pixels)
-          o[0] = acc_r;
-          o[1] = acc_g;
-          o[2] = acc_b;
-#else
-          atomicAdd(o + 0, acc_r);
-          atomicAdd(o + 1, acc_g);
-          atomicAdd(o + 2, acc_b);
-#endif
-#ifndef RTC_EXP_NOCOST
+          if (!shared) {  // the whole ray tree ran in this lane: the pixel is written exactly once
+            o[0] = acc_r;
+            o[1] = acc_g;
+            o[2] = acc_b;
+          } else {
+            atomicAdd(o + 0, acc_r);
+            atomicAdd(o + 1, acc_g);
+            atomicAdd(o + 2, acc_b);
+          }
           if (map.cost != nullptr) atomicAdd(map.cost + my_chunk, share_rays);
-#endif
           share_rays = 0u;
           has_pixel = false;
         }
@@ -869,6 +869,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           mailbox[drank].p = stack[base++];
           mailbox[drank].out_index = out_index;
           mailbox[drank].chunk = my_chunk;
+          shared = true;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -879,6 +880,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           my_chunk = mailbox[irank].chunk;
           have_cur = true;
           has_pixel = true;
+          shared = true;
           acc_r = acc_g = acc_b = 0.0;
           n_stolen++;
         }
@@ -970,6 +972,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           cur.remaining = max_depth;
           have_cur = true;
           has_pixel = true;
+          shared = false;
           want = false;
           out_index = oi;
           my_chunk = cur_chunk;

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""One-GPU rehearsal of the N-GPU tile split: renders each rank's share of the frame by itself and times it.
+
+    python tools/scale_sim.py [--scene cover.json] [--tiles 16,32,64] [--worlds 2,4,8]
+
+The render time of the slowest share bounds the N-GPU step from below (the gather overlaps the next frame);
+`compute_eff` = T(full frame) / (N * max_r T(share r)) is the part of the strong-scaling efficiency that the
+partition itself decides (load balance + per-launch fixed cost).  Real multi-GPU runs are the driver's.
+"""
+import argparse, importlib, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="cover.json")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--depth", type=int, default=5)
+    ap.add_argument("--tiles", default="16,32,64")
+    ap.add_argument("--worlds", default="2,4,8")
+    ap.add_argument("--reps", type=int, default=30)
+    args = ap.parse_args()
+    import torch
+    rtc = importlib.import_module("ray-tracer-challenge_amd")
+    hs = rtc.HostScene.from_file(args.scene)
+    cam = hs.camera(args.width, args.height)
+    W, H = cam.hsize, cam.vsize
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    sptr = stream.cuda_stream
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(args.reps):
+            fn()
+        b.record(stream)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / args.reps
+
+    gpu = rtc.GpuScene(hs.desc)
+    canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+    t_full = timed(lambda: gpu.render_device(cam, canvas.data_ptr(), args.depth, None, sptr))
+    print(json.dumps({"scene": args.scene, "full_ms": t_full}), flush=True)
+    for tile in [int(x) for x in args.tiles.split(",")]:
+        tx, ty = rtc.tile_grid(W, H, tile, tile)
+        for world in [int(x) for x in args.worlds.split(",")]:
+            ts = []
+            for rank in range(world):
+                g = rtc.GpuScene(hs.desc)      # one handle per simulated rank: its own schedule feedback
+                first, stride, count, padded = rtc.tiles_of_rank(tx * ty, rank, world)
+                buf = torch.zeros((padded, tile, tile, 3), dtype=torch.float64, device="cuda")
+                ts.append(timed(lambda: g.render_tiles_device(cam, buf.data_ptr(), tile, tile, first, stride, count,
+                                                              args.depth, sptr)))
+                g.close()
+            print(json.dumps({"tile": tile, "world": world, "max_ms": max(ts), "mean_ms": sum(ts) / world,
+                              "ideal_ms": t_full / world, "compute_eff": t_full / (world * max(ts))}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
