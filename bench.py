@@ -121,6 +121,12 @@ def main():
     ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints a version banner
+    # there at communicator creation) are sent to stderr for the duration of the run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     rtc = importlib.import_module("ray-tracer-challenge_amd")
@@ -273,7 +279,8 @@ def main():
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)
                 result["config"]["gpu_vs_cpu_frame_time"] = result["cpu_baseline"]["ms_per_frame_extrapolated"] / ms_per_step
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -23,6 +23,9 @@
 
 #define RTC_NODE_BIT 0x80000000u
 #define RTC_NO_LEAF 0xFFFFFFFFu
+#define RTC_NO_ITEM 0xFFFFFFFFu
+#define RTC_PACKET_ITEMS 16u
+#define RTC_ITEM_MAX_CHUNKS 0x100000u  // chunk index bits of a schedule item
 
 // per-lane traversal stack (node indices) and secondary-ray stack capacities
 #ifndef RTC_TRAV_STACK
@@ -131,14 +134,15 @@ struct DevPixelMap {
   uint32_t chunks_x;            // chunks per row of the rectangle / of one tile
   uint32_t chunks_per_region;   // chunks in the rectangle / in one tile
   uint32_t n_chunks;            // total
-  uint32_t n_units;             // entries the work counter runs over: n_chunks, or the length of `order`
-  // Optional schedule: a permutation of the chunks (an entry may also name ONE 8-pixel row of a chunk:
-  // bit 31 set, row in bits 28..30).  Chunks that look at objects whose material branches the ray tree
-  // (reflective AND transparent) are handed out first, so the longest jobs start at t = 0 instead of
-  // becoming the tail of the launch.  Scheduling only: results do not depend on it.
+  uint32_t n_units;             // what the work counter runs over: n_chunks, or the number of packets in `order`
+  // Optional schedule: PACKETS of RTC_PACKET_ITEMS items, one packet per pull of the work counter.  An item
+  // names a run of pixels of one chunk: chunk | start << 20 | (len - 1) << 26, RTC_NO_ITEM = unused slot.
+  // The host packs them so that every packet costs about the same (runs of expensive pixels - ray trees
+  // through glass - padded with cheap ones) and hands the most expensive packets out first.
+  // Scheduling only: results do not depend on it.
   const uint32_t* __restrict__ order;
-  // Optional per-chunk cost output (rays traced for the chunk's pixels), zeroed before the launch; the
-  // host sorts the next frame's schedule by it (longest job first).
+  // Optional per-pixel cost output (rays traced for the pixel, indexed like the canvas), zeroed before
+  // the launch; the host packs the next frames' schedule by it.
   uint32_t* __restrict__ cost;
 };
 
@@ -146,7 +150,7 @@ struct DevStats {  // zeroed before every launch; counters get one atomic per wa
   unsigned long long primary, secondary, shadow_calls, shadow_traced, overflow;
   unsigned int next_chunk;  // work counter of the persistent waves
   unsigned int stolen;      // rays handed from one lane to another (diagnostic)
-  unsigned long long prof[8];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
+  unsigned long long prof[16];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
   unsigned long long prof2[8];  // trace invocations (wave level) and active lanes: closest, shadow, behind
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
   unsigned long long prof_log[4096][4];            // per wave: lifetime, iterations, units, first<<32|last unit

@@ -733,8 +733,6 @@ struct Pending {
 struct Mail {
   Pending p;
   size_t out_index;
-  uint32_t chunk;  // chunk the pixel belongs to (per-chunk cost feedback)
-  uint32_t pad_;
 };
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
@@ -793,8 +791,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
 
-  // wave-uniform chunk cursor
-  uint32_t chunk_pos = 64u, chunk_end = 64u, cur_chunk = 0u;
+  // wave-uniform cursor: the packet the wave pulled last (lane i < 16 holds its item i), the item that is
+  // open, and the run of pixels of one 8x8 chunk that item names
+  uint32_t items = RTC_NO_ITEM, item_next = RTC_PACKET_ITEMS;
+  uint32_t chunk_pos = 64u, chunk_end = 64u;
   uint32_t chunk_rx0 = 0u, chunk_ry0 = 0u, chunk_px0 = 0u, chunk_py0 = 0u, chunk_w = 0u, chunk_h = 0u;
   size_t chunk_out0 = 0;
   bool drained = false;
@@ -803,7 +803,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   bool has_pixel = false, have_cur = false;
   bool shared = false;  // part of this pixel's ray tree runs (or ran) in another lane
   size_t out_index = 0;
-  uint32_t my_chunk = 0u, share_rays = 0u;  // cost feedback: rays this lane spent on its share of the pixel
+  uint32_t share_rays = 0u;  // cost feedback: rays this lane spent on its share of the pixel
   double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
@@ -817,7 +817,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   Mail* const mailbox = lds_mail[threadIdx.x >> 6];
 
 #ifdef RTC_PROFILE
-  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long prof_t = __builtin_amdgcn_s_memtime();
   const unsigned long long prof_start = prof_t;
   unsigned prof_sec = 0;
@@ -847,12 +847,19 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             atomicAdd(o + 1, acc_g);
             atomicAdd(o + 2, acc_b);
           }
-          if (map.cost != nullptr) atomicAdd(map.cost + my_chunk, share_rays);
+          if (map.cost != nullptr) {  // rays this pixel took: next frame's schedule is packed by it
+            if (!shared) {
+              map.cost[out_index] = share_rays;
+            } else {
+              atomicAdd(map.cost + out_index, share_rays);
+            }
+          }
           share_rays = 0u;
           has_pixel = false;
         }
       }
     }
+    RTC_STAMP(8);
     // ---- 2a. work sharing inside the wave: an idle lane takes the oldest pending ray (the root of the
     // largest unexplored sub-tree) of a busy lane.  Without this a pixel whose ray tree has 2^(depth+1)-1
     // nodes occupies ONE lane for that many iterations.
@@ -868,7 +875,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (donor && drank < pairs) {
           mailbox[drank].p = stack[base++];
           mailbox[drank].out_index = out_index;
-          mailbox[drank].chunk = my_chunk;
           shared = true;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -877,7 +883,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (idle && irank < pairs) {
           cur = mailbox[irank].p;
           out_index = mailbox[irank].out_index;
-          my_chunk = mailbox[irank].chunk;
           have_cur = true;
           has_pixel = true;
           shared = true;
@@ -886,36 +891,41 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         }
       }
     }
+    RTC_STAMP(9);
     // ---- 2b. deal new pixels to the lanes that still want one
     bool want = !have_cur;
     unsigned long long wmask = __ballot(want);
     while (wmask) {
       if (chunk_pos >= chunk_end) {
-        if (drained) break;
-        uint32_t c = 0u;
-        if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= map.n_units) {
-          drained = true;
-          break;
-        }
-        chunk_pos = 0u;
-        chunk_end = 64u;
-#ifdef RTC_PROFILE
-        prof_last_unit = c;
-        prof_first_unit = static_cast<unsigned>((__builtin_amdgcn_s_memtime() - prof_start) >> 8);  // time of the last fetch
-        prof_units += 1ull;
-#endif
-        if (map.order != nullptr) {
-          // a unit of the schedule: a whole chunk, or (bit 31) one 8-pixel row of a heavy chunk
-          const uint32_t unit = map.order[c];
-          c = unit & 0x0FFFFFFFu;
-          if (unit & 0x80000000u) {
-            chunk_pos = ((unit >> 28) & 7u) * 8u;
-            chunk_end = chunk_pos + 8u;
+        uint32_t unit = RTC_NO_ITEM;
+        if (item_next < RTC_PACKET_ITEMS) unit = __builtin_amdgcn_readlane(items, item_next);
+        if (unit == RTC_NO_ITEM) {  // the packet is used up: pull the next one
+          if (drained) break;
+          uint32_t c = 0u;
+          if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
+          c = __builtin_amdgcn_readfirstlane(c);
+          if (c >= map.n_units) {
+            drained = true;
+            break;
           }
+#ifdef RTC_PROFILE
+          prof_last_unit = c;
+          prof_first_unit = static_cast<unsigned>((__builtin_amdgcn_s_memtime() - prof_start) >> 8);  // time of the last fetch
+          prof_units += 1ull;
+#endif
+          if (map.order != nullptr) {
+            items = lane < RTC_PACKET_ITEMS ? map.order[static_cast<size_t>(c) * RTC_PACKET_ITEMS + lane] : RTC_NO_ITEM;
+          } else {  // unscheduled: packet c is chunk c, whole
+            items = lane == 0u ? c : RTC_NO_ITEM;
+          }
+          item_next = 0u;
+          continue;
         }
-        cur_chunk = c;
+        item_next++;
+        // an item: pixels [start, start + len) of chunk c, in the chunk's row-major 8x8 numbering
+        const uint32_t c = map.order != nullptr ? (unit & 0xFFFFFu) : unit;
+        chunk_pos = map.order != nullptr ? ((unit >> 20) & 63u) : 0u;
+        chunk_end = map.order != nullptr ? chunk_pos + (unit >> 26) + 1u : 64u;
         // wave-uniform placement of the chunk, once per fetch (scalar unit)
         const uint32_t region = c / map.chunks_per_region;
         const uint32_t cr = c - region * map.chunks_per_region;
@@ -975,7 +985,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           shared = false;
           want = false;
           out_index = oi;
-          my_chunk = cur_chunk;
           acc_r = acc_g = acc_b = 0.0;
           n_primary++;
         }  // pixels of an edge tile outside the image stay 0 (the canvas is zeroed before the launch)
@@ -1027,6 +1036,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       if (kind == 3u || kind == 6u) hcy = S.cyl[geom];
     }
     const DevMaterial mat = mats[mat_index];
+    RTC_STAMP(10);
     const double t = hv.t;
     const double ptx = ray.ox + ray.dx * t, pty = ray.oy + ray.dy * t, ptz = ray.oz + ray.dz * t;  // ray.position
     const double ex = -ray.dx, ey = -ray.dy, ez = -ray.dz;                                          // eyev
@@ -1117,6 +1127,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       ny = -ny;
       nz = -nz;
     }
+    RTC_STAMP(11);
     const double eps = 1e-5;
     const double ovx = ptx + nx * eps, ovy = pty + ny * eps, ovz = ptz + nz * eps;  // over_point
     const double unx = ptx - nx * eps, uny = pty - ny * eps, unz = ptz - nz * eps;  // under_point
@@ -1129,6 +1140,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       const double opy = row_pt(M + 4, ovx, ovy, ovz);
       const double opz = row_pt(M + 8, ovx, ovy, ovz);
       const Rgb color = pattern_at(pats, mat.pattern, opx, opy, opz);
+      RTC_STAMP(12);
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
       // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
       const bool shadow_matters = !(mat.diffuse == 0.0 && mat.specular == 0.0);
@@ -1248,6 +1260,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         w_refract = mat.transparency * (1.0 - reflectance);
       }
     }
+    RTC_STAMP(13);
     Pending child;
     child.remaining = cur.remaining - 1u;
     if (do_reflect) {
@@ -1284,7 +1297,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   RTC_STAMP(7);
   prof_acc[7] = prof_iters;  // slot 7 reports main-loop iterations (wave-level), not cycles
   if (lane == 0u) {
-    for (int i = 0; i < 8; ++i) atomicAdd(&stats->prof[i], prof_acc[i]);
+    for (int i = 0; i < 16; ++i) atomicAdd(&stats->prof[i], prof_acc[i]);
     atomicMin(&stats->prof_t0, prof_t - prof_start);  // shortest / longest wave lifetime (s_memtime is
     atomicMax(&stats->prof_t1, ((prof_t - prof_start) << 24) | (prof_last_unit & 0xFFFFFFull));  // longest wave + its last unit
     atomicAdd(&stats->prof_busy, prof_t - prof_start);
