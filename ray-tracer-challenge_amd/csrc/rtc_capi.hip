@@ -16,10 +16,10 @@
 
 extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                              const uint32_t max_depth, double* __restrict__ out,
-                                             DevStats* __restrict__ stats);
+                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                       const uint32_t max_depth, double* __restrict__ out,
-                                                      DevStats* __restrict__ stats);
+                                                      DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 
 namespace {
 
@@ -71,7 +71,8 @@ struct rtc_scene {
   int device = 0;
   hipStream_t stream = nullptr;
   DevScene dev{};
-  DevStats* d_stats = nullptr;
+  DevStats* d_stats = nullptr;  // two, used alternately (see DevStats)
+  uint32_t stats_parity = 0;    // which of the two the last launch counted in
   double* d_frame = nullptr;  // staging for rtc_render (host output)
   size_t frame_capacity = 0;  // in doubles
   DevBuf<uint32_t> roots, kids;
@@ -928,16 +929,21 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   // chunks to hand out, 4 waves each); the waves pull chunks until the counter runs out.
   const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   const uint32_t blocks = std::max(1u, std::min(resident, (map.n_units + 3u) / 4u));
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, sizeof(DevStats), stream));
-  HIP_TRY(hipMemsetAsync(&s->d_stats->prof_t0, 0xFF, sizeof(unsigned long long), stream));
+  s->stats_parity ^= 1u;
+  DevStats* const st_now = s->d_stats + s->stats_parity;
+  DevStats* const st_next = s->d_stats + (s->stats_parity ^ 1u);
+#ifdef RTC_PROFILE
+  HIP_TRY(hipMemsetAsync(st_now, 0, sizeof(DevStats), stream));
+  HIP_TRY(hipMemsetAsync(&st_now->prof_t0, 0xFF, sizeof(unsigned long long), stream));
+#endif
   // the kernel ADDS each lane's share of a pixel (shares of one ray tree may finish in several lanes)
   HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
   if (lds) {
     hipLaunchKernelGGL(rtc_render_kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth,
-                       d_out, s->d_stats);
+                       d_out, st_now, st_next);
   } else {
     hipLaunchKernelGGL(rtc_render_kernel_bigworld, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map,
-                       max_depth, d_out, s->d_stats);
+                       max_depth, d_out, st_now, st_next);
   }
   HIP_TRY(hipGetLastError());
   return RTC_OK;
@@ -1332,8 +1338,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->leaf_parent.upload(leaf_parent));
   HIP_TRY(s->node_parent.upload(node_parent));
   HIP_TRY(s->light.upload(light));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), sizeof(DevStats)));
-  HIP_TRY(hipMemset(s->d_stats, 0, sizeof(DevStats)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
+  HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
   s->max_trav_stack = max_stack;
   s->branching = branching_spheres;
   s->branching_everywhere = branching_everywhere;
@@ -1477,13 +1483,14 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipDeviceSynchronize());
   static DevStats h;  // large in diagnostic layouts: keep it off the stack
-  HIP_TRY(hipMemcpy(&h, s->d_stats, sizeof h, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&h, s->d_stats + s->stats_parity, sizeof h, hipMemcpyDeviceToHost));
   out->primary = h.primary;
   out->secondary = h.secondary;
   out->shadow_calls = h.shadow_calls;
   out->shadow_traced = h.shadow_traced;
   out->overflow = h.overflow;
-  if (getenv("RTC_PROFILE_DUMP")) {  // diagnostic builds (-DRTC_PROFILE) only
+#ifdef RTC_PROFILE
+  if (getenv("RTC_PROFILE_DUMP")) {
     std::fprintf(stderr, "rtc prof:");
     for (int i = 0; i < 16; ++i) std::fprintf(stderr, " %llu", h.prof[i]);
     std::fprintf(stderr, " | wave lifetime min %llu max %llu (last unit %llu) sum %llu | stolen %u\n", h.prof_t0,
@@ -1500,6 +1507,7 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
       }
     }
   }
+#endif
   return RTC_OK;
 }
 

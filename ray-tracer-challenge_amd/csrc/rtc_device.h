@@ -146,12 +146,17 @@ struct DevPixelMap {
   uint32_t* __restrict__ cost;
 };
 
-struct DevStats {  // zeroed before every launch; counters get one atomic per wave
+// Zero at the start of every launch; counters get one atomic per wave.  A scene owns TWO of these and
+// alternates: launch n counts in [n & 1] and clears [(n + 1) & 1] for its successor (stream order makes
+// that safe), so no launch needs a memset of its own.
+struct DevStats {
   unsigned long long primary, secondary, shadow_calls, shadow_traced, overflow;
   unsigned int next_chunk;  // work counter of the persistent waves
   unsigned int stolen;      // rays handed from one lane to another (diagnostic)
-  unsigned long long prof[16];  // -DRTC_PROFILE diagnostic builds only: wave cycles per section
+#ifdef RTC_PROFILE          // diagnostic builds only (cleared by a host memset there)
+  unsigned long long prof[16];  // wave cycles per section
   unsigned long long prof2[8];  // trace invocations (wave level) and active lanes: closest, shadow, behind
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
   unsigned long long prof_log[4096][4];            // per wave: lifetime, iterations, units, first<<32|last unit
+#endif
 };

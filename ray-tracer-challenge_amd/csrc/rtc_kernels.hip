@@ -755,7 +755,15 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 template <bool LDS>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
-                                            DevStats* __restrict__ stats) {
+                                            DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+#ifndef RTC_PROFILE
+  if (blockIdx.x == 0u) {  // the next launch's counters (see DevStats)
+    uint32_t* z = reinterpret_cast<uint32_t*>(next_stats);
+    for (uint32_t i = threadIdx.x; i < sizeof(DevStats) / sizeof(uint32_t); i += blockDim.x) z[i] = 0u;
+  }
+#else
+  (void)next_stats;
+#endif
   // Small-world tables (World.objects records + bounding spheres, materials, patterns, lights):
   // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
   // chases pointers through memory.  Larger worlds run the same code on the tables in memory.
@@ -893,7 +901,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     }
     RTC_STAMP(9);
     // ---- 2b. deal new pixels to the lanes that still want one
-    bool want = !have_cur;
+    bool want = !have_cur, got_pixel = false;
+    uint32_t new_px = 0u, new_py = 0u;
     unsigned long long wmask = __ballot(want);
     while (wmask) {
       if (chunk_pos >= chunk_end) {
@@ -955,42 +964,46 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         const uint32_t rx = chunk_rx0 + (k & 7u), ry = chunk_ry0 + (k >> 3);
         const bool in_buffer = rx < chunk_w && ry < chunk_h;
         const uint32_t px = chunk_px0 + rx, py = chunk_py0 + ry;
-        const size_t oi = chunk_out0 + static_cast<size_t>(ry) * chunk_w + rx;
         if (in_buffer && px < cam.hsize && py < cam.vsize) {
-          // Camera.rayForPixel, camera.zig:64-76
-          const double xoffset = (static_cast<double>(px) + 0.5) * cam.pixel_size;
-          const double yoffset = (static_cast<double>(py) + 0.5) * cam.pixel_size;
-          const double world_x = cam.half_width - xoffset;
-          const double world_y = cam.half_height - yoffset;
-          const double pix_x = row_pt(cam.inv + 0, world_x, world_y, -1.0);
-          const double pix_y = row_pt(cam.inv + 4, world_x, world_y, -1.0);
-          const double pix_z = row_pt(cam.inv + 8, world_x, world_y, -1.0);
-          cur.ray.ox = row_pt(cam.inv + 0, 0.0, 0.0, 0.0);
-          cur.ray.oy = row_pt(cam.inv + 4, 0.0, 0.0, 0.0);
-          cur.ray.oz = row_pt(cam.inv + 8, 0.0, 0.0, 0.0);
-          double dx = pix_x - cur.ray.ox, dy = pix_y - cur.ray.oy, dz = pix_z - cur.ray.oz;
-          const double mag = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);  // Tuple.normalized, tuple.zig:109-116
-          if (mag != 0.0) {
-            dx = dx / mag;
-            dy = dy / mag;
-            dz = dz / mag;
-          }
-          cur.ray.dx = dx;
-          cur.ray.dy = dy;
-          cur.ray.dz = dz;
-          cur.weight = 1.0;
-          cur.remaining = max_depth;
-          have_cur = true;
-          has_pixel = true;
-          shared = false;
+          new_px = px;
+          new_py = py;
+          got_pixel = true;
           want = false;
-          out_index = oi;
-          acc_r = acc_g = acc_b = 0.0;
-          n_primary++;
+          out_index = chunk_out0 + static_cast<size_t>(ry) * chunk_w + rx;
         }  // pixels of an edge tile outside the image stay 0 (the canvas is zeroed before the launch)
       }
       chunk_pos += min(avail, static_cast<uint32_t>(__builtin_popcountll(wmask)));
       wmask = __ballot(want);
+    }
+    if (got_pixel) {  // once per refill, however many items the pixels came from
+      // Camera.rayForPixel, camera.zig:64-76
+      const double xoffset = (static_cast<double>(new_px) + 0.5) * cam.pixel_size;
+      const double yoffset = (static_cast<double>(new_py) + 0.5) * cam.pixel_size;
+      const double world_x = cam.half_width - xoffset;
+      const double world_y = cam.half_height - yoffset;
+      const double pix_x = row_pt(cam.inv + 0, world_x, world_y, -1.0);
+      const double pix_y = row_pt(cam.inv + 4, world_x, world_y, -1.0);
+      const double pix_z = row_pt(cam.inv + 8, world_x, world_y, -1.0);
+      cur.ray.ox = row_pt(cam.inv + 0, 0.0, 0.0, 0.0);
+      cur.ray.oy = row_pt(cam.inv + 4, 0.0, 0.0, 0.0);
+      cur.ray.oz = row_pt(cam.inv + 8, 0.0, 0.0, 0.0);
+      double dx = pix_x - cur.ray.ox, dy = pix_y - cur.ray.oy, dz = pix_z - cur.ray.oz;
+      const double mag = __builtin_sqrt((dx * dx + dy * dy) + dz * dz);  // Tuple.normalized, tuple.zig:109-116
+      if (mag != 0.0) {
+        dx = dx / mag;
+        dy = dy / mag;
+        dz = dz / mag;
+      }
+      cur.ray.dx = dx;
+      cur.ray.dy = dy;
+      cur.ray.dz = dz;
+      cur.weight = 1.0;
+      cur.remaining = max_depth;
+      have_cur = true;
+      has_pixel = true;
+      shared = false;
+      acc_r = acc_g = acc_b = 0.0;
+      n_primary++;
     }
     if (!__any(have_cur)) break;
     if (!have_cur) continue;
@@ -1328,13 +1341,13 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
-                  double* __restrict__ out, DevStats* __restrict__ stats) {
-  render_body<true>(S, cam, map, max_depth, out, stats);
+                  double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // Same kernel for worlds whose World.objects table does not fit the LDS staging area.
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
-                           double* __restrict__ out, DevStats* __restrict__ stats) {
-  render_body<false>(S, cam, map, max_depth, out, stats);
+                           double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<false>(S, cam, map, max_depth, out, stats, next_stats);
 }
