@@ -105,6 +105,8 @@ struct rtc_scene {
   uint64_t launches_with_key = 0;
   bool order_from_cost = false;
   hipStream_t last_stream = nullptr;
+  void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack
+  size_t ray_stack_capacity = 0;   // bytes
 };
 
 namespace {
@@ -929,6 +931,19 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   // chunks to hand out, 4 waves each); the waves pull chunks until the counter runs out.
   const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   const uint32_t blocks = std::max(1u, std::min(resident, (map.n_units + 3u) / 4u));
+  {
+    const size_t need = static_cast<size_t>(blocks) * 4u * (max_depth + 2u) * 64u * 64u;
+    if (need > s->ray_stack_capacity) {
+      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
+      s->d_ray_stack = nullptr;
+      s->ray_stack_capacity = 0;
+      HIP_TRY(hipMalloc(&s->d_ray_stack, need));
+      s->ray_stack_capacity = need;
+    }
+    map.ray_stack = static_cast<PendingRec*>(s->d_ray_stack);
+    map.ray_stack_levels = max_depth + 2u;
+  }
   s->stats_parity ^= 1u;
   DevStats* const st_now = s->d_stats + s->stats_parity;
   DevStats* const st_next = s->d_stats + (s->stats_parity ^ 1u);
@@ -937,7 +952,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   HIP_TRY(hipMemsetAsync(&st_now->prof_t0, 0xFF, sizeof(unsigned long long), stream));
 #endif
   // the kernel ADDS each lane's share of a pixel (shares of one ray tree may finish in several lanes)
+#ifndef RTC_EXP_NOMEMSET
   HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
+#endif
   if (lds) {
     hipLaunchKernelGGL(rtc_render_kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth,
                        d_out, st_now, st_next);
@@ -1402,6 +1419,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->d_order) (void)hipFree(s->d_order);
   if (s->d_cost) (void)hipFree(s->d_cost);
+  if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   delete s;
 }
 

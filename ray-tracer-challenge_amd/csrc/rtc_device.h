@@ -91,6 +91,13 @@ struct BvhNode {
   uint32_t pad_[2];
 };
 
+// One pending secondary ray on a lane's stack (see DevPixelMap::ray_stack): origin, direction, weight,
+// remaining depth; exactly one 64-byte line.
+struct __attribute__((aligned(64))) PendingRec {
+  double v[7];
+  uint32_t remaining, pad_;
+};
+
 struct DevScene {
   const RootRec* __restrict__ root_recs;
   const RootCull* __restrict__ root_cull;
@@ -144,6 +151,10 @@ struct DevPixelMap {
   // Optional per-pixel cost output (rays traced for the pixel, indexed like the canvas), zeroed before
   // the launch; the host packs the next frames' schedule by it.
   uint32_t* __restrict__ cost;
+  // The lanes' stacks of pending secondary rays: [resident waves][ray_stack_levels][64 lanes] records of
+  // 64 bytes, owned by the scene handle and sized for the launch (max_depth + 2 levels).
+  PendingRec* __restrict__ ray_stack;
+  uint32_t ray_stack_levels;
 };
 
 // Zero at the start of every launch; counters get one atomic per wave.  A scene owns TWO of these and

@@ -729,6 +729,29 @@ struct Pending {
   uint32_t remaining;
 };
 
+// A Pending as it sits on a lane's stack in memory: one 64-byte line, moved as four 16-byte accesses.
+typedef unsigned long long Quad2 __attribute__((ext_vector_type(2)));  // 16 bytes, moved as bits
+__device__ __forceinline__ unsigned long long dbits(double x) { return __builtin_bit_cast(unsigned long long, x); }
+__device__ __forceinline__ double bitsd(unsigned long long x) { return __builtin_bit_cast(double, x); }
+__device__ __forceinline__ void store_pending(PendingRec* dst, const Pending& p) {
+  Quad2* d = reinterpret_cast<Quad2*>(dst);
+  Quad2 a, b, c, e;
+  a.x = dbits(p.ray.ox); a.y = dbits(p.ray.oy);
+  b.x = dbits(p.ray.oz); b.y = dbits(p.ray.dx);
+  c.x = dbits(p.ray.dy); c.y = dbits(p.ray.dz);
+  e.x = dbits(p.weight); e.y = p.remaining;
+  d[0] = a; d[1] = b; d[2] = c; d[3] = e;
+}
+__device__ __forceinline__ Pending load_pending(const PendingRec* src) {
+  const Quad2* d = reinterpret_cast<const Quad2*>(src);
+  const Quad2 a = d[0], b = d[1], c = d[2], e = d[3];
+  Pending p;
+  p.ray = {bitsd(a.x), bitsd(a.y), bitsd(b.x), bitsd(b.y), bitsd(c.x), bitsd(c.y)};
+  p.weight = bitsd(e.x);
+  p.remaining = static_cast<uint32_t>(e.y);
+  return p;
+}
+
 // One ray in flight between two lanes of a wave, with the canvas pixel its colour is added to.
 struct Mail {
   Pending p;
@@ -820,7 +843,12 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   cur.remaining = 0u;
   // The lane's pending refraction siblings: a deque.  The lane itself pops the newest entry (depth
   // first); an idle neighbour may take the OLDEST one (the largest sub-tree) through the mailbox.
-  Pending stack[RTC_RAY_STACK];
+  // It lives in a buffer of its own rather than in scratch: scratch interleaves the lanes dword by dword,
+  // so ONE lane pushing one 64-byte entry touches 16 different cache lines; here a lane's entry is one
+  // 64-byte line and a whole wave's push is 4 KB contiguous.  Layout [wave][level][lane].
+  PendingRec* const stack = map.ray_stack +
+      (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * map.ray_stack_levels * 64u + lane;
+  const int stack_cap = static_cast<int>(map.ray_stack_levels);
   int sp = 0, base = 0;
   Mail* const mailbox = lds_mail[threadIdx.x >> 6];
 
@@ -840,17 +868,32 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     // pixel whose whole ray tree stayed in one lane (most of them) is stored once.
     if (!have_cur) {
       if (sp > base) {
-        cur = stack[--sp];
+        cur = load_pending(stack + static_cast<size_t>(--sp) * 64u);
         have_cur = true;
       } else {
         sp = base = 0;
         if (has_pixel) {
           double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
+#ifdef RTC_EXP_NOWRITE  // traffic experiment only: the canvas is never written
+          if (acc_r == 12345.678) {
+#elif defined(RTC_EXP_STORE)  // traffic experiment only (wrong for shared pixels)
+          if (true) {
+#else
           if (!shared) {  // the whole ray tree ran in this lane: the pixel is written exactly once
-            o[0] = acc_r;
-            o[1] = acc_g;
+#endif
+            // 24 B at an 8-byte-aligned address: one 16-byte and one 8-byte store (gfx950 takes unaligned
+            // vector accesses) instead of three separate write requests
+            typedef double Double2 __attribute__((ext_vector_type(2), aligned(8)));
+            Double2 rg;
+            rg.x = acc_r;
+            rg.y = acc_g;
+            *reinterpret_cast<Double2*>(o) = rg;
             o[2] = acc_b;
-          } else {
+          } else
+#ifdef RTC_EXP_NOWRITE
+          if (acc_r == 12345.678)
+#endif
+          {
             atomicAdd(o + 0, acc_r);
             atomicAdd(o + 1, acc_g);
             atomicAdd(o + 2, acc_b);
@@ -881,7 +924,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         const uint32_t irank = static_cast<uint32_t>(__builtin_popcountll(imask & lanes_below));
         const uint32_t drank = static_cast<uint32_t>(__builtin_popcountll(dmask & lanes_below));
         if (donor && drank < pairs) {
-          mailbox[drank].p = stack[base++];
+          mailbox[drank].p = load_pending(stack + static_cast<size_t>(base++) * 64u);
           mailbox[drank].out_index = out_index;
           shared = true;
         }
@@ -1291,8 +1334,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       p.remaining = cur.remaining - 1u;
       n_secondary++;
       if (do_reflect) {  // both children: the reflection continues in registers, the refraction waits
-        if (sp < RTC_RAY_STACK) {
-          stack[sp++] = p;
+        if (sp < stack_cap) {
+          store_pending(stack + static_cast<size_t>(sp++) * 64u, p);
         } else {
           overflow = 1u;
         }
