@@ -169,7 +169,10 @@ def main():
         n_tiles = tx * ty
         first, stride, count, padded = rtc.tiles_of_rank(n_tiles, rank, world)
         bufs = [torch.zeros((padded, TILE, TILE, 3), dtype=torch.float64, device="cuda") for _ in range(2)]
-        gathered = [[torch.empty_like(bufs[0]) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+        # rank 0 receives straight into [world][padded][T][T][3]: the gather list is that buffer's rows
+        gathered = ([torch.empty((world,) + tuple(bufs[0].shape), dtype=torch.float64, device="cuda") for _ in range(2)]
+                    if rank == 0 else [None, None])
+        gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None, None]
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda") if rank == 0 else None
         comm = torch.cuda.Stream()
         rendered = [torch.cuda.Event() for _ in range(2)]
@@ -184,11 +187,10 @@ def main():
             rendered[b].record(stream)
             with torch.cuda.stream(comm):            # gather + un-permute of frame i under the render of frame i+1
                 comm.wait_event(rendered[b])
-                dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0)
-                if rank == 0:
-                    t = torch.stack(gathered[b], dim=1).reshape(padded * world, TILE, TILE, 3)[:n_tiles]
-                    full = t.view(ty, tx, TILE, TILE, 3).permute(0, 2, 1, 3, 4).reshape(ty * TILE, tx * TILE, 3)
-                    canvas.copy_(full[:H, :W])
+                dist.gather(bufs[b], gather_list[b], dst=0)
+                if rank == 0:                        # one un-permute kernel: tiles -> row-major canvas
+                    rtc.assemble_tiles_device(gathered[b].data_ptr(), world, padded, TILE, TILE, W, H,
+                                              canvas.data_ptr(), comm.cuda_stream)
                 gathered_ev[b].record(comm)
 
         def finish():
@@ -230,9 +232,11 @@ def main():
         ref = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
         gpu.render_device(cam, ref.data_ptr(), args.depth, None, sptr)
         torch.cuda.synchronize()
-        if not torch.equal(ref, canvas):
-            raise SystemExit("tile path result differs from the plain render")
-        print("check ok: assembled canvas == plain render", file=sys.stderr)
+        # shares of one pixel's ray tree are summed in arrival order: equal up to the last bits
+        worst = float((ref - canvas).abs().max().item())
+        if not worst < 1e-12:
+            raise SystemExit(f"tile path result differs from the plain render: max |delta| = {worst}")
+        print(f"check ok: assembled canvas vs plain render, max |delta| = {worst:.3g}", file=sys.stderr)
     if rank == 0:
         rays = stats["primary"] + stats["secondary"]
         ms_per_step = elapsed * 1e3 / args.steps

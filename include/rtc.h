@@ -205,6 +205,18 @@ int rtc_render_tiles_device(rtc_scene *scene, const rtc_camera *cam, uint32_t ma
                             uint32_t tile_stride, uint32_t n_my_tiles,
                             double *d_rgb_out, void *hip_stream);
 
+/*
+ * Rank 0 of the tile partition, after the gather: copies the ranks' compact tile
+ * buffers d_gathered[world][padded_tiles][tile_h][tile_w][3] (rank r's k-th tile
+ * is tile r + k * world of the row-major tiling) into the row-major canvas
+ * d_canvas[vsize][hsize][3].  Device to device on the current device,
+ * asynchronous on `hip_stream` (which must not be NULL).  Needs no scene.
+ * Replaces the row-major Canvas the reference fills in place (camera.zig:121).
+ */
+int rtc_assemble_tiles_device(const double *d_gathered, uint32_t world, uint32_t padded_tiles,
+                              uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
+                              double *d_canvas, void *hip_stream);
+
 /* Waits for the work enqueued on the handle's own stream. */
 int rtc_scene_synchronize(rtc_scene *scene);
 

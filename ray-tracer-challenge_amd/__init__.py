@@ -78,7 +78,7 @@ class Stats(C.Structure):
 
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_device",
-               "rtc_render_tiles_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
+               "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
                "rtc_status_name"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
@@ -104,6 +104,7 @@ def hip_lib():
         lib.rtc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p]
         lib.rtc_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 5 + [C.c_void_p, C.c_void_p]
+        lib.rtc_assemble_tiles_device.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
         lib.rtc_scene_synchronize.argtypes = [C.c_void_p]
         lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         _hip = lib
@@ -271,6 +272,12 @@ def tiles_of_rank(n_tiles, rank, world):
     count = (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
     padded = (n_tiles + world - 1) // world
     return rank, world, count, padded
+
+
+def assemble_tiles_device(d_gathered_ptr, world, padded, tile_w, tile_h, hsize, vsize, d_canvas_ptr, stream):
+    """Device-side twin of assemble_tiles (rank 0, after the gather); asynchronous on `stream`."""
+    _check_hip(hip_lib().rtc_assemble_tiles_device(d_gathered_ptr, world, padded, tile_w, tile_h, hsize, vsize,
+                                                   d_canvas_ptr, stream))
 
 
 def assemble_tiles(gathered, hsize, vsize, tile_w, tile_h, world):

@@ -20,6 +20,9 @@ extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera c
 extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                       const uint32_t max_depth, double* __restrict__ out,
                                                       DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
+                                               const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
+                                               const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
 
 namespace {
 
@@ -1484,6 +1487,24 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
   if (st != RTC_OK) return st;
   HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, need * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  return RTC_OK;
+}
+
+int rtc_assemble_tiles_device(const double* d_gathered, uint32_t world, uint32_t padded_tiles, uint32_t tile_w,
+                              uint32_t tile_h, uint32_t hsize, uint32_t vsize, double* d_canvas, void* hip_stream) {
+  g_error.clear();
+  if (!d_gathered || !d_canvas || !hip_stream) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (world == 0 || tile_w == 0 || tile_h == 0 || hsize == 0 || vsize == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "world %u tile %ux%u image %ux%u", world, tile_w, tile_h, hsize, vsize);
+  const uint64_t n_tiles = static_cast<uint64_t>((hsize + tile_w - 1) / tile_w) * ((vsize + tile_h - 1) / tile_h);
+  if (static_cast<uint64_t>(padded_tiles) * world < n_tiles)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "%u ranks x %u tiles cannot hold the %llu tiles of the image", world, padded_tiles,
+                (unsigned long long)n_tiles);
+  const size_t n = static_cast<size_t>(hsize) * vsize * 3u;
+  const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
+  hipLaunchKernelGGL(rtc_assemble_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_gathered,
+                     world, padded_tiles, tile_w, tile_h, hsize, vsize, d_canvas);
+  HIP_TRY(hipGetLastError());
   return RTC_OK;
 }
 

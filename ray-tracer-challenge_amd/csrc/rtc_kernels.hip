@@ -1394,3 +1394,23 @@ rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixel
                            double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
   render_body<false>(S, cam, map, max_depth, out, stats, next_stats);
 }
+
+// Rank 0's un-permute after the tile gather: one thread per canvas channel value, so both the read (a run
+// of tile_w * 3 doubles inside one tile row) and the write (the canvas row) are contiguous across a wave.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world, const uint32_t padded,
+                    const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize, const uint32_t vsize,
+                    double* __restrict__ canvas) {
+  const size_t n = static_cast<size_t>(hsize) * vsize * 3u;
+  const uint32_t tiles_x = (hsize + tile_w - 1u) / tile_w;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t pixel = i / 3u;
+    const uint32_t ch = static_cast<uint32_t>(i - pixel * 3u);
+    const uint32_t y = static_cast<uint32_t>(pixel / hsize), x = static_cast<uint32_t>(pixel - static_cast<size_t>(y) * hsize);
+    const uint32_t tile = (y / tile_h) * tiles_x + x / tile_w;
+    const uint32_t r = tile % world, k = tile / world;
+    const size_t src = (((static_cast<size_t>(r) * padded + k) * tile_h + y % tile_h) * tile_w + x % tile_w) * 3u + ch;
+    canvas[i] = gathered[src];
+  }
+}

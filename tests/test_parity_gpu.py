@@ -94,6 +94,19 @@ def test_interleaved_tiles_reassemble(rtc):
         gathered[rank] = buf.cpu().numpy()
     img = rtc.assemble_tiles(gathered, cam.hsize, cam.vsize, tw, th, world)
     assert np.abs(img - full).max() < REPEAT_TOL
+    # the device-side un-permute rank 0 runs after the gather (rtc_assemble_tiles_device): same bytes
+    stream = torch.cuda.Stream()
+    d_gathered = torch.from_numpy(gathered).cuda()
+    d_canvas = torch.full((cam.vsize, cam.hsize, 3), -1.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    rtc.assemble_tiles_device(d_gathered.data_ptr(), world, padded, tw, th, cam.hsize, cam.vsize,
+                              d_canvas.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert np.array_equal(d_canvas.cpu().numpy(), img)
+    with pytest.raises(rtc.RtcError) as e:   # too few tiles for the image
+        rtc.assemble_tiles_device(d_gathered.data_ptr(), world, 1, tw, th, cam.hsize, cam.vsize,
+                                  d_canvas.data_ptr(), stream.cuda_stream)
+    assert e.value.name == "InvalidArgument"
 
 
 def test_repeat_renders_agree(rtc):
