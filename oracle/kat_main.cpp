@@ -470,6 +470,23 @@ static void patternKats() {  // pattern.zig:152-177, checkers.zig:33-54, stripes
   expectColor("rings.zig:47", "rings_diag", rg.patternAt(point(0.708, 0, 0.708)), B, 0.0);
 }
 
+static void powKats() {  // Zig std.math.pow as restated by zig_pow (not part of the reference tree: identities only)
+  expectNear("std/math/pow.zig", "pow_2_10", zig_pow(2.0, 10.0), 1024.0, 0.0);
+  expectNear("std/math/pow.zig", "pow_half_sq", zig_pow(0.5, 2.0), 0.25, 0.0);
+  expectNear("std/math/pow.zig", "pow_neg_exp", zig_pow(2.0, -2.0), 0.25, 0.0);
+  expectNear("std/math/pow.zig", "pow_neg_base_odd", zig_pow(-2.0, 3.0), -8.0, 0.0);
+  expectNear("std/math/pow.zig", "pow_sqrt_case", zig_pow(4.0, 0.5), 2.0, 0.0);
+  expectNear("std/math/pow.zig", "pow_y0", zig_pow(123.4, 0.0), 1.0, 0.0);
+  expectNear("std/math/pow.zig", "pow_x0", zig_pow(0.0, 3.3), 0.0, 0.0);
+  expectNear("std/math/pow.zig", "pow_frac_0.8923", zig_pow(0.8923, 3.3), 0.686572, 1e-6);
+  expectNear("std/math/pow.zig", "pow_frac_1.5", zig_pow(1.5, 3.3), 3.811546, 1e-6);
+  expectNear("std/math/pow.zig", "pow_frac_37.45", zig_pow(37.45, 3.3), 155736.7160616, 1e-6);
+  expectTrue("std/math/pow.zig", "pow_neg_base_frac_is_nan", std::isnan(zig_pow(-8.0, 1.0 / 3.0)));
+  // the integer path agrees with libm to the accumulated rounding of its ~2*log2(y) multiplications
+  expectNear("std/math/pow.zig", "pow_shininess_200", zig_pow(0.97, 200.0) / std::pow(0.97, 200.0), 1.0, 1e-13);
+  expectNear("std/math/pow.zig", "pow_schlick_5", zig_pow(0.3, 5.0) / std::pow(0.3, 5.0), 1.0, 1e-15);
+}
+
 static void worldKats() {  // world.zig:293-892
   const World w = World::defaultWorld();
   expectTs("world.zig:293", "world_intersect", w.intersect({point(0, 0, -5), vec3(0, 0, 1)}), {4.0, 4.5, 5.5, 6.0});
@@ -683,6 +700,7 @@ int main() {
   refractionIndexKats();
   materialKats();
   patternKats();
+  powKats();
   worldKats();
   cameraKats();
   std::printf("KAT-SUMMARY total=%d failed=%d\n", g_total, g_failed);

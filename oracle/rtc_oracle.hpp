@@ -604,6 +604,80 @@ inline Tuple Shape::localNormalAt(Tuple p, const Intersection& h) const {
   }
 }
 
+// ------------------------------------------------------------------ std.math.pow
+// material.zig:69 and world.zig:288 call Zig's std.math.pow(f64, x, y).  That function is part of the Zig
+// standard library (the toolchain, `zig-version: master` in .github/workflows/deploy.yml), not of the
+// reference tree; its published algorithm (lib/std/math/pow.zig, "ported from Go's math.Pow") is restated
+// here: special cases, then x^y = x^frac(y) * x^int(y) with the integer power by binary exponentiation on
+// the frexp mantissa (exponents tracked separately) and one final scalbn.  It is NOT libm's correctly
+// rounded-ish pow: for shininess = 300 the two differ in the last few ulps.
+inline double zig_pow(double x, double y) {
+  const double inf = std::numeric_limits<double>::infinity();
+  if (y == 0.0 || x == 1.0) return 1.0;
+  if (std::isnan(x) || std::isnan(y)) return std::numeric_limits<double>::quiet_NaN();
+  if (y == 1.0) return x;
+  auto is_odd_integer = [](double v) {
+    if (std::fabs(v) >= 9007199254740992.0) return false;  // 2^53: every such double is even
+    double ip;
+    const double fp = std::modf(v, &ip);
+    return fp == 0.0 && (static_cast<long long>(ip) & 1) == 1;
+  };
+  if (x == 0.0) {
+    if (y < 0.0) return is_odd_integer(y) ? std::copysign(inf, x) : inf;
+    return is_odd_integer(y) ? x : 0.0;
+  }
+  if (std::isinf(y)) {
+    if (x == -1.0) return 1.0;
+    if ((std::fabs(x) < 1.0) == (y > 0.0)) return 0.0;
+    return inf;
+  }
+  if (std::isinf(x)) {
+    if (x < 0.0) {
+      if (y < 0.0) return is_odd_integer(y) ? -0.0 : 0.0;
+      return is_odd_integer(y) ? -inf : inf;
+    }
+    return y < 0.0 ? 0.0 : inf;
+  }
+  if (y == 0.5) return std::sqrt(x);
+  if (y == -0.5) return 1.0 / std::sqrt(x);
+  double yi;
+  double yf = std::modf(std::fabs(y), &yi);
+  if (yf != 0.0 && x < 0.0) return std::numeric_limits<double>::quiet_NaN();
+  if (yi >= 9223372036854775808.0) return std::exp(y * std::log(x));  // 1 << 63
+  double a1 = 1.0;  // the result is a1 * 2^ae
+  int ae = 0;
+  if (yf != 0.0) {
+    if (yf > 0.5) {
+      yf -= 1.0;
+      yi += 1.0;
+    }
+    a1 = std::exp(yf * std::log(x));
+  }
+  int xe;
+  double x1 = std::frexp(x, &xe);
+  for (long long i = static_cast<long long>(yi); i != 0; i >>= 1) {
+    if (xe < -(1 << 12) || (1 << 12) < xe) {  // catastrophic overflow
+      ae += xe;
+      break;
+    }
+    if (i & 1) {
+      a1 *= x1;
+      ae += xe;
+    }
+    x1 *= x1;
+    xe <<= 1;
+    if (x1 < 0.5) {
+      x1 += x1;
+      xe -= 1;
+    }
+  }
+  if (y < 0.0) {
+    a1 = 1.0 / a1;
+    ae = -ae;
+  }
+  return std::ldexp(a1, ae);
+}
+
 // ------------------------------------------------------------------ material.zig:40-74
 inline Color Material::lighting(const Light& light, const Shape* object, Tuple pt, Tuple point_to_eye, Tuple normal,
                                 bool in_shadow) const {
@@ -620,7 +694,7 @@ inline Color Material::lighting(const Light& light, const Shape* object, Tuple p
     const Tuple reflected = reflect(point_to_light, normal);
     const double reflect_dot_eye = dot(negate(reflected), point_to_eye);
     if (reflect_dot_eye > 0.0) {
-      specular_ = cmul(light.intensity, specular * std::pow(reflect_dot_eye, shininess));
+      specular_ = cmul(light.intensity, specular * zig_pow(reflect_dot_eye, shininess));
     }
   }
   return cadd(cadd(ambient_, diffuse_), specular_);
@@ -693,7 +767,7 @@ struct PreComputations {  // world.zig:194-210
     }
     const double frac = (n1 - n2) / (n1 + n2);
     const double r0 = frac * frac;
-    return r0 + (1.0 - r0) * std::pow(1 - cos, 5);
+    return r0 + (1.0 - r0) * zig_pow(1 - cos, 5);
   }
 };
 

@@ -30,8 +30,8 @@
 //     reference's;
 //   * arithmetic is FP64 in the reference's evaluation order and this file is compiled with
 //     -ffp-contract=off (the reference's Zig float mode is strict: no FMA contraction), so
-//     every t, point and normal is bit-identical to the CPU restatement; only pow() (specular,
-//     schlick) may differ in the last ulp.  No MFMA: nothing here is a dense contraction.
+//     every t, point and normal is bit-identical to the CPU restatement; pow() (specular, schlick)
+//     follows Zig's std.math.pow algorithm (zig_pow below).  No MFMA: nothing here is a dense contraction.
 #include "rtc_device.h"
 
 // Diagnostic build only (-DRTC_PROFILE): wave time per section of the main loop, from s_memtime stamps,
@@ -721,6 +721,78 @@ __device__ __forceinline__ Rgb pattern_at(const DevPattern* __restrict__ pat, ui
   return {ca.r + (cb.r - ca.r) * fpart, ca.g + (cb.g - ca.g) * fpart, ca.b + (cb.b - ca.b) * fpart};
 }
 
+// std.math.pow(f64, x, y) as Zig's standard library computes it (lib/std/math/pow.zig, a port of Go's
+// math.Pow; the reference calls it at material.zig:69 and world.zig:288): special cases, then
+// x^y = x^frac(y) * x^int(y), the integer power by binary exponentiation on the frexp mantissa with the
+// exponent carried separately, one scalbn at the end.  Same statement as oracle/rtc_oracle.hpp zig_pow.
+// For the scenes' integer shininess this is a dozen multiplications instead of libm's pow().
+__device__ __forceinline__ bool is_odd_integer(double v) {
+  if (__builtin_fabs(v) >= 9007199254740992.0) return false;
+  const double ip = __builtin_trunc(v);
+  return v == ip && (static_cast<long long>(ip) & 1ll) == 1ll;
+}
+__device__ __forceinline__ double zig_pow(double x, double y) {
+  const double inf = kInf;
+  if (y == 0.0 || x == 1.0) return 1.0;
+  if (x != x || y != y) return __builtin_nan("");
+  if (y == 1.0) return x;
+  if (x == 0.0) {
+    if (y < 0.0) return is_odd_integer(y) ? __builtin_copysign(inf, x) : inf;
+    return is_odd_integer(y) ? x : 0.0;
+  }
+  if (__builtin_isinf(y)) {
+    if (x == -1.0) return 1.0;
+    if ((__builtin_fabs(x) < 1.0) == (y > 0.0)) return 0.0;
+    return inf;
+  }
+  if (__builtin_isinf(x)) {
+    if (x < 0.0) {
+      if (y < 0.0) return is_odd_integer(y) ? -0.0 : 0.0;
+      return is_odd_integer(y) ? -inf : inf;
+    }
+    return y < 0.0 ? 0.0 : inf;
+  }
+  if (y == 0.5) return __builtin_sqrt(x);
+  if (y == -0.5) return 1.0 / __builtin_sqrt(x);
+  const double ay = __builtin_fabs(y);
+  double yi = __builtin_trunc(ay);
+  double yf = ay - yi;  // modf: exact
+  if (yf != 0.0 && x < 0.0) return __builtin_nan("");
+  if (yi >= 9223372036854775808.0) return exp(y * log(x));
+  double a1 = 1.0;
+  int ae = 0;
+  if (yf != 0.0) {
+    if (yf > 0.5) {
+      yf -= 1.0;
+      yi += 1.0;
+    }
+    a1 = exp(yf * log(x));
+  }
+  int xe;
+  double x1 = frexp(x, &xe);
+  for (long long i = static_cast<long long>(yi); i != 0; i >>= 1) {
+    if (xe < -(1 << 12) || (1 << 12) < xe) {
+      ae += xe;
+      break;
+    }
+    if (i & 1ll) {
+      a1 *= x1;
+      ae += xe;
+    }
+    x1 *= x1;
+    xe <<= 1;
+    if (x1 < 0.5) {
+      x1 += x1;
+      xe -= 1;
+    }
+  }
+  if (y < 0.0) {
+    a1 = 1.0 / a1;
+    ae = -ae;
+  }
+  return ldexp(a1, ae);
+}
+
 // One pending secondary ray of the colorAt recursion (world.zig:157-189): the colour it
 // returns is multiplied by `weight` on its way up to the pixel.
 struct Pending {
@@ -1091,9 +1163,30 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       mat_index = meta.z;
       if (kind == 3u || kind == 6u) hcy = S.cyl[geom];
     }
-    const DevMaterial mat = mats[mat_index];
     RTC_STAMP(10);
     const double t = hv.t;
+    // ---- n1 / n2 of PreComputations.new (world.zig:229-255), needed only if a refracted ray can be
+    // spawned.  Traced FIRST, while nothing of the shading is live yet (register peak, see pass 1 / 2 below).
+    double n1 = 1.0, n2 = 1.0;
+    if (cur.remaining != 0u && !(mats[mat_index].transparency == 0.0)) {
+      RTC_STAMP(5);
+      BehindVisitor bv;
+      bv.hit_leaf = hv.leaf;
+      bv.hit_t = t;
+      RTC_COUNT(4);
+      trace(S, recs, cull, ray, bv, overflow);
+      RTC_STAMP(6);
+      bv.flush();
+      const double hit_ior = mats[mat_index].ior;
+      if (bv.best_leaf != RTC_NO_LEAF) n1 = mats[bv.best_mat].ior;
+      if (!bv.hit_open) {
+        n2 = hit_ior;
+      } else if (bv.best_excl_leaf != RTC_NO_LEAF) {
+        n2 = mats[bv.best_excl_mat].ior;
+      } else if (bv.hit_dups >= 2u) {
+        n2 = hit_ior;
+      }
+    }
     const double ptx = ray.ox + ray.dx * t, pty = ray.oy + ray.dy * t, ptz = ray.oz + ray.dz * t;  // ray.position
     const double ex = -ray.dx, ey = -ray.dy, ez = -ray.dz;                                          // eyev
     // Shape.normalAt (shape.zig:338-350): local point, local normal, normalToWorld
@@ -1186,15 +1279,15 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_STAMP(11);
     const double eps = 1e-5;
     const double ovx = ptx + nx * eps, ovy = pty + ny * eps, ovz = ptz + nz * eps;  // over_point
-    const double unx = ptx - nx * eps, uny = pty - ny * eps, unz = ptz - nz * eps;  // under_point
+    // Pattern.patternAtShape (pattern.zig:128-131) looks the colour up at over_point in object space
+    const double opx = row_pt(M + 0, ovx, ovy, ovz);
+    const double opy = row_pt(M + 4, ovx, ovy, ovz);
+    const double opz = row_pt(M + 8, ovx, ovy, ovz);
 
     // ---- World.shadeHit, lights loop (world.zig:89-96)
     double sr = 0.0, sg = 0.0, sb = 0.0;
     {
-      // Pattern.patternAtShape (pattern.zig:128-131) at over_point; same for every light
-      const double opx = row_pt(M + 0, ovx, ovy, ovz);
-      const double opy = row_pt(M + 4, ovx, ovy, ovz);
-      const double opz = row_pt(M + 8, ovx, ovy, ovz);
+      const DevMaterial& mat = mats[mat_index];
       const Rgb color = pattern_at(pats, mat.pattern, opx, opy, opz);
       RTC_STAMP(12);
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
@@ -1229,7 +1322,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         }
         // Material.lighting (material.zig:40-74)
         const double er = color.r * L[3], eg = color.g * L[4], eb = color.b * L[5];  // effective_color
-        double lr_ = er * mat.ambient, lg_ = eg * mat.ambient, lb_ = eb * mat.ambient;
+        const double ka = mat.ambient;
+        double lr_ = er * ka, lg_ = eg * ka, lb_ = eb * ka;
         if (!shadowed) {
           double dr = 0.0, dg = 0.0, db = 0.0, pr = 0.0, pg = 0.0, pb = 0.0;
           if (light_dot_normal >= 0.0) {
@@ -1241,7 +1335,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             const double rx = lvx - nx * two_dot, ry = lvy - ny * two_dot, rz = lvz - nz * two_dot;
             const double reflect_dot_eye = ((-rx) * ex + (-ry) * ey) + (-rz) * ez;
             if (reflect_dot_eye > 0.0) {
-              const double ks = mat.specular * pow(reflect_dot_eye, mat.shininess);
+              const double ks = mat.specular * zig_pow(reflect_dot_eye, mat.shininess);
               pr = L[3] * ks;
               pg = L[4] * ks;
               pb = L[5] * ks;
@@ -1263,6 +1357,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_STAMP(6);
     // ---- reflectedColor / refractedColor / schlick (world.zig:98-107, 157-189, 272-289)
     if (cur.remaining == 0u) continue;
+    const DevMaterial& mat = mats[mat_index];
     const bool do_reflect = !(mat.reflective == 0.0);
     const bool transparent = !(mat.transparency == 0.0);
     if (!do_reflect && !transparent) continue;
@@ -1272,23 +1367,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     bool do_refract = false;
     double n_ratio = 1.0, sin2_t = 0.0;
     if (transparent) {
-      RTC_STAMP(5);
-      BehindVisitor bv;
-      bv.hit_leaf = hv.leaf;
-      bv.hit_t = t;
-      RTC_COUNT(4);
-      trace(S, recs, cull, ray, bv, overflow);
-      RTC_STAMP(6);
-      bv.flush();
-      double n1 = 1.0, n2 = 1.0;
-      if (bv.best_leaf != RTC_NO_LEAF) n1 = mats[bv.best_mat].ior;
-      if (!bv.hit_open) {
-        n2 = mat.ior;
-      } else if (bv.best_excl_leaf != RTC_NO_LEAF) {
-        n2 = mats[bv.best_excl_mat].ior;
-      } else if (bv.hit_dups >= 2u) {
-        n2 = mat.ior;
-      }
       n_ratio = n1 / n2;
       sin2_t = n_ratio * n_ratio * (1.0 - cos_i * cos_i);
       do_refract = !(sin2_t > 1.0);
@@ -1310,7 +1388,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         } else {
           const double frac = (n1 - n2) / (n1 + n2);
           const double r0 = frac * frac;
-          reflectance = r0 + (1.0 - r0) * pow(1.0 - c, 5.0);
+          reflectance = r0 + (1.0 - r0) * zig_pow(1.0 - c, 5.0);
         }
         w_reflect = mat.reflective * reflectance;
         w_refract = mat.transparency * (1.0 - reflectance);
@@ -1328,6 +1406,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (do_refract) {
       const double cos_t = __builtin_sqrt(1.0 - sin2_t);
       const double k = n_ratio * cos_i - cos_t;
+      const double unx = ptx - nx * eps, uny = pty - ny * eps, unz = ptz - nz * eps;  // under_point
       Pending p;
       p.ray = {unx, uny, unz, nx * k - ex * n_ratio, ny * k - ey * n_ratio, nz * k - ez * n_ratio};
       p.weight = cur.weight * w_refract;
