@@ -14,7 +14,9 @@ directory name contains a hyphen, so import it with
 `importlib.import_module("ray-tracer-challenge_amd")`.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -87,6 +89,29 @@ _hip = None
 _host = None
 
 
+def _one_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAME as ROCm's, other file).
+    A process that loads librtc_hip.so first (bound to /opt/rocm's copy) and torch later ends up with TWO
+    HIP/HSA runtimes driving one GPU, and stream handles passed between them belong to the wrong one.  When
+    torch is installed its copy is mapped first, so that the loader resolves our DT_NEEDED to it and one
+    runtime serves both (what happens anyway when torch is imported before this package)."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for name in ("libamdhip64.so",):
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def hip_lib():
     """librtc_hip.so; raises if the library has not been built (no fallback)."""
     global _hip
@@ -94,6 +119,7 @@ def hip_lib():
         path = os.path.join(LIB_DIR, "librtc_hip.so")
         if not os.path.exists(path):
             raise RtcError("LibraryMissing", f"{path} not built: run `make` or __graft_entry__.build()")
+        _one_hip_runtime()
         lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         lib.rtc_last_error.restype = C.c_char_p
         lib.rtc_status_name.restype = C.c_char_p

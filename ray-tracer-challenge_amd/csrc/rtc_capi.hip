@@ -1360,6 +1360,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
+  HIP_TRY(hipDeviceSynchronize());  // launches may come on any stream: the zeroes must be there by then
   s->max_trav_stack = max_stack;
   s->branching = branching_spheres;
   s->branching_everywhere = branching_everywhere;

@@ -19,6 +19,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # A hung kernel must not sit there silently: pytest-timeout (when installed) dumps the Python stacks and
+    # ends the process, so the test that hung is named in the log.
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(240, method="thread"))
+
+
 def _built():
     need = ["ray-tracer-challenge_amd/lib/librtc_hip.so", "ray-tracer-challenge_amd/lib/librtc_host.so",
             "ray-tracer-challenge_amd/lib/rtc_host_kat", "oracle/build/liboracle.so", "oracle/build/oracle_kat"]
