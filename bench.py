@@ -268,8 +268,11 @@ def main():
                 "kernel": "rtc_render_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
                 "note": "HBM is NOT what binds this kernel: the compulsory traffic is the canvas (24*W*H B) plus "
-                        "a few KB of scene tables that live in LDS; the binding limit is FP64 vector issue, see "
-                        "roofline_valu.  `traffic` is FETCH_SIZE*2 + WRITE_SIZE of profiles/ (separate PMC passes).",
+                        "a few KB of scene tables that live in LDS; the binding limit is per-wave FP64 issue "
+                        "latency, see roofline_valu.  `traffic` is FETCH_SIZE*2 + WRITE_SIZE of profiles/ (separate "
+                        "PMC passes): fabric-side requests of the L2s, mostly the lanes' pending-ray stacks and "
+                        "register spills cycling through L2 into the Infinity Cache (DESIGN.md section 5), not canvas "
+                        "bytes.",
             }
             if fl is not None:
                 tf = fl / (kernel_ms * 1e-3) / 1e12

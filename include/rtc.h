@@ -59,7 +59,7 @@ enum {
   RTC_CYLINDER = 3,        /* shapes/cylinder.zig */
   RTC_TRIANGLE = 4,        /* shapes/triangle.zig:17-81   */
   RTC_SMOOTH_TRIANGLE = 5, /* shapes/triangle.zig:210-274 */
-  RTC_CONE = 6             /* shapes/cone.zig (not implemented by the kernel yet -> RTC_ERR_UNSUPPORTED) */
+  RTC_CONE = 6             /* shapes/cone.zig; geometry in the cyl_* tables like a cylinder */
 };
 
 /* ---- pattern kinds: Pattern(T).Variant tags (patterns/pattern.zig:34-45) ---- */
@@ -71,7 +71,8 @@ enum {
   RTC_PAT_RADIAL_GRADIENT = 4, /* patterns/gradient.zig */
   RTC_PAT_CHECKERS = 5,        /* patterns/checkers.zig */
   RTC_PAT_BLEND = 6,           /* patterns/blend.zig    */
-  RTC_PAT_PERTURB = 7,         /* patterns/perturb.zig  (unsupported) */
+  RTC_PAT_PERTURB = 7,         /* patterns/perturb.zig: pat_a = the perturbed pattern, pat_rgb = PerturbInfo
+                                  {scale_value, octaves, persistence} (defaults 0.3, 3, 0.8) */
   RTC_PAT_TEXTURE_MAP = 8,     /* patterns/texture_map.zig (unsupported) */
   RTC_PAT_TEST = 9             /* TestPattern, pattern.zig:136-150: colour = pattern-space point */
 };

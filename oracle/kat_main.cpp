@@ -470,6 +470,11 @@ static void patternKats() {  // pattern.zig:152-177, checkers.zig:33-54, stripes
   expectColor("rings.zig:47", "rings_diag", rg.patternAt(point(0.708, 0, 0.708)), B, 0.0);
 }
 
+static void noiseKats() {  // noise.zig:106-109 (exact comparisons in the reference)
+  expectNear("noise.zig:107", "noise_3.14_42_7", perlinNoise(3.14, 42, 7), 0.13691995878400012, 0.0);
+  expectNear("noise.zig:108", "noise_-4.20_10_6", perlinNoise(-4.20, 10, 6), 0.14208000000000043, 0.0);
+}
+
 static void powKats() {  // Zig std.math.pow as restated by zig_pow (not part of the reference tree: identities only)
   expectNear("std/math/pow.zig", "pow_2_10", zig_pow(2.0, 10.0), 1024.0, 0.0);
   expectNear("std/math/pow.zig", "pow_half_sq", zig_pow(0.5, 2.0), 0.25, 0.0);
@@ -700,6 +705,7 @@ int main() {
   refractionIndexKats();
   materialKats();
   patternKats();
+  noiseKats();
   powKats();
   worldKats();
   cameraKats();

@@ -222,6 +222,63 @@ enum PatternKind : uint8_t {  // == RTC_PAT_* (include/rtc.h)
   PAT_CHECKERS = 5, PAT_BLEND = 6, PAT_PERTURB = 7, PAT_TEXTURE_MAP = 8, PAT_TEST = 9
 };
 
+// ------------------------------------------------------------------ noise.zig (Perlin's improved noise)
+// noise.zig:6-23: Ken Perlin's reference permutation (public constant of the algorithm), doubled (noise.zig:25-33)
+inline const uint8_t* perlinPermutation() {
+  static const uint8_t permutation[256] = {
+      151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142,
+      8,   99,  37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203,
+      117, 35,  11,  32,  57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165,
+      71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,
+      55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,
+      18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250,
+      124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189,
+      28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,
+      129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,
+      242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,
+      181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,  222, 114,
+      67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
+  return permutation;
+}
+// noise.zig:51-97.  The reference indexes a doubled table with u8 sums (overflow is undefined there);
+// p[k] == p[k & 255] for every k < 512, so every reading of those sums gives the value computed here.
+inline double perlinNoise(double x, double y, double z) {
+  const uint8_t* p = perlinPermutation();
+  auto P = [&](int i) { return static_cast<int>(p[i & 255]); };
+  const int X = static_cast<int>(static_cast<long long>(std::floor(x)) & 255);
+  const int Y = static_cast<int>(static_cast<long long>(std::floor(y)) & 255);
+  const int Z = static_cast<int>(static_cast<long long>(std::floor(z)) & 255);
+  x -= std::floor(x);
+  y -= std::floor(y);
+  z -= std::floor(z);
+  auto fade = [](double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); };
+  auto lerp = [](double t, double a, double b) { return a + t * (b - a); };
+  auto grad = [](int hash, double gx, double gy, double gz) {
+    const int h = hash & 15;
+    const double u = h < 8 ? gx : gy;
+    const double v = h < 4 ? gy : ((h == 12 || h == 14) ? gx : gz);
+    return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+  };
+  const double u = fade(x), v = fade(y), w = fade(z);
+  const int A = P(X) + Y, AA = P(A) + Z, AB = P(A + 1) + Z;
+  const int B = P(X + 1) + Y, BA = P(B) + Z, BB = P(B + 1) + Z;
+  return lerp(w,
+              lerp(v, lerp(u, grad(P(AA), x, y, z), grad(P(BA), x - 1, y, z)),
+                   lerp(u, grad(P(AB), x, y - 1, z), grad(P(BB), x - 1, y - 1, z))),
+              lerp(v, lerp(u, grad(P(AA + 1), x, y, z - 1), grad(P(BA + 1), x - 1, y, z - 1)),
+                   lerp(u, grad(P(AB + 1), x, y - 1, z - 1), grad(P(BB + 1), x - 1, y - 1, z - 1))));
+}
+inline double octaveNoise(double x, double y, double z, unsigned octaves, double persistence) {  // noise.zig:35-49
+  double total = 0.0, frequency = 1.0, amplitude = 1.0, max_value = 0.0;
+  for (unsigned i = 0; i < octaves; ++i) {
+    total += perlinNoise(x * frequency, y * frequency, z * frequency) * amplitude;
+    max_value += amplitude;
+    amplitude *= persistence;
+    frequency *= 2.0;
+  }
+  return total / max_value;
+}
+
 struct Pattern {
   Matrix transform = Matrix::identity();
   Matrix inverse = Matrix::identity();
@@ -266,6 +323,13 @@ struct Pattern {
       case PAT_BLEND: {                                             // blend.zig
         const Color ca = a->patternAt(object_point), cb = b->patternAt(object_point);
         return cmul(cadd(ca, cb), 0.5);
+      }
+      case PAT_PERTURB: {                                           // perturb.zig:31-46; rgb = PerturbInfo
+        const unsigned octaves = static_cast<unsigned>(rgb.g);
+        const Tuple offset = vec3(octaveNoise(object_point.x, object_point.y, object_point.z, octaves, rgb.b),
+                                  octaveNoise(object_point.x, object_point.y, object_point.z + 1.0, octaves, rgb.b),
+                                  octaveNoise(object_point.x, object_point.y, object_point.z + 2.0, octaves, rgb.b));
+        return a->patternAt(add(object_point, mul(offset, rgb.r)));
       }
       default: throw std::runtime_error("oracle: unsupported pattern kind");
     }

@@ -496,6 +496,7 @@ bool selectChainOnly(const rtc_scene_desc& d, uint32_t idx, int depth = 0) {
     case RTC_PAT_STRIPES:
     case RTC_PAT_CHECKERS:
     case RTC_PAT_RINGS: return selectChainOnly(d, d.pat_a[idx], depth + 1) && selectChainOnly(d, d.pat_b[idx], depth + 1);
+    case RTC_PAT_PERTURB: return selectChainOnly(d, d.pat_a[idx], depth + 1);
     default: return false;
   }
 }
@@ -1004,10 +1005,15 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   for (uint32_t i = 0; i < d.n_patterns; ++i) {
     if (!affineRow(d.pat_inv + 16ull * i)) return fail(RTC_ERR_NOT_AFFINE, "pattern %u: last row is not (0,0,0,1)", i);
     const uint8_t k = d.pat_kind[i];
-    if (k == RTC_PAT_PERTURB || k == RTC_PAT_TEXTURE_MAP || k > RTC_PAT_TEST)
+    if (k == RTC_PAT_TEXTURE_MAP || k > RTC_PAT_TEST)
       return fail(RTC_ERR_UNSUPPORTED, "pattern %u: kind %u is not implemented by this kernel", i, k);
     if (d.pat_a[i] >= d.n_patterns || d.pat_b[i] >= d.n_patterns)
       return fail(RTC_ERR_BAD_INDEX, "pattern %u: sub-pattern index out of range", i);
+    if (k == RTC_PAT_PERTURB) {  // pat_rgb = PerturbInfo {scale_value, octaves, persistence}
+      const double oct = d.pat_rgb[3ull * i + 1];
+      if (!(oct >= 0.0 && oct <= 64.0) || oct != std::floor(oct))
+        return fail(RTC_ERR_INVALID_ARGUMENT, "pattern %u: perturb octaves %g", i, oct);
+    }
   }
   for (uint32_t i = 0; i < d.n_patterns; ++i) {
     const uint8_t k = d.pat_kind[i];

@@ -659,11 +659,67 @@ struct Rgb {
   double r, g, b;
 };
 
+// noise.zig: Ken Perlin's improved noise (reference permutation noise.zig:6-23; the doubled table of
+// noise.zig:25-33 is p[k & 255]).  Same statement as oracle/rtc_oracle.hpp perlinNoise / octaveNoise.
+__constant__ uint8_t kPerlinPermutation[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103, 30,  69,  142,
+    8,   99,  37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,  197, 62,  94,  252, 219, 203,
+    117, 35,  11,  32,  57,  177, 33,  88,  237, 149, 56,  87,  174, 20,  125, 136, 171, 168, 68,  175, 74,  165,
+    71,  134, 139, 48,  27,  166, 77,  146, 158, 231, 83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,
+    55,  46,  245, 40,  244, 102, 143, 54,  65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,
+    18,  169, 200, 196, 135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250,
+    124, 123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,  182, 189,
+    28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101, 155, 167, 43,  172, 9,
+    129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185, 112, 104, 218, 246, 97,  228, 251, 34,
+    242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,  51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,
+    181, 199, 106, 157, 184, 84,  204, 176, 115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,  222, 114,
+    67,  29,  24,  72,  243, 141, 128, 195, 78,  66,  215, 61,  156, 180};
+__device__ __forceinline__ int perlin_p(int i) { return static_cast<int>(kPerlinPermutation[i & 255]); }
+__device__ __forceinline__ double perlin_grad(int hash, double x, double y, double z) {  // noise.zig:90-96
+  const int h = hash & 15;
+  const double u = h < 8 ? x : y;
+  const double v = h < 4 ? y : ((h == 12 || h == 14) ? x : z);
+  return ((h & 1) == 0 ? u : -u) + ((h & 2) == 0 ? v : -v);
+}
+__device__ __forceinline__ double perlin_fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+__device__ __forceinline__ double perlin_lerp(double t, double a, double b) { return a + t * (b - a); }
+__device__ __noinline__ double perlin_noise(double x, double y, double z) {  // noise.zig:51-89
+  const double fx = __builtin_floor(x), fy = __builtin_floor(y), fz = __builtin_floor(z);
+  const int X = static_cast<int>(static_cast<long long>(fx) & 255ll);
+  const int Y = static_cast<int>(static_cast<long long>(fy) & 255ll);
+  const int Z = static_cast<int>(static_cast<long long>(fz) & 255ll);
+  x -= fx;
+  y -= fy;
+  z -= fz;
+  const double u = perlin_fade(x), v = perlin_fade(y), w = perlin_fade(z);
+  const int A = perlin_p(X) + Y, AA = perlin_p(A) + Z, AB = perlin_p(A + 1) + Z;
+  const int B = perlin_p(X + 1) + Y, BA = perlin_p(B) + Z, BB = perlin_p(B + 1) + Z;
+  return perlin_lerp(
+      w,
+      perlin_lerp(v, perlin_lerp(u, perlin_grad(perlin_p(AA), x, y, z), perlin_grad(perlin_p(BA), x - 1.0, y, z)),
+                  perlin_lerp(u, perlin_grad(perlin_p(AB), x, y - 1.0, z), perlin_grad(perlin_p(BB), x - 1.0, y - 1.0, z))),
+      perlin_lerp(v,
+                  perlin_lerp(u, perlin_grad(perlin_p(AA + 1), x, y, z - 1.0), perlin_grad(perlin_p(BA + 1), x - 1.0, y, z - 1.0)),
+                  perlin_lerp(u, perlin_grad(perlin_p(AB + 1), x, y - 1.0, z - 1.0),
+                              perlin_grad(perlin_p(BB + 1), x - 1.0, y - 1.0, z - 1.0))));
+}
+__device__ __forceinline__ double octave_noise(double x, double y, double z, uint32_t octaves, double persistence) {
+  double total = 0.0, frequency = 1.0, amplitude = 1.0, max_value = 0.0;  // noise.zig:35-49
+  for (uint32_t i = 0; i < octaves; ++i) {
+    total += perlin_noise(x * frequency, y * frequency, z * frequency) * amplitude;
+    max_value += amplitude;
+    amplitude *= persistence;
+    frequency *= 2.0;
+  }
+  return total / max_value;
+}
+
 // Follows a chain of "selecting" patterns (stripes / checkers / rings) down to a solid or
 // test pattern.  Sub-patterns are evaluated at the OBJECT-space point with their own inverse
 // (stripes.zig:27-33).  Returns false if the chain ends in a mixing pattern (idx then names it).
-__device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat, uint32_t& idx, double ox, double oy,
-                                              double oz, Rgb& out) {
+// A perturb on the way moves the object point, for everything below it: (ox, oy, oz) is in/out.
+__device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat, uint32_t& idx, double& ox, double& oy,
+                                              double& oz, Rgb& out) {
   for (int guard = 0; guard < 64; ++guard) {
     const DevPattern& P = pat[idx];
     const uint32_t kind = P.kind;
@@ -685,6 +741,16 @@ __device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat
       idx = (zig_mod2((__builtin_floor(px) + __builtin_floor(py)) + __builtin_floor(pz)) < 1.0) ? ab.x : ab.y;
     } else if (kind == 2) {  // rings.zig:27-33
       idx = (zig_mod2(__builtin_floor(__builtin_sqrt(px * px + pz * pz))) < 1.0) ? ab.x : ab.y;
+    } else if (kind == 7) {  // perturb.zig:31-46: the wrapped pattern is looked up at a jittered OBJECT point
+      const uint32_t octaves = static_cast<uint32_t>(P.rgb[1]);
+      const double persistence = P.rgb[2], scale = P.rgb[0];
+      const double n0 = octave_noise(ox, oy, oz, octaves, persistence);
+      const double n1 = octave_noise(ox, oy, oz + 1.0, octaves, persistence);
+      const double n2 = octave_noise(ox, oy, oz + 2.0, octaves, persistence);
+      ox = ox + n0 * scale;
+      oy = oy + n1 * scale;
+      oz = oz + n2 * scale;
+      idx = ab.x;
     } else {
       return false;  // gradient / radial gradient / blend: needs both children
     }
@@ -706,8 +772,11 @@ __device__ __forceinline__ Rgb pattern_at(const DevPattern* __restrict__ pat, ui
   const double pz = row_pt(m + 8, ox, oy, oz);
   uint32_t ia = P.a, ib = P.b;
   Rgb ca{0, 0, 0}, cb{0, 0, 0};
-  pattern_chain(pat, ia, ox, oy, oz, ca);
-  pattern_chain(pat, ib, ox, oy, oz, cb);
+  {  // both children start from the mixing pattern's own object point (a perturb below moves its copy only)
+    double ax = ox, ay = oy, az = oz, bx = ox, by = oy, bz = oz;
+    pattern_chain(pat, ia, ax, ay, az, ca);
+    pattern_chain(pat, ib, bx, by, bz, cb);
+  }
   if (kind == 6) {  // blend.zig:21-24
     return {(ca.r + cb.r) * 0.5, (ca.g + cb.g) * 0.5, (ca.b + cb.b) * 0.5};
   }

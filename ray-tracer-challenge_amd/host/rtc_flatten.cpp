@@ -35,7 +35,11 @@ struct Flattener {
     std::string key;
     key.push_back(static_cast<char>(p.kind));
     appendBits(key, &p.inverse.d[0][0], 16);
-    const double rgb[3] = {p.rgb.r, p.rgb.g, p.rgb.b};
+    // a perturb pattern has no colour of its own: the slot carries PerturbInfo (rtc.h, pat_rgb)
+    const bool perturb = p.kind == PatternKind::Perturb;
+    const double rgb[3] = {perturb ? p.perturb_scale : p.rgb.r, perturb ? static_cast<double>(p.perturb_octaves) : p.rgb.g,
+                           perturb ? p.perturb_persistence : p.rgb.b};
+    if (perturb) b = a;
     appendBits(key, rgb, 3);
     key.append(reinterpret_cast<const char*>(&a), 4);
     key.append(reinterpret_cast<const char*>(&b), 4);

@@ -33,6 +33,9 @@ struct Pattern {  // patterns/pattern.zig:21-49
   PatternKind kind = PatternKind::Solid;
   Color rgb{1, 1, 1};                 // solid.zig:14
   std::shared_ptr<const Pattern> a, b;  // higher-order patterns keep pointers (stripes.zig:19-20)
+  // Perturb.PerturbInfo defaults (perturb.zig:21-25); the scene grammar cannot change them (scene.zig:356)
+  double perturb_scale = 0.3, perturb_persistence = 0.8;
+  unsigned perturb_octaves = 3;
 
   static Pattern solid(Color c) {
     Pattern p;

@@ -28,6 +28,8 @@ CASES = [
     ("cubes.json", 60, 30, 5),
     ("cylinders.json", 80, 40, 5),
     ("groups.json", 60, 20, 5),
+    ("xyz.json", 64, 36, 5),
+    ("perturb_demo.json", 80, 45, 5),
 ]
 
 

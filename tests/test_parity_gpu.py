@@ -30,6 +30,9 @@ CASES = [
     ("cubes.json", 150, 75, 5),
     ("cylinders.json", 160, 80, 5),
     ("groups.json", 150, 50, 5),                        # cones + cylinder in divided groups
+    ("xyz.json", 160, 90, 5),                           # gradient + rings patterns, shininess 1600
+    ("perturb_demo.json", 160, 90, 5),                  # perturb (Perlin noise) over every other pattern kind
+    ("nefertiti.json", 90, 150, 5),                     # 99 944-triangle OBJ, perturbed gradient
     ("cover.json", 33, 17, 0),                          # depth 0: no secondary rays at all
     ("fresnel.json", 17, 33, 1),
 ]
@@ -266,9 +269,15 @@ def _random_scene(seed):
         return {"type": {"solid": [round(rnd.random(), 3) for _ in range(3)]}}
 
     def pattern(depth=0):
-        k = rnd.choice(["solid", "solid", "stripes", "checkers", "rings", "gradient", "radial-gradient", "blend"])
+        kinds = ["solid", "solid", "stripes", "checkers", "rings", "gradient", "radial-gradient", "blend"]
+        if seed > 16:   # later seeds add Perlin-noise perturbation (seeds 1..16 keep the scenes they always had)
+            kinds.append("perturb")
+        k = rnd.choice(kinds)
         if k == "solid" or depth >= 2:
             return solid()
+        if k == "perturb":
+            inner = pattern(depth + 1)
+            return {"type": {"perturb": inner}, "transform": [{"scale": [rnd.uniform(0.3, 2.0)] * 3}]}
         sub = (lambda: solid()) if k in ("gradient", "radial-gradient", "blend") else (lambda: pattern(depth + 1))
         p = {"type": {k: [sub(), sub()]}}
         if rnd.random() < 0.7:
@@ -332,7 +341,7 @@ def _random_scene(seed):
                                   "to": [0, 0.5, 0], "up": [0, 1, 0]}, "lights": lights, "objects": objs})
 
 
-@pytest.mark.parametrize("seed", list(range(1, 17)))
+@pytest.mark.parametrize("seed", list(range(1, 23)))
 def test_random_scenes(rtc, seed):
     hs = rtc.HostScene(_random_scene(seed))
     cam = hs.camera()
