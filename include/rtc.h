@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 1u
+#define RTC_ABI_VERSION 2u
 
 /* ---- status codes; names mirror the reference's Zig error names where one exists ---- */
 typedef enum rtc_status {
@@ -76,6 +76,12 @@ enum {
   RTC_PAT_TEXTURE_MAP = 8,     /* patterns/texture_map.zig (unsupported) */
   RTC_PAT_TEST = 9             /* TestPattern, pattern.zig:136-150: colour = pattern-space point */
 };
+
+/* rtc_scene_desc::node_op (shapes/csg.zig:16-20) */
+#define RTC_CSG_NONE 0u
+#define RTC_CSG_UNION 1u
+#define RTC_CSG_INTERSECTION 2u
+#define RTC_CSG_DIFFERENCE 3u
 
 /* Children / roots are encoded as one u32: high bit set = group node index, else leaf index. */
 #define RTC_CHILD_NODE_BIT 0x80000000u
@@ -141,7 +147,10 @@ typedef struct rtc_scene_desc {
   const double *node_min;        /* [n_nodes][3] Group._bbox min (bounding_box.zig:21)     */
   const double *node_max;        /* [n_nodes][3]                                           */
   const uint32_t *node_first;    /* first entry of this group's children in children[]     */
-  const uint32_t *node_count;    /* Group.children.items.len                               */
+  const uint32_t *node_count;    /* Group.children.items.len; exactly 2 for a csg node     */
+  const uint8_t *node_op;        /* [n_nodes] RTC_CSG_NONE for a Group, else the Csg.operation
+                                    (csg.zig:16-20): children[first] is `left`, [first+1] `right`,
+                                    node_min/max the csg's _bbox (shape.zig:257-261)          */
   uint32_t n_children;
   const uint32_t *children;      /* mixed list, RTC_CHILD_NODE_BIT marks a sub-group       */
 

@@ -470,6 +470,63 @@ static void patternKats() {  // pattern.zig:152-177, checkers.zig:33-54, stripes
   expectColor("rings.zig:47", "rings_diag", rg.patternAt(point(0.708, 0, 0.708)), B, 0.0);
 }
 
+static Shape makeCsg(Shape left, Shape right, CsgOp op) {  // shape.zig:253-283 for leaf children at identity
+  Shape c = Shape::make(CSG);
+  c.csg_op = op;
+  c.bmin = point(-1, -1, -1);
+  c.bmax = point(1, 1, 1);
+  c.children.push_back(std::move(left));
+  c.children.push_back(std::move(right));
+  return c;
+}
+
+static void csgKats() {  // csg.zig:143-258
+  struct Row { CsgOp op; bool lhit, inl, inr, result; };
+  const Row rows[] = {
+      {CSG_UNION, true, true, true, false},         {CSG_UNION, true, true, false, true},
+      {CSG_UNION, true, false, true, false},        {CSG_UNION, true, false, false, true},
+      {CSG_UNION, false, true, true, false},        {CSG_UNION, false, true, false, false},
+      {CSG_UNION, false, false, true, true},        {CSG_UNION, false, false, false, true},
+      {CSG_INTERSECTION, true, true, true, true},   {CSG_INTERSECTION, true, true, false, false},
+      {CSG_INTERSECTION, true, false, true, true},  {CSG_INTERSECTION, true, false, false, false},
+      {CSG_INTERSECTION, false, true, true, true},  {CSG_INTERSECTION, false, true, false, true},
+      {CSG_INTERSECTION, false, false, true, false}, {CSG_INTERSECTION, false, false, false, false},
+      {CSG_DIFFERENCE, true, true, true, false},    {CSG_DIFFERENCE, true, true, false, true},
+      {CSG_DIFFERENCE, true, false, true, false},   {CSG_DIFFERENCE, true, false, false, true},
+      {CSG_DIFFERENCE, false, true, true, true},    {CSG_DIFFERENCE, false, true, false, true},
+      {CSG_DIFFERENCE, false, false, true, false},  {CSG_DIFFERENCE, false, false, false, false}};
+  int k = 0;
+  for (const Row& r : rows)
+    expectTrue("csg.zig:162-191", "intersection_allowed_" + std::to_string(k++),
+               intersectionAllowed(r.op, r.lhit, r.inl, r.inr) == r.result);
+  // csg.zig:193-225: filtering {1:s1, 2:s2, 3:s1, 4:s2}
+  const struct { CsgOp op; size_t x0, x1; } filt[] = {{CSG_UNION, 0, 3}, {CSG_INTERSECTION, 1, 2}, {CSG_DIFFERENCE, 0, 1}};
+  for (const auto& f : filt) {
+    Shape c = makeCsg(Shape::make(SPHERE), Shape::make(CUBE), f.op);
+    const Shape* s1 = &c.children[0];
+    const Shape* s2 = &c.children[1];
+    const Intersections xs{{1.0, s1}, {2.0, s2}, {3.0, s1}, {4.0, s2}};
+    const Intersections r = csgFilter(c, xs);
+    expectTrue("csg.zig:221-223", "filter_op" + std::to_string(f.op),
+               r.size() == 2 && r[0].t == xs[f.x0].t && r[0].object == xs[f.x0].object && r[1].t == xs[f.x1].t &&
+                   r[1].object == xs[f.x1].object);
+  }
+  {  // csg.zig:228-240
+    Shape c = makeCsg(Shape::make(SPHERE), Shape::make(CUBE), CSG_UNION);
+    expectTrue("csg.zig:239", "ray_misses_csg", c.intersect({point(0, 2, -5), vec3(0, 0, 1)}).empty());
+  }
+  {  // csg.zig:242-258
+    Shape s2 = Shape::make(SPHERE);
+    s2.setTransform(Matrix::identity().translate(0, 0, 0.5));
+    Shape c = makeCsg(Shape::make(SPHERE), std::move(s2), CSG_UNION);
+    c.bmax = point(1, 1, 1.5);  // union of the children's parent-space boxes
+    const Intersections xs = c.intersect({point(0, 0, -5), vec3(0, 0, 1)});
+    expectTrue("csg.zig:254-258", "ray_hits_csg",
+               xs.size() == 2 && xs[0].t == 4.0 && xs[0].object == &c.children[0] && xs[1].t == 6.5 &&
+                   xs[1].object == &c.children[1]);
+  }
+}
+
 static void noiseKats() {  // noise.zig:106-109 (exact comparisons in the reference)
   expectNear("noise.zig:107", "noise_3.14_42_7", perlinNoise(3.14, 42, 7), 0.13691995878400012, 0.0);
   expectNear("noise.zig:108", "noise_-4.20_10_6", perlinNoise(-4.20, 10, 6), 0.14208000000000043, 0.0);
@@ -705,6 +762,7 @@ int main() {
   refractionIndexKats();
   materialKats();
   patternKats();
+  csgKats();
   noiseKats();
   powKats();
   worldKats();

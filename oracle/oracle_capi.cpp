@@ -95,6 +95,11 @@ orc::Shape buildNode(const rtc_scene_desc& d, const OracleScene& os, uint32_t no
   if (static_cast<uint64_t>(first) + count > d.n_children) throw std::runtime_error("BadIndex: children");
   g.children.reserve(count);
   for (uint32_t i = 0; i < count; ++i) g.children.push_back(buildRef(d, os, d.children[first + i]));
+  if (d.node_op && d.node_op[node] != RTC_CSG_NONE) {
+    if (count != 2 || d.node_op[node] > RTC_CSG_DIFFERENCE) throw std::runtime_error("InvalidArgument: csg node");
+    g.kind = orc::CSG;
+    g.csg_op = static_cast<orc::CsgOp>(d.node_op[node]);
+  }
   return g;
 }
 

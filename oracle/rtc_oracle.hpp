@@ -354,8 +354,9 @@ struct Material {  // material.zig:18-25
 // ------------------------------------------------------------------ shapes
 enum ShapeKind : uint8_t {
   SPHERE = 0, PLANE = 1, CUBE = 2, CYLINDER = 3, TRIANGLE = 4, SMOOTH_TRIANGLE = 5, CONE = 6,  // == RTC_*
-  GROUP = 100, BOUNDING_BOX = 101, TEST_SHAPE = 102
+  GROUP = 100, BOUNDING_BOX = 101, TEST_SHAPE = 102, CSG = 103
 };
+enum CsgOp : uint8_t { CSG_UNION = 1, CSG_INTERSECTION = 2, CSG_DIFFERENCE = 3 };  // csg.zig:16-20, == RTC_CSG_*
 
 struct Intersection {  // shape.zig:23-47
   double t;
@@ -395,7 +396,8 @@ struct Shape {
   Tuple p1{}, e1{}, e2{}, normal{}, n1{}, n2{}, n3{};
   // bounding box / group
   Tuple bmin = point(INF, INF, INF), bmax = point(-INF, -INF, -INF);
-  std::vector<Shape> children;
+  std::vector<Shape> children;  // a csg: {left, right} (csg.zig:28-29)
+  CsgOp csg_op = CSG_UNION;
 
   static Shape make(ShapeKind k) {
     Shape s;
@@ -491,6 +493,41 @@ inline bool coneCheckCap(const Ray& ray, double t, double radius) {  // cone.zig
   const double x = ray.origin.x + t * ray.direction.x;
   const double z = ray.origin.z + t * ray.direction.z;
   return x * x + z * z <= radius * radius;
+}
+
+// csg.zig:112-118
+inline bool intersectionAllowed(CsgOp op, bool lhit, bool inl, bool inr) {
+  switch (op) {
+    case CSG_UNION: return (lhit && !inr) || !(lhit || inl);
+    case CSG_INTERSECTION: return (lhit && inr) || (!lhit && inl);
+    case CSG_DIFFERENCE: return (lhit && !inr) || (!lhit && inl);
+  }
+  return false;
+}
+// csg.zig:120-139
+inline bool csgIncludes(const Shape& a, const Shape& b) {
+  if (a.kind == GROUP) {
+    for (const Shape& child : a.children)
+      if (csgIncludes(child, b)) return true;
+    return false;
+  }
+  if (a.kind == CSG) return csgIncludes(a.children[0], b) || csgIncludes(a.children[1], b);
+  return a.id == b.id;
+}
+// csg.zig:51-72
+inline Intersections csgFilter(const Shape& csg, const Intersections& xs) {
+  bool inl = false, inr = false;
+  Intersections result;
+  for (const Intersection& i : xs) {
+    const bool lhit = csgIncludes(csg.children[0], *i.object);
+    if (intersectionAllowed(csg.csg_op, lhit, inl, inr)) result.push_back(i);
+    if (lhit) {
+      inl = !inl;
+    } else {
+      inr = !inr;
+    }
+  }
+  return result;
 }
 
 inline Intersections Shape::localIntersect(const Ray& ray) const {
@@ -619,13 +656,25 @@ inline Intersections Shape::localIntersect(const Ray& ray) const {
       sortIntersections(xs);
       return xs;
     }
+    case CSG: {  // csg.zig:74-95
+      static const Matrix kIdentity = Matrix::identity();
+      counters().bbox_tests++;
+      Intersections bbox_xs;
+      slabIntersect(bmin, bmax, ray.transform(kIdentity), this, bbox_xs);
+      if (bbox_xs.empty()) return xs;
+      xs = children[0].intersect(ray);
+      const Intersections rightxs = children[1].intersect(ray);
+      xs.insert(xs.end(), rightxs.begin(), rightxs.end());
+      sortIntersections(xs);
+      return csgFilter(*this, xs);
+    }
     case TEST_SHAPE: return xs;  // shape.zig:411-420
   }
   return xs;
 }
 
 inline Intersections Shape::intersect(const Ray& ray) const {
-  if (kind == GROUP) return localIntersect(ray);
+  if (kind == GROUP || kind == CSG) return localIntersect(ray);
   if (kind != BOUNDING_BOX) {
     counters().leaf_tests++;
     counters().xforms++;

@@ -58,6 +58,7 @@ class SceneDesc(C.Structure):
         ("n_patterns", C.c_uint32), ("pat_kind", _u8p), ("pat_inv", _dp), ("pat_rgb", _dp),
         ("pat_a", _u32p), ("pat_b", _u32p),
         ("n_nodes", C.c_uint32), ("node_min", _dp), ("node_max", _dp), ("node_first", _u32p), ("node_count", _u32p),
+        ("node_op", _u8p),
         ("n_children", C.c_uint32), ("children", _u32p),
         ("n_roots", C.c_uint32), ("roots", _u32p),
         ("n_lights", C.c_uint32), ("light_pos", _dp), ("light_rgb", _dp),

@@ -88,7 +88,11 @@ struct rtc_scene {
   DevBuf<DevMaterial> mat;
   DevBuf<uint2> node_kids;
   DevBuf<BvhNode> bvh;
-  DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent;
+  DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent, node_info;
+  DevBuf<uint2> node_range;
+  bool has_csg = false;
+  void* d_csg_buf = nullptr;       // DevPixelMap::csg_buf, only for scenes with csg nodes
+  size_t csg_buf_capacity = 0;     // bytes
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
   // heavy-first scheduling hint (see DevPixelMap::order)
@@ -947,6 +951,19 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     }
     map.ray_stack = static_cast<PendingRec*>(s->d_ray_stack);
     map.ray_stack_levels = max_depth + 2u;
+    s->dev.csg_buf = nullptr;
+    if (s->has_csg) {
+      const size_t need_csg = static_cast<size_t>(blocks) * 4u * RTC_CSG_ENTRIES * 64u * sizeof(CsgRec);
+      if (need_csg > s->csg_buf_capacity) {
+        HIP_TRY(hipStreamSynchronize(s->last_stream));
+        if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
+        s->d_csg_buf = nullptr;
+        s->csg_buf_capacity = 0;
+        HIP_TRY(hipMalloc(&s->d_csg_buf, need_csg));
+        s->csg_buf_capacity = need_csg;
+      }
+      s->dev.csg_buf = static_cast<CsgRec*>(s->d_csg_buf);
+    }
   }
   s->stats_parity ^= 1u;
   DevStats* const st_now = s->d_stats + s->stats_parity;
@@ -1037,6 +1054,14 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     if (!ids.insert(d.leaf_id[i]).second)
       return fail(RTC_ERR_UNSUPPORTED, "leaf %u: Shape.id %u appears on more than one leaf", i, d.leaf_id[i]);
   }
+  bool has_csg = false;
+  for (uint32_t n = 0; n < d.n_nodes && d.node_op; ++n) {
+    if (d.node_op[n] == RTC_CSG_NONE) continue;
+    if (d.node_op[n] > RTC_CSG_DIFFERENCE) return fail(RTC_ERR_INVALID_ARGUMENT, "node %u: csg operation %u", n, d.node_op[n]);
+    if (d.node_count[n] != 2) return fail(RTC_ERR_INVALID_ARGUMENT, "csg node %u has %u children, not left and right", n, d.node_count[n]);
+    has_csg = true;
+  }
+  auto opOf = [&](uint32_t n) -> uint32_t { return d.node_op ? d.node_op[n] : RTC_CSG_NONE; };
   std::vector<uint8_t> leaf_seen(d.n_leaves, 0), node_seen(d.n_nodes, 0);
   uint32_t max_stack = 0;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
@@ -1109,9 +1134,104 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   std::vector<uint32_t> bvh_leaves;
   std::vector<uint32_t> bvh_root_of(d.n_roots, 0);
   float bvh_mag = 0.0f;
+  // ---- reference-tree bookkeeping for every node: parent, which child of its parent it is (a csg's left
+  // is child 0), the contiguous range of depth-first leaves below it, and the csg UNITS: a csg whose parent
+  // is not a csg.  A unit is evaluated as a whole (its leaves' entries are merged, sorted and filtered by
+  // every csg node on the way up, csg.zig:51-95), so the candidate BVH treats it as one primitive.
+  std::vector<uint32_t> node_info(d.n_nodes, 0);       // op | slot << 8 | side << 16 | is_unit << 17
+  std::vector<uint2> node_range(d.n_nodes, uint2{0, 0});
+  std::vector<uint8_t> leaf_side(n_live, 0);
+  {
+    struct Frame { uint32_t node, next, unit, first_leaf; };
+    std::vector<uint32_t> unit_slots(d.n_nodes, 0);  // csg nodes counted per unit (indexed by the unit's node)
+    uint32_t next_leaf = 0;
+    for (uint32_t i = 0; i < d.n_roots; ++i) {
+      const uint32_t r = d.roots[i];
+      if (!(r & RTC_CHILD_NODE_BIT)) {
+        next_leaf++;
+        continue;
+      }
+      std::vector<Frame> frames;
+      auto enter = [&](uint32_t n, uint32_t parent, uint32_t side, uint32_t unit) -> int {
+        uint32_t info = opOf(n);
+        if (info != RTC_CSG_NONE) {
+          if (unit == RTC_NO_LEAF) {
+            unit = n;
+            info |= 1u << 17;
+          }
+          const uint32_t slot = unit_slots[unit]++;
+          if (slot >= 32) return fail(RTC_ERR_UNSUPPORTED, "csg node %u: more than 32 csg nodes under one csg", n);
+          info |= slot << 8;
+        }
+        info |= side << 16;
+        node_info[n] = info;
+        node_parent[n] = parent;
+        frames.push_back({n, 0, unit, next_leaf});
+        return RTC_OK;
+      };
+      int st = enter(r & ~RTC_CHILD_NODE_BIT, RTC_NO_LEAF, 0, RTC_NO_LEAF);
+      if (st != RTC_OK) return st;
+      while (!frames.empty()) {
+        Frame& f = frames.back();
+        if (f.next >= d.node_count[f.node]) {
+          node_range[f.node] = uint2{f.first_leaf, next_leaf - f.first_leaf};
+          frames.pop_back();
+          continue;
+        }
+        const uint32_t k = f.next++;
+        const uint32_t c = d.children[d.node_first[f.node] + k];
+        const uint32_t node = f.node, unit = f.unit;
+        if (c & RTC_CHILD_NODE_BIT) {
+          st = enter(c & ~RTC_CHILD_NODE_BIT, node, k == 0 ? 0u : 1u, unit);  // `f` is dangling from here on
+          if (st != RTC_OK) return st;
+        } else {
+          leaf_parent[dfs_of[c]] = node;
+          leaf_side[dfs_of[c]] = k == 0 ? 0 : 1;
+          next_leaf++;
+        }
+      }
+    }
+  }
+  for (uint32_t l = 0; l < n_live; ++l)
+    if (leaf_side[l]) leaf_meta[l].x |= 0x400u;
+  // ---- the candidate BVH of every top-level GROUP (a top-level csg is one unit and needs none)
+  auto unitPrim = [&](uint32_t n) {
+    BvhPrim p;
+    // world box of everything below the unit
+    std::vector<uint32_t> todo{n};
+    Aabb box;
+    bool bounded = true;
+    bool any = false;
+    while (!todo.empty()) {
+      const uint32_t m = todo.back();
+      todo.pop_back();
+      for (uint32_t k = 0; k < d.node_count[m]; ++k) {
+        const uint32_t c = d.children[d.node_first[m] + k];
+        if (c & RTC_CHILD_NODE_BIT) {
+          todo.push_back(c & ~RTC_CHILD_NODE_BIT);
+        } else {
+          const Aabb b = leafWorldBox(d, c);
+          if (!b.finite()) {
+            bounded = false;
+          } else {
+            for (int a = 0; a < 3; ++a) {
+              box.lo[a] = any ? std::fmin(box.lo[a], b.lo[a]) : b.lo[a];
+              box.hi[a] = any ? std::fmax(box.hi[a], b.hi[a]) : b.hi[a];
+            }
+            any = true;
+          }
+        }
+      }
+    }
+    p.box = (bounded && any) ? box : Aabb{};
+    for (int a = 0; a < 3; ++a) p.c[a] = p.box.finite() ? 0.5 * (p.box.lo[a] + p.box.hi[a]) : 0.0;
+    p.leaf = RTC_NODE_BIT | n;
+    return p;
+  };
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     const uint32_t r = d.roots[i];
     if (!(r & RTC_CHILD_NODE_BIT)) continue;
+    if (opOf(r & ~RTC_CHILD_NODE_BIT) != RTC_CSG_NONE) continue;
     std::vector<BvhPrim> items;
     std::vector<uint32_t> todo{r & ~RTC_CHILD_NODE_BIT};
     while (!todo.empty()) {
@@ -1120,10 +1240,12 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       for (uint32_t k = 0; k < d.node_count[n]; ++k) {
         const uint32_t c = d.children[d.node_first[n] + k];
         if (c & RTC_CHILD_NODE_BIT) {
-          node_parent[c & ~RTC_CHILD_NODE_BIT] = n;
-          todo.push_back(c & ~RTC_CHILD_NODE_BIT);
+          if (opOf(c & ~RTC_CHILD_NODE_BIT) != RTC_CSG_NONE) {
+            items.push_back(unitPrim(c & ~RTC_CHILD_NODE_BIT));
+          } else {
+            todo.push_back(c & ~RTC_CHILD_NODE_BIT);
+          }
         } else {
-          leaf_parent[dfs_of[c]] = n;
           BvhPrim p;
           p.box = leafWorldBox(d, c);
           for (int a = 0; a < 3; ++a) p.c[a] = p.box.finite() ? 0.5 * (p.box.lo[a] + p.box.hi[a]) : 0.0;
@@ -1164,6 +1286,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
             const uint32_t first = (r & ~RTC_NODE_BIT) >> 3, count = (r & 7u) + 1u;
             for (uint32_t k = 0; k < count; ++k) {
               const uint32_t leaf = bvh_leaves[first + k];
+              if (leaf & RTC_NODE_BIT) continue;  // a csg unit
               const Aabb& w = world[leaf];
               if (w.finite())
                 for (int a = 0; a < 3; ++a)
@@ -1186,7 +1309,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
           todo.push_back({N.c1, N.lo1, N.hi1});
         } else {
           const uint32_t first = (it.ref & ~RTC_NODE_BIT) >> 3, count = (it.ref & 7u) + 1u;
-          for (uint32_t k = 0; k < count; ++k) seen[bvh_leaves[first + k]]++;
+          for (uint32_t k = 0; k < count; ++k)
+            if (!(bvh_leaves[first + k] & RTC_NODE_BIT)) seen[bvh_leaves[first + k]]++;
         }
       }
     }
@@ -1214,14 +1338,55 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     Sphere sp;
     if (ref & RTC_CHILD_NODE_BIT) {
       const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
-      R.kind_flags = RTC_ROOT_IS_GROUP;
+      R.kind_flags = RTC_ROOT_IS_GROUP | (opOf(n) != RTC_CSG_NONE ? RTC_ROOT_IS_CSG : 0u);
       R.index = n;
       R.geom = bvh_root_of[i];
       // every entry of the group lies on a line that passes the group's own box test
       const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
       const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
       const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-      if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
+      bool csg_below = false;
+      {
+        std::vector<uint32_t> todo{n};
+        while (!todo.empty() && !csg_below) {
+          const uint32_t m = todo.back();
+          todo.pop_back();
+          csg_below = opOf(m) != RTC_CSG_NONE;
+          for (uint32_t k = 0; k < d.node_count[m]; ++k)
+            if (d.children[d.node_first[m] + k] & RTC_CHILD_NODE_BIT) todo.push_back(d.children[d.node_first[m] + k] & ~RTC_CHILD_NODE_BIT);
+        }
+      }
+      if (!csg_below) {
+        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
+      } else if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+        // A csg keeps the box it was built with when a transform is pushed through it (shape.zig:298-302),
+        // so its leaves - and the entries they report - may lie outside it and outside the groups above.
+        // "The line misses the box => no entry" still holds; "the box is behind the origin => so is every
+        // entry" does not.  The sphere therefore covers the box AND the leaves' world boxes.
+        Aabb all;
+        all.add(lo);
+        all.add(hi);
+        bool bounded = true;
+        std::vector<uint32_t> todo{n};
+        while (!todo.empty() && bounded) {
+          const uint32_t m = todo.back();
+          todo.pop_back();
+          for (uint32_t k = 0; k < d.node_count[m] && bounded; ++k) {
+            const uint32_t c = d.children[d.node_first[m] + k];
+            if (c & RTC_CHILD_NODE_BIT) {
+              todo.push_back(c & ~RTC_CHILD_NODE_BIT);
+            } else {
+              const Aabb b = leafWorldBox(d, c);
+              if (b.finite()) {
+                all.merge(b);
+              } else {
+                bounded = false;
+              }
+            }
+          }
+        }
+        if (bounded && all.finite()) sp = sphereOfBox(I, all.lo, all.hi);
+      }
     } else {
       const uint8_t k = d.leaf_kind[ref];
       const uint32_t g = d.leaf_geom[ref];
@@ -1363,6 +1528,9 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->bvh_leaf.upload(bvh_leaves));
   HIP_TRY(s->leaf_parent.upload(leaf_parent));
   HIP_TRY(s->node_parent.upload(node_parent));
+  HIP_TRY(s->node_info.upload(node_info));
+  HIP_TRY(s->node_range.upload(node_range));
+  s->has_csg = has_csg;
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
@@ -1401,6 +1569,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.bvh_leaf = s->bvh_leaf.p;
   D.leaf_parent = s->leaf_parent.p;
   D.node_parent = s->node_parent.p;
+  D.node_info = s->node_info.p;
+  D.node_range = s->node_range.p;
   D.bvh_mag = bvh_mag;
   D.node_box = s->node_box.p;
   D.node_kids = s->node_kids.p;
@@ -1430,6 +1600,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_order) (void)hipFree(s->d_order);
   if (s->d_cost) (void)hipFree(s->d_cost);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
+  if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
   delete s;
 }
 

@@ -65,6 +65,7 @@ struct RootRec {
   double pad_[2];        // 144-byte stride: per-lane LDS reads of different records spread over the banks
 };
 #define RTC_ROOT_IS_GROUP 0x8000u
+#define RTC_ROOT_IS_CSG 0x4000u  // with IS_GROUP: the root is a csg unit, `index` its node
 // Small-world limits: scenes within all four get their tables staged in LDS (34 KB per work-group);
 // anything larger runs the same kernel reading the tables from memory.
 #define RTC_LDS_ROOTS 128
@@ -98,6 +99,15 @@ struct __attribute__((aligned(64))) PendingRec {
   uint32_t remaining, pad_;
 };
 
+// One intersection of a csg unit under evaluation (csg.zig:74-95 builds, sorts and filters such a list);
+// the per-lane lists live in DevPixelMap::csg_buf as [wave][entry][lane].
+struct __attribute__((aligned(32))) CsgRec {
+  double t, u, v;
+  uint32_t leaf;
+  uint32_t flags;  // bit 0: survives every csg filter above it; bit 1: already handed to the visitor
+};
+#define RTC_CSG_ENTRIES 32u
+
 struct DevScene {
   const RootRec* __restrict__ root_recs;
   const RootCull* __restrict__ root_cull;
@@ -113,6 +123,12 @@ struct DevScene {
   const uint32_t* __restrict__ bvh_leaf;   // leaf indices referenced by BvhNode leaf ranges
   const uint32_t* __restrict__ leaf_parent;  // reference Group node directly above each leaf (RTC_NO_LEAF: none)
   const uint32_t* __restrict__ node_parent;  // reference Group above each Group node (RTC_NO_LEAF: none)
+  // csg (csg.zig): per node  op (RTC_CSG_*, bits 0..1) | slot << 8 (index of a csg node inside its unit, < 32)
+  //                | side << 16 (1: this node is the `right` child of its parent) | is_unit << 17;
+  // node_range = {first depth-first leaf below the node, count}.  leaf_meta.x bit 10 = the leaf's own side.
+  const uint32_t* __restrict__ node_info;
+  const uint2* __restrict__ node_range;
+  CsgRec* csg_buf;  // per-launch scratch of the csg units' intersection lists; null unless the scene has csg nodes
   const double* __restrict__ node_box;  // [n_nodes][6]
   const uint2* __restrict__ node_kids;  // {first, count}
   const uint32_t* __restrict__ kids;

@@ -349,6 +349,128 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
                [&](double t, double u, double v) { vis.entry(leaf, shadow, meta.z, t, u, v); });
 }
 
+// ------------------------------------------------------------------------------------------
+// CSG (shapes/csg.zig).  A csg UNIT (a csg node whose parent is not a csg) is evaluated as a whole:
+//   1. every leaf below it appends its entries - if the ray's line passes the box of every Group and Csg
+//      above the leaf (csg.zig:79-83 tests the csg's own, never re-boxed, _bbox like a group does);
+//   2. the list is sorted by t, stably: ties keep depth-first leaf order, which is what the reference's
+//      nested (left ++ right, stable sort) produces at every level (csg.zig:85-93, group.zig:52-60);
+//   3. one pass in that order applies filterIntersections (csg.zig:51-72) of EVERY csg node of the unit at
+//      once: an entry climbs from its leaf towards the unit; at each csg node it is tested against that
+//      node's (inl, inr), toggles one of them, and stops climbing where it is filtered out - exactly the
+//      entries the inner csg would have passed up are the ones that reach (and toggle) the outer one.
+// The survivors are what Csg.localIntersect returns; the caller hands them to its visitor.
+// Not inlined: scenes without csg never run it and its registers stay out of the main loop's budget.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool csg_rule(uint32_t op, bool lhit, bool inl, bool inr) {  // csg.zig:112-118
+  if (op == 1u) return (lhit && !inr) || !(lhit || inl);
+  if (op == 2u) return (lhit && inr) || (!lhit && inl);
+  return (lhit && !inr) || (!lhit && inl);
+}
+
+__device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, const Ray& ray, unsigned& overflow) {
+  CsgRec* const buf = S.csg_buf + (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * RTC_CSG_ENTRIES * 64u +
+                      (threadIdx.x & 63u);
+  const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
+  const uint2 range = S.node_range[unit];
+  uint32_t n = 0;
+  uint32_t cur_xf = 0xFFFFFFFFu;
+  Ray lr = ray;
+  for (uint32_t leaf = range.x; leaf < range.x + range.y; ++leaf) {
+    const uint4 meta = S.leaf_meta[leaf];
+    if (meta.y != cur_xf) {
+      lr = xform_ray(S.xf + 12ull * meta.y, ray);
+      cur_xf = meta.y;
+    }
+    const uint32_t kind = meta.x & 0xFFu;
+    CylParams cy{0.0, 0.0, false};
+    if (kind == 3u || kind == 6u) {
+      const DevCyl c = S.cyl[meta.w];
+      cy = {c.ymin, c.ymax, c.closed != 0u};
+    }
+    bool any = false, boxes = false;
+    leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr, [&](double t, double u, double v) {
+      if (!any) {
+        any = true;
+        boxes = chain_ok(S, leaf, ray, t, degenerate);
+      }
+      if (!boxes) return;
+      if (n >= RTC_CSG_ENTRIES) {
+        overflow = 1u;
+        return;
+      }
+      // insertion sort by t, stable (equal t: the later entry stays behind)
+      uint32_t i = n;
+      while (i > 0u && buf[static_cast<size_t>(i - 1u) * 64u].t > t) {
+        buf[static_cast<size_t>(i) * 64u] = buf[static_cast<size_t>(i - 1u) * 64u];
+        --i;
+      }
+      CsgRec rec;
+      rec.t = t;
+      rec.u = u;
+      rec.v = v;
+      rec.leaf = leaf;
+      rec.flags = 0u;
+      buf[static_cast<size_t>(i) * 64u] = rec;
+      ++n;
+    });
+  }
+  uint32_t inl = 0u, inr = 0u;  // one bit per csg node of the unit (node_info slot)
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t leaf = buf[static_cast<size_t>(i) * 64u].leaf;
+    uint32_t side = (S.leaf_meta[leaf].x >> 10) & 1u;
+    uint32_t cur = S.leaf_parent[leaf];
+    bool survives = true;
+    for (int guard = 0; guard < 4096; ++guard) {
+      const uint32_t info = S.node_info[cur];
+      const uint32_t op = info & 3u;
+      if (op != 0u) {
+        const uint32_t bit = 1u << ((info >> 8) & 31u);
+        const bool lhit = side == 0u;
+        const bool allowed = csg_rule(op, lhit, (inl & bit) != 0u, (inr & bit) != 0u);
+        if (lhit) {
+          inl ^= bit;
+        } else {
+          inr ^= bit;
+        }
+        if (!allowed) {
+          survives = false;
+          break;
+        }
+      }
+      if (cur == unit) break;
+      side = (info >> 16) & 1u;
+      cur = S.node_parent[cur];
+    }
+    buf[static_cast<size_t>(i) * 64u].flags = survives ? 1u : 0u;
+  }
+  return n;
+}
+
+// Hands the surviving entries of a csg unit to a visitor.  The closest-hit and shadow reductions take
+// them in list order; the containers walk (BehindVisitor) needs the entries of one leaf together.
+template <class V>
+__device__ __forceinline__ void visit_csg(const DevScene& S, uint32_t unit, const Ray& ray, V& vis, unsigned& overflow) {
+  const uint32_t n = csg_collect(S, unit, ray, overflow);
+  CsgRec* const buf = S.csg_buf + (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * RTC_CSG_ENTRIES * 64u +
+                      (threadIdx.x & 63u);
+  for (uint32_t i = 0; i < n; ++i) {
+    const CsgRec a = buf[static_cast<size_t>(i) * 64u];
+    if (a.flags != 1u) continue;
+    const uint4 meta = S.leaf_meta[a.leaf];
+    vis.entry(a.leaf, (meta.x >> 8) & 1u, meta.z, a.t, a.u, a.v);
+    if (V::kBehindOnly) {  // the leaf's remaining survivors right away
+      for (uint32_t j = i + 1u; j < n; ++j) {
+        const CsgRec b = buf[static_cast<size_t>(j) * 64u];
+        if (b.flags == 1u && b.leaf == a.leaf) {
+          vis.entry(b.leaf, (meta.x >> 8) & 1u, meta.z, b.t, b.u, b.v);
+          buf[static_cast<size_t>(j) * 64u].flags = 3u;
+        }
+      }
+    }
+  }
+}
+
 // Walks the candidate BVH of one group (BvhNode, rtc_device.h) with an FP32 copy of the ray.  The boxes
 // were rounded outward at upload; `delta` adds what the FP32 ray and slab arithmetic can be off by
 // (5e-7 * (|o| + largest box coordinate)), so a leaf whose exact test would produce an entry is never
@@ -379,7 +501,14 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
     const uint32_t ref = stack[--sp];
     if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
       const uint32_t first = (ref & ~RTC_NODE_BIT) >> 3, count = (ref & 7u) + 1u;
-      for (uint32_t i = 0; i < count; ++i) visit_leaf(S, S.bvh_leaf[first + i], ray, degenerate, cur_xf, lr, vis);
+      for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t e = S.bvh_leaf[first + i];
+        if (e & RTC_NODE_BIT) {  // a csg unit inside the group
+          visit_csg(S, e & ~RTC_NODE_BIT, ray, vis, overflow);
+        } else {
+          visit_leaf(S, e, ray, degenerate, cur_xf, lr, vis);
+        }
+      }
       continue;
     }
     const BvhNode& N = S.bvh[ref];
@@ -509,7 +638,11 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       }
       vis.set_root(RTC_NO_LEAF);
 #ifndef RTC_EXP_SMALL
-      traverse_bvh(S, R.geom, ray, vis, overflow);
+      if (kf & RTC_ROOT_IS_CSG) {
+        visit_csg(S, R.index, ray, vis, overflow);
+      } else {
+        traverse_bvh(S, R.geom, ray, vis, overflow);
+      }
 #endif
     }  // while (mine)
   }

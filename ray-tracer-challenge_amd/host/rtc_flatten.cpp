@@ -79,7 +79,7 @@ struct Flattener {
 
   // Returns the encoded child reference, or UINT32_MAX for shapes that can never be hit.
   uint32_t visit(const Shape& s) {
-    if (s.kind == ShapeKind::Group) return RTC_CHILD_NODE_BIT | visitGroup(s);
+    if (s.kind == ShapeKind::Group || s.kind == ShapeKind::Csg) return RTC_CHILD_NODE_BIT | visitGroup(s);
     if (s.kind == ShapeKind::TestShape) return UINT32_MAX;  // shape.zig:411-420: no intersections
     const uint32_t leaf = static_cast<uint32_t>(out.leaf_kind.size());
     uint8_t kind = RTC_SPHERE;
@@ -127,8 +127,17 @@ struct Flattener {
     std::vector<uint32_t> refs;
     out.node_first.push_back(0);
     out.node_count.push_back(0);
+    out.node_op.push_back(g.isCsg() ? static_cast<uint8_t>(g.csg_op) : RTC_CSG_NONE);
     for (const Shape& c : g.children) {
-      const uint32_t r = visit(c);
+      uint32_t r = visit(c);
+      if (r == UINT32_MAX && g.isCsg()) {  // a csg always has a left and a right: an empty group stands in
+        r = RTC_CHILD_NODE_BIT | static_cast<uint32_t>(out.node_first.size());
+        push3(out.node_min, BoundingBox{}.min);
+        push3(out.node_max, BoundingBox{}.max);
+        out.node_first.push_back(static_cast<uint32_t>(out.children.size()));
+        out.node_count.push_back(0);
+        out.node_op.push_back(RTC_CSG_NONE);
+      }
       if (r != UINT32_MAX) refs.push_back(r);
     }
     // children of one group are contiguous in children[]; sub-groups were appended first.
@@ -195,6 +204,7 @@ rtc_scene_desc FlatScene::desc() const {
   d.node_max = node_max.data();
   d.node_first = node_first.data();
   d.node_count = node_count.data();
+  d.node_op = node_op.data();
   d.n_children = static_cast<uint32_t>(children.size());
   d.children = children.data();
   d.n_roots = static_cast<uint32_t>(roots.size());

@@ -30,6 +30,7 @@ struct FlatScene {
   std::vector<uint32_t> pat_a, pat_b;
   std::vector<double> node_min, node_max;
   std::vector<uint32_t> node_first, node_count, children, roots;
+  std::vector<uint8_t> node_op;
   std::vector<double> light_pos, light_rgb;
 
   // View over the vectors above; valid while *this is alive and unmodified.

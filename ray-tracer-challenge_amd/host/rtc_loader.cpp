@@ -329,8 +329,26 @@ Shape parseObject(const Value& object, const InheritedState& inherited, const De
       st.casts_shadow = casts_shadow;
       shape.addChild(parseObject(child, st, definitions, load_file_data, depth + 1));
     }
-  } else if (t == "csg") {
-    throw Error("UnsupportedFeature", "csg shapes (shapes/csg.zig) are outside this build's scope");
+  } else if (t == "csg") {  // scene.zig:547-575
+    requireObject(payload, "csg");
+    checkFields(payload, {"left", "right", "operation"}, "csg");
+    InheritedState st;
+    st.material = material;
+    st.casts_shadow = casts_shadow;
+    Shape left = parseObject(requireField(payload, "left", "csg"), st, definitions, load_file_data, depth + 1);
+    Shape right = parseObject(requireField(payload, "right", "csg"), st, definitions, load_file_data, depth + 1);
+    const std::string& op = asString(requireField(payload, "operation", "csg"), "operation");
+    CsgOp o;
+    if (op == "union") {
+      o = CsgOp::Union;
+    } else if (op == "intersection") {
+      o = CsgOp::Intersection;
+    } else if (op == "difference") {
+      o = CsgOp::Difference;
+    } else {
+      throw Error("InvalidEnumTag", "csg.operation " + op);
+    }
+    shape = Shape::csg(std::move(left), std::move(right), o);
   } else {
     throw Error("UnknownField", "object.type." + t);
   }

@@ -44,6 +44,7 @@ BoundingBox Shape::bounds() const {
       box.add(p3);
       break;
     case ShapeKind::Group:  // group.zig:81-83
+    case ShapeKind::Csg:    // csg.zig:106-108
       box = bbox;
       break;
   }
@@ -57,6 +58,11 @@ void Shape::setTransform(const Matrix4& m) {
     for (Shape& child : children) child.setTransform(m.mul(child.transform));
     bbox = bbox.transform(m);
     (void)nextShapeId();  // the replacement bbox Shape consumes an id (bounding_box.zig:59)
+  } else if (kind == ShapeKind::Csg) {
+    // CSG pass the transformation on to their children too, but keep the box they were built with
+    // (shape.zig:298-302 has no counterpart of the group's re-boxing): restated as is.
+    children[0].setTransform(m.mul(children[0].transform));
+    children[1].setTransform(m.mul(children[1].transform));
   } else {
     transform = m;
     inverse = m.inverse();  // throws Error("NotInvertible")
@@ -93,6 +99,11 @@ void Shape::makeSubgroup(std::vector<Shape> list) {
 }
 
 void Shape::divide(size_t threshold) {
+  if (kind == ShapeKind::Csg) {  // shape.zig:393-396
+    children[0].divide(threshold);
+    children[1].divide(threshold);
+    return;
+  }
   if (kind != ShapeKind::Group) return;
   if (children.size() >= threshold) {
     auto parts = partitionChildren();
@@ -103,7 +114,7 @@ void Shape::divide(size_t threshold) {
 }
 
 size_t Shape::leafCount() const {
-  if (kind != ShapeKind::Group) return 1;
+  if (kind != ShapeKind::Group && kind != ShapeKind::Csg) return 1;
   size_t n = 0;
   for (const Shape& c : children) n += c.leafCount();
   return n;

@@ -140,8 +140,9 @@ struct BoundingBox {  // bounding_box.zig:21-22
 
 // ---------------------------------------------------------------- shapes
 enum class ShapeKind : uint8_t {
-  Sphere, Plane, Cube, Cylinder, Cone, Triangle, SmoothTriangle, Group, TestShape
+  Sphere, Plane, Cube, Cylinder, Cone, Triangle, SmoothTriangle, Group, TestShape, Csg
 };
+enum class CsgOp : uint8_t { Union = 1, Intersection = 2, Difference = 3 };  // csg.zig:16-20 (== RTC_CSG_*)
 
 size_t nextShapeId();  // shape.zig:123-130 — process-wide counter (also bumped by bounding boxes)
 
@@ -159,9 +160,10 @@ struct Shape {
   bool closed = false;
   // triangle / smooth triangle (triangle.zig:21-26, 214-221)
   Tuple p1, p2, p3, e1, e2, normal, n1, n2, n3;
-  // group (group.zig:21-23)
+  // group (group.zig:21-23); a csg keeps {left, right} here (csg.zig:28-31)
   std::vector<Shape> children;
   BoundingBox bbox;
+  CsgOp csg_op = CsgOp::Union;
 
   static Shape make(ShapeKind k) {
     Shape s;
@@ -206,7 +208,20 @@ struct Shape {
     return s;
   }
 
+  // shape.zig:253-283.  The box is the union of the children's parent-space boxes AT CONSTRUCTION; unlike a
+  // group's it is never re-boxed when a transform is pushed through the csg later (shape.zig:298-302).
+  static Shape csg(Shape left, Shape right, CsgOp op) {
+    Shape s = make(ShapeKind::Csg);
+    s.csg_op = op;
+    s.bbox = left.parentSpaceBounds();
+    s.bbox.merge(right.parentSpaceBounds());
+    s.children.push_back(std::move(left));
+    s.children.push_back(std::move(right));
+    return s;
+  }
+
   bool isGroup() const { return kind == ShapeKind::Group; }
+  bool isCsg() const { return kind == ShapeKind::Csg; }
 
   // shape.zig:353-362 + per-kind bounds(): object-space box.
   BoundingBox bounds() const;

@@ -412,6 +412,67 @@ static void flattenKats() {
                                          (f2.roots[0] & RTC_CHILD_NODE_BIT) && f2.xf_inv.size() == 9 * 16);
 }
 
+static void csgKats() {  // csg.zig:143-154, shape.zig:253-302,393-396, scene.zig:547-575
+  {
+    Shape s1 = Shape::sphere(), s2 = Shape::cube();
+    const size_t id1 = s1.id, id2 = s2.id;
+    Shape c = Shape::csg(s1, s2, CsgOp::Union);
+    report("csg.zig:152", "csg_left_right", c.isCsg() && c.children.size() == 2 && c.children[0].id == id1 && c.children[1].id == id2 &&
+                                                c.csg_op == CsgOp::Union);
+  }
+  {  // the box is the union of the children's parent-space boxes at construction (shape.zig:257-261) ...
+    Shape s1 = Shape::sphere();
+    Shape s2 = Shape::sphere();
+    s2.setTransform(Matrix4::identity().translate(0, 0, 0.5));
+    Shape c = Shape::csg(s1, s2, CsgOp::Union);
+    expectT("shape.zig:259", "csg_bbox_min", c.bounds().min, Tuple::point(-1, -1, -1));
+    expectT("shape.zig:261", "csg_bbox_max", c.bounds().max, Tuple::point(1, 1, 1.5));
+    // ... and a transform set on the csg goes to the children only: the csg keeps its box (shape.zig:298-302)
+    c.setTransform(Matrix4::identity().translate(10, 0, 0));
+    expectT("shape.zig:300", "csg_pushes_transform_left", c.children[0].transform.tupleMul(Tuple::point(0, 0, 0)), Tuple::point(10, 0, 0));
+    expectT("shape.zig:301", "csg_pushes_transform_right", c.children[1].transform.tupleMul(Tuple::point(0, 0, 0)), Tuple::point(10, 0, 0.5));
+    expectT("shape.zig:298", "csg_box_not_reboxed", c.bounds().max, Tuple::point(1, 1, 1.5));
+  }
+  {  // divide() recurses into both sides (shape.zig:393-396)
+    Shape g = Shape::group();
+    for (int i = 0; i < 9; ++i) {
+      Shape s = Shape::sphere();
+      s.setTransform(Matrix4::identity().translate(3.0 * i, 0, 0));
+      g.addChild(s);
+    }
+    Shape c = Shape::csg(g, Shape::cube(), CsgOp::Difference);
+    c.divide(8);
+    bool subdivided = false;
+    for (const Shape& k : c.children[0].children) subdivided |= k.isGroup();
+    report("shape.zig:394", "csg_divide_recurses", subdivided && c.leafCount() == 10);
+    World w;
+    w.objects.push_back(c);
+    const FlatScene f = flattenWorld(w);
+    report("flatten", "csg_node", f.roots.size() == 1 && (f.roots[0] & RTC_CHILD_NODE_BIT) && f.node_op.size() == f.nodeCount() &&
+                                      f.node_op[f.roots[0] & ~RTC_CHILD_NODE_BIT] == RTC_CSG_DIFFERENCE &&
+                                      f.node_count[f.roots[0] & ~RTC_CHILD_NODE_BIT] == 2 && f.leafCount() == 10);
+  }
+  {  // scene grammar (scene.zig:147-151, 547-575)
+    const char* js = R"({ "camera": { "width": 10, "height": 10, "field-of-view": 1, "from": [0,0,-5], "to": [0,0,0], "up": [0,1,0] },
+      "lights": [], "objects": [ { "type": { "csg": { "operation": "intersection",
+         "left": { "type": { "sphere": {} } }, "right": { "type": { "cube": {} }, "transform": [ { "translate": [0.5, 0, 0] } ] } } },
+         "material": { "ambient": 0.7 } } ] })";
+    const SceneInfo info = parseScene(js, directoryLoader(""));
+    const Shape& c = info.world.objects[0];
+    report("scene.zig:573", "parse_csg", c.isCsg() && c.csg_op == CsgOp::Intersection && c.children[0].kind == ShapeKind::Sphere &&
+                                           c.children[1].kind == ShapeKind::Cube && c.children[1].material.ambient == 0.7);
+    bool threw = false;
+    try {
+      parseScene(R"({ "camera": { "width": 1, "height": 1, "field-of-view": 1, "from": [0,0,-5], "to": [0,0,0], "up": [0,1,0] }, "lights": [],
+        "objects": [ { "type": { "csg": { "operation": "xor", "left": { "type": { "sphere": {} } }, "right": { "type": { "cube": {} } } } } } ] })",
+                 directoryLoader(""));
+    } catch (const Error& e) {
+      threw = std::string(e.name) == "InvalidEnumTag";
+    }
+    report("scene.zig:150", "csg_bad_operation", threw);
+  }
+}
+
 int main() {
   mathKats();
   boxKats();
@@ -420,6 +481,7 @@ int main() {
   objKats();
   canvasKats();
   flattenKats();
+  csgKats();
   std::printf("KAT-SUMMARY total=%d failed=%d\n", g_total, g_failed);
   return g_failed ? 1 : 0;
 }

@@ -30,6 +30,8 @@ CASES = [
     ("groups.json", 60, 20, 5),
     ("xyz.json", 64, 36, 5),
     ("perturb_demo.json", 80, 45, 5),
+    ("csg.json", 80, 45, 5),
+    ("csg_demo.json", 80, 45, 5),
 ]
 
 

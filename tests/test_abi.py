@@ -53,7 +53,7 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
     d.abi_version = 99
     assert lib.rtc_scene_create(C.byref(d), C.byref(out)) == 1
     assert b"InvalidArgument" in lib.rtc_last_error()
-    d.abi_version = 1
+    d.abi_version = 2   # RTC_ABI_VERSION (node_op was added in 2)
     # a non-affine inverse (last row != (0,0,0,1))
     xf = hs.array("xf_inv", d.n_xforms, 16)
     saved = xf[0, 12]
@@ -72,3 +72,15 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
     ids[1] = ids[0]
     assert lib.rtc_scene_create(C.byref(d), C.byref(out)) == 4
     ids[1] = saved_id
+    # a csg node must have exactly a left and a right child
+    hs2 = rtc.HostScene.from_file("csg.json")
+    d2 = hs2.desc
+    cnt = hs2.array("node_count", d2.n_nodes)
+    cnt[0] = 1
+    assert lib.rtc_scene_create(C.byref(d2), C.byref(out)) == 1
+    assert b"csg node" in lib.rtc_last_error()
+    cnt[0] = 2
+    ops = hs2.array("node_op", d2.n_nodes)
+    ops[0] = 9
+    assert lib.rtc_scene_create(C.byref(d2), C.byref(out)) == 1
+    ops[0] = 3

@@ -33,6 +33,8 @@ CASES = [
     ("xyz.json", 160, 90, 5),                           # gradient + rings patterns, shininess 1600
     ("perturb_demo.json", 160, 90, 5),                  # perturb (Perlin noise) over every other pattern kind
     ("nefertiti.json", 90, 150, 5),                     # 99 944-triangle OBJ, perturbed gradient
+    ("csg.json", 160, 90, 5),                           # three nested csg levels, unbounded cylinders
+    ("csg_demo.json", 160, 90, 5),                      # csg in a group, group in a csg, glass lens, stale csg box
     ("cover.json", 33, 17, 0),                          # depth 0: no secondary rays at all
     ("fresnel.json", 17, 33, 1),
 ]
@@ -316,6 +318,22 @@ def _random_scene(seed):
             o["casts-shadow"] = False
         return o
 
+    def csg(depth):
+        def side():
+            r = rnd.random()
+            if depth < 2 and r < 0.25:
+                return csg(depth + 1)
+            if depth < 2 and r < 0.4:
+                return group(depth + 1, rnd.randint(2, 4))
+            return leaf(1.2)
+        o = {"type": {"csg": {"operation": rnd.choice(["union", "intersection", "difference"]),
+                              "left": side(), "right": side()}}}
+        if rnd.random() < 0.3:   # a transform pushed through the csg: its box stays where it was built
+            o["transform"] = [{"translate": [rnd.uniform(-0.4, 0.4), rnd.uniform(0, 0.3), rnd.uniform(-0.4, 0.4)]}]
+        if rnd.random() < 0.4:
+            o["material"] = material()
+        return o
+
     def group(depth, n):
         kids = []
         for _ in range(n):
@@ -335,13 +353,18 @@ def _random_scene(seed):
              "material": {"transparency": 0.9, "reflective": 0.2, "refractive-index": 1.0003, "diffuse": 0.1}}]
     objs += [leaf(4.0) for _ in range(rnd.randint(3, 8))]
     objs += [group(0, rnd.randint(6, 14)) for _ in range(rnd.randint(1, 3))]
+    if seed > 22:   # later seeds add csg: top-level, and inside a group (seeds 1..22 keep their scenes)
+        objs += [csg(0) for _ in range(rnd.randint(1, 3))]
+        g = group(1, rnd.randint(2, 4))
+        g["type"]["group"].append(csg(1))
+        objs.append(g)
     lights = [{"point-light": {"position": [rnd.uniform(-8, 8), rnd.uniform(4, 10), rnd.uniform(-10, -4)],
                                "intensity": [rnd.uniform(0.3, 1.0)] * 3}} for _ in range(rnd.randint(1, 3))]
     return json.dumps({"camera": {"width": 96, "height": 64, "field-of-view": 1.0, "from": [rnd.uniform(-3, 3), 3, -9],
                                   "to": [0, 0.5, 0], "up": [0, 1, 0]}, "lights": lights, "objects": objs})
 
 
-@pytest.mark.parametrize("seed", list(range(1, 23)))
+@pytest.mark.parametrize("seed", list(range(1, 31)))
 def test_random_scenes(rtc, seed):
     hs = rtc.HostScene(_random_scene(seed))
     cam = hs.camera()
