@@ -48,7 +48,7 @@ typedef enum rtc_status {
   RTC_ERR_BAD_INDEX = 5,        /* an index array points outside its table                          */
   RTC_ERR_NO_DEVICE = 6,        /* no HIP device / HIP runtime failure; message carries hipError    */
   RTC_ERR_NOT_AFFINE = 7,       /* a shape/pattern inverse whose last row is not (0,0,0,1)          */
-  RTC_ERR_OVERFLOW = 8          /* a per-ray device stack overflowed (BVH deeper than RTC_MAX_STACK) */
+  RTC_ERR_OVERFLOW = 8          /* a per-lane device stack or csg intersection list overflowed        */
 } rtc_status;
 
 /* ---- leaf kinds: the Shape(T).Variant tags that can be hit (shape.zig:99-111) ---- */
@@ -175,7 +175,7 @@ typedef struct rtc_stats {
   uint64_t secondary;     /* reflectedColor + refractedColor calls that recurse (world.zig:164,186) */
   uint64_t shadow_calls;  /* isShadowed calls the reference makes (world.zig:92)                */
   uint64_t shadow_traced; /* shadow rays this library actually traced (skips provably inert ones) */
-  uint64_t overflow;      /* lanes whose traversal stack overflowed (must be 0)                 */
+  uint64_t overflow;      /* lanes that overflowed a stack / csg list (must be 0)                */
 } rtc_stats;
 
 typedef struct rtc_scene rtc_scene; /* opaque; owns the device copies and one HIP stream */

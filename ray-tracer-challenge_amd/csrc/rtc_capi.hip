@@ -20,6 +20,12 @@ extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera c
 extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                       const uint32_t max_depth, double* __restrict__ out,
                                                       DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_csg(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                 const uint32_t max_depth, double* __restrict__ out,
+                                                 DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_bigworld_csg(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                          const uint32_t max_depth, double* __restrict__ out,
+                                                          DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
                                                const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
                                                const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
@@ -976,13 +982,10 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
 #ifndef RTC_EXP_NOMEMSET
   HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
 #endif
-  if (lds) {
-    hipLaunchKernelGGL(rtc_render_kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth,
-                       d_out, st_now, st_next);
-  } else {
-    hipLaunchKernelGGL(rtc_render_kernel_bigworld, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map,
-                       max_depth, d_out, st_now, st_next);
-  }
+  auto* const kernel = s->has_csg ? (lds ? rtc_render_kernel_csg : rtc_render_kernel_bigworld_csg)
+                                  : (lds ? rtc_render_kernel : rtc_render_kernel_bigworld);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
+                     st_next);
   HIP_TRY(hipGetLastError());
   return RTC_OK;
 }
@@ -1545,9 +1548,10 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
     int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, has_csg ? rtc_render_kernel_csg : rtc_render_kernel, 256, 0));
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel_bigworld, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, has_csg ? rtc_render_kernel_bigworld_csg : rtc_render_kernel_bigworld, 256, 0));
     s->blocks_per_cu_big = static_cast<uint32_t>(std::max(nb, 1));
     if (const char* e = getenv("RTC_BLOCKS_PER_CU")) {  // experiment knob
       const int v = atoi(e);
@@ -1665,6 +1669,11 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
   if (st != RTC_OK) return st;
   HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, need * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  // a lane that ran out of traversal stack, pending-ray stack or csg list space has dropped work: the image
+  // is not the reference's.  Say so instead of returning it (asynchronous callers check rtc_get_stats).
+  unsigned long long dropped = 0;
+  HIP_TRY(hipMemcpy(&dropped, &(s->d_stats + s->stats_parity)->overflow, sizeof dropped, hipMemcpyDeviceToHost));
+  if (dropped) return fail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", dropped);
   return RTC_OK;
 }
 

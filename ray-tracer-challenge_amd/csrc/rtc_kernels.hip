@@ -475,7 +475,7 @@ __device__ __forceinline__ void visit_csg(const DevScene& S, uint32_t unit, cons
 // were rounded outward at upload; `delta` adds what the FP32 ray and slab arithmetic can be off by
 // (5e-7 * (|o| + largest box coordinate)), so a leaf whose exact test would produce an entry is never
 // skipped; visitors prune by t-interval with their own slack.
-template <class V>
+template <bool CSG, class V>
 __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, const Ray& ray, V& vis,
                                              unsigned& overflow) {
   const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
@@ -503,8 +503,8 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
       const uint32_t first = (ref & ~RTC_NODE_BIT) >> 3, count = (ref & 7u) + 1u;
       for (uint32_t i = 0; i < count; ++i) {
         const uint32_t e = S.bvh_leaf[first + i];
-        if (e & RTC_NODE_BIT) {  // a csg unit inside the group
-          visit_csg(S, e & ~RTC_NODE_BIT, ray, vis, overflow);
+        if (CSG && (e & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_csg kernels have this path)
+          if constexpr (CSG) visit_csg(S, e & ~RTC_NODE_BIT, ray, vis, overflow);
         } else {
           visit_leaf(S, e, ray, degenerate, cur_xf, lr, vis);
         }
@@ -608,7 +608,7 @@ __device__ __forceinline__ bool root_culled(const RootCull& R, const RayF& ray) 
 //           the 144-byte-strided root records (per-lane LDS addresses; the stride spreads the banks).
 // Rays of one wave are a mix of pixels and bounces after a few iterations, so the union of the lanes'
 // survivors is most of the world while each lane's own list is 2-4 roots long.
-template <class V>
+template <bool CSG, class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
                                       const RootCull* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow) {
   const RayF rf = ray_f32(ray, S.cull_cmax);
@@ -638,10 +638,10 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       }
       vis.set_root(RTC_NO_LEAF);
 #ifndef RTC_EXP_SMALL
-      if (kf & RTC_ROOT_IS_CSG) {
-        visit_csg(S, R.index, ray, vis, overflow);
+      if (CSG && (kf & RTC_ROOT_IS_CSG)) {
+        if constexpr (CSG) visit_csg(S, R.index, ray, vis, overflow);
       } else {
-        traverse_bvh(S, R.geom, ray, vis, overflow);
+        traverse_bvh<CSG>(S, R.geom, ray, vis, overflow);
       }
 #endif
     }  // while (mine)
@@ -1049,7 +1049,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // reflection / refraction children (one continues in registers, the other goes to the lane's stack).
 // Exit: the counter runs past n_chunks (`drained`) and no lane holds a ray; every wave reaches it.
 // ------------------------------------------------------------------------------------------
-template <bool LDS>
+template <bool LDS, bool CSG>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
@@ -1336,7 +1336,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 #endif
     ClosestVisitor hv;
     RTC_COUNT(0);
-    trace(S, recs, cull, ray, hv, overflow);
+    trace<CSG>(S, recs, cull, ray, hv, overflow);
     RTC_STAMP(2);
     if (hv.leaf == RTC_NO_LEAF) continue;  // black (world.zig:119)
 
@@ -1376,7 +1376,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
       RTC_COUNT(4);
-      trace(S, recs, cull, ray, bv, overflow);
+      trace<CSG>(S, recs, cull, ray, bv, overflow);
       RTC_STAMP(6);
       bv.flush();
       const double hit_ior = mats[mat_index].ior;
@@ -1518,7 +1518,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
           RTC_STAMP(3);
           RTC_COUNT(2);
-          trace(S, recs, cull, sray, sv, overflow);
+          trace<CSG>(S, recs, cull, sray, sv, overflow);
           RTC_STAMP(4);
           shadowed = sv.shadowed;
         }
@@ -1666,14 +1666,29 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                   double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, false>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // Same kernel for worlds whose World.objects table does not fit the LDS staging area.
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                            double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<false>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<false, false>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
+// The same two kernels with the csg path compiled in (scenes that have csg nodes).  Kept apart because the
+// out-of-line csg evaluation costs the main loop ~150 spilled VGPRs at every trace site (1.07 -> 1.38 ms on
+// cover.json when it was part of the only kernel).
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
+rtc_render_kernel_csg(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                      double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, true>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
+rtc_render_kernel_bigworld_csg(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                               double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<false, true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // Rank 0's un-permute after the tile gather: one thread per canvas channel value, so both the read (a run

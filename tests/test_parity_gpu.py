@@ -376,3 +376,19 @@ def test_random_scenes(rtc, seed):
     assert delta.max() < TOL, (seed, delta.max(), np.unravel_index(np.argmax(delta), delta.shape))
     st = gpu.stats()
     assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0
+
+
+def test_csg_list_overflow_is_reported(rtc):
+    """A csg whose list would need more than RTC_CSG_ENTRIES = 32 slots on some ray fails loudly (no truncation)."""
+    import json
+    spheres = [{"type": {"sphere": {}}, "transform": [{"scale": [0.2 + 0.05 * i] * 3}]} for i in range(20)]
+    scene = {"camera": {"width": 32, "height": 32, "field-of-view": 0.6, "from": [0, 0, -6], "to": [0, 0, 0], "up": [0, 1, 0]},
+             "lights": [{"point-light": {"position": [-5, 5, -5], "intensity": [1, 1, 1]}}],
+             "objects": [{"type": {"csg": {"operation": "union", "left": {"type": {"group": spheres}},
+                                           "right": {"type": {"cube": {}}}}}}]}
+    hs = rtc.HostScene(json.dumps(scene))
+    gpu = rtc.GpuScene(hs.desc)
+    with pytest.raises(rtc.RtcError) as e:
+        gpu.render(hs.camera(), 5)
+    assert e.value.name == "StackOverflow"
+    assert gpu.stats()["overflow"] > 0
