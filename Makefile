@@ -41,7 +41,7 @@ $(LIB)/librtc_hip.so: $(LIB)/rtc_kernels.o $(LIB)/rtc_capi.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
 
 $(LIB)/librtc_host.so: $(HOST_SRC) $(HOST_HDR) $(LIB)/librtc_hip.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -lrtc_hip -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -lrtc_hip -lz -Wl,-rpath,'$$ORIGIN'
 
 $(LIB)/rtc_host_kat: tests/cpp/host_kat_main.cpp $(LIB)/librtc_host.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -o $@ tests/cpp/host_kat_main.cpp -L$(LIB) -lrtc_host -lrtc_hip -Wl,-rpath,'$$ORIGIN'

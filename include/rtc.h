@@ -73,9 +73,20 @@ enum {
   RTC_PAT_BLEND = 6,           /* patterns/blend.zig    */
   RTC_PAT_PERTURB = 7,         /* patterns/perturb.zig: pat_a = the perturbed pattern, pat_rgb = PerturbInfo
                                   {scale_value, octaves, persistence} (defaults 0.3, 3, 0.8) */
-  RTC_PAT_TEXTURE_MAP = 8,     /* patterns/texture_map.zig (unsupported) */
+  RTC_PAT_TEXTURE_MAP = 8,     /* patterns/texture_map.zig: pat_a = index into the tex_* tables */
   RTC_PAT_TEST = 9             /* TestPattern, pattern.zig:136-150: colour = pattern-space point */
 };
+
+/* rtc_scene_desc::tex_mapping: TextureMap variants (texture_map.zig:173-305) */
+#define RTC_TEX_SPHERICAL 0u
+#define RTC_TEX_PLANAR 1u
+#define RTC_TEX_CYLINDRICAL 2u
+#define RTC_TEX_CUBIC 3u
+/* rtc_scene_desc::uv_kind: UvPattern variants (texture_map.zig:9-121) */
+#define RTC_UV_ALIGN_CHECK 0u /* uv_sub = central, upper-left, upper-right, bottom-left, bottom-right */
+#define RTC_UV_CHECKERS 1u    /* uv_size = width, height; uv_sub[0..1] = a, b                        */
+#define RTC_UV_IMAGE 2u       /* uv_image = image index, uv_interp = 0 none / 1 bilinear             */
+#define RTC_UV_TEST 3u        /* UvTestPattern: colour = (u, v, 0)                                   */
 
 /* rtc_scene_desc::node_op (shapes/csg.zig:16-20) */
 #define RTC_CSG_NONE 0u
@@ -160,6 +171,24 @@ typedef struct rtc_scene_desc {
   uint32_t n_lights;             /* World.lights (world.zig:25), point lights (light.zig)  */
   const double *light_pos;       /* [n_lights][3] */
   const double *light_rgb;       /* [n_lights][3] */
+
+  /* Texture maps (patterns/texture_map.zig); all counts may be 0 and the pointers NULL.    */
+  uint32_t n_texmaps;            /* a pattern of kind RTC_PAT_TEXTURE_MAP names one by pat_a */
+  const uint8_t *tex_mapping;    /* RTC_TEX_*                                              */
+  const uint32_t *tex_uv;        /* [n_texmaps][6] uv-pattern per face, Cubic.Face order front, back, left,
+                                    right, up, down (texture_map.zig:216); other mappings use entry 0 */
+  uint32_t n_uvs;
+  const uint8_t *uv_kind;        /* RTC_UV_*                                               */
+  const double *uv_size;         /* [n_uvs][2] UvCheckers width, height                    */
+  const uint32_t *uv_sub;        /* [n_uvs][5] pattern indices (see RTC_UV_*)              */
+  const uint32_t *uv_image;      /* [n_uvs] image index (RTC_UV_IMAGE)                     */
+  const uint8_t *uv_interp;      /* [n_uvs] UvImage.Interpolation: 0 None, 1 Bilinear      */
+  uint32_t n_images;             /* Canvas(T) behind a UvImage (canvas.zig:34-46)          */
+  const uint32_t *img_width;
+  const uint32_t *img_height;
+  const uint64_t *img_offset;    /* first pixel of the image in img_rgb                    */
+  const float *img_rgb;          /* [pixels][3], row-major: the f32 colour zigimg's iterator yields, which
+                                    canvas.zig:41 widens to T                               */
 } rtc_scene_desc;
 
 /* Camera(T) after Camera.new + setTransform (camera.zig:18-61). */

@@ -470,6 +470,128 @@ static void patternKats() {  // pattern.zig:152-177, checkers.zig:33-54, stripes
   expectColor("rings.zig:47", "rings_diag", rg.patternAt(point(0.708, 0, 0.708)), B, 0.0);
 }
 
+static Pattern solidPattern(Color c) {
+  Pattern p;
+  p.kind = PAT_SOLID;
+  p.rgb = c;
+  return p;
+}
+
+static void textureMapKats() {  // texture_map.zig:336-568
+  const Tuple nowhere = point(0, 0, 0);
+  {  // :350-361 checker pattern in 2D
+    const Pattern black = solidPattern({0, 0, 0}), white = solidPattern({1, 1, 1});
+    UvPattern ck;
+    ck.kind = UV_CHECKERS;
+    ck.width = ck.height = 2;
+    ck.sub[0] = &black;
+    ck.sub[1] = &white;
+    const struct { double u, v; Color want; } rows[] = {{0.0, 0.0, {0, 0, 0}}, {0.5, 0.0, {1, 1, 1}}, {0.0, 0.5, {1, 1, 1}},
+                                                        {0.5, 0.5, {0, 0, 0}}, {1.0, 1.0, {0, 0, 0}}};
+    int k = 0;
+    for (const auto& r : rows) expectColor("texture_map.zig:356-360", "uv_checkers_" + std::to_string(k++), ck.uvPatternAt(r.u, r.v, nowhere), r.want);
+  }
+  auto mapping = [&](const char* where, const std::string& name, TexMapping m, Tuple p, double u, double v) {
+    TextureMap tm;
+    tm.mapping = m;  // faces default to the uv test pattern: colour = (u, v, 0)
+    const Color c = tm.patternAt(p, nowhere);
+    expectNear(where, name + "_u", c.r, u);
+    expectNear(where, name + "_v", c.g, v);
+  };
+  {  // :371-381 spherical
+    const double r = 1.0 / std::sqrt(2.0);
+    const struct { Tuple p; double u, v; } rows[] = {{point(0, 0, -1), 0.0, 0.5}, {point(1, 0, 0), 0.25, 0.5}, {point(0, 0, 1), 0.5, 0.5},
+                                                     {point(-1, 0, 0), 0.75, 0.5}, {point(0, 1, 0), 0.5, 1.0}, {point(0, -1, 0), 0.5, 0.0},
+                                                     {point(r, r, 0), 0.25, 0.75}};
+    int k = 0;
+    for (const auto& row : rows) mapping("texture_map.zig:374-380", "spherical_" + std::to_string(k++), TEX_SPHERICAL, row.p, row.u, row.v);
+  }
+  {  // :383-393 planar
+    const struct { Tuple p; double u, v; } rows[] = {{point(0.25, 0, 0.5), 0.25, 0.5}, {point(0.25, 0, -0.25), 0.25, 0.75},
+                                                     {point(0.25, 0.5, -0.25), 0.25, 0.75}, {point(1.25, 0, 0.5), 0.25, 0.5},
+                                                     {point(0.25, 0, -1.75), 0.25, 0.25}, {point(1, 0, -1), 0.0, 0.0}, {point(0, 0, 0), 0.0, 0.0}};
+    int k = 0;
+    for (const auto& row : rows) mapping("texture_map.zig:386-392", "planar_" + std::to_string(k++), TEX_PLANAR, row.p, row.u, row.v);
+  }
+  {  // :395-408 cylindrical
+    const struct { Tuple p; double u, v; } rows[] = {
+        {point(0, 0, -1), 0.0, 0.0},          {point(0, 0.5, -1), 0.0, 0.5},           {point(0, 1, -1), 0.0, 0.0},
+        {point(0.70711, 0.5, -0.70711), 0.125, 0.5}, {point(1, 0.5, 0), 0.25, 0.5},    {point(0.70711, 0.5, 0.70711), 0.375, 0.5},
+        {point(0, -0.25, 1), 0.5, 0.75},      {point(-0.70711, 0.5, 0.70711), 0.625, 0.5}, {point(-1, 1.25, 0), 0.75, 0.25},
+        {point(-0.70711, 0.5, -0.70711), 0.875, 0.5}};
+    int k = 0;
+    for (const auto& row : rows) mapping("texture_map.zig:398-407", "cylindrical_" + std::to_string(k++), TEX_CYLINDRICAL, row.p, row.u, row.v);
+  }
+  const Color red{1, 0, 0}, yellow{1, 1, 0}, brown{1, 0.5, 0}, green{0, 1, 0}, cyan{0, 1, 1}, blue{0, 0, 1}, purple{1, 0, 1}, white{1, 1, 1};
+  const Pattern s_red = solidPattern(red), s_yellow = solidPattern(yellow), s_brown = solidPattern(brown), s_green = solidPattern(green),
+                s_cyan = solidPattern(cyan), s_blue = solidPattern(blue), s_purple = solidPattern(purple), s_white = solidPattern(white);
+  auto align = [](const Pattern* c, const Pattern* ul, const Pattern* ur, const Pattern* bl, const Pattern* br) {
+    UvPattern uv;
+    uv.kind = UV_ALIGN_CHECK;
+    uv.sub[0] = c; uv.sub[1] = ul; uv.sub[2] = ur; uv.sub[3] = bl; uv.sub[4] = br;
+    return uv;
+  };
+  {  // :423-429 layout of the align check pattern
+    const UvPattern uv = align(&s_white, &s_red, &s_yellow, &s_green, &s_cyan);
+    expectColor("texture_map.zig:424", "align_central", uv.uvPatternAt(0.5, 0.5, nowhere), white);
+    expectColor("texture_map.zig:425", "align_ul", uv.uvPatternAt(0.1, 0.9, nowhere), red);
+    expectColor("texture_map.zig:426", "align_ur", uv.uvPatternAt(0.9, 0.9, nowhere), yellow);
+    expectColor("texture_map.zig:427", "align_bl", uv.uvPatternAt(0.1, 0.1, nowhere), green);
+    expectColor("texture_map.zig:428", "align_br", uv.uvPatternAt(0.9, 0.1, nowhere), cyan);
+  }
+  {  // :431-440 faces, :450-478 per-face uv, :480-546 colours on a mapped cube (face and uv through the test pattern, then colours)
+    TextureMap cube;
+    cube.mapping = TEX_CUBIC;
+    cube.faces[0] = align(&s_cyan, &s_red, &s_yellow, &s_brown, &s_green);      // front
+    cube.faces[1] = align(&s_green, &s_purple, &s_cyan, &s_white, &s_blue);     // back
+    cube.faces[2] = align(&s_yellow, &s_cyan, &s_red, &s_blue, &s_brown);       // left
+    cube.faces[3] = align(&s_red, &s_yellow, &s_purple, &s_green, &s_white);    // right
+    cube.faces[4] = align(&s_brown, &s_cyan, &s_purple, &s_red, &s_yellow);     // up
+    cube.faces[5] = align(&s_purple, &s_brown, &s_green, &s_blue, &s_white);    // down
+    const struct { Tuple p; Color want; } rows[] = {
+        {point(-1, 0, 0), yellow},      {point(-1, 0.9, -0.9), cyan},   {point(-1, 0.9, 0.9), red},     {point(-1, -0.9, -0.9), blue},
+        {point(-1, -0.9, 0.9), brown},  {point(0, 0, 1), cyan},         {point(-0.9, 0.9, 1), red},     {point(0.9, 0.9, 1), yellow},
+        {point(-0.9, -0.9, 1), brown},  {point(0.9, -0.9, 1), green},   {point(1, 0, 0), red},          {point(1, 0.9, 0.9), yellow},
+        {point(1, 0.9, -0.9), purple},  {point(1, -0.9, 0.9), green},   {point(1, -0.9, -0.9), white},  {point(0, 0, -1), green},
+        {point(0.9, 0.9, -1), purple},  {point(-0.9, 0.9, -1), cyan},   {point(0.9, -0.9, -1), white},  {point(-0.9, -0.9, -1), blue},
+        {point(0, 1, 0), brown},        {point(-0.9, 1, -0.9), cyan},   {point(0.9, 1, -0.9), purple},  {point(-0.9, 1, 0.9), red},
+        {point(0.9, 1, 0.9), yellow},   {point(0, -1, 0), purple},      {point(-0.9, -1, 0.9), brown},  {point(0.9, -1, 0.9), green},
+        {point(-0.9, -1, -0.9), blue},  {point(0.9, -1, -0.9), white}};
+    int k = 0;
+    for (const auto& row : rows) expectColor("texture_map.zig:514-545", "mapped_cube_" + std::to_string(k++), cube.patternAt(row.p, nowhere), row.want, 0.0);
+    TextureMap probe;
+    probe.mapping = TEX_CUBIC;  // all faces = test pattern: (u, v)
+    const struct { const char* where; Tuple p; double u, v; } uvs[] = {
+        {"texture_map.zig:451", point(-0.5, 0.5, 1), 0.25, 0.75},  {"texture_map.zig:452", point(0.5, -0.5, 1), 0.75, 0.25},
+        {"texture_map.zig:456", point(0.5, 0.5, -1), 0.25, 0.75},  {"texture_map.zig:457", point(-0.5, -0.5, -1), 0.75, 0.25},
+        {"texture_map.zig:461", point(-1, 0.5, -0.5), 0.25, 0.75}, {"texture_map.zig:462", point(-1, -0.5, 0.5), 0.75, 0.25},
+        {"texture_map.zig:466", point(1, 0.5, 0.5), 0.25, 0.75},   {"texture_map.zig:467", point(1, -0.5, -0.5), 0.75, 0.25},
+        {"texture_map.zig:471", point(-0.5, 1, -0.5), 0.25, 0.75}, {"texture_map.zig:472", point(0.5, 1, 0.5), 0.75, 0.25},
+        {"texture_map.zig:476", point(-0.5, -1, 0.5), 0.25, 0.75}, {"texture_map.zig:477", point(0.5, -1, -0.5), 0.75, 0.25}};
+    k = 0;
+    for (const auto& row : uvs) {
+      const Color c = probe.patternAt(row.p, nowhere);
+      expectNear(row.where, "cube_uv_" + std::to_string(k) + "_u", c.r, row.u);
+      expectNear(row.where, "cube_uv_" + std::to_string(k++) + "_v", c.g, row.v);
+    }
+  }
+  {  // :548-568 canvas-based pattern (P3, max 10: value / 10; rows cycle 0..9 shifted by the row index)
+    UvImage im;
+    im.width = im.height = 10;
+    im.rgb.resize(300);
+    for (size_t y = 0; y < 10; ++y)
+      for (size_t x = 0; x < 10; ++x)
+        for (int c = 0; c < 3; ++c) im.rgb[3 * (y * 10 + x) + c] = static_cast<double>((x + y) % 10) / 10.0;
+    UvPattern uv;
+    uv.kind = UV_IMAGE;
+    uv.image = &im;
+    expectColor("texture_map.zig:564", "uv_image_0_0", uv.uvPatternAt(0.0, 0.0, nowhere), {0.9, 0.9, 0.9});
+    expectColor("texture_map.zig:565", "uv_image_0.3_0", uv.uvPatternAt(0.3, 0.0, nowhere), {0.2, 0.2, 0.2});
+    expectColor("texture_map.zig:566", "uv_image_0.6_0.3", uv.uvPatternAt(0.6, 0.3, nowhere), {0.1, 0.1, 0.1});
+    expectColor("texture_map.zig:567", "uv_image_1_1", uv.uvPatternAt(1.0, 1.0, nowhere), {0.9, 0.9, 0.9});
+  }
+}
+
 static Shape makeCsg(Shape left, Shape right, CsgOp op) {  // shape.zig:253-283 for leaf children at identity
   Shape c = Shape::make(CSG);
   c.csg_op = op;
@@ -762,6 +884,7 @@ int main() {
   refractionIndexKats();
   materialKats();
   patternKats();
+  textureMapKats();
   csgKats();
   noiseKats();
   powKats();

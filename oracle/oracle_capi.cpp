@@ -20,6 +20,8 @@ thread_local std::string g_error;
 
 struct OracleScene {
   std::vector<orc::Pattern> patterns;  // stable addresses: sized once
+  std::vector<orc::TextureMap> texmaps;
+  std::vector<orc::UvImage> images;
   orc::World world;
 };
 
@@ -119,6 +121,45 @@ OracleScene* buildScene(const rtc_scene_desc& d) {
     if (d.pat_a[i] >= d.n_patterns || d.pat_b[i] >= d.n_patterns) throw std::runtime_error("BadIndex: sub-pattern");
     p.a = &os->patterns[d.pat_a[i]];
     p.b = &os->patterns[d.pat_b[i]];
+  }
+  // texture maps (rtc.h tex_*, uv_*, img_*)
+  os->images.resize(d.n_images);
+  for (uint32_t i = 0; i < d.n_images; ++i) {
+    orc::UvImage& im = os->images[i];
+    im.width = d.img_width[i];
+    im.height = d.img_height[i];
+    if (im.width == 0 || im.height == 0) throw std::runtime_error("InvalidArgument: empty image");
+    const float* src = d.img_rgb + 3 * d.img_offset[i];
+    im.rgb.assign(src, src + 3 * im.width * im.height);  // canvas.zig:41 widens zigimg's f32 colour to T
+  }
+  os->texmaps.resize(d.n_texmaps);
+  for (uint32_t i = 0; i < d.n_texmaps; ++i) {
+    orc::TextureMap& tm = os->texmaps[i];
+    if (d.tex_mapping[i] > RTC_TEX_CUBIC) throw std::runtime_error("Unsupported: texture mapping");
+    tm.mapping = static_cast<orc::TexMapping>(d.tex_mapping[i]);
+    for (int f = 0; f < 6; ++f) {
+      const uint32_t u = d.tex_uv[6 * i + f];
+      if (u >= d.n_uvs) throw std::runtime_error("BadIndex: uv pattern");
+      orc::UvPattern& uv = tm.faces[f];
+      if (d.uv_kind[u] > RTC_UV_TEST) throw std::runtime_error("Unsupported: uv pattern kind");
+      uv.kind = static_cast<orc::UvKind>(d.uv_kind[u]);
+      uv.width = d.uv_size[2 * u];
+      uv.height = d.uv_size[2 * u + 1];
+      for (int k = 0; k < 5; ++k) {
+        if (d.uv_sub[5 * u + k] >= d.n_patterns) throw std::runtime_error("BadIndex: uv sub-pattern");
+        uv.sub[k] = &os->patterns[d.uv_sub[5 * u + k]];
+      }
+      if (uv.kind == orc::UV_IMAGE) {
+        if (d.uv_image[u] >= d.n_images) throw std::runtime_error("BadIndex: image");
+        uv.image = &os->images[d.uv_image[u]];
+      }
+      uv.bilinear = d.uv_interp[u] != 0;
+    }
+  }
+  for (uint32_t i = 0; i < d.n_patterns; ++i) {
+    if (os->patterns[i].kind != orc::PAT_TEXTURE_MAP) continue;
+    if (d.pat_a[i] >= d.n_texmaps) throw std::runtime_error("BadIndex: texture map");
+    os->patterns[i].texture_map = &os->texmaps[d.pat_a[i]];
   }
   for (uint32_t i = 0; i < d.n_roots; ++i) os->world.objects.push_back(buildRef(d, *os, d.roots[i]));
   for (uint32_t i = 0; i < d.n_lights; ++i) {

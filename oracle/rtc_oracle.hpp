@@ -279,6 +279,34 @@ inline double octaveNoise(double x, double y, double z, unsigned octaves, double
   return total / max_value;
 }
 
+// ------------------------------------------------------------------ texture_map.zig
+struct Pattern;
+struct UvImage {  // Canvas(T) behind a UvImage (texture_map.zig:66-105)
+  size_t width = 0, height = 0;
+  std::vector<double> rgb;  // [height][width][3]
+  Color at(size_t x, size_t y) const {  // Canvas.getPixelPointer(x, y).?.*; out of bounds is a panic there
+    if (x >= width) x = width - 1;
+    if (y >= height) y = height - 1;
+    const double* p = &rgb[3 * (y * width + x)];
+    return {p[0], p[1], p[2]};
+  }
+};
+enum UvKind : uint8_t { UV_ALIGN_CHECK = 0, UV_CHECKERS = 1, UV_IMAGE = 2, UV_TEST = 3 };     // == RTC_UV_*
+enum TexMapping : uint8_t { TEX_SPHERICAL = 0, TEX_PLANAR = 1, TEX_CYLINDRICAL = 2, TEX_CUBIC = 3 };  // == RTC_TEX_*
+struct UvPattern {
+  UvKind kind = UV_TEST;
+  double width = 0.0, height = 0.0;
+  const Pattern* sub[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  const UvImage* image = nullptr;
+  bool bilinear = false;
+  Color uvPatternAt(double u, double v, Tuple object_point) const;
+};
+struct TextureMap {
+  TexMapping mapping = TEX_SPHERICAL;
+  UvPattern faces[6];  // Cubic.Face order: front, back, left, right, up, down (texture_map.zig:216)
+  Color patternAt(Tuple pattern_point, Tuple object_point) const;
+};
+
 struct Pattern {
   Matrix transform = Matrix::identity();
   Matrix inverse = Matrix::identity();
@@ -286,6 +314,7 @@ struct Pattern {
   Color rgb{1, 1, 1};
   const Pattern* a = nullptr;
   const Pattern* b = nullptr;
+  const TextureMap* texture_map = nullptr;
 
   void setTransform(const Matrix& m) {  // pattern.zig:103
     transform = m;
@@ -324,6 +353,7 @@ struct Pattern {
         const Color ca = a->patternAt(object_point), cb = b->patternAt(object_point);
         return cmul(cadd(ca, cb), 0.5);
       }
+      case PAT_TEXTURE_MAP: return texture_map->patternAt(pp, object_point);  // texture_map.zig:322-330
       case PAT_PERTURB: {                                           // perturb.zig:31-46; rgb = PerturbInfo
         const unsigned octaves = static_cast<unsigned>(rgb.g);
         const Tuple offset = vec3(octaveNoise(object_point.x, object_point.y, object_point.z, octaves, rgb.b),
@@ -335,6 +365,84 @@ struct Pattern {
     }
   }
 };
+
+inline Color UvPattern::uvPatternAt(double u, double v, Tuple object_point) const {
+  switch (kind) {
+    case UV_TEST: return {u, v, 0.0};  // texture_map.zig:13-17
+    case UV_ALIGN_CHECK:               // texture_map.zig:30-39
+      if (v > 0.8) {
+        if (u < 0.2) return sub[1]->patternAt(object_point);
+        if (u > 0.8) return sub[2]->patternAt(object_point);
+      } else if (v < 0.2) {
+        if (u < 0.2) return sub[3]->patternAt(object_point);
+        if (u > 0.8) return sub[4]->patternAt(object_point);
+      }
+      return sub[0]->patternAt(object_point);
+    case UV_CHECKERS: {  // texture_map.zig:52-60
+      const double u_adj = std::floor(u * width), v_adj = std::floor(v * height);
+      return (zigMod(u_adj + v_adj, 2.0) < 1.0) ? sub[0]->patternAt(object_point) : sub[1]->patternAt(object_point);
+    }
+    case UV_IMAGE: {  // texture_map.zig:74-103
+      const double v_flip = 1.0 - v;
+      const double x = u * static_cast<double>(image->width - 1);
+      const double y = v_flip * static_cast<double>(image->height - 1);
+      auto idx = [](double f) { return f <= 0.0 ? size_t{0} : static_cast<size_t>(f); };  // @intFromFloat; negative is UB there
+      if (!bilinear) return image->at(idx(std::round(x)), idx(std::round(y)));  // @round: half away from zero
+      const double x1 = std::floor(x), x2 = std::ceil(x), y1 = std::floor(y), y2 = std::ceil(y);
+      const Color c11 = image->at(idx(x1), idx(y1)), c21 = image->at(idx(x2), idx(y1));
+      const Color c12 = image->at(idx(x1), idx(y2)), c22 = image->at(idx(x2), idx(y2));
+      // on an integer coordinate x1 == x2 and both weights are 0: the reference returns black there
+      const Color cx1 = cadd(cmul(c11, x2 - x), cmul(c21, x - x1));
+      const Color cx2 = cadd(cmul(c12, x2 - x), cmul(c22, x - x1));
+      return cadd(cmul(cx1, y2 - y), cmul(cx2, y - y1));
+    }
+  }
+  return {0.0, 0.0, 0.0};
+}
+
+inline Color TextureMap::patternAt(Tuple p, Tuple object_point) const {
+  const double kPi = 3.14159265358979323846264338327950288;  // std.math.pi
+  switch (mapping) {
+    case TEX_SPHERICAL: {  // texture_map.zig:180-195
+      const double theta = std::atan2(p.x, p.z);
+      const double radius = magnitude(vec3(p.x, p.y, p.z));
+      const double phi = std::acos(p.y / radius);
+      const double raw_u = theta / (2.0 * kPi);
+      const double u = 1.0 - (raw_u + 0.5);
+      const double v = 1.0 - phi / kPi;
+      return faces[0].uvPatternAt(u, v, object_point);
+    }
+    case TEX_PLANAR:  // texture_map.zig:201-205
+      return faces[0].uvPatternAt(zigMod(p.x, 1.0), zigMod(p.z, 1.0), object_point);
+    case TEX_CYLINDRICAL: {  // texture_map.zig:210-217
+      const double theta = std::atan2(p.x, p.z);
+      const double raw_u = theta / (2.0 * kPi);
+      const double u = 1.0 - (raw_u + 0.5);
+      return faces[0].uvPatternAt(u, zigMod(p.y, 1.0), object_point);
+    }
+    case TEX_CUBIC: {  // texture_map.zig:219-303
+      const double coord = std::fmax(std::fabs(p.x), std::fmax(std::fabs(p.y), std::fabs(p.z)));
+      enum { FRONT = 0, BACK = 1, LEFT = 2, RIGHT = 3, UP = 4, DOWN = 5 };
+      int face = BACK;
+      if (coord == p.x) face = RIGHT;
+      else if (coord == -p.x) face = LEFT;
+      else if (coord == p.y) face = UP;
+      else if (coord == -p.y) face = DOWN;
+      else if (coord == p.z) face = FRONT;
+      double u = 0.0, v = 0.0;
+      switch (face) {
+        case FRONT: u = zigMod(p.x + 1.0, 2.0) / 2.0; v = zigMod(p.y + 1.0, 2.0) / 2.0; break;
+        case BACK: u = zigMod(1.0 - p.x, 2.0) / 2.0; v = zigMod(p.y + 1.0, 2.0) / 2.0; break;
+        case LEFT: u = zigMod(p.z + 1.0, 2.0) / 2.0; v = zigMod(p.y + 1.0, 2.0) / 2.0; break;
+        case RIGHT: u = zigMod(1.0 - p.z, 2.0) / 2.0; v = zigMod(p.y + 1.0, 2.0) / 2.0; break;
+        case UP: u = zigMod(p.x + 1.0, 2.0) / 2.0; v = zigMod(1.0 - p.z, 2.0) / 2.0; break;
+        default: u = zigMod(p.x + 1.0, 2.0) / 2.0; v = zigMod(p.z + 1.0, 2.0) / 2.0; break;
+      }
+      return faces[face].uvPatternAt(u, v, object_point);
+    }
+  }
+  return {0.0, 0.0, 0.0};
+}
 
 struct Light {  // light.zig
   Tuple position;

@@ -62,6 +62,11 @@ class SceneDesc(C.Structure):
         ("n_children", C.c_uint32), ("children", _u32p),
         ("n_roots", C.c_uint32), ("roots", _u32p),
         ("n_lights", C.c_uint32), ("light_pos", _dp), ("light_rgb", _dp),
+        ("n_texmaps", C.c_uint32), ("tex_mapping", _u8p), ("tex_uv", _u32p),
+        ("n_uvs", C.c_uint32), ("uv_kind", _u8p), ("uv_size", _dp), ("uv_sub", _u32p), ("uv_image", _u32p),
+        ("uv_interp", _u8p),
+        ("n_images", C.c_uint32), ("img_width", _u32p), ("img_height", _u32p), ("img_offset", C.POINTER(C.c_uint64)),
+        ("img_rgb", C.POINTER(C.c_float)),
     ]
 
 

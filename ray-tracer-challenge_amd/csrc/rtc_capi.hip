@@ -20,10 +20,10 @@ extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera c
 extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                       const uint32_t max_depth, double* __restrict__ out,
                                                       DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
-extern "C" __global__ void rtc_render_kernel_csg(const DevScene S, const DevCamera cam, const DevPixelMap map,
+extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                  const uint32_t max_depth, double* __restrict__ out,
                                                  DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
-extern "C" __global__ void rtc_render_kernel_bigworld_csg(const DevScene S, const DevCamera cam, const DevPixelMap map,
+extern "C" __global__ void rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                           const uint32_t max_depth, double* __restrict__ out,
                                                           DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
@@ -96,7 +96,12 @@ struct rtc_scene {
   DevBuf<BvhNode> bvh;
   DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent, node_info;
   DevBuf<uint2> node_range;
+  DevBuf<DevTexMap> tex;
+  DevBuf<DevUv> uv;
+  DevBuf<DevImage> img;
+  DevBuf<float> img_rgb;
   bool has_csg = false;
+  bool ext_kernel = false;         // csg nodes or texture maps: the *_ext kernels
   void* d_csg_buf = nullptr;       // DevPixelMap::csg_buf, only for scenes with csg nodes
   size_t csg_buf_capacity = 0;     // bytes
   uint32_t max_trav_stack = 0;
@@ -507,6 +512,17 @@ bool selectChainOnly(const rtc_scene_desc& d, uint32_t idx, int depth = 0) {
     case RTC_PAT_CHECKERS:
     case RTC_PAT_RINGS: return selectChainOnly(d, d.pat_a[idx], depth + 1) && selectChainOnly(d, d.pat_b[idx], depth + 1);
     case RTC_PAT_PERTURB: return selectChainOnly(d, d.pat_a[idx], depth + 1);
+    case RTC_PAT_TEXTURE_MAP: {  // every pattern any face can select
+      if (d.pat_a[idx] >= d.n_texmaps) return false;
+      for (int f = 0; f < 6; ++f) {
+        const uint32_t u = d.tex_uv[6ull * d.pat_a[idx] + f];
+        if (u >= d.n_uvs) return false;
+        const int n_sub = d.uv_kind[u] == RTC_UV_ALIGN_CHECK ? 5 : (d.uv_kind[u] == RTC_UV_CHECKERS ? 2 : 0);
+        for (int k = 0; k < n_sub; ++k)
+          if (d.uv_sub[5ull * u + k] >= d.n_patterns || !selectChainOnly(d, d.uv_sub[5ull * u + k], depth + 1)) return false;
+      }
+      return true;
+    }
     default: return false;
   }
 }
@@ -982,7 +998,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
 #ifndef RTC_EXP_NOMEMSET
   HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
 #endif
-  auto* const kernel = s->has_csg ? (lds ? rtc_render_kernel_csg : rtc_render_kernel_bigworld_csg)
+  auto* const kernel = s->ext_kernel ? (lds ? rtc_render_kernel_ext : rtc_render_kernel_bigworld_ext)
                                   : (lds ? rtc_render_kernel : rtc_render_kernel_bigworld);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
@@ -1025,14 +1041,30 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   for (uint32_t i = 0; i < d.n_patterns; ++i) {
     if (!affineRow(d.pat_inv + 16ull * i)) return fail(RTC_ERR_NOT_AFFINE, "pattern %u: last row is not (0,0,0,1)", i);
     const uint8_t k = d.pat_kind[i];
-    if (k == RTC_PAT_TEXTURE_MAP || k > RTC_PAT_TEST)
-      return fail(RTC_ERR_UNSUPPORTED, "pattern %u: kind %u is not implemented by this kernel", i, k);
+    if (k > RTC_PAT_TEST) return fail(RTC_ERR_UNSUPPORTED, "pattern %u: kind %u is not implemented by this kernel", i, k);
+    if (k == RTC_PAT_TEXTURE_MAP && d.pat_a[i] >= d.n_texmaps)
+      return fail(RTC_ERR_BAD_INDEX, "pattern %u: texture map index out of range", i);
     if (d.pat_a[i] >= d.n_patterns || d.pat_b[i] >= d.n_patterns)
       return fail(RTC_ERR_BAD_INDEX, "pattern %u: sub-pattern index out of range", i);
     if (k == RTC_PAT_PERTURB) {  // pat_rgb = PerturbInfo {scale_value, octaves, persistence}
       const double oct = d.pat_rgb[3ull * i + 1];
       if (!(oct >= 0.0 && oct <= 64.0) || oct != std::floor(oct))
         return fail(RTC_ERR_INVALID_ARGUMENT, "pattern %u: perturb octaves %g", i, oct);
+    }
+  }
+  for (uint32_t i = 0; i < d.n_texmaps; ++i) {
+    if (d.tex_mapping[i] > RTC_TEX_CUBIC) return fail(RTC_ERR_UNSUPPORTED, "texture map %u: mapping %u", i, d.tex_mapping[i]);
+    for (int f = 0; f < 6; ++f)
+      if (d.tex_uv[6ull * i + f] >= d.n_uvs) return fail(RTC_ERR_BAD_INDEX, "texture map %u: uv pattern index out of range", i);
+  }
+  for (uint32_t i = 0; i < d.n_uvs; ++i) {
+    if (d.uv_kind[i] > RTC_UV_TEST) return fail(RTC_ERR_UNSUPPORTED, "uv pattern %u: kind %u", i, d.uv_kind[i]);
+    for (int k = 0; k < 5; ++k)
+      if (d.uv_sub[5ull * i + k] >= d.n_patterns) return fail(RTC_ERR_BAD_INDEX, "uv pattern %u: sub-pattern index out of range", i);
+    if (d.uv_kind[i] == RTC_UV_IMAGE) {
+      if (d.uv_image[i] >= d.n_images) return fail(RTC_ERR_BAD_INDEX, "uv pattern %u: image index out of range", i);
+      const uint32_t im = d.uv_image[i];
+      if (d.img_width[im] == 0 || d.img_height[im] == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "image %u is empty", im);
     }
   }
   for (uint32_t i = 0; i < d.n_patterns; ++i) {
@@ -1065,6 +1097,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     has_csg = true;
   }
   auto opOf = [&](uint32_t n) -> uint32_t { return d.node_op ? d.node_op[n] : RTC_CSG_NONE; };
+  bool ext_kernel = has_csg;
+  for (uint32_t i = 0; i < d.n_patterns; ++i) ext_kernel |= d.pat_kind[i] == RTC_PAT_TEXTURE_MAP;
   std::vector<uint8_t> leaf_seen(d.n_leaves, 0), node_seen(d.n_nodes, 0);
   uint32_t max_stack = 0;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
@@ -1531,9 +1565,39 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->bvh_leaf.upload(bvh_leaves));
   HIP_TRY(s->leaf_parent.upload(leaf_parent));
   HIP_TRY(s->node_parent.upload(node_parent));
+  {
+    std::vector<DevTexMap> tex(d.n_texmaps);
+    for (uint32_t i = 0; i < d.n_texmaps; ++i) {
+      tex[i].mapping = d.tex_mapping[i];
+      for (int f = 0; f < 6; ++f) tex[i].uv[f] = d.tex_uv[6ull * i + f];
+      tex[i].pad_ = 0;
+    }
+    std::vector<DevUv> uv(d.n_uvs);
+    for (uint32_t i = 0; i < d.n_uvs; ++i) {
+      std::memset(&uv[i], 0, sizeof(DevUv));
+      uv[i].width = d.uv_size[2ull * i];
+      uv[i].height = d.uv_size[2ull * i + 1];
+      uv[i].kind = d.uv_kind[i];
+      uv[i].interp = d.uv_interp[i];
+      uv[i].image = d.uv_image[i];
+      for (int k = 0; k < 5; ++k) uv[i].sub[k] = d.uv_sub[5ull * i + k];
+    }
+    std::vector<DevImage> img(d.n_images);
+    size_t total_px = 0;
+    for (uint32_t i = 0; i < d.n_images; ++i) {
+      img[i] = DevImage{d.img_offset[i], d.img_width[i], d.img_height[i]};
+      total_px = std::max<size_t>(total_px, d.img_offset[i] + static_cast<size_t>(d.img_width[i]) * d.img_height[i]);
+    }
+    std::vector<float> rgb(d.img_rgb, d.img_rgb + 3 * total_px);
+    HIP_TRY(s->tex.upload(tex));
+    HIP_TRY(s->uv.upload(uv));
+    HIP_TRY(s->img.upload(img));
+    HIP_TRY(s->img_rgb.upload(rgb));
+  }
   HIP_TRY(s->node_info.upload(node_info));
   HIP_TRY(s->node_range.upload(node_range));
   s->has_csg = has_csg;
+  s->ext_kernel = ext_kernel;
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
@@ -1548,10 +1612,10 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
     int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, has_csg ? rtc_render_kernel_csg : rtc_render_kernel, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ext_kernel ? rtc_render_kernel_ext : rtc_render_kernel, 256, 0));
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &nb, has_csg ? rtc_render_kernel_bigworld_csg : rtc_render_kernel_bigworld, 256, 0));
+        &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));
     s->blocks_per_cu_big = static_cast<uint32_t>(std::max(nb, 1));
     if (const char* e = getenv("RTC_BLOCKS_PER_CU")) {  // experiment knob
       const int v = atoi(e);
@@ -1574,6 +1638,10 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.leaf_parent = s->leaf_parent.p;
   D.node_parent = s->node_parent.p;
   D.node_info = s->node_info.p;
+  D.tex = s->tex.p;
+  D.uv = s->uv.p;
+  D.img = s->img.p;
+  D.img_rgb = s->img_rgb.p;
   D.node_range = s->node_range.p;
   D.bvh_mag = bvh_mag;
   D.node_box = s->node_box.p;

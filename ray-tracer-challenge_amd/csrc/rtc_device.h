@@ -99,6 +99,23 @@ struct __attribute__((aligned(64))) PendingRec {
   uint32_t remaining, pad_;
 };
 
+// Texture maps (patterns/texture_map.zig); in memory, not LDS: few scenes have them.
+struct DevTexMap {   // 32 B
+  uint32_t mapping;  // RTC_TEX_*
+  uint32_t uv[6];    // DevUv per face (Cubic.Face order), entry 0 for the other mappings
+  uint32_t pad_;
+};
+struct DevUv {       // 64 B
+  double width, height;      // UvCheckers
+  uint32_t kind, interp, image, pad_;
+  uint32_t sub[5];           // pattern indices
+  uint32_t pad2_[3];
+};
+struct DevImage {    // 16 B
+  uint64_t offset;   // first pixel in img_rgb
+  uint32_t width, height;
+};
+
 // One intersection of a csg unit under evaluation (csg.zig:74-95 builds, sorts and filters such a list);
 // the per-lane lists live in DevPixelMap::csg_buf as [wave][entry][lane].
 struct __attribute__((aligned(32))) CsgRec {
@@ -128,6 +145,10 @@ struct DevScene {
   // node_range = {first depth-first leaf below the node, count}.  leaf_meta.x bit 10 = the leaf's own side.
   const uint32_t* __restrict__ node_info;
   const uint2* __restrict__ node_range;
+  const DevTexMap* __restrict__ tex;
+  const DevUv* __restrict__ uv;
+  const DevImage* __restrict__ img;
+  const float* __restrict__ img_rgb;  // [pixels][3]
   CsgRec* csg_buf;  // per-launch scratch of the csg units' intersection lists; null unless the scene has csg nodes
   const double* __restrict__ node_box;  // [n_nodes][6]
   const uint2* __restrict__ node_kids;  // {first, count}

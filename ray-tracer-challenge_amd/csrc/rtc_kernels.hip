@@ -788,6 +788,12 @@ __device__ __forceinline__ double zig_mod2(double x) {
   return (x < 0.0) ? fmod2(a + 2.0) : a;
 }
 
+// the same for a divisor that is a power of two (1 and 2 in texture_map.zig): x / y, trunc and the product are exact
+__device__ __forceinline__ double zig_mod(double x, double y) {
+  const double a = x - y * __builtin_trunc(x / y);
+  return (x < 0.0) ? (a + y) - y * __builtin_trunc((a + y) / y) : a;
+}
+
 struct Rgb {
   double r, g, b;
 };
@@ -847,12 +853,99 @@ __device__ __forceinline__ double octave_noise(double x, double y, double z, uin
   return total / max_value;
 }
 
+// TextureMap.patternAt + UvPattern.uvPatternAt (texture_map.zig).  Returns the sub-pattern the uv pattern
+// selects (align check, uv checkers), or RTC_NO_LEAF with the colour in `out` (uv test pattern, uv image).
+// Out of line: scenes without texture maps never run it.
+__device__ __noinline__ uint32_t texture_map_at(const DevScene& S, uint32_t tex, double px, double py, double pz, Rgb& out) {
+  const DevTexMap tm = S.tex[tex];
+  const double kPi = 3.14159265358979323846264338327950288;
+  double u, v;
+  uint32_t face = 0u;
+  if (tm.mapping == 0u) {  // spherical, texture_map.zig:180-195
+    const double theta = atan2(px, pz);
+    const double radius = __builtin_sqrt((px * px + py * py) + pz * pz);
+    const double phi = acos(py / radius);
+    const double raw_u = theta / (2.0 * kPi);
+    u = 1.0 - (raw_u + 0.5);
+    v = 1.0 - phi / kPi;
+  } else if (tm.mapping == 1u) {  // planar, :201-205
+    u = zig_mod(px, 1.0);
+    v = zig_mod(pz, 1.0);
+  } else if (tm.mapping == 2u) {  // cylindrical, :210-217
+    const double theta = atan2(px, pz);
+    const double raw_u = theta / (2.0 * kPi);
+    u = 1.0 - (raw_u + 0.5);
+    v = zig_mod(py, 1.0);
+  } else {  // cubic, :219-303; faces: front 0, back 1, left 2, right 3, up 4, down 5
+    const double coord = zmax(__builtin_fabs(px), zmax(__builtin_fabs(py), __builtin_fabs(pz)));
+    face = 1u;
+    if (coord == px) face = 3u;
+    else if (coord == -px) face = 2u;
+    else if (coord == py) face = 4u;
+    else if (coord == -py) face = 5u;
+    else if (coord == pz) face = 0u;
+    switch (face) {
+      case 0u: u = zig_mod(px + 1.0, 2.0) / 2.0; v = zig_mod(py + 1.0, 2.0) / 2.0; break;
+      case 1u: u = zig_mod(1.0 - px, 2.0) / 2.0; v = zig_mod(py + 1.0, 2.0) / 2.0; break;
+      case 2u: u = zig_mod(pz + 1.0, 2.0) / 2.0; v = zig_mod(py + 1.0, 2.0) / 2.0; break;
+      case 3u: u = zig_mod(1.0 - pz, 2.0) / 2.0; v = zig_mod(py + 1.0, 2.0) / 2.0; break;
+      case 4u: u = zig_mod(px + 1.0, 2.0) / 2.0; v = zig_mod(1.0 - pz, 2.0) / 2.0; break;
+      default: u = zig_mod(px + 1.0, 2.0) / 2.0; v = zig_mod(pz + 1.0, 2.0) / 2.0; break;
+    }
+  }
+  const DevUv uv = S.uv[tm.uv[face]];
+  if (uv.kind == 0u) {  // align check, :30-39
+    uint32_t k = 0u;
+    if (v > 0.8) {
+      if (u < 0.2) k = 1u;
+      else if (u > 0.8) k = 2u;
+    } else if (v < 0.2) {
+      if (u < 0.2) k = 3u;
+      else if (u > 0.8) k = 4u;
+    }
+    return uv.sub[k];
+  }
+  if (uv.kind == 1u) {  // uv checkers, :52-60
+    const double u_adj = __builtin_floor(u * uv.width), v_adj = __builtin_floor(v * uv.height);
+    return (zig_mod(u_adj + v_adj, 2.0) < 1.0) ? uv.sub[0] : uv.sub[1];
+  }
+  if (uv.kind == 3u) {  // uv test pattern, :13-17
+    out = {u, v, 0.0};
+    return RTC_NO_LEAF;
+  }
+  // uv image, :74-103
+  const DevImage im = S.img[uv.image];
+  const float* __restrict__ rgb = S.img_rgb + 3ull * im.offset;
+  auto pixel = [&](double fx, double fy) {  // Canvas.getPixelPointer(@intFromFloat(fx), @intFromFloat(fy)).?.*
+    uint32_t x = fx <= 0.0 ? 0u : static_cast<uint32_t>(fx), y = fy <= 0.0 ? 0u : static_cast<uint32_t>(fy);
+    x = min(x, im.width - 1u);  // outside the canvas the reference panics; clamped here
+    y = min(y, im.height - 1u);
+    const float* p = rgb + 3ull * (static_cast<size_t>(y) * im.width + x);
+    return Rgb{static_cast<double>(p[0]), static_cast<double>(p[1]), static_cast<double>(p[2])};
+  };
+  const double v_flip = 1.0 - v;
+  const double x = u * static_cast<double>(im.width - 1u);
+  const double y = v_flip * static_cast<double>(im.height - 1u);
+  if (uv.interp == 0u) {
+    out = pixel(round(x), round(y));  // @round: half away from zero
+    return RTC_NO_LEAF;
+  }
+  const double x1 = __builtin_floor(x), x2 = __builtin_ceil(x), y1 = __builtin_floor(y), y2 = __builtin_ceil(y);
+  const Rgb c11 = pixel(x1, y1), c21 = pixel(x2, y1), c12 = pixel(x1, y2), c22 = pixel(x2, y2);
+  const double wx1 = x2 - x, wx2 = x - x1, wy1 = y2 - y, wy2 = y - y1;  // both 0 on an integer coordinate (as there)
+  const Rgb cx1{c11.r * wx1 + c21.r * wx2, c11.g * wx1 + c21.g * wx2, c11.b * wx1 + c21.b * wx2};
+  const Rgb cx2{c12.r * wx1 + c22.r * wx2, c12.g * wx1 + c22.g * wx2, c12.b * wx1 + c22.b * wx2};
+  out = {cx1.r * wy1 + cx2.r * wy2, cx1.g * wy1 + cx2.g * wy2, cx1.b * wy1 + cx2.b * wy2};
+  return RTC_NO_LEAF;
+}
+
 // Follows a chain of "selecting" patterns (stripes / checkers / rings) down to a solid or
 // test pattern.  Sub-patterns are evaluated at the OBJECT-space point with their own inverse
 // (stripes.zig:27-33).  Returns false if the chain ends in a mixing pattern (idx then names it).
 // A perturb on the way moves the object point, for everything below it: (ox, oy, oz) is in/out.
-__device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat, uint32_t& idx, double& ox, double& oy,
-                                              double& oz, Rgb& out) {
+template <bool EXT>
+__device__ __forceinline__ bool pattern_chain(const DevScene& S, const DevPattern* __restrict__ pat, uint32_t& idx,
+                                              double& ox, double& oy, double& oz, Rgb& out) {
   for (int guard = 0; guard < 64; ++guard) {
     const DevPattern& P = pat[idx];
     const uint32_t kind = P.kind;
@@ -874,6 +967,16 @@ __device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat
       idx = (zig_mod2((__builtin_floor(px) + __builtin_floor(py)) + __builtin_floor(pz)) < 1.0) ? ab.x : ab.y;
     } else if (kind == 2) {  // rings.zig:27-33
       idx = (zig_mod2(__builtin_floor(__builtin_sqrt(px * px + pz * pz))) < 1.0) ? ab.x : ab.y;
+    } else if (EXT && kind == 8) {  // texture_map.zig: (u, v) from the PATTERN point, then a uv pattern
+      if constexpr (EXT) {          // (only the *_ext kernels carry this path)
+        Rgb c;
+        const uint32_t next = texture_map_at(S, P.a, px, py, pz, c);
+        if (next == RTC_NO_LEAF) {
+          out = c;
+          return true;
+        }
+        idx = next;  // align check / uv checkers select a sub-pattern, evaluated at the object point
+      }
     } else if (kind == 7) {  // perturb.zig:31-46: the wrapped pattern is looked up at a jittered OBJECT point
       const uint32_t octaves = static_cast<uint32_t>(P.rgb[1]);
       const double persistence = P.rgb[2], scale = P.rgb[0];
@@ -894,10 +997,11 @@ __device__ __forceinline__ bool pattern_chain(const DevPattern* __restrict__ pat
 
 // Pattern.patternAt for the whole table.  Mixing patterns (gradient.zig, blend.zig) may sit
 // anywhere in a select-chain but their own children must be select-chains (validated at create).
-__device__ __forceinline__ Rgb pattern_at(const DevPattern* __restrict__ pat, uint32_t idx, double ox, double oy,
-                                          double oz) {
+template <bool EXT>
+__device__ __forceinline__ Rgb pattern_at(const DevScene& S, const DevPattern* __restrict__ pat, uint32_t idx, double ox,
+                                          double oy, double oz) {
   Rgb out;
-  if (pattern_chain(pat, idx, ox, oy, oz, out)) return out;
+  if (pattern_chain<EXT>(S, pat, idx, ox, oy, oz, out)) return out;
   const DevPattern& P = pat[idx];
   const uint32_t kind = P.kind;
   const double* __restrict__ m = P.inv;
@@ -907,8 +1011,8 @@ __device__ __forceinline__ Rgb pattern_at(const DevPattern* __restrict__ pat, ui
   Rgb ca{0, 0, 0}, cb{0, 0, 0};
   {  // both children start from the mixing pattern's own object point (a perturb below moves its copy only)
     double ax = ox, ay = oy, az = oz, bx = ox, by = oy, bz = oz;
-    pattern_chain(pat, ia, ax, ay, az, ca);
-    pattern_chain(pat, ib, bx, by, bz, cb);
+    pattern_chain<EXT>(S, pat, ia, ax, ay, az, ca);
+    pattern_chain<EXT>(S, pat, ib, bx, by, bz, cb);
   }
   if (kind == 6) {  // blend.zig:21-24
     return {(ca.r + cb.r) * 0.5, (ca.g + cb.g) * 0.5, (ca.b + cb.b) * 0.5};
@@ -1490,7 +1594,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     double sr = 0.0, sg = 0.0, sb = 0.0;
     {
       const DevMaterial& mat = mats[mat_index];
-      const Rgb color = pattern_at(pats, mat.pattern, opx, opy, opz);
+      const Rgb color = pattern_at<CSG>(S, pats, mat.pattern, opx, opy, opz);
       RTC_STAMP(12);
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
       // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
@@ -1676,17 +1780,17 @@ rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixel
   render_body<false, false>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
-// The same two kernels with the csg path compiled in (scenes that have csg nodes).  Kept apart because the
-// out-of-line csg evaluation costs the main loop ~150 spilled VGPRs at every trace site (1.07 -> 1.38 ms on
-// cover.json when it was part of the only kernel).
+// The same two kernels with the csg and texture-map paths compiled in (template flag CSG), for scenes that
+// have csg nodes or texture maps.  Kept apart because the out-of-line calls cost the main loop ~150 spilled
+// VGPRs at every trace site (1.07 -> 1.38 ms on cover.json when csg was part of the only kernel).
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
-rtc_render_kernel_csg(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                       double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
   render_body<true, true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
-rtc_render_kernel_bigworld_csg(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                                double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
   render_body<false, true>(S, cam, map, max_depth, out, stats, next_stats);
 }

@@ -2,6 +2,7 @@
 #include "rtc_flatten.hpp"
 
 #include <cstring>
+#include <map>
 
 namespace rtc {
 
@@ -28,10 +29,51 @@ struct Flattener {
     return id;
   }
 
+  std::map<const UvImageData*, uint32_t> image_ids;
+
+  uint32_t internImage(const std::shared_ptr<const UvImageData>& im) {
+    auto it = image_ids.find(im.get());
+    if (it != image_ids.end()) return it->second;
+    const uint32_t id = static_cast<uint32_t>(out.img_width.size());
+    out.img_width.push_back(static_cast<uint32_t>(im->width));
+    out.img_height.push_back(static_cast<uint32_t>(im->height));
+    out.img_offset.push_back(out.img_rgb.size() / 3);
+    out.img_rgb.insert(out.img_rgb.end(), im->rgb.begin(), im->rgb.end());
+    image_ids.emplace(im.get(), id);
+    return id;
+  }
+
+  uint32_t internUv(const UvPattern& uv) {
+    uint32_t sub[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < uv.sub.size() && i < 5; ++i) sub[i] = internPattern(*uv.sub[i]);
+    const uint32_t image = uv.kind == UvKind::Image ? internImage(uv.image) : 0u;
+    const uint32_t id = static_cast<uint32_t>(out.uv_kind.size());
+    out.uv_kind.push_back(static_cast<uint8_t>(uv.kind));
+    out.uv_size.push_back(uv.width);
+    out.uv_size.push_back(uv.height);
+    out.uv_sub.insert(out.uv_sub.end(), sub, sub + 5);
+    out.uv_image.push_back(image);
+    out.uv_interp.push_back(uv.bilinear ? 1 : 0);
+    return id;
+  }
+
+  uint32_t internTextureMap(const TextureMap& tm) {
+    uint32_t uv[6];
+    for (size_t f = 0; f < 6; ++f) uv[f] = f < tm.faces.size() ? internUv(tm.faces[f]) : uv[0];
+    const uint32_t id = static_cast<uint32_t>(out.tex_mapping.size());
+    out.tex_mapping.push_back(static_cast<uint8_t>(tm.mapping));
+    out.tex_uv.insert(out.tex_uv.end(), uv, uv + 6);
+    return id;
+  }
+
   uint32_t internPattern(const Pattern& p) {
     uint32_t a = 0, b = 0;
     if (p.a) a = internPattern(*p.a);
     if (p.b) b = internPattern(*p.b);
+    if (p.kind == PatternKind::TextureMap) {  // pat_a names the texture map; every one is its own table entry
+      a = internTextureMap(*p.texture_map);
+      b = 0;
+    }
     std::string key;
     key.push_back(static_cast<char>(p.kind));
     appendBits(key, &p.inverse.d[0][0], 16);
@@ -212,6 +254,20 @@ rtc_scene_desc FlatScene::desc() const {
   d.n_lights = static_cast<uint32_t>(light_pos.size() / 3);
   d.light_pos = light_pos.data();
   d.light_rgb = light_rgb.data();
+  d.n_texmaps = static_cast<uint32_t>(tex_mapping.size());
+  d.tex_mapping = tex_mapping.data();
+  d.tex_uv = tex_uv.data();
+  d.n_uvs = static_cast<uint32_t>(uv_kind.size());
+  d.uv_kind = uv_kind.data();
+  d.uv_size = uv_size.data();
+  d.uv_sub = uv_sub.data();
+  d.uv_image = uv_image.data();
+  d.uv_interp = uv_interp.data();
+  d.n_images = static_cast<uint32_t>(img_width.size());
+  d.img_width = img_width.data();
+  d.img_height = img_height.data();
+  d.img_offset = img_offset.data();
+  d.img_rgb = img_rgb.data();
   return d;
 }
 

@@ -31,6 +31,12 @@ struct FlatScene {
   std::vector<double> node_min, node_max;
   std::vector<uint32_t> node_first, node_count, children, roots;
   std::vector<uint8_t> node_op;
+  // texture maps (rtc.h tex_*, uv_*, img_*)
+  std::vector<uint8_t> tex_mapping, uv_kind, uv_interp;
+  std::vector<uint32_t> tex_uv, uv_sub, uv_image, img_width, img_height;
+  std::vector<double> uv_size;
+  std::vector<uint64_t> img_offset;
+  std::vector<float> img_rgb;
   std::vector<double> light_pos, light_rgb;
 
   // View over the vectors above; valid while *this is alive and unmodified.

@@ -12,7 +12,10 @@
 //   obj.zig:53-283      ObjParser
 #include "rtc_loader.hpp"
 
+#include <zlib.h>
+
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -132,7 +135,168 @@ Matrix4 parseTransform(const Value& list) {
 }
 
 // ---- scene.zig:300-405 ------------------------------------------------------------------
-Pattern parsePattern(const Value& cfg) {
+// A PNG as zigimg hands it to Canvas.fromImage (scene.zig:282-285, canvas.zig:34-46): every pixel as an f32
+// colour, channel / max (zigimg color.zig toF32Color; the pinned zigimg is not in the tree).  Supports what
+// the reference's data files are and a little more: non-interlaced, 8 or 16 bits, grey / RGB / palette /
+// with alpha (dropped: canvas.zig:41 keeps r, g, b).
+UvImageData decodePng(const std::string& bytes) {
+  auto be32 = [&](size_t off) {
+    return (static_cast<uint32_t>(static_cast<unsigned char>(bytes[off])) << 24) |
+           (static_cast<uint32_t>(static_cast<unsigned char>(bytes[off + 1])) << 16) |
+           (static_cast<uint32_t>(static_cast<unsigned char>(bytes[off + 2])) << 8) |
+           static_cast<uint32_t>(static_cast<unsigned char>(bytes[off + 3]));
+  };
+  static const unsigned char kSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (bytes.size() < 8 + 25 || std::memcmp(bytes.data(), kSig, 8) != 0)
+    throw Error("Unsupported", "image: not a PNG (the reference decodes other formats through zigimg)");
+  uint32_t width = 0, height = 0;
+  unsigned depth = 0, color = 0, interlace = 0;
+  std::string idat;
+  std::vector<unsigned char> palette;
+  size_t off = 8;
+  bool seen_ihdr = false, seen_iend = false;
+  while (off + 12 <= bytes.size() && !seen_iend) {
+    const uint32_t len = be32(off);
+    const std::string type = bytes.substr(off + 4, 4);
+    if (off + 12 + static_cast<size_t>(len) > bytes.size()) throw Error("EndOfStream", "png chunk " + type);
+    const size_t data = off + 8;
+    if (type == "IHDR") {
+      if (len != 13) throw Error("InvalidData", "png IHDR");
+      width = be32(data);
+      height = be32(data + 4);
+      depth = static_cast<unsigned char>(bytes[data + 8]);
+      color = static_cast<unsigned char>(bytes[data + 9]);
+      interlace = static_cast<unsigned char>(bytes[data + 12]);
+      seen_ihdr = true;
+    } else if (type == "PLTE") {
+      palette.assign(bytes.begin() + data, bytes.begin() + data + len);
+    } else if (type == "IDAT") {
+      idat.append(bytes, data, len);
+    } else if (type == "IEND") {
+      seen_iend = true;
+    }
+    off += 12 + static_cast<size_t>(len);
+  }
+  if (!seen_ihdr || width == 0 || height == 0) throw Error("InvalidData", "png without IHDR");
+  if (interlace != 0) throw Error("Unsupported", "interlaced png");
+  if (depth != 8 && depth != 16) throw Error("Unsupported", "png bit depth " + std::to_string(depth));
+  unsigned channels = 0;
+  switch (color) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: throw Error("InvalidData", "png colour type");
+  }
+  if (color == 3 && depth != 8) throw Error("Unsupported", "png palette depth");
+  const size_t bpp = channels * (depth / 8), stride = static_cast<size_t>(width) * bpp;
+  std::vector<unsigned char> raw((stride + 1) * height);
+  uLongf out_len = static_cast<uLongf>(raw.size());
+  if (uncompress(raw.data(), &out_len, reinterpret_cast<const Bytef*>(idat.data()), static_cast<uLong>(idat.size())) != Z_OK ||
+      out_len != raw.size())
+    throw Error("InvalidData", "png IDAT does not inflate to the image size");
+  // undo the scanline filters (PNG spec 9.2)
+  std::vector<unsigned char> img(stride * height);
+  for (uint32_t y = 0; y < height; ++y) {
+    const unsigned char filter = raw[(stride + 1) * y];
+    const unsigned char* in = &raw[(stride + 1) * y + 1];
+    unsigned char* cur = &img[stride * y];
+    const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+    for (size_t i = 0; i < stride; ++i) {
+      const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+      int pred = 0;
+      switch (filter) {
+        case 0: pred = 0; break;
+        case 1: pred = a; break;
+        case 2: pred = b; break;
+        case 3: pred = (a + b) / 2; break;
+        case 4: {
+          const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default: throw Error("InvalidData", "png filter type");
+      }
+      cur[i] = static_cast<unsigned char>(in[i] + pred);
+    }
+  }
+  UvImageData out;
+  out.width = width;
+  out.height = height;
+  out.rgb.resize(static_cast<size_t>(width) * height * 3);
+  auto sample = [&](const unsigned char* p) {  // one channel as zigimg's toF32Color
+    return depth == 8 ? static_cast<float>(p[0]) / 255.0f : static_cast<float>((p[0] << 8) | p[1]) / 65535.0f;
+  };
+  for (size_t i = 0; i < static_cast<size_t>(width) * height; ++i) {
+    const unsigned char* px = &img[i * bpp];
+    float r, g, b;
+    if (color == 3) {
+      const size_t k = px[0];
+      if (3 * k + 2 >= palette.size()) throw Error("InvalidData", "png palette index");
+      r = static_cast<float>(palette[3 * k]) / 255.0f;
+      g = static_cast<float>(palette[3 * k + 1]) / 255.0f;
+      b = static_cast<float>(palette[3 * k + 2]) / 255.0f;
+    } else if (channels <= 2) {
+      r = g = b = sample(px);
+    } else {
+      r = sample(px);
+      g = sample(px + depth / 8);
+      b = sample(px + 2 * (depth / 8));
+    }
+    out.rgb[3 * i] = r;
+    out.rgb[3 * i + 1] = g;
+    out.rgb[3 * i + 2] = b;
+  }
+  return out;
+}
+
+Pattern parsePattern(const Value& cfg, const FileLoader& load_file_data);
+
+// scene.zig:243-298
+UvPattern parseUvPattern(const Value& cfg, const FileLoader& load_file_data) {
+  const auto& kv = unionMember(cfg, "uv-pattern");
+  const std::string& t = kv.first;
+  UvPattern uv;
+  auto sub = [&](const Value& v) { return std::make_shared<const Pattern>(parsePattern(v, load_file_data)); };
+  if (t == "align-check") {
+    requireObject(kv.second, "align-check");
+    checkFields(kv.second, {"central", "upper-left", "upper-right", "bottom-left", "bottom-right"}, "align-check");
+    uv.kind = UvKind::AlignCheck;
+    for (const char* f : {"central", "upper-left", "upper-right", "bottom-left", "bottom-right"})
+      uv.sub.push_back(sub(requireField(kv.second, f, "align-check")));
+  } else if (t == "checkers") {
+    requireObject(kv.second, "uv checkers");
+    checkFields(kv.second, {"width", "height", "patterns"}, "uv checkers");
+    uv.kind = UvKind::Checkers;
+    uv.width = asFloat(requireField(kv.second, "width", "uv checkers"), "width");
+    uv.height = asFloat(requireField(kv.second, "height", "uv checkers"), "height");
+    const Value& ps = requireField(kv.second, "patterns", "uv checkers");
+    requireArray(ps, "patterns");
+    if (ps.arr.size() != 2) throw Error("LengthMismatch", "uv checkers patterns");
+    uv.sub.push_back(sub(ps.arr[0]));
+    uv.sub.push_back(sub(ps.arr[1]));
+  } else if (t == "image") {
+    requireObject(kv.second, "image");
+    checkFields(kv.second, {"file", "interpolation"}, "image");
+    uv.kind = UvKind::Image;
+    const std::string& file = asString(requireField(kv.second, "file", "image"), "file");
+    if (const Value* ip = kv.second.find("interpolation")) {
+      const std::string& mode = asString(*ip, "interpolation");
+      if (mode == "bilinear") {
+        uv.bilinear = true;
+      } else if (mode != "none") {
+        throw Error("InvalidEnumTag", "image.interpolation " + mode);
+      }
+    }
+    uv.image = std::make_shared<const UvImageData>(decodePng(load_file_data(file)));
+  } else {
+    throw Error("UnknownField", "uv-pattern." + t);
+  }
+  return uv;
+}
+
+Pattern parsePattern(const Value& cfg, const FileLoader& load_file_data) {
   requireObject(cfg, "pattern");
   checkFields(cfg, {"type", "transform"}, "pattern");
   const auto& kv = unionMember(requireField(cfg, "type", "pattern"), "pattern.type");
@@ -141,7 +305,7 @@ Pattern parsePattern(const Value& cfg) {
   auto two = [&](PatternKind k) {
     requireArray(kv.second, t.c_str());
     if (kv.second.arr.size() != 2) throw Error("LengthMismatch", t);
-    return Pattern::binary(k, parsePattern(kv.second.arr[0]), parsePattern(kv.second.arr[1]));
+    return Pattern::binary(k, parsePattern(kv.second.arr[0], load_file_data), parsePattern(kv.second.arr[1], load_file_data));
   };
   if (t == "solid") {
     double c[3];
@@ -161,10 +325,33 @@ Pattern parsePattern(const Value& cfg) {
     pat = two(PatternKind::Blend);
   } else if (t == "perturb") {
     pat.kind = PatternKind::Perturb;
-    pat.a = std::make_shared<const Pattern>(parsePattern(kv.second));
-  } else if (t == "texture-map") {
-    // texture maps need the zigimg PNG decoder (scene.zig:282-285); outside the hot path scope.
-    throw Error("UnsupportedFeature", "texture-map patterns");
+    pat.a = std::make_shared<const Pattern>(parsePattern(kv.second, load_file_data));
+  } else if (t == "texture-map") {  // scene.zig:366-396
+    const auto& mk = unionMember(kv.second, "texture-map");
+    TextureMap tm;
+    auto single = [&](TexMapping m) {
+      requireObject(mk.second, mk.first.c_str());
+      checkFields(mk.second, {"uv-pattern"}, mk.first.c_str());
+      tm.mapping = m;
+      tm.faces.push_back(parseUvPattern(requireField(mk.second, "uv-pattern", mk.first.c_str()), load_file_data));
+    };
+    if (mk.first == "spherical") {
+      single(TexMapping::Spherical);
+    } else if (mk.first == "planar") {
+      single(TexMapping::Planar);
+    } else if (mk.first == "cylindrical") {
+      single(TexMapping::Cylindrical);
+    } else if (mk.first == "cubic") {
+      requireObject(mk.second, "cubic");
+      checkFields(mk.second, {"front", "back", "left", "right", "up", "down"}, "cubic");
+      tm.mapping = TexMapping::Cubic;
+      for (const char* f : {"front", "back", "left", "right", "up", "down"})  // scene.zig:387-393, Cubic.Face order
+        tm.faces.push_back(parseUvPattern(requireField(mk.second, f, "cubic"), load_file_data));
+    } else {
+      throw Error("UnknownField", "texture-map." + mk.first);
+    }
+    pat.kind = PatternKind::TextureMap;
+    pat.texture_map = std::make_shared<const TextureMap>(std::move(tm));
   } else {
     throw Error("UnknownField", "pattern.type." + t);
   }
@@ -175,7 +362,7 @@ Pattern parsePattern(const Value& cfg) {
 }
 
 // ---- scene.zig:407-430 ------------------------------------------------------------------
-Material parseMaterial(const Value& cfg, const std::optional<Material>& inherited) {
+Material parseMaterial(const Value& cfg, const std::optional<Material>& inherited, const FileLoader& load_file_data) {
   requireObject(cfg, "material");
   checkFields(cfg, {"pattern", "ambient", "diffuse", "specular", "shininess", "reflective", "transparency",
                     "refractive-index"}, "material");
@@ -184,7 +371,7 @@ Material parseMaterial(const Value& cfg, const std::optional<Material>& inherite
     const Value* v = cfg.find(k);
     return (v && v->type != Value::Null) ? v : nullptr;
   };
-  if (auto* v = present("pattern")) mat.pattern = parsePattern(*v);
+  if (auto* v = present("pattern")) mat.pattern = parsePattern(*v, load_file_data);
   if (auto* v = present("ambient")) mat.ambient = asFloat(*v, "ambient");
   if (auto* v = present("diffuse")) mat.diffuse = asFloat(*v, "diffuse");
   if (auto* v = present("specular")) mat.specular = asFloat(*v, "specular");
@@ -213,10 +400,10 @@ const Value* presentField(const Value& obj, const char* k) {
 }
 
 // scene.zig:164-190
-Info inherit(const Value& object, const InheritedState& inherited) {
+Info inherit(const Value& object, const InheritedState& inherited, const FileLoader& load_file_data) {
   Info info;
   if (const Value* m = presentField(object, "material")) {
-    info.material = parseMaterial(*m, inherited.material);
+    info.material = parseMaterial(*m, inherited.material, load_file_data);
   } else {
     info.material = inherited.material;
   }
@@ -250,7 +437,7 @@ Shape parseObject(const Value& object, const InheritedState& inherited, const De
   requireObject(object, "object");
   checkFields(object, {"type", "transform", "material", "casts-shadow"}, "object");
 
-  const Info info = inherit(object, inherited);
+  const Info info = inherit(object, inherited, load_file_data);
   std::optional<Material> material = info.material;
   Matrix4 transform = info.transform;
   std::optional<bool> casts_shadow = info.casts_shadow;
@@ -276,7 +463,7 @@ Shape parseObject(const Value& object, const InheritedState& inherited, const De
     parent_state.material = parent.material;
     parent_state.transform = parent.transform;
     parent_state.casts_shadow = parent.casts_shadow;
-    const Info again = inherit(object, parent_state);
+    const Info again = inherit(object, parent_state, load_file_data);
     material = again.material;
     transform = again.transform;
     casts_shadow = again.casts_shadow;

@@ -27,6 +27,26 @@ enum class PatternKind : uint8_t {  // numeric values == RTC_PAT_* in include/rt
   Checkers = 5, Blend = 6, Perturb = 7, TextureMap = 8, Test = 9
 };
 
+// ---------------------------------------------------------------- texture maps (patterns/texture_map.zig)
+struct Pattern;
+struct UvImageData {  // Canvas(T) made by Canvas.fromImage (canvas.zig:34-46): zigimg's f32 colour per pixel
+  size_t width = 0, height = 0;
+  std::vector<float> rgb;  // [height][width][3]
+};
+enum class UvKind : uint8_t { AlignCheck = 0, Checkers = 1, Image = 2, Test = 3 };        // == RTC_UV_*
+enum class TexMapping : uint8_t { Spherical = 0, Planar = 1, Cylindrical = 2, Cubic = 3 };  // == RTC_TEX_*
+struct UvPattern {  // texture_map.zig:107-171
+  UvKind kind = UvKind::Test;
+  double width = 0.0, height = 0.0;                 // UvCheckers
+  std::vector<std::shared_ptr<const Pattern>> sub;  // align check: central, ul, ur, bl, br; checkers: a, b
+  std::shared_ptr<const UvImageData> image;         // UvImage
+  bool bilinear = false;
+};
+struct TextureMap {  // texture_map.zig:173-330
+  TexMapping mapping = TexMapping::Spherical;
+  std::vector<UvPattern> faces;  // one, or six in Cubic.Face order: front, back, left, right, up, down
+};
+
 struct Pattern {  // patterns/pattern.zig:21-49
   Matrix4 transform = Matrix4::identity();
   Matrix4 inverse = Matrix4::identity();
@@ -36,6 +56,7 @@ struct Pattern {  // patterns/pattern.zig:21-49
   // Perturb.PerturbInfo defaults (perturb.zig:21-25); the scene grammar cannot change them (scene.zig:356)
   double perturb_scale = 0.3, perturb_persistence = 0.8;
   unsigned perturb_octaves = 3;
+  std::shared_ptr<const TextureMap> texture_map;  // PatternKind::TextureMap
 
   static Pattern solid(Color c) {
     Pattern p;

@@ -32,6 +32,9 @@ CASES = [
     ("perturb_demo.json", 80, 45, 5),
     ("csg.json", 80, 45, 5),
     ("csg_demo.json", 80, 45, 5),
+    ("align_check.json", 80, 40, 5),
+    ("earth.json", 80, 40, 5),
+    ("texture_demo.json", 80, 45, 5),
 ]
 
 

@@ -35,6 +35,9 @@ CASES = [
     ("nefertiti.json", 90, 150, 5),                     # 99 944-triangle OBJ, perturbed gradient
     ("csg.json", 160, 90, 5),                           # three nested csg levels, unbounded cylinders
     ("csg_demo.json", 160, 90, 5),                      # csg in a group, group in a csg, glass lens, stale csg box
+    ("align_check.json", 200, 100, 5),                  # cubic texture maps, align-check uv patterns
+    ("earth.json", 200, 100, 5),                        # spherical map of a PNG, bilinear
+    ("texture_demo.json", 160, 90, 5),                  # all four mappings, uv checkers / images, maps under other patterns
     ("cover.json", 33, 17, 0),                          # depth 0: no secondary rays at all
     ("fresnel.json", 17, 33, 1),
 ]
