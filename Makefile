@@ -19,7 +19,7 @@ CXXFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra
 
 HOST_SRC := $(PKG)/host/rtc_scene.cpp $(PKG)/host/rtc_loader.cpp $(PKG)/host/rtc_flatten.cpp \
             $(PKG)/host/rtc_api.cpp $(PKG)/host/rtc_host_capi.cpp
-HOST_HDR := $(wildcard $(PKG)/host/*.hpp) include/rtc.h
+HOST_HDR := $(wildcard $(PKG)/host/*.hpp) include/rtc.h include/rtc_host.h
 
 all: hip host oracle
 

@@ -89,7 +89,7 @@ RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_rende
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
                "rtc_status_name"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
-                "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
+                "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
 _hip = None
 _host = None
@@ -159,6 +159,8 @@ def host_lib():
         lib.rtch_scene_desc.argtypes = [C.c_void_p]
         lib.rtch_scene_desc.restype = C.POINTER(SceneDesc)
         lib.rtch_scene_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Camera)]
+        lib.rtch_camera_rotate.argtypes = [C.c_void_p, C.c_double]
+        lib.rtch_camera_move.argtypes = [C.c_void_p, C.c_double]
         lib.rtch_camera_make.argtypes = [C.c_uint32, C.c_uint32, C.c_double, _dp, _dp, _dp, C.POINTER(Camera)]
         lib.rtch_canvas_ppm.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
         lib.rtch_canvas_ppm.restype = C.c_size_t
@@ -201,6 +203,14 @@ class HostScene:
         cam = Camera()
         _check_host(host_lib().rtch_scene_camera(self._h, width, height, C.byref(cam)))
         return cam
+
+    def rotate_camera(self, angle):
+        """Renderer.rotateCamera (lib.zig:166-178): orbit the camera around its target, about `up`."""
+        _check_host(host_lib().rtch_camera_rotate(self._h, C.c_double(angle)))
+
+    def move_camera(self, distance):
+        """Renderer.moveCamera (lib.zig:180-190): move the camera along its line of sight by distance * |to - from|."""
+        _check_host(host_lib().rtch_camera_move(self._h, C.c_double(distance)))
 
     def array(self, field, count, width=1, dtype=None):
         """numpy view of one table of the flat description (writable: tests patch tables)."""

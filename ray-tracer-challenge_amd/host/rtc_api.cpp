@@ -27,6 +27,26 @@ Canvas Renderer::render(const Camera& camera, unsigned max_depth) {
   return image;
 }
 
+void rotateCamera(Camera& camera, double angle) {  // lib.zig:166-178
+  Tuple from = camera.saved_from;
+  const Tuple to = camera.saved_to, up = camera.saved_up;
+  const Tuple delta = Tuple::point(0.0, 0.0, 0.0).sub(to);
+  from = from.add(delta);
+  from = Matrix4::identity().rotate(up, angle).tupleMul(from);
+  from = from.sub(delta);
+  camera.setTransform(Matrix4::viewTransform(from, to, up));
+  camera.saved_from = from;
+}
+
+void moveCamera(Camera& camera, double distance) {  // lib.zig:180-190
+  Tuple from = camera.saved_from;
+  const Tuple to = camera.saved_to, up = camera.saved_up;
+  const Tuple delta = to.sub(from).mul(distance);
+  from = from.add(delta);
+  camera.setTransform(Matrix4::viewTransform(from, to, up));
+  camera.saved_from = from;
+}
+
 Canvas render(const Camera& camera, const World& world) {
   Renderer r(world);
   return r.render(camera, 5);

@@ -59,6 +59,12 @@ class Renderer {
   rtc_scene* scene_ = nullptr;
 };
 
+// The interactive mode of the WASM library (lib.zig:166-190): the scene stays loaded (one Renderer, one
+// rtc_scene on the GPU) while the camera orbits its target or moves along its line of sight; each call
+// updates the camera's transform and its saved from/to/up exactly like Renderer.rotateCamera / moveCamera.
+void rotateCamera(Camera& camera, double angle);   // lib.zig:166-178
+void moveCamera(Camera& camera, double distance);  // lib.zig:180-190
+
 // Camera.render(world): upload, render at depth 5, download.
 Canvas render(const Camera& camera, const World& world);
 

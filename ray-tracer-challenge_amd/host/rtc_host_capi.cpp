@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 
+#include "../../include/rtc_host.h"
 #include "rtc_api.hpp"
 #include "rtc_loader.hpp"
 
@@ -66,6 +67,15 @@ int rtch_scene_camera(void* h, uint32_t width, uint32_t height, rtc_camera* out)
     c.setTransform(c0.transform);
     *out = rtc::flattenCamera(c);
   });
+}
+
+// lib.zig:166-190 on the scene's own camera (the "preheated" interactive mode): the next rtch_scene_camera
+// returns the moved camera; the GPU scene handle is untouched.
+int rtch_camera_rotate(void* h, double angle) {
+  return guarded([&] { rtc::rotateCamera(static_cast<HostScene*>(h)->info.camera, angle); });
+}
+int rtch_camera_move(void* h, double distance) {
+  return guarded([&] { rtc::moveCamera(static_cast<HostScene*>(h)->info.camera, distance); });
 }
 
 // Camera.new + viewTransform for callers that build cameras themselves (camera.zig:33-61).

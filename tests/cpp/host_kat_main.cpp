@@ -473,6 +473,24 @@ static void csgKats() {  // csg.zig:143-154, shape.zig:253-302,393-396, scene.zi
   }
 }
 
+static void cameraMotionKats() {  // lib.zig:166-190 (no tests in the reference: geometric identities of the two functions)
+  Camera c = Camera::create(100, 50, 1.0);
+  c.saved_from = Tuple::point(0, 1, -5);
+  c.saved_to = Tuple::point(0, 1, 0);
+  c.saved_up = Tuple::vec3(0, 1, 0);
+  c.setTransform(Matrix4::viewTransform(c.saved_from, c.saved_to, c.saved_up));
+  moveCamera(c, 0.2);  // a fifth of the way to the target
+  expectT("lib.zig:185", "move_from", c.saved_from, Tuple::point(0, 1, -4));
+  expectT("lib.zig:188", "move_view", c.transform.tupleMul(Tuple::point(0, 1, 0)), Tuple::point(0, 0, -4));
+  rotateCamera(c, PI / 2);  // quarter orbit about `up` through the target
+  const double r = c.saved_from.sub(c.saved_to).magnitude();
+  report("lib.zig:173", "rotate_keeps_distance", std::fabs(r - 4.0) < 1e-12 && std::fabs(c.saved_from.y - 1.0) < 1e-12);
+  report("lib.zig:172", "rotate_quarter_turn", std::fabs(std::fabs(c.saved_from.x) - 4.0) < 1e-9 && std::fabs(c.saved_from.z) < 1e-9);
+  expectT("lib.zig:176", "rotate_view_looks_at_target", c.transform.tupleMul(Tuple::point(0, 1, 0)), Tuple::point(0, 0, -4));
+  rotateCamera(c, -PI / 2);
+  expectT("lib.zig:172", "rotate_back", c.saved_from, Tuple::point(0, 1, -4));
+}
+
 int main() {
   mathKats();
   boxKats();
@@ -482,6 +500,7 @@ int main() {
   canvasKats();
   flattenKats();
   csgKats();
+  cameraMotionKats();
   std::printf("KAT-SUMMARY total=%d failed=%d\n", g_total, g_failed);
   return g_failed ? 1 : 0;
 }

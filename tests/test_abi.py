@@ -21,8 +21,11 @@ def test_header_symbols_are_exported(rtc):
 
 
 def test_host_symbols_are_exported(rtc):
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "rtc_host.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(rtch_[a-z_0-9]+)\s*\(", text)))
+    assert set(names) == set(rtc.HOST_SYMBOLS), names
     lib = rtc.host_lib()
-    for n in rtc.HOST_SYMBOLS:
+    for n in names:
         assert getattr(lib, n) is not None
 
 

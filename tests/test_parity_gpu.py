@@ -395,3 +395,27 @@ def test_csg_list_overflow_is_reported(rtc):
         gpu.render(hs.camera(), 5)
     assert e.value.name == "StackOverflow"
     assert gpu.stats()["overflow"] > 0
+
+
+def test_interactive_camera_loop(rtc):
+    """The "preheated" mode of lib.zig:135-190: ONE scene handle on the GPU, the camera orbits and dollies between
+    frames (rotateCamera / moveCamera); every frame matches the oracle and the RGBA8 framebuffer is its clamp."""
+    import oracle_binding as ob
+    hs = rtc.HostScene.from_file("reflection_and_refraction.json")
+    gpu = rtc.GpuScene(hs.desc)
+    osc = ob.OracleScene(hs.desc)
+    frames = []
+    for step in range(4):
+        cam = hs.camera(96, 54)
+        got = gpu.render(cam, 5)
+        want, _ = osc.render(cam, 5)
+        assert np.abs(got - want).max() < TOL, step
+        frames.append(got)
+        rgba = rtc.canvas_rgba8(got)
+        assert rgba.shape == (54, 96, 4) and (rgba[..., 3] == 255).all()
+        assert np.array_equal(rgba[..., :3], np.clip(np.floor(got * 255.0 + 0.5), 0, 255).astype(np.uint8))   # color.zig:61-71 (@round: half away from 0)
+        if step % 2 == 0:
+            hs.rotate_camera(0.35)
+        else:
+            hs.move_camera(0.15)
+    assert np.abs(frames[0] - frames[1]).max() > 1e-3 and np.abs(frames[1] - frames[2]).max() > 1e-3
