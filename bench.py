@@ -286,6 +286,16 @@ def main():
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)
                 result["config"]["gpu_vs_cpu_frame_time"] = result["cpu_baseline"]["ms_per_frame_extrapolated"] / ms_per_step
+        else:
+            # rank 0's share of the frame: its tiles' canvas bytes over its own kernel time (HIP events on its stream)
+            ab = 24 * count * TILE * TILE
+            gbs = ab / (kernel_ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "rtc_render_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
+                "note": "rank 0's kernel over rank 0's tiles (1/%d of the frame); see the 1-GPU line for the counters "
+                        "and DESIGN.md section 8 for what bounds the split of a 1 ms frame" % world,
+            }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if dist is not None:
