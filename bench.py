@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--tile-path", action="store_true",
                     help="run the multi-GPU code path (tiles + gather + un-permute) even with one rank")
     ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N ranks on ONE GPU over gloo (tiles staged through host memory): exercises the N > 1 code "
+                         "path where only one GPU exists; the numbers mean nothing")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): libraries that chat on fd 1 (RCCL prints a version banner
@@ -138,13 +141,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU implementation")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.tile_path:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:   # single-process rehearsal of the tile path
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     hs = rtc.HostScene.from_file(args.scene)
     cam = hs.camera(args.width, args.height)
@@ -187,7 +195,15 @@ def main():
             rendered[b].record(stream)
             with torch.cuda.stream(comm):            # gather + un-permute of frame i under the render of frame i+1
                 comm.wait_event(rendered[b])
-                dist.gather(bufs[b], gather_list[b], dst=0)
+                if args.rehearse:                    # gloo has no device gather: through host memory
+                    comm.synchronize()
+                    host = [torch.empty(bufs[b].shape, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
+                    dist.gather(bufs[b].cpu(), host, dst=0)
+                    if rank == 0:
+                        for r in range(world):
+                            gather_list[b][r].copy_(host[r])
+                else:
+                    dist.gather(bufs[b], gather_list[b], dst=0)
                 if rank == 0:                        # one un-permute kernel: tiles -> row-major canvas
                     rtc.assemble_tiles_device(gathered[b].data_ptr(), world, padded, TILE, TILE, W, H,
                                               canvas.data_ptr(), comm.cuda_stream)
@@ -223,14 +239,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     stats = gpu.stats()                              # counters of the last launch on this rank
     if dist is not None:
         v = torch.tensor([stats["primary"], stats["secondary"], stats["shadow_calls"], stats["shadow_traced"]],
-                         dtype=torch.int64, device="cuda")
+                         dtype=torch.int64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(v)
         stats = dict(zip(["primary", "secondary", "shadow_calls", "shadow_traced"], [int(x) for x in v.tolist()]))
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev]))   # HIP events on the launch stream

@@ -419,3 +419,23 @@ def test_interactive_camera_loop(rtc):
         else:
             hs.move_camera(0.15)
     assert np.abs(frames[0] - frames[1]).max() > 1e-3 and np.abs(frames[1] - frames[2]).max() > 1e-3
+
+
+def test_bench_multi_rank_path_rehearsal():
+    """bench.py's N > 1 code path (tile split, gather, rtc_assemble_tiles_device, stats reduction, the JSON line) with
+    two ranks on the ONE GPU of this box over gloo (--rehearse); real RCCL runs over N GPUs are the driver's."""
+    import json
+    import subprocess
+    import sys
+    repo = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", _os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "480", "--height", "270", "--rehearse", "--check"]
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "check ok" in out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout            # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and "roofline" in line
+    assert line["config"]["rays_per_frame"]["primary"] == 480 * 270
