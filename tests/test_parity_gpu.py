@@ -439,3 +439,68 @@ def test_bench_multi_rank_path_rehearsal():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and "roofline" in line
     assert line["config"]["rays_per_frame"]["primary"] == 480 * 270
+
+
+def _json_scene(objects, lights, w=24, h=16):
+    import json
+    return json.dumps({"camera": {"width": w, "height": h, "field-of-view": 1.0, "from": [0, 1.5, -5], "to": [0, 1, 0], "up": [0, 1, 0]},
+                       "lights": lights, "objects": objects})
+
+
+def _parity(rtc, scene_json, depth=5, cam_size=None):
+    import oracle_binding as ob
+    hs = rtc.HostScene(scene_json)
+    cam = hs.camera(*cam_size) if cam_size else hs.camera()
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(cam, depth)
+    want, counters = ob.OracleScene(hs.desc).render(cam, depth)
+    assert got.shape == want.shape and np.isfinite(got).all()
+    assert np.abs(got - want).max() < TOL
+    st = gpu.stats()
+    assert [st["primary"], st["secondary"], st["shadow_calls"]] == [counters["primary"], counters["secondary"], counters["shadow"]]
+    return got
+
+
+LIGHT = {"point-light": {"position": [-5, 8, -6], "intensity": [1, 1, 1]}}
+BALL = {"type": {"sphere": {}}, "transform": [{"translate": [0, 1, 0]}],
+        "material": {"reflective": 0.5, "transparency": 0.5, "refractive-index": 1.4}}
+FLOOR = {"type": {"plane": {}}, "material": {"reflective": 0.3}}
+
+
+def test_edge_empty_world_and_no_lights(rtc):
+    """World.objects empty -> every pixel black (world.zig:119); no lights -> shadeHit sums nothing (world.zig:89)."""
+    assert np.all(_parity(rtc, _json_scene([], [LIGHT])) == 0.0)
+    assert np.all(_parity(rtc, _json_scene([], [])) == 0.0)
+    _parity(rtc, _json_scene([FLOOR, BALL], []))     # reflections / refractions of nothing but black: still traced
+
+
+@pytest.mark.parametrize("size", [(1, 1), (1, 7), (9, 1), (8, 8), (9, 9), (63, 65), (130, 3)])
+def test_edge_ragged_image_sizes(rtc, size):
+    """Canvas sizes around the 8x8 chunk and 64-lane wave boundaries, incl. a single pixel and single rows / columns."""
+    _parity(rtc, _json_scene([FLOOR, BALL], [LIGHT]), cam_size=size)
+
+
+def test_edge_depth_limits(rtc):
+    """remaining = 0 spawns nothing (world.zig:158,172); 16 is the deepest the per-lane stacks allow; 17 is refused."""
+    scene = _json_scene([FLOOR, BALL, {"type": {"sphere": {}}, "transform": [{"translate": [1.8, 1, 0.5]}],
+                                       "material": {"reflective": 0.9, "transparency": 0.9, "refractive-index": 1.1}}], [LIGHT])
+    _parity(rtc, scene, depth=0)
+    _parity(rtc, scene, depth=1)
+    _parity(rtc, scene, depth=16, cam_size=(12, 8))
+    hs = rtc.HostScene(scene)
+    with pytest.raises(rtc.RtcError) as e:
+        rtc.GpuScene(hs.desc).render(hs.camera(), 17)
+    assert e.value.name == "InvalidArgument"
+
+
+def test_edge_many_lights_and_materials(rtc):
+    """More lights / materials / patterns than the LDS staging area holds: the table-in-memory kernel variant."""
+    lights = [{"point-light": {"position": [6 * np.cos(k), 6 + (k % 3), 6 * np.sin(k) - 2], "intensity": [0.06, 0.05, 0.07]}}
+              for k in range(20)]
+    objs = [FLOOR]
+    for k in range(70):
+        objs.append({"type": {"sphere": {}}, "transform": [{"scale": [0.2, 0.2, 0.2]}, {"translate": [(k % 10) * 0.5 - 2.2, 0.2 + (k // 10) * 0.45, 0]}],
+                     "material": {"pattern": {"type": {"stripes": [{"type": {"solid": [k / 70, 0.3, 0.6]}}, {"type": {"solid": [0.9, k / 70, 0.1]}}]},
+                                              "transform": [{"scale": [0.1 + 0.01 * k] * 3}]},
+                                  "shininess": 10 + k, "reflective": 0.1 if k % 7 == 0 else 0.0}})
+    _parity(rtc, _json_scene(objs, lights, 40, 24))
