@@ -66,7 +66,7 @@ struct RootRec {
 };
 #define RTC_ROOT_IS_GROUP 0x8000u
 #define RTC_ROOT_IS_CSG 0x4000u  // with IS_GROUP: the root is a csg unit, `index` its node
-// Small-world limits: scenes within all four get their tables staged in LDS (34 KB per work-group);
+// Small-world limits: scenes within all four get their tables staged in LDS (50.7 KB per work-group with the mailbox);
 // anything larger runs the same kernel reading the tables from memory.
 #define RTC_LDS_ROOTS 128
 #define RTC_LDS_MATERIALS 64

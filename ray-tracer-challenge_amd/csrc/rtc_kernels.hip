@@ -13,21 +13,26 @@
 //   Material.lighting, Pattern.patternAt    material.zig:40-74, patterns/*.zig
 //   World.reflectedColor / refractedColor   world.zig:157-189
 //
-// Design (MI355X-first, not a translation of the reference's control flow):
-//   * one lane = one pixel; the reflection/refraction recursion is an explicit per-lane
-//     stack of (ray, weight, remaining) entries, colour accumulated top-down;
+//   Csg.localIntersect / filterIntersections shapes/csg.zig:51-95      (the *_ext kernels)
+//   Perturb + noise, TextureMap / UvPattern  patterns/perturb.zig, noise.zig, patterns/texture_map.zig
+//
+// Design (MI355X-first, not a translation of the reference's control flow; DESIGN.md section 3):
+//   * persistent waves pull PACKETS of pixels from an atomic counter and deal them to idle lanes; one ray per
+//     lane per iteration; the reflection/refraction recursion is an explicit per-lane stack of
+//     (ray, weight, remaining) entries in a line-per-entry buffer, colour accumulated top-down; idle lanes take
+//     the oldest pending ray of busy neighbours through an LDS mailbox;
 //   * the reference builds, sorts and scans a heap-allocated list of ALL intersections for
 //     every ray (and again for every shadow ray).  Here the three things that list is used
 //     for are computed by streaming reductions over exactly the same candidate set:
 //       - the hit   = min over entries with t >= 0 of (t, depth-first leaf index),
 //       - shadowed  = exists entry with 0 <= t < distance on a shadow-casting leaf,
 //       - n1 / n2   = refractive index of the "open" leaf whose last entry before the hit
-//                     comes latest (see behind_visitor), which is what the containers walk
+//                     comes latest (see BehindVisitor), which is what the containers walk
 //                     of world.zig:229-255 evaluates to;
-//   * top-level World.objects are walked by a wave-uniform loop (leaf records come in through
-//     scalar loads); groups are walked by a per-lane stack traversal of the reference's own
-//     group tree with the reference's own boxes and slab test, so the candidate set is the
-//     reference's;
+//   * top-level World.objects: tables staged in LDS, an FP32 bounding-sphere pass over all of them, then each
+//     lane runs the exact FP64 test on its own survivors; groups: a candidate BVH (FP32, world space) proposes
+//     leaves, and a proposed leaf counts only if the ray passes the reference's own box test of every Group
+//     above it (chain_ok), so the entries that reach the reductions are exactly the reference's;
 //   * arithmetic is FP64 in the reference's evaluation order and this file is compiled with
 //     -ffp-contract=off (the reference's Zig float mode is strict: no FMA contraction), so
 //     every t, point and normal is bit-identical to the CPU restatement; pow() (specular, schlick)
