@@ -34,7 +34,7 @@ $(LIB):
 $(LIB)/rtc_kernels.o: $(PKG)/csrc/rtc_kernels.hip $(PKG)/csrc/rtc_device.h | $(LIB)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
-$(LIB)/rtc_capi.o: $(PKG)/csrc/rtc_capi.hip $(PKG)/csrc/rtc_device.h include/rtc.h | $(LIB)
+$(LIB)/rtc_capi.o: $(PKG)/csrc/rtc_capi.hip $(wildcard $(PKG)/csrc/*.h) include/rtc.h | $(LIB)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
 
 $(LIB)/librtc_hip.so: $(LIB)/rtc_kernels.o $(LIB)/rtc_capi.o

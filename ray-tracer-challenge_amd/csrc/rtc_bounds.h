@@ -1,0 +1,383 @@
+// rtc_bounds.h — conservative world-space bounds of leaves and roots, and the builder of the candidate BVH
+// (DESIGN.md section 3): everything here only ever REMOVES work that provably contributes no entry.
+#pragma once
+#include "rtc_host_internal.h"
+
+namespace {
+
+
+// ---- conservative world-space bounding spheres for the root-loop rejection test ----------------
+// These only ever REMOVE work whose result is provably "no entry"; they are computed in plain double
+// arithmetic with an inflated radius, never feed a colour, and so need not follow reference rounding.
+// Forward transform (object -> world) = inverse of the stored affine inverse; false if singular.
+bool forwardOf(const double* inv16, double M[12]) {
+  const double a = inv16[0], b = inv16[1], c = inv16[2], d = inv16[4], e = inv16[5], f = inv16[6], g = inv16[8],
+               h = inv16[9], i = inv16[10];
+  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+  const double r[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
+                       (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
+                       (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+  const double tx = inv16[3], ty = inv16[7], tz = inv16[11];
+  for (int k = 0; k < 3; ++k) {
+    M[4 * k + 0] = r[3 * k + 0];
+    M[4 * k + 1] = r[3 * k + 1];
+    M[4 * k + 2] = r[3 * k + 2];
+    M[4 * k + 3] = -(r[3 * k + 0] * tx + r[3 * k + 1] * ty + r[3 * k + 2] * tz);
+  }
+  for (int k = 0; k < 12; ++k)
+    if (!std::isfinite(M[k])) return false;
+  return true;
+}
+
+Sphere sphereOfPoints(const double (*pts)[3], int n) {
+  Sphere s;
+  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::fmin(mn[k], pts[i][k]);
+      mx[k] = std::fmax(mx[k], pts[i][k]);
+    }
+  s.cx = 0.5 * (mn[0] + mx[0]);
+  s.cy = 0.5 * (mn[1] + mx[1]);
+  s.cz = 0.5 * (mn[2] + mx[2]);
+  double r2 = 0;
+  for (int i = 0; i < n; ++i) {
+    const double dx = pts[i][0] - s.cx, dy = pts[i][1] - s.cy, dz = pts[i][2] - s.cz;
+    r2 = std::fmax(r2, dx * dx + dy * dy + dz * dz);
+  }
+  s.r = std::sqrt(r2);
+  return s;
+}
+
+// Object-space box [lo,hi] pushed through M; any convex shape inside the box is inside the sphere.
+Sphere sphereOfBox(const double M[12], const double lo[3], const double hi[3]) {
+  for (int k = 0; k < 3; ++k)
+    if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return Sphere{};
+  double pts[8][3];
+  for (int c = 0; c < 8; ++c) {
+    const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+    for (int k = 0; k < 3; ++k) pts[c][k] = M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3];
+  }
+  return sphereOfPoints(pts, 8);
+}
+
+Sphere leafSphere(const rtc_scene_desc& d, uint32_t leaf) {
+  double M[12];
+  if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[leaf], M)) return Sphere{};
+  const uint32_t g = d.leaf_geom[leaf];
+  switch (d.leaf_kind[leaf]) {
+    case RTC_SPHERE: {
+      // radius = largest singular value of the 3x3 part = sqrt(largest eigenvalue of A = M3^T M3),
+      // from the closed-form (trigonometric) eigenvalues of a symmetric 3x3 matrix, with a margin;
+      // the Frobenius norm is an always-valid upper bound and caps it.
+      double fro = 0;
+      for (int k = 0; k < 3; ++k) fro += M[4 * k] * M[4 * k] + M[4 * k + 1] * M[4 * k + 1] + M[4 * k + 2] * M[4 * k + 2];
+      double A[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = M[i] * M[j] + M[4 + i] * M[4 + j] + M[8 + i] * M[8 + j];
+      double r2 = fro;
+      {
+        const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
+        const double p2 = (A[0][0] - q) * (A[0][0] - q) + (A[1][1] - q) * (A[1][1] - q) + (A[2][2] - q) * (A[2][2] - q) + 2.0 * p1;
+        double lmax = q;
+        if (p2 > 0.0) {
+          const double pp = std::sqrt(p2 / 6.0);
+          double B[3][3];
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) B[i][j] = (A[i][j] - (i == j ? q : 0.0)) / pp;
+          const double detB = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
+                              B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+          const double rr = std::fmax(-1.0, std::fmin(1.0, detB / 2.0));
+          lmax = q + 2.0 * pp * std::cos(std::acos(rr) / 3.0);
+        }
+        if (std::isfinite(lmax) && lmax > 0.0) r2 = std::fmin(r2, lmax * (1.0 + 1e-6));
+      }
+      Sphere s;
+      s.cx = M[3];
+      s.cy = M[7];
+      s.cz = M[11];
+      s.r = std::sqrt(r2);
+      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+      const Sphere box = sphereOfBox(M, lo, hi);  // also valid; keep the tighter one
+      return (box.finite() && box.r < s.r) ? box : s;
+    }
+    case RTC_CUBE: {
+      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+      return sphereOfBox(M, lo, hi);
+    }
+    case RTC_CYLINDER: {
+      const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
+      return sphereOfBox(M, lo, hi);
+    }
+    case RTC_CONE:
+      // NOT bounded by its truncated box: for a ray parallel to one of the cone's halves the reference
+      // appends the single surface hit t = -c / 2b WITHOUT the min < y < max filter (cone.zig:79-86),
+      // so a truncated cone can report an entry anywhere on the infinite double cone.
+      return Sphere{};
+    case RTC_TRIANGLE:
+    case RTC_SMOOTH_TRIANGLE: {
+      double pts[3][3];
+      for (int v = 0; v < 3; ++v) {
+        double p[3];
+        for (int k = 0; k < 3; ++k)
+          p[k] = d.tri_p1[3ull * g + k] + (v == 1 ? d.tri_e1[3ull * g + k] : 0.0) + (v == 2 ? d.tri_e2[3ull * g + k] : 0.0);
+        for (int k = 0; k < 3; ++k) pts[v][k] = M[4 * k] * p[0] + M[4 * k + 1] * p[1] + M[4 * k + 2] * p[2] + M[4 * k + 3];
+      }
+      return sphereOfPoints(pts, 3);
+    }
+    default: return Sphere{};  // planes are unbounded
+  }
+}
+
+Sphere inflate(Sphere s) {
+  if (!s.finite()) return Sphere{};
+  s.r = s.r * (1.0 + 1e-6) + 1e-9;
+  return s;
+}
+
+
+// ---- candidate BVH (BvhNode, rtc_device.h) ------------------------------------------------------
+struct Aabb {
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  void add(const double p[3]) {
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::fmin(lo[k], p[k]);
+      hi[k] = std::fmax(hi[k], p[k]);
+    }
+  }
+  void merge(const Aabb& o) {
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::fmin(lo[k], o.lo[k]);
+      hi[k] = std::fmax(hi[k], o.hi[k]);
+    }
+  }
+  bool finite() const {
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) return false;
+    return true;
+  }
+  double area() const {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+const float kHuge = 3.0e38f;  // "unbounded" in an FP32 box
+
+// World-space box of one leaf: the object-space box of the shape pushed through the forward transform.
+Aabb leafWorldBox(const rtc_scene_desc& d, uint32_t leaf) {
+  Aabb box;
+  double M[12];
+  if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[leaf], M)) return Aabb{};
+  auto addObjectBox = [&](const double lo[3], const double hi[3]) {
+    for (int k = 0; k < 3; ++k)
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
+        box = Aabb{};
+        return;
+      }
+    for (int c = 0; c < 8; ++c) {
+      const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
+      double p[3];
+      for (int k = 0; k < 3; ++k) p[k] = M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3];
+      box.add(p);
+    }
+  };
+  const uint32_t g = d.leaf_geom[leaf];
+  switch (d.leaf_kind[leaf]) {
+    case RTC_SPHERE:
+    case RTC_CUBE: {
+      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
+      addObjectBox(lo, hi);
+      break;
+    }
+    case RTC_CYLINDER: {
+      const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
+      addObjectBox(lo, hi);
+      break;
+    }
+    case RTC_CONE:
+      break;  // unbounded, see leafSphere(): the parallel-ray entry ignores the truncation
+    case RTC_TRIANGLE:
+    case RTC_SMOOTH_TRIANGLE:
+      for (int v = 0; v < 3; ++v) {
+        double q[3], p[3];
+        for (int k = 0; k < 3; ++k)
+          q[k] = d.tri_p1[3ull * g + k] + (v == 1 ? d.tri_e1[3ull * g + k] : 0.0) + (v == 2 ? d.tri_e2[3ull * g + k] : 0.0);
+        for (int k = 0; k < 3; ++k) p[k] = M[4 * k] * q[0] + M[4 * k + 1] * q[1] + M[4 * k + 2] * q[2] + M[4 * k + 3];
+        box.add(p);
+      }
+      break;
+    default: break;  // planes are unbounded
+  }
+  return box;
+}
+
+struct BvhPrim {
+  Aabb box;        // may be non-finite: treated as unbounded
+  double c[3];     // centroid (0 for unbounded)
+  uint32_t leaf;   // depth-first leaf index
+};
+
+struct BvhBuilder {
+  std::vector<BvhNode>& nodes;
+  std::vector<uint32_t>& leaves;
+  std::vector<BvhPrim> prims;
+  float mag = 0.0f;
+
+  static float down(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) > v) f = std::nextafterf(f, -INFINITY);
+    return f;
+  }
+  static float up(double v) {
+    float f = static_cast<float>(v);
+    if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
+    return f;
+  }
+  void storeBox(const Aabb& b, float lo[3], float hi[3]) {
+    if (!b.finite()) {
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = -kHuge;
+        hi[k] = kHuge;
+      }
+      return;
+    }
+    for (int k = 0; k < 3; ++k) {
+      // rounded outward plus a relative cushion; the kernel adds the ray-dependent part of the margin
+      const double pad = 1e-6 * (std::fabs(b.lo[k]) + std::fabs(b.hi[k])) + 1e-30;
+      lo[k] = down(b.lo[k] - pad);
+      hi[k] = up(b.hi[k] + pad);
+      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
+        lo[k] = -kHuge;
+        hi[k] = kHuge;
+      } else {
+        mag = std::fmax(mag, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
+      }
+    }
+  }
+  Aabb boundsOf(size_t first, size_t count) const {
+    Aabb b;
+    bool unbounded = false;
+    for (size_t i = first; i < first + count; ++i) {
+      if (!prims[i].box.finite()) unbounded = true;
+      else b.merge(prims[i].box);
+    }
+    if (unbounded) {
+      for (int k = 0; k < 3; ++k) {
+        b.lo[k] = -INFINITY;
+        b.hi[k] = INFINITY;
+      }
+    }
+    return b;
+  }
+  // returns the child reference for prims[first, first+count)
+  uint32_t build(size_t first, size_t count) {
+    if (count <= 4) {
+      const uint32_t at = static_cast<uint32_t>(leaves.size());
+      for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
+      return RTC_NODE_BIT | (at << 3) | static_cast<uint32_t>(count - 1);
+    }
+    // centroid bounds -> split axis; 16-bin SAH along it
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = first; i < first + count; ++i)
+      for (int k = 0; k < 3; ++k) {
+        clo[k] = std::fmin(clo[k], prims[i].c[k]);
+        chi[k] = std::fmax(chi[k], prims[i].c[k]);
+      }
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+      if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    size_t mid = first + count / 2;
+    const double extent = chi[axis] - clo[axis];
+    bool split_done = false;
+    if (extent > 0.0 && std::isfinite(extent)) {
+      constexpr int kBins = 16;
+      Aabb bin_box[kBins];
+      size_t bin_n[kBins] = {};
+      auto binOf = [&](const BvhPrim& p) {
+        int b = static_cast<int>((p.c[axis] - clo[axis]) / extent * kBins);
+        return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+      };
+      for (size_t i = first; i < first + count; ++i) {
+        const int b = binOf(prims[i]);
+        bin_n[b]++;
+        if (prims[i].box.finite()) bin_box[b].merge(prims[i].box);
+      }
+      double right_area[kBins];
+      size_t right_n[kBins];
+      Aabb acc;
+      size_t n = 0;
+      for (int b = kBins - 1; b > 0; --b) {
+        acc.merge(bin_box[b]);
+        n += bin_n[b];
+        right_area[b] = acc.finite() ? acc.area() : 0.0;
+        right_n[b] = n;
+      }
+      acc = Aabb{};
+      n = 0;
+      double best = INFINITY;
+      int best_b = -1;
+      for (int b = 0; b < kBins - 1; ++b) {
+        acc.merge(bin_box[b]);
+        n += bin_n[b];
+        if (n == 0 || right_n[b + 1] == 0) continue;
+        const double cost = (acc.finite() ? acc.area() : 0.0) * n + right_area[b + 1] * right_n[b + 1];
+        if (cost < best) {
+          best = cost;
+          best_b = b;
+        }
+      }
+      if (best_b >= 0) {
+        auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
+                                 [&](const BvhPrim& p) { return binOf(p) <= best_b; });
+        mid = static_cast<size_t>(it - prims.begin());
+        split_done = mid > first && mid < first + count;
+      }
+    }
+    if (!split_done) {
+      mid = first + count / 2;
+      std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                       [&](const BvhPrim& a, const BvhPrim& b) { return a.c[axis] < b.c[axis]; });
+    }
+    const uint32_t me = static_cast<uint32_t>(nodes.size());
+    nodes.emplace_back();
+    const Aabb b0 = boundsOf(first, mid - first), b1 = boundsOf(mid, first + count - mid);
+    const uint32_t c0 = build(first, mid - first);
+    const uint32_t c1 = build(mid, first + count - mid);
+    BvhNode& N = nodes[me];
+    storeBox(b0, N.lo0, N.hi0);
+    storeBox(b1, N.lo1, N.hi1);
+    N.c0 = c0;
+    N.c1 = c1;
+    N.pad_[0] = N.pad_[1] = 0;
+    return me;
+  }
+  // root node index of a BVH over `items` (always a node, so the kernel can start from a node)
+  uint32_t buildRoot(std::vector<BvhPrim> items) {
+    prims = std::move(items);
+    const uint32_t me = static_cast<uint32_t>(nodes.size());
+    if (prims.size() > 4) return build(0, prims.size());
+    nodes.emplace_back();
+    BvhNode N;
+    std::memset(&N, 0, sizeof N);
+    for (int k = 0; k < 3; ++k) {  // empty boxes: never entered
+      N.lo0[k] = N.lo1[k] = kHuge;
+      N.hi0[k] = N.hi1[k] = -kHuge;
+    }
+    N.c0 = N.c1 = RTC_NO_LEAF;  // empty child
+    if (!prims.empty()) {
+      storeBox(boundsOf(0, prims.size()), N.lo0, N.hi0);
+      N.c0 = build(0, prims.size());
+    }
+    nodes[me] = N;
+    return me;
+  }
+};
+
+bool affineRow(const double* m16) {  // last row must be exactly (0,0,0,1); -0 is accepted
+  return m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0;
+}
+
+}  // namespace

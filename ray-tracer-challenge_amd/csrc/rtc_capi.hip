@@ -30,483 +30,11 @@ extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gather
                                                const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
                                                const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
 
-namespace {
-
-thread_local std::string g_error;
-
-int fail(int status, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  std::vsnprintf(buf, sizeof buf, fmt, ap);
-  va_end(ap);
-  g_error = std::string(rtc_status_name(status)) + ": " + buf;
-  return status;
-}
-
-#define HIP_TRY(expr)                                                                         \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess) {                                                                   \
-      return fail(e_ == hipErrorOutOfMemory ? RTC_ERR_OUT_OF_MEMORY : RTC_ERR_NO_DEVICE,      \
-                  "%s -> %s", #expr, hipGetErrorString(e_));                                  \
-    }                                                                                         \
-  } while (0)
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t upload(const std::vector<T>& v) {
-    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);  // never a null table
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), bytes);
-    if (e != hipSuccess) return e;
-    if (!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
-    return e;
-  }
-};
-
-}  // namespace
-
-// conservative world-space bounding sphere (see leafSphere below)
-struct Sphere {
-  double cx = 0, cy = 0, cz = 0, r = INFINITY;
-  bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
-};
-
-struct rtc_scene {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  DevScene dev{};
-  DevStats* d_stats = nullptr;  // two, used alternately (see DevStats)
-  uint32_t stats_parity = 0;    // which of the two the last launch counted in
-  double* d_frame = nullptr;  // staging for rtc_render (host output)
-  size_t frame_capacity = 0;  // in doubles
-  DevBuf<uint32_t> roots, kids;
-  DevBuf<RootRec> root_recs;
-  DevBuf<RootCull> root_cull;
-  DevBuf<uint4> leaf_meta;
-  DevBuf<double> xf, tri, trin, node_box, light;
-  DevBuf<DevPattern> pat;
-  DevBuf<DevCyl> cyl;
-  DevBuf<DevMaterial> mat;
-  DevBuf<uint2> node_kids;
-  DevBuf<BvhNode> bvh;
-  DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent, node_info;
-  DevBuf<uint2> node_range;
-  DevBuf<DevTexMap> tex;
-  DevBuf<DevUv> uv;
-  DevBuf<DevImage> img;
-  DevBuf<float> img_rgb;
-  bool has_csg = false;
-  bool ext_kernel = false;         // csg nodes or texture maps: the *_ext kernels
-  void* d_csg_buf = nullptr;       // DevPixelMap::csg_buf, only for scenes with csg nodes
-  size_t csg_buf_capacity = 0;     // bytes
-  uint32_t max_trav_stack = 0;
-  uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
-  // heavy-first scheduling hint (see DevPixelMap::order)
-  std::vector<Sphere> occupied;    // bounding spheres of every bounded root
-  bool unbounded_nonplane = false; // a root other than a plane without a finite bound (cannot be projected)
-  std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
-  bool branching_everywhere = false;  // such a root without a finite bound
-  std::vector<uint32_t> h_order;
-  uint32_t* d_order = nullptr;
-  size_t order_capacity = 0;
-  std::vector<double> order_key;   // camera + map the cached (heuristic) order was built for
-  // measured-cost feedback: per-chunk ray counts of the previous launch with the same pixel map
-  uint32_t* d_cost = nullptr;
-  size_t cost_capacity = 0;
-  std::vector<uint32_t> cost_key;  // pixel map the costs / the cost-sorted order belong to
-  std::vector<uint32_t> h_cost;
-  uint64_t launches_with_key = 0;
-  bool order_from_cost = false;
-  bool cost_pending = false;       // the previous launch measured per-pixel costs: the next one packs from them
-  rtc_camera cost_cam{};           // camera (and depth) of that measurement ...
-  uint32_t cost_depth = 0;
-  rtc_camera sched_cam{};          // ... and of the measurement the current schedule was packed from
-  uint32_t sched_depth = 0;
-  hipStream_t last_stream = nullptr;
-  void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack
-  size_t ray_stack_capacity = 0;   // bytes
-};
+#include "rtc_host_internal.h"
+#include "rtc_bounds.h"
+#include "rtc_schedule.h"
 
 namespace {
-
-// ---- conservative world-space bounding spheres for the root-loop rejection test ----------------
-// These only ever REMOVE work whose result is provably "no entry"; they are computed in plain double
-// arithmetic with an inflated radius, never feed a colour, and so need not follow reference rounding.
-// Forward transform (object -> world) = inverse of the stored affine inverse; false if singular.
-bool forwardOf(const double* inv16, double M[12]) {
-  const double a = inv16[0], b = inv16[1], c = inv16[2], d = inv16[4], e = inv16[5], f = inv16[6], g = inv16[8],
-               h = inv16[9], i = inv16[10];
-  const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
-  const double r[9] = {(e * i - f * h) / det, (c * h - b * i) / det, (b * f - c * e) / det,
-                       (f * g - d * i) / det, (a * i - c * g) / det, (c * d - a * f) / det,
-                       (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
-  const double tx = inv16[3], ty = inv16[7], tz = inv16[11];
-  for (int k = 0; k < 3; ++k) {
-    M[4 * k + 0] = r[3 * k + 0];
-    M[4 * k + 1] = r[3 * k + 1];
-    M[4 * k + 2] = r[3 * k + 2];
-    M[4 * k + 3] = -(r[3 * k + 0] * tx + r[3 * k + 1] * ty + r[3 * k + 2] * tz);
-  }
-  for (int k = 0; k < 12; ++k)
-    if (!std::isfinite(M[k])) return false;
-  return true;
-}
-
-Sphere sphereOfPoints(const double (*pts)[3], int n) {
-  Sphere s;
-  double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int i = 0; i < n; ++i)
-    for (int k = 0; k < 3; ++k) {
-      mn[k] = std::fmin(mn[k], pts[i][k]);
-      mx[k] = std::fmax(mx[k], pts[i][k]);
-    }
-  s.cx = 0.5 * (mn[0] + mx[0]);
-  s.cy = 0.5 * (mn[1] + mx[1]);
-  s.cz = 0.5 * (mn[2] + mx[2]);
-  double r2 = 0;
-  for (int i = 0; i < n; ++i) {
-    const double dx = pts[i][0] - s.cx, dy = pts[i][1] - s.cy, dz = pts[i][2] - s.cz;
-    r2 = std::fmax(r2, dx * dx + dy * dy + dz * dz);
-  }
-  s.r = std::sqrt(r2);
-  return s;
-}
-
-// Object-space box [lo,hi] pushed through M; any convex shape inside the box is inside the sphere.
-Sphere sphereOfBox(const double M[12], const double lo[3], const double hi[3]) {
-  for (int k = 0; k < 3; ++k)
-    if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return Sphere{};
-  double pts[8][3];
-  for (int c = 0; c < 8; ++c) {
-    const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
-    for (int k = 0; k < 3; ++k) pts[c][k] = M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3];
-  }
-  return sphereOfPoints(pts, 8);
-}
-
-Sphere leafSphere(const rtc_scene_desc& d, uint32_t leaf) {
-  double M[12];
-  if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[leaf], M)) return Sphere{};
-  const uint32_t g = d.leaf_geom[leaf];
-  switch (d.leaf_kind[leaf]) {
-    case RTC_SPHERE: {
-      // radius = largest singular value of the 3x3 part = sqrt(largest eigenvalue of A = M3^T M3),
-      // from the closed-form (trigonometric) eigenvalues of a symmetric 3x3 matrix, with a margin;
-      // the Frobenius norm is an always-valid upper bound and caps it.
-      double fro = 0;
-      for (int k = 0; k < 3; ++k) fro += M[4 * k] * M[4 * k] + M[4 * k + 1] * M[4 * k + 1] + M[4 * k + 2] * M[4 * k + 2];
-      double A[3][3];
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) A[i][j] = M[i] * M[j] + M[4 + i] * M[4 + j] + M[8 + i] * M[8 + j];
-      double r2 = fro;
-      {
-        const double p1 = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        const double q = (A[0][0] + A[1][1] + A[2][2]) / 3.0;
-        const double p2 = (A[0][0] - q) * (A[0][0] - q) + (A[1][1] - q) * (A[1][1] - q) + (A[2][2] - q) * (A[2][2] - q) + 2.0 * p1;
-        double lmax = q;
-        if (p2 > 0.0) {
-          const double pp = std::sqrt(p2 / 6.0);
-          double B[3][3];
-          for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) B[i][j] = (A[i][j] - (i == j ? q : 0.0)) / pp;
-          const double detB = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1]) - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0]) +
-                              B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
-          const double rr = std::fmax(-1.0, std::fmin(1.0, detB / 2.0));
-          lmax = q + 2.0 * pp * std::cos(std::acos(rr) / 3.0);
-        }
-        if (std::isfinite(lmax) && lmax > 0.0) r2 = std::fmin(r2, lmax * (1.0 + 1e-6));
-      }
-      Sphere s;
-      s.cx = M[3];
-      s.cy = M[7];
-      s.cz = M[11];
-      s.r = std::sqrt(r2);
-      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
-      const Sphere box = sphereOfBox(M, lo, hi);  // also valid; keep the tighter one
-      return (box.finite() && box.r < s.r) ? box : s;
-    }
-    case RTC_CUBE: {
-      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
-      return sphereOfBox(M, lo, hi);
-    }
-    case RTC_CYLINDER: {
-      const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
-      return sphereOfBox(M, lo, hi);
-    }
-    case RTC_CONE:
-      // NOT bounded by its truncated box: for a ray parallel to one of the cone's halves the reference
-      // appends the single surface hit t = -c / 2b WITHOUT the min < y < max filter (cone.zig:79-86),
-      // so a truncated cone can report an entry anywhere on the infinite double cone.
-      return Sphere{};
-    case RTC_TRIANGLE:
-    case RTC_SMOOTH_TRIANGLE: {
-      double pts[3][3];
-      for (int v = 0; v < 3; ++v) {
-        double p[3];
-        for (int k = 0; k < 3; ++k)
-          p[k] = d.tri_p1[3ull * g + k] + (v == 1 ? d.tri_e1[3ull * g + k] : 0.0) + (v == 2 ? d.tri_e2[3ull * g + k] : 0.0);
-        for (int k = 0; k < 3; ++k) pts[v][k] = M[4 * k] * p[0] + M[4 * k + 1] * p[1] + M[4 * k + 2] * p[2] + M[4 * k + 3];
-      }
-      return sphereOfPoints(pts, 3);
-    }
-    default: return Sphere{};  // planes are unbounded
-  }
-}
-
-Sphere inflate(Sphere s) {
-  if (!s.finite()) return Sphere{};
-  s.r = s.r * (1.0 + 1e-6) + 1e-9;
-  return s;
-}
-
-
-// ---- candidate BVH (BvhNode, rtc_device.h) ------------------------------------------------------
-struct Aabb {
-  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  void add(const double p[3]) {
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = std::fmin(lo[k], p[k]);
-      hi[k] = std::fmax(hi[k], p[k]);
-    }
-  }
-  void merge(const Aabb& o) {
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = std::fmin(lo[k], o.lo[k]);
-      hi[k] = std::fmax(hi[k], o.hi[k]);
-    }
-  }
-  bool finite() const {
-    for (int k = 0; k < 3; ++k)
-      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) return false;
-    return true;
-  }
-  double area() const {
-    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-    return 2.0 * (dx * dy + dy * dz + dz * dx);
-  }
-};
-
-const float kHuge = 3.0e38f;  // "unbounded" in an FP32 box
-
-// World-space box of one leaf: the object-space box of the shape pushed through the forward transform.
-Aabb leafWorldBox(const rtc_scene_desc& d, uint32_t leaf) {
-  Aabb box;
-  double M[12];
-  if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[leaf], M)) return Aabb{};
-  auto addObjectBox = [&](const double lo[3], const double hi[3]) {
-    for (int k = 0; k < 3; ++k)
-      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
-        box = Aabb{};
-        return;
-      }
-    for (int c = 0; c < 8; ++c) {
-      const double x = (c & 1) ? hi[0] : lo[0], y = (c & 2) ? hi[1] : lo[1], z = (c & 4) ? hi[2] : lo[2];
-      double p[3];
-      for (int k = 0; k < 3; ++k) p[k] = M[4 * k] * x + M[4 * k + 1] * y + M[4 * k + 2] * z + M[4 * k + 3];
-      box.add(p);
-    }
-  };
-  const uint32_t g = d.leaf_geom[leaf];
-  switch (d.leaf_kind[leaf]) {
-    case RTC_SPHERE:
-    case RTC_CUBE: {
-      const double lo[3] = {-1, -1, -1}, hi[3] = {1, 1, 1};
-      addObjectBox(lo, hi);
-      break;
-    }
-    case RTC_CYLINDER: {
-      const double lo[3] = {-1, d.cyl_min[g], -1}, hi[3] = {1, d.cyl_max[g], 1};
-      addObjectBox(lo, hi);
-      break;
-    }
-    case RTC_CONE:
-      break;  // unbounded, see leafSphere(): the parallel-ray entry ignores the truncation
-    case RTC_TRIANGLE:
-    case RTC_SMOOTH_TRIANGLE:
-      for (int v = 0; v < 3; ++v) {
-        double q[3], p[3];
-        for (int k = 0; k < 3; ++k)
-          q[k] = d.tri_p1[3ull * g + k] + (v == 1 ? d.tri_e1[3ull * g + k] : 0.0) + (v == 2 ? d.tri_e2[3ull * g + k] : 0.0);
-        for (int k = 0; k < 3; ++k) p[k] = M[4 * k] * q[0] + M[4 * k + 1] * q[1] + M[4 * k + 2] * q[2] + M[4 * k + 3];
-        box.add(p);
-      }
-      break;
-    default: break;  // planes are unbounded
-  }
-  return box;
-}
-
-struct BvhPrim {
-  Aabb box;        // may be non-finite: treated as unbounded
-  double c[3];     // centroid (0 for unbounded)
-  uint32_t leaf;   // depth-first leaf index
-};
-
-struct BvhBuilder {
-  std::vector<BvhNode>& nodes;
-  std::vector<uint32_t>& leaves;
-  std::vector<BvhPrim> prims;
-  float mag = 0.0f;
-
-  static float down(double v) {
-    float f = static_cast<float>(v);
-    if (static_cast<double>(f) > v) f = std::nextafterf(f, -INFINITY);
-    return f;
-  }
-  static float up(double v) {
-    float f = static_cast<float>(v);
-    if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
-    return f;
-  }
-  void storeBox(const Aabb& b, float lo[3], float hi[3]) {
-    if (!b.finite()) {
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = -kHuge;
-        hi[k] = kHuge;
-      }
-      return;
-    }
-    for (int k = 0; k < 3; ++k) {
-      // rounded outward plus a relative cushion; the kernel adds the ray-dependent part of the margin
-      const double pad = 1e-6 * (std::fabs(b.lo[k]) + std::fabs(b.hi[k])) + 1e-30;
-      lo[k] = down(b.lo[k] - pad);
-      hi[k] = up(b.hi[k] + pad);
-      if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) {
-        lo[k] = -kHuge;
-        hi[k] = kHuge;
-      } else {
-        mag = std::fmax(mag, std::fmax(std::fabs(lo[k]), std::fabs(hi[k])));
-      }
-    }
-  }
-  Aabb boundsOf(size_t first, size_t count) const {
-    Aabb b;
-    bool unbounded = false;
-    for (size_t i = first; i < first + count; ++i) {
-      if (!prims[i].box.finite()) unbounded = true;
-      else b.merge(prims[i].box);
-    }
-    if (unbounded) {
-      for (int k = 0; k < 3; ++k) {
-        b.lo[k] = -INFINITY;
-        b.hi[k] = INFINITY;
-      }
-    }
-    return b;
-  }
-  // returns the child reference for prims[first, first+count)
-  uint32_t build(size_t first, size_t count) {
-    if (count <= 4) {
-      const uint32_t at = static_cast<uint32_t>(leaves.size());
-      for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
-      return RTC_NODE_BIT | (at << 3) | static_cast<uint32_t>(count - 1);
-    }
-    // centroid bounds -> split axis; 16-bin SAH along it
-    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (size_t i = first; i < first + count; ++i)
-      for (int k = 0; k < 3; ++k) {
-        clo[k] = std::fmin(clo[k], prims[i].c[k]);
-        chi[k] = std::fmax(chi[k], prims[i].c[k]);
-      }
-    int axis = 0;
-    for (int k = 1; k < 3; ++k)
-      if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
-    size_t mid = first + count / 2;
-    const double extent = chi[axis] - clo[axis];
-    bool split_done = false;
-    if (extent > 0.0 && std::isfinite(extent)) {
-      constexpr int kBins = 16;
-      Aabb bin_box[kBins];
-      size_t bin_n[kBins] = {};
-      auto binOf = [&](const BvhPrim& p) {
-        int b = static_cast<int>((p.c[axis] - clo[axis]) / extent * kBins);
-        return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-      };
-      for (size_t i = first; i < first + count; ++i) {
-        const int b = binOf(prims[i]);
-        bin_n[b]++;
-        if (prims[i].box.finite()) bin_box[b].merge(prims[i].box);
-      }
-      double right_area[kBins];
-      size_t right_n[kBins];
-      Aabb acc;
-      size_t n = 0;
-      for (int b = kBins - 1; b > 0; --b) {
-        acc.merge(bin_box[b]);
-        n += bin_n[b];
-        right_area[b] = acc.finite() ? acc.area() : 0.0;
-        right_n[b] = n;
-      }
-      acc = Aabb{};
-      n = 0;
-      double best = INFINITY;
-      int best_b = -1;
-      for (int b = 0; b < kBins - 1; ++b) {
-        acc.merge(bin_box[b]);
-        n += bin_n[b];
-        if (n == 0 || right_n[b + 1] == 0) continue;
-        const double cost = (acc.finite() ? acc.area() : 0.0) * n + right_area[b + 1] * right_n[b + 1];
-        if (cost < best) {
-          best = cost;
-          best_b = b;
-        }
-      }
-      if (best_b >= 0) {
-        auto it = std::partition(prims.begin() + first, prims.begin() + first + count,
-                                 [&](const BvhPrim& p) { return binOf(p) <= best_b; });
-        mid = static_cast<size_t>(it - prims.begin());
-        split_done = mid > first && mid < first + count;
-      }
-    }
-    if (!split_done) {
-      mid = first + count / 2;
-      std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
-                       [&](const BvhPrim& a, const BvhPrim& b) { return a.c[axis] < b.c[axis]; });
-    }
-    const uint32_t me = static_cast<uint32_t>(nodes.size());
-    nodes.emplace_back();
-    const Aabb b0 = boundsOf(first, mid - first), b1 = boundsOf(mid, first + count - mid);
-    const uint32_t c0 = build(first, mid - first);
-    const uint32_t c1 = build(mid, first + count - mid);
-    BvhNode& N = nodes[me];
-    storeBox(b0, N.lo0, N.hi0);
-    storeBox(b1, N.lo1, N.hi1);
-    N.c0 = c0;
-    N.c1 = c1;
-    N.pad_[0] = N.pad_[1] = 0;
-    return me;
-  }
-  // root node index of a BVH over `items` (always a node, so the kernel can start from a node)
-  uint32_t buildRoot(std::vector<BvhPrim> items) {
-    prims = std::move(items);
-    const uint32_t me = static_cast<uint32_t>(nodes.size());
-    if (prims.size() > 4) return build(0, prims.size());
-    nodes.emplace_back();
-    BvhNode N;
-    std::memset(&N, 0, sizeof N);
-    for (int k = 0; k < 3; ++k) {  // empty boxes: never entered
-      N.lo0[k] = N.lo1[k] = kHuge;
-      N.hi0[k] = N.hi1[k] = -kHuge;
-    }
-    N.c0 = N.c1 = RTC_NO_LEAF;  // empty child
-    if (!prims.empty()) {
-      storeBox(boundsOf(0, prims.size()), N.lo0, N.hi0);
-      N.c0 = build(0, prims.size());
-    }
-    nodes[me] = N;
-    return me;
-  }
-};
-
-bool affineRow(const double* m16) {  // last row must be exactly (0,0,0,1); -0 is accepted
-  return m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0;
-}
 
 bool selectChainOnly(const rtc_scene_desc& d, uint32_t idx, int depth = 0) {
   if (depth > 64) return false;
@@ -593,312 +121,6 @@ DevCamera devCamera(const rtc_camera& c) {
   d.hsize = c.hsize;
   d.vsize = c.vsize;
   return d;
-}
-
-inline uint32_t scheduleItem(uint32_t chunk, uint32_t start, uint32_t len) {
-  return chunk | (start << 20) | ((len - 1u) << 26);
-}
-
-int uploadSchedule(rtc_scene* s, hipStream_t stream) {
-  const std::vector<uint32_t>& order = s->h_order;
-  if (order.size() > s->order_capacity) {
-    if (s->d_order) (void)hipFree(s->d_order);
-    s->d_order = nullptr;
-    s->order_capacity = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_order), order.size() * sizeof(uint32_t)));
-    s->order_capacity = order.size();
-  }
-  HIP_TRY(hipMemcpyAsync(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  return RTC_OK;
-}
-
-// Schedule from the MEASURED per-pixel ray counts of an earlier frame with the same pixel map.
-//
-// One wave's fair share of the frame is F = total rays / resident waves.  A chunk that costs more than
-// cap = alpha * F would BE the critical path if one wave had to run it alone (a frame split over several
-// GPUs leaves each of them few chunks per wave; measured: tools/scale_sim.py), so it is cut into
-// rows, and rows into shorter runs, until every run costs <= cap.  The runs are dealt longest-first into
-// bins of <= 64 pixels whose cost stays near cap; a bin is then topped up to 64 pixels with rows of the
-// cheapest chunks of the frame (one or two rays per pixel), so the wave that pulls it starts with all lanes
-// busy and the cheap pixels' lanes become free just as the expensive pixels' ray trees fan out (the
-// kernel's intra-wave sharing moves the sub-trees over).  Every other chunk stays whole: neighbouring
-// pixels in one wave is what keeps the traversal coherent.  Packets go out most expensive first.
-void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost, double n_waves) {
-  static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
-  static const double fill = getenv("RTC_SPLIT_FILL") ? atof(getenv("RTC_SPLIT_FILL")) : 1.0;
-  struct Item { uint32_t cost, code, npx; };
-  const uint32_t n_chunks = map.n_chunks;
-  std::vector<uint32_t> pc(static_cast<size_t>(n_chunks) * 64u);  // per chunk, its pixels' costs
-  std::vector<uint64_t> chunk_cost(n_chunks, 0);
-  double total = 0.0;
-  for (uint32_t c = 0; c < n_chunks; ++c) {
-    const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
-    const uint32_t ccy = cr / map.chunks_x;
-    const uint32_t rx0 = (cr - ccy * map.chunks_x) * 8u, ry0 = ccy * 8u;
-    const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
-    const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
-    for (uint32_t k = 0; k < 64u; ++k) {
-      const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
-      const uint32_t v = (rx < w && ry < h) ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
-      pc[static_cast<size_t>(c) * 64u + k] = v;
-      chunk_cost[c] += v;
-    }
-    total += static_cast<double>(chunk_cost[c]);
-  }
-  const double cap = std::max(1.0, alpha * total / std::max(1.0, n_waves));
-  std::vector<Item> whole, runs;
-  for (uint32_t c = 0; c < n_chunks; ++c) {
-    if (static_cast<double>(chunk_cost[c]) <= cap) {
-      whole.push_back({static_cast<uint32_t>(chunk_cost[c]), scheduleItem(c, 0, 64), 64u});
-      continue;
-    }
-    const uint32_t* k = &pc[static_cast<size_t>(c) * 64u];
-    for (uint32_t r = 0; r < 8u; ++r) {
-      uint32_t start = r * 8u, acc = 0u;
-      for (uint32_t i = r * 8u; i < r * 8u + 8u; ++i) {
-        if (i > start && static_cast<double>(acc + k[i]) > cap) {
-          runs.push_back({acc, scheduleItem(c, start, i - start), i - start});
-          start = i;
-          acc = 0u;
-        }
-        acc += k[i];
-      }
-      runs.push_back({acc, scheduleItem(c, start, r * 8u + 8u - start), r * 8u + 8u - start});
-    }
-  }
-  std::vector<uint32_t>& out = s->h_order;
-  out.clear();
-  struct Packet { uint64_t cost; uint32_t npx, n_items; uint32_t items[RTC_PACKET_ITEMS]; };
-  std::vector<Packet> packets;
-  std::sort(whole.begin(), whole.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
-  size_t light_end = whole.size();  // whole[light_end..] have been cut up as filler
-  if (!runs.empty()) {
-    std::sort(runs.begin(), runs.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
-    uint64_t run_cost = 0, run_px = 0;
-    for (const Item& it : runs) run_cost += it.cost, run_px += it.npx;
-    const size_t n_bins = std::max<size_t>({1, static_cast<size_t>((run_px + 63) / 64),
-                                            static_cast<size_t>(static_cast<double>(run_cost) / (fill * cap)) + 1});
-    packets.assign(n_bins, Packet{0, 0, 0, {}});
-    const uint32_t kRunItems = RTC_PACKET_ITEMS - 4u;  // slots kept free for filler rows
-    // longest-first into the cheapest bin that still has room (a heap of bins by cost)
-    auto cmp = [&](uint32_t a, uint32_t b) { return packets[a].cost > packets[b].cost; };
-    std::vector<uint32_t> heap(n_bins);
-    for (size_t i = 0; i < n_bins; ++i) heap[i] = static_cast<uint32_t>(i);
-    std::make_heap(heap.begin(), heap.end(), cmp);
-    std::vector<uint32_t> skipped;
-    for (const Item& it : runs) {
-      skipped.clear();
-      bool placed = false;
-      while (!heap.empty()) {
-        std::pop_heap(heap.begin(), heap.end(), cmp);
-        const uint32_t b = heap.back();
-        heap.pop_back();
-        Packet& P = packets[b];
-        if (P.npx + it.npx <= 64u && P.n_items < kRunItems) {
-          P.items[P.n_items++] = it.code;
-          P.npx += it.npx;
-          P.cost += it.cost;
-          placed = true;
-          if (P.npx < 64u && P.n_items < kRunItems) skipped.push_back(b);
-          break;
-        }
-        skipped.push_back(b);
-        if (skipped.size() > 32) break;  // bounded search; a fresh packet takes the run
-      }
-      for (uint32_t b : skipped) {
-        heap.push_back(b);
-        std::push_heap(heap.begin(), heap.end(), cmp);
-      }
-      if (!placed) {
-        Packet P{it.cost, it.npx, 1, {}};
-        P.items[0] = it.code;
-        packets.push_back(P);  // not in the heap: it stays as it is
-      }
-    }
-    // top up with rows of the cheapest whole chunks
-    uint32_t filler_chunk = 0, filler_row = 8;  // rows of whole[light_end] still unused
-    for (Packet& P : packets) {
-      while (P.npx + 8u <= 64u && P.n_items < RTC_PACKET_ITEMS) {
-        if (filler_row == 8u) {
-          if (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap) break;
-          --light_end;
-          filler_chunk = whole[light_end].code & 0xFFFFFu;
-          filler_row = 0;
-        }
-        const uint32_t* k = &pc[static_cast<size_t>(filler_chunk) * 64u + filler_row * 8u];
-        uint32_t rc = 0;
-        for (int i = 0; i < 8; ++i) rc += k[i];
-        P.items[P.n_items++] = scheduleItem(filler_chunk, filler_row * 8u, 8);
-        P.npx += 8u;
-        P.cost += rc;
-        ++filler_row;
-      }
-      if (filler_row == 8u && (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap)) break;
-    }
-    // rows of a filler chunk that no packet took
-    if (filler_row < 8u) {
-      Packet P{0, 0, 0, {}};
-      for (; filler_row < 8u; ++filler_row) {
-        P.items[P.n_items++] = scheduleItem(filler_chunk, filler_row * 8u, 8);
-        P.npx += 8u;
-        const uint32_t* k = &pc[static_cast<size_t>(filler_chunk) * 64u + filler_row * 8u];
-        for (int i = 0; i < 8; ++i) P.cost += k[i];
-      }
-      packets.push_back(P);
-    }
-  }
-  for (size_t i = 0; i < light_end; ++i) {
-    Packet P{whole[i].cost, 64u, 1, {}};
-    P.items[0] = whole[i].code;
-    packets.push_back(P);
-  }
-  packets.erase(std::remove_if(packets.begin(), packets.end(), [](const Packet& P) { return P.n_items == 0; }), packets.end());
-  std::stable_sort(packets.begin(), packets.end(), [](const Packet& a, const Packet& b) { return a.cost > b.cost; });
-  out.assign(packets.size() * RTC_PACKET_ITEMS, RTC_NO_ITEM);
-  for (size_t i = 0; i < packets.size(); ++i)
-    for (uint32_t j = 0; j < packets[i].n_items; ++j) out[i * RTC_PACKET_ITEMS + j] = packets[i].items[j];
-  // every pixel of every chunk exactly once, whatever the packing did: otherwise fall back to whole chunks
-  {
-    std::vector<uint8_t> seen(static_cast<size_t>(n_chunks) * 64u, 0);
-    bool ok = true;
-    size_t covered = 0;
-    for (uint32_t it : out) {
-      if (it == RTC_NO_ITEM) continue;
-      const uint32_t c = it & 0xFFFFFu, start = (it >> 20) & 63u, len = (it >> 26) + 1u;
-      if (c >= n_chunks || start + len > 64u) {
-        ok = false;
-        break;
-      }
-      for (uint32_t k = start; k < start + len; ++k) {
-        if (seen[static_cast<size_t>(c) * 64u + k]++) ok = false;
-        ++covered;
-      }
-    }
-    if (!ok || covered != seen.size()) {
-      std::fprintf(stderr, "rtc: schedule packing lost or duplicated pixels (%zu of %zu): using whole chunks\n", covered, seen.size());
-      out.assign(static_cast<size_t>(n_chunks) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
-      for (uint32_t c = 0; c < n_chunks; ++c) out[static_cast<size_t>(c) * RTC_PACKET_ITEMS] = scheduleItem(c, 0, 64);
-    }
-  }
-  if (getenv("RTC_PROFILE_DUMP")) {
-    std::vector<uint64_t> pcst;
-    uint64_t hpx[5] = {0, 0, 0, 0, 0}, hit[5] = {0, 0, 0, 0, 0};
-    for (const Packet& P : packets) {
-      pcst.push_back(P.cost);
-      hpx[P.npx == 64 ? 4 : P.npx / 16]++;
-      hit[P.n_items == 1 ? 0 : 1 + (P.n_items - 1) / 5]++;
-    }
-    std::sort(pcst.begin(), pcst.end());
-    auto q = [&](double f) { return pcst.empty() ? 0ull : (unsigned long long)pcst[std::min(pcst.size() - 1, (size_t)(f * pcst.size()))]; };
-    std::fprintf(stderr, "rtc packets: cost min %llu p10 %llu med %llu p90 %llu p99 %llu max %llu | px<16 %llu <32 %llu <48 %llu <64 %llu =64 %llu | items 1: %llu 2-5: %llu 6-10: %llu 11-15: %llu 16: %llu\n",
-                 q(0), q(0.1), q(0.5), q(0.9), q(0.99), q(1.0), (unsigned long long)hpx[0], (unsigned long long)hpx[1], (unsigned long long)hpx[2], (unsigned long long)hpx[3], (unsigned long long)hpx[4],
-                 (unsigned long long)hit[0], (unsigned long long)hit[1], (unsigned long long)hit[2], (unsigned long long)hit[3], (unsigned long long)hit[4]);
-  }
-  if (getenv("RTC_PROFILE_DUMP"))
-    std::fprintf(stderr, "rtc schedule: %zu packets (%zu runs of %zu split chunks, %zu filler chunks), cap %.0f rays, total %.0f\n",
-                 packets.size(), runs.size(), static_cast<size_t>(n_chunks) - whole.size(), whole.size() - light_end, cap, total);
-}
-
-// Heavy-first chunk order (DevPixelMap::order): chunks whose pixels may look straight at an object with a
-// branching material come first.  A heuristic on the host, cached per (camera, map); never affects results.
-int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_t stream) {
-  map.order = nullptr;
-  map.n_units = map.n_chunks;
-  if (map.n_chunks >= RTC_ITEM_MAX_CHUNKS) return RTC_OK;  // chunk index must fit the item encoding
-  if (map.n_chunks < 64) return RTC_OK;
-  const bool rank_heavy = !s->branching.empty() && !s->branching_everywhere;
-  const bool rank_trivial = !s->occupied.empty() && !s->unbounded_nonplane;
-  if (!rank_heavy && !rank_trivial) return RTC_OK;
-  std::vector<double> key{static_cast<double>(cam.hsize), static_cast<double>(cam.vsize), cam.half_width, cam.half_height,
-                          cam.pixel_size};
-  key.insert(key.end(), cam.inv_view, cam.inv_view + 16);
-  const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
-  for (size_t i = 0; i < offsetof(DevPixelMap, n_units) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
-  if (key == s->order_key && s->d_order) {
-    map.order = s->d_order;
-    map.n_units = static_cast<uint32_t>(s->h_order.size() / RTC_PACKET_ITEMS);
-    return RTC_OK;
-  }
-  // forward view matrix (world -> camera)
-  double V[12];
-  if (!forwardOf(cam.inv_view, V)) return RTC_OK;
-  struct Box { double x0, x1, y0, y1; };  // pixel-space boxes of projected bounding spheres
-  // false: the sphere cannot be projected (camera inside / next to it): give up on that ranking
-  auto project = [&](const std::vector<Sphere>& spheres, std::vector<Box>& boxes) {
-    for (const Sphere& sp : spheres) {
-      const double X = V[0] * sp.cx + V[1] * sp.cy + V[2] * sp.cz + V[3];
-      const double Y = V[4] * sp.cx + V[5] * sp.cy + V[6] * sp.cz + V[7];
-      const double Z = V[8] * sp.cx + V[9] * sp.cy + V[10] * sp.cz + V[11];
-      const double depth = -Z;  // the camera looks down -z (camera.zig:70)
-      if (depth <= sp.r * 1.05) {
-        if (depth > -sp.r) return false;
-        continue;  // entirely behind the camera
-      }
-      // silhouette of the sphere on the image plane z = -1: per axis the interval tan(theta -+ alpha)
-      auto extent = [&](double c, double& lo, double& hi) {
-        const double theta = std::atan2(c, depth);
-        const double alpha = std::asin(std::fmin(1.0, sp.r / std::sqrt(c * c + depth * depth)));
-        if (theta + alpha >= 1.5 || theta - alpha <= -1.5) return false;
-        lo = std::tan(theta - alpha);
-        hi = std::tan(theta + alpha);
-        return true;
-      };
-      double wx0, wx1, wy0, wy1;
-      if (!extent(X, wx0, wx1) || !extent(Y, wy0, wy1)) return false;
-      // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
-      boxes.push_back({(cam.half_width - wx1) / cam.pixel_size - 1.5, (cam.half_width - wx0) / cam.pixel_size + 0.5,
-                       (cam.half_height - wy1) / cam.pixel_size - 1.5, (cam.half_height - wy0) / cam.pixel_size + 0.5});
-    }
-    return true;
-  };
-  std::vector<Box> heavy_boxes, any_boxes;
-  const bool have_heavy = rank_heavy && project(s->branching, heavy_boxes) && !heavy_boxes.empty();
-  const bool have_any = rank_trivial && project(s->occupied, any_boxes);
-  if (!have_heavy && !have_any) return RTC_OK;
-  // Longest-job-first: [chunks looking at a branching material][chunks looking at any bounded object]
-  // [chunks that can only see unbounded planes or nothing: one or two rays per pixel].  The launch ends
-  // when the LAST unit handed out is finished, so the cheapest work goes last.
-  std::vector<uint32_t> order;
-  order.reserve(map.n_chunks);
-  std::vector<uint32_t> medium, trivial;
-  for (uint32_t c = 0; c < map.n_chunks; ++c) {
-    const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
-    const uint32_t ccy = cr / map.chunks_x;
-    double px0 = (cr - ccy * map.chunks_x) * 8.0, py0 = ccy * 8.0;
-    if (map.mode == 0u) {
-      px0 += map.x0;
-      py0 += map.y0;
-    } else {
-      const uint32_t tile = map.first_tile + region * map.tile_stride, ty = tile / map.tiles_x;
-      px0 += static_cast<double>(tile - ty * map.tiles_x) * map.tile_w;
-      py0 += static_cast<double>(ty) * map.tile_h;
-    }
-    auto overlaps = [&](const std::vector<Box>& boxes) {
-      for (const Box& b : boxes)
-        if (px0 + 8.0 >= b.x0 && px0 <= b.x1 && py0 + 8.0 >= b.y0 && py0 <= b.y1) return true;
-      return false;
-    };
-    if (have_heavy && overlaps(heavy_boxes)) {
-      order.push_back(c);
-    } else if (!have_any || overlaps(any_boxes)) {
-      medium.push_back(c);
-    } else {
-      trivial.push_back(c);
-    }
-  }
-  if (order.size() + trivial.size() == 0 || order.size() == map.n_chunks || medium.size() == map.n_chunks) return RTC_OK;
-  if (getenv("RTC_PROFILE_DUMP"))
-    std::fprintf(stderr, "rtc schedule: %zu heavy, %zu medium, %zu trivial chunks\n", order.size(), medium.size(), trivial.size());
-  order.insert(order.end(), medium.begin(), medium.end());
-  order.insert(order.end(), trivial.begin(), trivial.end());
-  s->h_order.assign(order.size() * RTC_PACKET_ITEMS, RTC_NO_ITEM);  // one whole chunk per packet
-  for (size_t i = 0; i < order.size(); ++i) s->h_order[i * RTC_PACKET_ITEMS] = scheduleItem(order[i], 0, 64);
-  const int st = uploadSchedule(s, stream);
-  if (st != RTC_OK) return st;
-  s->order_key = key;
-  map.order = s->d_order;
-  map.n_units = static_cast<uint32_t>(order.size());
-  return RTC_OK;
 }
 
 int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,

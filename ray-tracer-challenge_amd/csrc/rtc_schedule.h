@@ -1,0 +1,315 @@
+// rtc_schedule.h — the order in which the persistent waves are handed pixels ("Schedule"):
+// the geometric first-frame heuristic and the packing from measured per-pixel ray counts.  Never affects results.
+#pragma once
+#include "rtc_host_internal.h"
+#include "rtc_bounds.h"
+
+namespace {
+
+inline uint32_t scheduleItem(uint32_t chunk, uint32_t start, uint32_t len) {
+  return chunk | (start << 20) | ((len - 1u) << 26);
+}
+
+int uploadSchedule(rtc_scene* s, hipStream_t stream) {
+  const std::vector<uint32_t>& order = s->h_order;
+  if (order.size() > s->order_capacity) {
+    if (s->d_order) (void)hipFree(s->d_order);
+    s->d_order = nullptr;
+    s->order_capacity = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_order), order.size() * sizeof(uint32_t)));
+    s->order_capacity = order.size();
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  return RTC_OK;
+}
+
+// Schedule from the MEASURED per-pixel ray counts of an earlier frame with the same pixel map.
+//
+// One wave's fair share of the frame is F = total rays / resident waves.  A chunk that costs more than
+// cap = alpha * F would BE the critical path if one wave had to run it alone (a frame split over several
+// GPUs leaves each of them few chunks per wave; measured: tools/scale_sim.py), so it is cut into
+// rows, and rows into shorter runs, until every run costs <= cap.  The runs are dealt longest-first into
+// bins of <= 64 pixels whose cost stays near cap; a bin is then topped up to 64 pixels with rows of the
+// cheapest chunks of the frame (one or two rays per pixel), so the wave that pulls it starts with all lanes
+// busy and the cheap pixels' lanes become free just as the expensive pixels' ray trees fan out (the
+// kernel's intra-wave sharing moves the sub-trees over).  Every other chunk stays whole: neighbouring
+// pixels in one wave is what keeps the traversal coherent.  Packets go out most expensive first.
+void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost, double n_waves) {
+  static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
+  static const double fill = getenv("RTC_SPLIT_FILL") ? atof(getenv("RTC_SPLIT_FILL")) : 1.0;
+  struct Item { uint32_t cost, code, npx; };
+  const uint32_t n_chunks = map.n_chunks;
+  std::vector<uint32_t> pc(static_cast<size_t>(n_chunks) * 64u);  // per chunk, its pixels' costs
+  std::vector<uint64_t> chunk_cost(n_chunks, 0);
+  double total = 0.0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
+    const uint32_t ccy = cr / map.chunks_x;
+    const uint32_t rx0 = (cr - ccy * map.chunks_x) * 8u, ry0 = ccy * 8u;
+    const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
+    const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
+    for (uint32_t k = 0; k < 64u; ++k) {
+      const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
+      const uint32_t v = (rx < w && ry < h) ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
+      pc[static_cast<size_t>(c) * 64u + k] = v;
+      chunk_cost[c] += v;
+    }
+    total += static_cast<double>(chunk_cost[c]);
+  }
+  const double cap = std::max(1.0, alpha * total / std::max(1.0, n_waves));
+  std::vector<Item> whole, runs;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    if (static_cast<double>(chunk_cost[c]) <= cap) {
+      whole.push_back({static_cast<uint32_t>(chunk_cost[c]), scheduleItem(c, 0, 64), 64u});
+      continue;
+    }
+    const uint32_t* k = &pc[static_cast<size_t>(c) * 64u];
+    for (uint32_t r = 0; r < 8u; ++r) {
+      uint32_t start = r * 8u, acc = 0u;
+      for (uint32_t i = r * 8u; i < r * 8u + 8u; ++i) {
+        if (i > start && static_cast<double>(acc + k[i]) > cap) {
+          runs.push_back({acc, scheduleItem(c, start, i - start), i - start});
+          start = i;
+          acc = 0u;
+        }
+        acc += k[i];
+      }
+      runs.push_back({acc, scheduleItem(c, start, r * 8u + 8u - start), r * 8u + 8u - start});
+    }
+  }
+  std::vector<uint32_t>& out = s->h_order;
+  out.clear();
+  struct Packet { uint64_t cost; uint32_t npx, n_items; uint32_t items[RTC_PACKET_ITEMS]; };
+  std::vector<Packet> packets;
+  std::sort(whole.begin(), whole.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+  size_t light_end = whole.size();  // whole[light_end..] have been cut up as filler
+  if (!runs.empty()) {
+    std::sort(runs.begin(), runs.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
+    uint64_t run_cost = 0, run_px = 0;
+    for (const Item& it : runs) run_cost += it.cost, run_px += it.npx;
+    const size_t n_bins = std::max<size_t>({1, static_cast<size_t>((run_px + 63) / 64),
+                                            static_cast<size_t>(static_cast<double>(run_cost) / (fill * cap)) + 1});
+    packets.assign(n_bins, Packet{0, 0, 0, {}});
+    const uint32_t kRunItems = RTC_PACKET_ITEMS - 4u;  // slots kept free for filler rows
+    // longest-first into the cheapest bin that still has room (a heap of bins by cost)
+    auto cmp = [&](uint32_t a, uint32_t b) { return packets[a].cost > packets[b].cost; };
+    std::vector<uint32_t> heap(n_bins);
+    for (size_t i = 0; i < n_bins; ++i) heap[i] = static_cast<uint32_t>(i);
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    std::vector<uint32_t> skipped;
+    for (const Item& it : runs) {
+      skipped.clear();
+      bool placed = false;
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const uint32_t b = heap.back();
+        heap.pop_back();
+        Packet& P = packets[b];
+        if (P.npx + it.npx <= 64u && P.n_items < kRunItems) {
+          P.items[P.n_items++] = it.code;
+          P.npx += it.npx;
+          P.cost += it.cost;
+          placed = true;
+          if (P.npx < 64u && P.n_items < kRunItems) skipped.push_back(b);
+          break;
+        }
+        skipped.push_back(b);
+        if (skipped.size() > 32) break;  // bounded search; a fresh packet takes the run
+      }
+      for (uint32_t b : skipped) {
+        heap.push_back(b);
+        std::push_heap(heap.begin(), heap.end(), cmp);
+      }
+      if (!placed) {
+        Packet P{it.cost, it.npx, 1, {}};
+        P.items[0] = it.code;
+        packets.push_back(P);  // not in the heap: it stays as it is
+      }
+    }
+    // top up with rows of the cheapest whole chunks
+    uint32_t filler_chunk = 0, filler_row = 8;  // rows of whole[light_end] still unused
+    for (Packet& P : packets) {
+      while (P.npx + 8u <= 64u && P.n_items < RTC_PACKET_ITEMS) {
+        if (filler_row == 8u) {
+          if (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap) break;
+          --light_end;
+          filler_chunk = whole[light_end].code & 0xFFFFFu;
+          filler_row = 0;
+        }
+        const uint32_t* k = &pc[static_cast<size_t>(filler_chunk) * 64u + filler_row * 8u];
+        uint32_t rc = 0;
+        for (int i = 0; i < 8; ++i) rc += k[i];
+        P.items[P.n_items++] = scheduleItem(filler_chunk, filler_row * 8u, 8);
+        P.npx += 8u;
+        P.cost += rc;
+        ++filler_row;
+      }
+      if (filler_row == 8u && (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap)) break;
+    }
+    // rows of a filler chunk that no packet took
+    if (filler_row < 8u) {
+      Packet P{0, 0, 0, {}};
+      for (; filler_row < 8u; ++filler_row) {
+        P.items[P.n_items++] = scheduleItem(filler_chunk, filler_row * 8u, 8);
+        P.npx += 8u;
+        const uint32_t* k = &pc[static_cast<size_t>(filler_chunk) * 64u + filler_row * 8u];
+        for (int i = 0; i < 8; ++i) P.cost += k[i];
+      }
+      packets.push_back(P);
+    }
+  }
+  for (size_t i = 0; i < light_end; ++i) {
+    Packet P{whole[i].cost, 64u, 1, {}};
+    P.items[0] = whole[i].code;
+    packets.push_back(P);
+  }
+  packets.erase(std::remove_if(packets.begin(), packets.end(), [](const Packet& P) { return P.n_items == 0; }), packets.end());
+  std::stable_sort(packets.begin(), packets.end(), [](const Packet& a, const Packet& b) { return a.cost > b.cost; });
+  out.assign(packets.size() * RTC_PACKET_ITEMS, RTC_NO_ITEM);
+  for (size_t i = 0; i < packets.size(); ++i)
+    for (uint32_t j = 0; j < packets[i].n_items; ++j) out[i * RTC_PACKET_ITEMS + j] = packets[i].items[j];
+  // every pixel of every chunk exactly once, whatever the packing did: otherwise fall back to whole chunks
+  {
+    std::vector<uint8_t> seen(static_cast<size_t>(n_chunks) * 64u, 0);
+    bool ok = true;
+    size_t covered = 0;
+    for (uint32_t it : out) {
+      if (it == RTC_NO_ITEM) continue;
+      const uint32_t c = it & 0xFFFFFu, start = (it >> 20) & 63u, len = (it >> 26) + 1u;
+      if (c >= n_chunks || start + len > 64u) {
+        ok = false;
+        break;
+      }
+      for (uint32_t k = start; k < start + len; ++k) {
+        if (seen[static_cast<size_t>(c) * 64u + k]++) ok = false;
+        ++covered;
+      }
+    }
+    if (!ok || covered != seen.size()) {
+      std::fprintf(stderr, "rtc: schedule packing lost or duplicated pixels (%zu of %zu): using whole chunks\n", covered, seen.size());
+      out.assign(static_cast<size_t>(n_chunks) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
+      for (uint32_t c = 0; c < n_chunks; ++c) out[static_cast<size_t>(c) * RTC_PACKET_ITEMS] = scheduleItem(c, 0, 64);
+    }
+  }
+  if (getenv("RTC_PROFILE_DUMP")) {
+    std::vector<uint64_t> pcst;
+    uint64_t hpx[5] = {0, 0, 0, 0, 0}, hit[5] = {0, 0, 0, 0, 0};
+    for (const Packet& P : packets) {
+      pcst.push_back(P.cost);
+      hpx[P.npx == 64 ? 4 : P.npx / 16]++;
+      hit[P.n_items == 1 ? 0 : 1 + (P.n_items - 1) / 5]++;
+    }
+    std::sort(pcst.begin(), pcst.end());
+    auto q = [&](double f) { return pcst.empty() ? 0ull : (unsigned long long)pcst[std::min(pcst.size() - 1, (size_t)(f * pcst.size()))]; };
+    std::fprintf(stderr, "rtc packets: cost min %llu p10 %llu med %llu p90 %llu p99 %llu max %llu | px<16 %llu <32 %llu <48 %llu <64 %llu =64 %llu | items 1: %llu 2-5: %llu 6-10: %llu 11-15: %llu 16: %llu\n",
+                 q(0), q(0.1), q(0.5), q(0.9), q(0.99), q(1.0), (unsigned long long)hpx[0], (unsigned long long)hpx[1], (unsigned long long)hpx[2], (unsigned long long)hpx[3], (unsigned long long)hpx[4],
+                 (unsigned long long)hit[0], (unsigned long long)hit[1], (unsigned long long)hit[2], (unsigned long long)hit[3], (unsigned long long)hit[4]);
+  }
+  if (getenv("RTC_PROFILE_DUMP"))
+    std::fprintf(stderr, "rtc schedule: %zu packets (%zu runs of %zu split chunks, %zu filler chunks), cap %.0f rays, total %.0f\n",
+                 packets.size(), runs.size(), static_cast<size_t>(n_chunks) - whole.size(), whole.size() - light_end, cap, total);
+}
+
+// Heavy-first chunk order (DevPixelMap::order): chunks whose pixels may look straight at an object with a
+// branching material come first.  A heuristic on the host, cached per (camera, map); never affects results.
+int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_t stream) {
+  map.order = nullptr;
+  map.n_units = map.n_chunks;
+  if (map.n_chunks >= RTC_ITEM_MAX_CHUNKS) return RTC_OK;  // chunk index must fit the item encoding
+  if (map.n_chunks < 64) return RTC_OK;
+  const bool rank_heavy = !s->branching.empty() && !s->branching_everywhere;
+  const bool rank_trivial = !s->occupied.empty() && !s->unbounded_nonplane;
+  if (!rank_heavy && !rank_trivial) return RTC_OK;
+  std::vector<double> key{static_cast<double>(cam.hsize), static_cast<double>(cam.vsize), cam.half_width, cam.half_height,
+                          cam.pixel_size};
+  key.insert(key.end(), cam.inv_view, cam.inv_view + 16);
+  const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
+  for (size_t i = 0; i < offsetof(DevPixelMap, n_units) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
+  if (key == s->order_key && s->d_order) {
+    map.order = s->d_order;
+    map.n_units = static_cast<uint32_t>(s->h_order.size() / RTC_PACKET_ITEMS);
+    return RTC_OK;
+  }
+  // forward view matrix (world -> camera)
+  double V[12];
+  if (!forwardOf(cam.inv_view, V)) return RTC_OK;
+  struct Box { double x0, x1, y0, y1; };  // pixel-space boxes of projected bounding spheres
+  // false: the sphere cannot be projected (camera inside / next to it): give up on that ranking
+  auto project = [&](const std::vector<Sphere>& spheres, std::vector<Box>& boxes) {
+    for (const Sphere& sp : spheres) {
+      const double X = V[0] * sp.cx + V[1] * sp.cy + V[2] * sp.cz + V[3];
+      const double Y = V[4] * sp.cx + V[5] * sp.cy + V[6] * sp.cz + V[7];
+      const double Z = V[8] * sp.cx + V[9] * sp.cy + V[10] * sp.cz + V[11];
+      const double depth = -Z;  // the camera looks down -z (camera.zig:70)
+      if (depth <= sp.r * 1.05) {
+        if (depth > -sp.r) return false;
+        continue;  // entirely behind the camera
+      }
+      // silhouette of the sphere on the image plane z = -1: per axis the interval tan(theta -+ alpha)
+      auto extent = [&](double c, double& lo, double& hi) {
+        const double theta = std::atan2(c, depth);
+        const double alpha = std::asin(std::fmin(1.0, sp.r / std::sqrt(c * c + depth * depth)));
+        if (theta + alpha >= 1.5 || theta - alpha <= -1.5) return false;
+        lo = std::tan(theta - alpha);
+        hi = std::tan(theta + alpha);
+        return true;
+      };
+      double wx0, wx1, wy0, wy1;
+      if (!extent(X, wx0, wx1) || !extent(Y, wy0, wy1)) return false;
+      // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
+      boxes.push_back({(cam.half_width - wx1) / cam.pixel_size - 1.5, (cam.half_width - wx0) / cam.pixel_size + 0.5,
+                       (cam.half_height - wy1) / cam.pixel_size - 1.5, (cam.half_height - wy0) / cam.pixel_size + 0.5});
+    }
+    return true;
+  };
+  std::vector<Box> heavy_boxes, any_boxes;
+  const bool have_heavy = rank_heavy && project(s->branching, heavy_boxes) && !heavy_boxes.empty();
+  const bool have_any = rank_trivial && project(s->occupied, any_boxes);
+  if (!have_heavy && !have_any) return RTC_OK;
+  // Longest-job-first: [chunks looking at a branching material][chunks looking at any bounded object]
+  // [chunks that can only see unbounded planes or nothing: one or two rays per pixel].  The launch ends
+  // when the LAST unit handed out is finished, so the cheapest work goes last.
+  std::vector<uint32_t> order;
+  order.reserve(map.n_chunks);
+  std::vector<uint32_t> medium, trivial;
+  for (uint32_t c = 0; c < map.n_chunks; ++c) {
+    const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
+    const uint32_t ccy = cr / map.chunks_x;
+    double px0 = (cr - ccy * map.chunks_x) * 8.0, py0 = ccy * 8.0;
+    if (map.mode == 0u) {
+      px0 += map.x0;
+      py0 += map.y0;
+    } else {
+      const uint32_t tile = map.first_tile + region * map.tile_stride, ty = tile / map.tiles_x;
+      px0 += static_cast<double>(tile - ty * map.tiles_x) * map.tile_w;
+      py0 += static_cast<double>(ty) * map.tile_h;
+    }
+    auto overlaps = [&](const std::vector<Box>& boxes) {
+      for (const Box& b : boxes)
+        if (px0 + 8.0 >= b.x0 && px0 <= b.x1 && py0 + 8.0 >= b.y0 && py0 <= b.y1) return true;
+      return false;
+    };
+    if (have_heavy && overlaps(heavy_boxes)) {
+      order.push_back(c);
+    } else if (!have_any || overlaps(any_boxes)) {
+      medium.push_back(c);
+    } else {
+      trivial.push_back(c);
+    }
+  }
+  if (order.size() + trivial.size() == 0 || order.size() == map.n_chunks || medium.size() == map.n_chunks) return RTC_OK;
+  if (getenv("RTC_PROFILE_DUMP"))
+    std::fprintf(stderr, "rtc schedule: %zu heavy, %zu medium, %zu trivial chunks\n", order.size(), medium.size(), trivial.size());
+  order.insert(order.end(), medium.begin(), medium.end());
+  order.insert(order.end(), trivial.begin(), trivial.end());
+  s->h_order.assign(order.size() * RTC_PACKET_ITEMS, RTC_NO_ITEM);  // one whole chunk per packet
+  for (size_t i = 0; i < order.size(); ++i) s->h_order[i * RTC_PACKET_ITEMS] = scheduleItem(order[i], 0, 64);
+  const int st = uploadSchedule(s, stream);
+  if (st != RTC_OK) return st;
+  s->order_key = key;
+  map.order = s->d_order;
+  map.n_units = static_cast<uint32_t>(order.size());
+  return RTC_OK;
+}
+
+}  // namespace
