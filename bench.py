@@ -63,6 +63,21 @@ def measured_traffic(scene, width, height, depth):
     return 2 * 1024 * t["fetch_size_kb"] + 1024 * t["write_size_kb"]
 
 
+def kernel_name(hs):
+    """Which variant of the render kernel rtc_capi.hip's launch() picks for this scene (rocprof shows the same name)."""
+    d = hs.desc
+    kinds = hs.array("leaf_kind", d.n_leaves)
+    pats = hs.array("pat_kind", d.n_patterns)
+    ops = hs.array("node_op", d.n_nodes)
+    ext = bool((pats == 8).any()) or bool(len(ops) and (ops != 0).any())
+    small = d.n_roots <= 128 and d.n_materials <= 64 and d.n_patterns <= 48 and d.n_lights <= 16
+    if ext:
+        return "rtc_render_kernel_ext" if small else "rtc_render_kernel_bigworld_ext"
+    if small and d.n_nodes == 0 and bool((kinds <= 2).all()):
+        return "rtc_render_kernel_simple"
+    return "rtc_render_kernel" if small else "rtc_render_kernel_bigworld"
+
+
 def algorithmic_flops(desc, hs, stats):
     """SURVEY §8(d) flop table, reference arithmetic: per ray, per leaf: 56 (ray->object) + test."""
     import numpy as np
@@ -288,7 +303,7 @@ def main():
             result["roofline"] = {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.scene, W, H, args.depth),
-                "kernel": "rtc_render_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
+                "kernel": kernel_name(hs), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
                 "note": "HBM is NOT what binds this kernel: the compulsory traffic is the canvas (24*W*H B) plus "
                         "a few KB of scene tables that live in LDS; the binding limit is per-wave FP64 issue "
@@ -315,7 +330,7 @@ def main():
             gbs = ab / (kernel_ms * 1e-3) / 1e9
             result["roofline"] = {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "rtc_render_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
+                "traffic": None, "kernel": kernel_name(hs), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "note": "rank 0's kernel over rank 0's tiles (1/%d of the frame); see the 1-GPU line for the counters "
                         "and DESIGN.md section 8 for what bounds the split of a 1 ms frame" % world,
             }

@@ -20,6 +20,9 @@ extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera c
 extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                       const uint32_t max_depth, double* __restrict__ out,
                                                       DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                    const uint32_t max_depth, double* __restrict__ out,
+                                                    DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                  const uint32_t max_depth, double* __restrict__ out,
                                                  DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
@@ -236,7 +239,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
 #endif
   auto* const kernel = s->ext_kernel ? (lds ? rtc_render_kernel_ext : rtc_render_kernel_bigworld_ext)
-                                  : (lds ? rtc_render_kernel : rtc_render_kernel_bigworld);
+                                     : (lds ? (s->simple_kernel ? rtc_render_kernel_simple : rtc_render_kernel) : rtc_render_kernel_bigworld);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
@@ -835,6 +838,11 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(s->node_range.upload(node_range));
   s->has_csg = has_csg;
   s->ext_kernel = ext_kernel;
+  // spheres, planes and cubes at top level only, small enough for the LDS tables: the `simple` kernel
+  s->simple_kernel = !ext_kernel && d.n_nodes == 0 && d.n_roots <= RTC_LDS_ROOTS && d.n_materials <= RTC_LDS_MATERIALS &&
+                     d.n_patterns <= RTC_LDS_PATTERNS && d.n_lights <= RTC_LDS_LIGHTS;
+  for (uint32_t i = 0; i < d.n_roots && s->simple_kernel; ++i)
+    s->simple_kernel = !(d.roots[i] & RTC_CHILD_NODE_BIT) && d.leaf_kind[d.roots[i]] <= RTC_CUBE;
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
@@ -849,7 +857,8 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
     int nb = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ext_kernel ? rtc_render_kernel_ext : rtc_render_kernel, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &nb, ext_kernel ? rtc_render_kernel_ext : (s->simple_kernel ? rtc_render_kernel_simple : rtc_render_kernel), 256, 0));
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));

@@ -44,4 +44,15 @@ def build_everything():
 
 @pytest.fixture(scope="session")
 def rtc():
-    return importlib.import_module("ray-tracer-challenge_amd")
+    mod = importlib.import_module("ray-tracer-challenge_amd")
+    # On a GPU box, let PyTorch bring up its HIP context BEFORE this library launches anything (the order bench.py
+    # and smoke() have always used).  Twice a GPU test run hung at the first torch.cuda call made after the
+    # library had already rendered in the same process; the cause was never found, this order never hung.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda")
+            torch.cuda.synchronize()
+    except ImportError:
+        pass
+    return mod
