@@ -223,6 +223,7 @@ struct BvhPrim {
 struct BvhBuilder {
   std::vector<BvhNode>& nodes;
   std::vector<uint32_t>& leaves;
+  uint32_t max_depth = 0;  // deepest path in nodes: what the kernel's traversal stack must hold
   std::vector<BvhPrim> prims;
   float mag = 0.0f;
 
@@ -273,7 +274,8 @@ struct BvhBuilder {
     return b;
   }
   // returns the child reference for prims[first, first+count)
-  uint32_t build(size_t first, size_t count) {
+  uint32_t build(size_t first, size_t count, uint32_t depth = 1) {
+    max_depth = std::max(max_depth, depth);
     // One leaf per BVH leaf: an FP32 box test is much cheaper than the exact FP64 leaf test it may save (measured
     // at 1 / 2 / 4 / 8 leaves per node: dragons 4K 9.7 / 10.2 / 10.8 / 12.0 ms, nefertiti 1.68 / 1.85 / 2.03 / 2.25 ms).
     static const size_t max_leaf = getenv("RTC_BVH_LEAF") ? std::min<size_t>(8, std::max<size_t>(1, atoi(getenv("RTC_BVH_LEAF")))) : 1;
@@ -354,8 +356,8 @@ struct BvhBuilder {
     const uint32_t me = static_cast<uint32_t>(nodes.size());
     nodes.emplace_back();
     const Aabb b0 = boundsOf(first, mid - first), b1 = boundsOf(mid, first + count - mid);
-    const uint32_t c0 = build(first, mid - first);
-    const uint32_t c1 = build(mid, first + count - mid);
+    const uint32_t c0 = build(first, mid - first, depth + 1);
+    const uint32_t c1 = build(mid, first + count - mid, depth + 1);
     BvhNode& N = nodes[me];
     storeBox(b0, N.lo0, N.hi0);
     storeBox(b1, N.lo1, N.hi1);

@@ -534,6 +534,9 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     BvhBuilder builder{bvh_nodes, bvh_leaves};
     bvh_root_of[i] = builder.buildRoot(std::move(items));
     bvh_mag = std::fmax(bvh_mag, builder.mag);
+    if (builder.max_depth + 1 > RTC_TRAV_STACK)
+      return fail(RTC_ERR_OVERFLOW, "root %u: candidate BVH is %u levels deep, the kernel's traversal stack holds %d", i,
+                  builder.max_depth, RTC_TRAV_STACK);
   }
   if (getenv("RTC_BVH_CHECK")) {
     // diagnostic: every leaf once, every stored child box contains the world boxes below it
