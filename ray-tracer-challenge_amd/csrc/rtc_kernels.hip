@@ -498,57 +498,66 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
   const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
   uint32_t cur_xf = 0xFFFFFFFFu;
   Ray lr = ray;
+  // "while-while" traversal: every lane first walks inner nodes until it holds a leaf (cheap FP32 box tests, one
+  // 64-byte fetch per step), then all lanes that hold one run the expensive exact FP64 leaf test TOGETHER.  With
+  // one loop that does either per iteration, lanes at leaves and lanes at nodes take turns (33 % of lanes active
+  // on dragons.json).
   uint32_t stack[RTC_TRAV_STACK];
   int sp = 0;
   stack[sp++] = root;
-  while (sp > 0 && !vis.done()) {
-    const uint32_t ref = stack[--sp];
-    if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
-      const uint32_t first = (ref & ~RTC_NODE_BIT) >> 3, count = (ref & 7u) + 1u;
-      for (uint32_t i = 0; i < count; ++i) {
-        const uint32_t e = S.bvh_leaf[first + i];
-        if (CSG && (e & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_csg kernels have this path)
-          if constexpr (CSG) visit_csg(S, e & ~RTC_NODE_BIT, ray, vis, overflow);
-        } else {
-          visit_leaf(S, e, ray, degenerate, cur_xf, lr, vis);
-        }
+  for (;;) {
+    uint32_t leaf_ref = RTC_NO_LEAF;
+    while (sp > 0 && !vis.done()) {
+      const uint32_t ref = stack[--sp];
+      if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
+        leaf_ref = ref;
+        break;
       }
-      continue;
-    }
-    const BvhNode& N = S.bvh[ref];
-    auto interval = [&](const float* lo, const float* hi, float& tn, float& tf) {
-      const float tnx = ((px ? lo[0] : hi[0]) - onx) * ix, tfx = ((px ? hi[0] : lo[0]) - ofx) * ix;
-      const float tny = ((py ? lo[1] : hi[1]) - ony) * iy, tfy = ((py ? hi[1] : lo[1]) - ofy) * iy;
-      const float tnz = ((pz ? lo[2] : hi[2]) - onz) * iz, tfz = ((pz ? hi[2] : lo[2]) - ofz) * iz;
-      tn = fmaxf(fmaxf(tnx, tny), tnz);  // fmaxf/fminf drop the NaN of 0 * inf (ray inside a slab, parallel to it)
-      tf = fminf(fminf(tfx, tfy), tfz);
-    };
-    float tn0, tf0, tn1, tf1;
-    interval(N.lo0, N.hi0, tn0, tf0);
-    interval(N.lo1, N.hi1, tn1, tf1);
+      const BvhNode& N = S.bvh[ref];
+      auto interval = [&](const float* lo, const float* hi, float& tn, float& tf) {
+        const float tnx = ((px ? lo[0] : hi[0]) - onx) * ix, tfx = ((px ? hi[0] : lo[0]) - ofx) * ix;
+        const float tny = ((py ? lo[1] : hi[1]) - ony) * iy, tfy = ((py ? hi[1] : lo[1]) - ofy) * iy;
+        const float tnz = ((pz ? lo[2] : hi[2]) - onz) * iz, tfz = ((pz ? hi[2] : lo[2]) - ofz) * iz;
+        tn = fmaxf(fmaxf(tnx, tny), tnz);  // fmaxf/fminf drop the NaN of 0 * inf (ray inside a slab, parallel to it)
+        tf = fminf(fminf(tfx, tfy), tfz);
+      };
+      float tn0, tf0, tn1, tf1;
+      interval(N.lo0, N.hi0, tn0, tf0);
+      interval(N.lo1, N.hi1, tn1, tf1);
 #if defined(RTC_EXP_NOBVHCULL)  // diagnostic: visit every node
-    const bool h0 = (N.c0 != RTC_NO_LEAF), h1 = (N.c1 != RTC_NO_LEAF);
+      const bool h0 = (N.c0 != RTC_NO_LEAF), h1 = (N.c1 != RTC_NO_LEAF);
 #elif defined(RTC_EXP_NOCULLF)  // diagnostic: box test only, no t-interval pruning
-    const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0);
-    const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1);
+      const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0);
+      const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1);
 #else
-    const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0) & !vis.cullf(tn0, tf0);
-    const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1) & !vis.cullf(tn1, tf1);
+      const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0) & !vis.cullf(tn0, tf0);
+      const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1) & !vis.cullf(tn1, tf1);
 #endif
-    if (h0 & h1) {
-      if (sp + 2 > RTC_TRAV_STACK) {
-        overflow = 1u;
-        continue;
+      if (h0 & h1) {
+        if (sp + 2 > RTC_TRAV_STACK) {
+          overflow = 1u;
+          continue;
+        }
+        const bool first0 = tn0 <= tn1;  // nearer child on top of the stack
+        stack[sp++] = first0 ? N.c1 : N.c0;
+        stack[sp++] = first0 ? N.c0 : N.c1;
+      } else if (h0 | h1) {
+        if (sp + 1 > RTC_TRAV_STACK) {
+          overflow = 1u;
+          continue;
+        }
+        stack[sp++] = h0 ? N.c0 : N.c1;
       }
-      const bool first0 = tn0 <= tn1;  // nearer child on top of the stack
-      stack[sp++] = first0 ? N.c1 : N.c0;
-      stack[sp++] = first0 ? N.c0 : N.c1;
-    } else if (h0 | h1) {
-      if (sp + 1 > RTC_TRAV_STACK) {
-        overflow = 1u;
-        continue;
+    }
+    if (leaf_ref == RTC_NO_LEAF) break;  // nothing left (or the visitor is done)
+    const uint32_t first = (leaf_ref & ~RTC_NODE_BIT) >> 3, count = (leaf_ref & 7u) + 1u;
+    for (uint32_t i = 0; i < count; ++i) {
+      const uint32_t e = S.bvh_leaf[first + i];
+      if (CSG && (e & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
+        if constexpr (CSG) visit_csg(S, e & ~RTC_NODE_BIT, ray, vis, overflow);
+      } else {
+        visit_leaf(S, e, ray, degenerate, cur_xf, lr, vis);
       }
-      stack[sp++] = h0 ? N.c0 : N.c1;
     }
   }
 }
