@@ -34,4 +34,5 @@ print("empty-ish launch (cheapest 8x8):", res[-1])
 print("heaviest 8x8 chunks:", res[:5])
 t, x, y, _, _ = res[0]
 for w, h in ((8, 8), (8, 1), (1, 1), (16, 16), (64, 64), (256, 256)):
-    print((w, h), timed((x, y, w, h), 10))
+    x0, y0 = min(x, args.width - w), min(y, args.height - h)   # keep the rectangle inside the image
+    print((w, h), timed((x0, y0, w, h), 10))
