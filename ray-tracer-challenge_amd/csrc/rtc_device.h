@@ -192,6 +192,7 @@ struct DevPixelMap {
   // 64 bytes, owned by the scene handle and sized for the launch (max_depth + 2 levels).
   PendingRec* __restrict__ ray_stack;
   uint32_t ray_stack_levels;
+  uint32_t pull_min_idle;  // a wave pulls its next packet only when at least this many lanes are idle (or none has a ray)
 };
 
 // Zero at the start of every launch; counters get one atomic per wave.  A scene owns TWO of these and

@@ -1344,6 +1344,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (item_next < RTC_PACKET_ITEMS) unit = __builtin_amdgcn_readlane(items, item_next);
         if (unit == RTC_NO_ITEM) {  // the packet is used up: pull the next one
           if (drained) break;
+          // A wave owns every pixel of a packet it pulls.  Pulling one for a couple of idle lanes would commit the
+          // wave to a whole packet more than its neighbours (when a frame is split over GPUs a wave's fair share is
+          // one or two packets): those lanes wait, or take over a sub-tree (step 2a), until enough of them are free.
+          if (static_cast<uint32_t>(__builtin_popcountll(wmask)) < map.pull_min_idle && __any(have_cur)) break;
           uint32_t c = 0u;
           if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
           c = __builtin_amdgcn_readfirstlane(c);
