@@ -1225,7 +1225,9 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   bool has_pixel = false, have_cur = false;
   bool shared = false;  // part of this pixel's ray tree runs (or ran) in another lane
   size_t out_index = 0;
-  uint32_t share_rays = 0u;  // cost feedback: rays this lane spent on its share of the pixel
+  // cost feedback: traces this lane spent on its share of the pixel (closest-hit 2, containers 2, shadow 1 each:
+  // roughly their shares of an iteration's time; a pixel behind glass costs several times a pixel on a wall per ray)
+  uint32_t share_rays = 0u;
   double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
@@ -1347,7 +1349,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           // A wave owns every pixel of a packet it pulls.  Pulling one for a couple of idle lanes would commit the
           // wave to a whole packet more than its neighbours (when a frame is split over GPUs a wave's fair share is
           // one or two packets): those lanes wait, or take over a sub-tree (step 2a), until enough of them are free.
-          if (static_cast<uint32_t>(__builtin_popcountll(wmask)) < map.pull_min_idle && __any(have_cur)) break;
+          if (static_cast<uint32_t>(__builtin_popcountll(wmask)) < map.pull_min_idle && __any(have_cur || got_pixel)) break;
           uint32_t c = 0u;
           if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
           c = __builtin_amdgcn_readfirstlane(c);
@@ -1446,7 +1448,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (!__any(have_cur)) break;
     if (!have_cur) continue;
     have_cur = false;  // `cur` is consumed; a spawned child may refill it below
-    share_rays++;
+    share_rays += 2u;
     cur.remaining = min(cur.remaining, max_depth);  // termination never depends on a value read back from memory
     const Ray ray = cur.ray;
 
@@ -1493,6 +1495,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     double n1 = 1.0, n2 = 1.0;
     if (cur.remaining != 0u && !(mats[mat_index].transparency == 0.0)) {
       RTC_STAMP(5);
+      share_rays += 2u;
       BehindVisitor bv;
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
@@ -1634,6 +1637,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         bool shadowed = false;
         if (shadow_matters && light_dot_normal >= 0.0) {
           n_shadow_traced++;
+          share_rays++;
           ShadowVisitor sv;
           sv.distance = distance;
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};

@@ -128,7 +128,9 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     }
     // top up with rows of the cheapest whole chunks
     uint32_t filler_chunk = 0, filler_row = 8;  // rows of whole[light_end] still unused
+    static const bool no_fill = getenv("RTC_SPLIT_NOFILL") != nullptr;  // experiment knob
     for (Packet& P : packets) {
+      if (no_fill) break;
       while (P.npx + 8u <= 64u && P.n_items < RTC_PACKET_ITEMS) {
         if (filler_row == 8u) {
           if (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap) break;
