@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstddef>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <unordered_set>
@@ -29,6 +30,8 @@ extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCame
 extern "C" __global__ void rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                           const uint32_t max_depth, double* __restrict__ out,
                                                           DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map,
+                                                 uint32_t* __restrict__ chunk_cost);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
                                                const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
                                                const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
@@ -159,14 +162,42 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     if (schedulable && s->cost_pending) {
       s->sched_cam = s->cost_cam;
       s->sched_depth = s->cost_depth;
+      const auto t_a = std::chrono::steady_clock::now();
       HIP_TRY(hipStreamSynchronize(s->last_stream));
-      s->h_cost.resize(out_pixels);
-      HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      const auto t_b = std::chrono::steady_clock::now();
+      // per-chunk sums first (a tiny kernel, 4 bytes per chunk to copy); the per-pixel costs only if a chunk must be split
+      if (map.n_chunks > s->chunk_cost_capacity) {
+        if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
+        s->d_chunk_cost = nullptr;
+        s->chunk_cost_capacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+        s->chunk_cost_capacity = map.n_chunks;
+      }
+      hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, s->last_stream, s->d_cost, map,
+                         s->d_chunk_cost);
+      HIP_TRY(hipGetLastError());
+      s->h_chunk_cost.resize(map.n_chunks);
+      HIP_TRY(hipMemcpyAsync(s->h_chunk_cost.data(), s->d_chunk_cost, s->h_chunk_cost.size() * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, s->last_stream));
+      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      const auto t_c = std::chrono::steady_clock::now();
       const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                         s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
-      packSchedule(s, map, s->h_cost, 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big));
+      const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+      if (!packWholeChunks(s, map, s->h_chunk_cost, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
+        s->h_cost.resize(out_pixels);
+        HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        packSchedule(s, map, s->h_cost, n_waves);
+      }
+      const auto t_d = std::chrono::steady_clock::now();
       const int st = uploadSchedule(s, stream);
       if (st != RTC_OK) return st;
+      if (getenv("RTC_PROFILE_DUMP")) {
+        const auto t_e = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "rtc re-pack: sync %.2f ms, cost copy %.2f ms, packing %.2f ms, upload %.2f ms\n", ms(t_a, t_b),
+                     ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e));
+      }
       s->order_from_cost = true;
       s->order_key.clear();  // the heuristic cache no longer describes d_order
     }
@@ -926,6 +957,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_frame) (void)hipFree(s->d_frame);
   if (s->d_order) (void)hipFree(s->d_order);
   if (s->d_cost) (void)hipFree(s->d_cost);
+  if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
   delete s;

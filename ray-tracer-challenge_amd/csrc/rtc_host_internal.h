@@ -104,6 +104,9 @@ struct rtc_scene {
   size_t cost_capacity = 0;
   std::vector<uint32_t> cost_key;  // pixel map the costs / the cost-sorted order belong to
   std::vector<uint32_t> h_cost;
+  uint32_t* d_chunk_cost = nullptr;  // per-chunk sums of d_cost (rtc_chunk_cost_kernel)
+  size_t chunk_cost_capacity = 0;
+  std::vector<uint32_t> h_chunk_cost;
   uint64_t launches_with_key = 0;
   bool order_from_cost = false;
   bool cost_pending = false;       // the previous launch measured per-pixel costs: the next one packs from them

@@ -1844,3 +1844,22 @@ rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world, c
     canvas[i] = gathered[src];
   }
 }
+
+// Per-chunk sums of the per-pixel cost array (DevPixelMap::cost), one thread per 8x8 chunk: what the host needs to
+// order whole chunks; the per-pixel values travel only if some chunk has to be split (rtc_schedule.h).
+extern "C" __global__ void __launch_bounds__(256)
+rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, uint32_t* __restrict__ chunk_cost) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= map.n_chunks) return;
+  const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
+  const uint32_t ccy = cr / map.chunks_x;
+  const uint32_t rx0 = (cr - ccy * map.chunks_x) * 8u, ry0 = ccy * 8u;
+  const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
+  const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
+  uint32_t sum = 0u;
+  for (uint32_t k = 0; k < 64u; ++k) {
+    const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
+    if (rx < w && ry < h) sum += cost[out0 + static_cast<size_t>(ry) * w + rx];
+  }
+  chunk_cost[c] = sum;
+}

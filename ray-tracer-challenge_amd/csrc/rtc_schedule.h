@@ -34,6 +34,28 @@ int uploadSchedule(rtc_scene* s, hipStream_t stream) {
 // busy and the cheap pixels' lanes become free just as the expensive pixels' ray trees fan out (the
 // kernel's intra-wave sharing moves the sub-trees over).  Every other chunk stays whole: neighbouring
 // pixels in one wave is what keeps the traversal coherent.  Packets go out most expensive first.
+// The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,
+// so every packet is one whole chunk, most expensive first.  Returns false if some chunk has to be split.
+bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost, double n_waves) {
+  static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
+  double total = 0.0;
+  uint32_t heaviest = 0;
+  for (uint32_t c : chunk_cost) {
+    total += c;
+    heaviest = std::max(heaviest, c);
+  }
+  const double cap = std::max(1.0, alpha * total / std::max(1.0, n_waves));
+  if (static_cast<double>(heaviest) > cap) return false;
+  std::vector<uint32_t> order(map.n_chunks);
+  for (uint32_t i = 0; i < map.n_chunks; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return chunk_cost[a] > chunk_cost[b]; });
+  s->h_order.assign(static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
+  for (uint32_t i = 0; i < map.n_chunks; ++i) s->h_order[static_cast<size_t>(i) * RTC_PACKET_ITEMS] = scheduleItem(order[i], 0, 64);
+  if (getenv("RTC_PROFILE_DUMP"))
+    std::fprintf(stderr, "rtc schedule: %u whole-chunk packets, heaviest %u, cap %.0f, total %.0f\n", map.n_chunks, heaviest, cap, total);
+  return true;
+}
+
 void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost, double n_waves) {
   static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
   static const double fill = getenv("RTC_SPLIT_FILL") ? atof(getenv("RTC_SPLIT_FILL")) : 1.0;
