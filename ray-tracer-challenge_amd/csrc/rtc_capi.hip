@@ -179,15 +179,22 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       s->h_chunk_cost.resize(map.n_chunks);
       HIP_TRY(hipMemcpyAsync(s->h_chunk_cost.data(), s->d_chunk_cost, s->h_chunk_cost.size() * sizeof(uint32_t),
                              hipMemcpyDeviceToHost, s->last_stream));
+      const size_t n_measured = s->measured_order.empty() ? map.n_chunks : s->measured_order.size() / RTC_PACKET_ITEMS;
+      s->h_packet_time.resize(n_measured);
+      HIP_TRY(hipMemcpyAsync(s->h_packet_time.data(), s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                             s->last_stream));
       HIP_TRY(hipStreamSynchronize(s->last_stream));
+      // what every chunk really took: a packet's time, shared among its items by their cost
+      std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
+      if (getenv("RTC_SCHED_BY_COST")) chunk_time = s->h_chunk_cost;  // experiment knob: ignore the measured times
       const auto t_c = std::chrono::steady_clock::now();
       const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                         s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
       const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
-      if (!packWholeChunks(s, map, s->h_chunk_cost, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
+      if (!packWholeChunks(s, map, chunk_time, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
         s->h_cost.resize(out_pixels);
         HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        packSchedule(s, map, s->h_cost, n_waves);
+        packSchedule(s, map, s->h_cost, s->h_chunk_cost, chunk_time, n_waves);
       }
       const auto t_d = std::chrono::steady_clock::now();
       const int st = uploadSchedule(s, stream);
@@ -215,11 +222,27 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
     const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed));
     s->cost_pending = collect;
+    map.packet_time = nullptr;
     if (collect) {
       map.cost = s->d_cost;
       s->cost_cam = cam;
       s->cost_depth = max_depth;
       HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
+      if (map.n_units > s->packet_time_capacity) {
+        HIP_TRY(hipStreamSynchronize(s->last_stream));
+        if (s->d_packet_time) (void)hipFree(s->d_packet_time);
+        s->d_packet_time = nullptr;
+        s->packet_time_capacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), static_cast<size_t>(map.n_units) * sizeof(uint32_t)));
+        s->packet_time_capacity = map.n_units;
+      }
+      HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
+      map.packet_time = s->d_packet_time;
+      if (map.order != nullptr) {
+        s->measured_order = s->h_order;  // the schedule this launch runs (and times)
+      } else {
+        s->measured_order.clear();
+      }
     } else {
       map.cost = nullptr;
     }
@@ -958,6 +981,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_order) (void)hipFree(s->d_order);
   if (s->d_cost) (void)hipFree(s->d_cost);
   if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
+  if (s->d_packet_time) (void)hipFree(s->d_packet_time);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
   delete s;

@@ -188,6 +188,9 @@ struct DevPixelMap {
   // Optional per-pixel cost output (rays traced for the pixel, indexed like the canvas), zeroed before
   // the launch; the host packs the next frames' schedule by it.
   uint32_t* __restrict__ cost;
+  // Optional, with `cost`: per PACKET of the schedule in use, the time (s_memtime ticks / 16) the wave that pulled
+  // it needed for it.  Costs say how work is distributed inside a chunk; times say how long a chunk really takes.
+  uint32_t* __restrict__ packet_time;
   // The lanes' stacks of pending secondary rays: [resident waves][ray_stack_levels][64 lanes] records of
   // 64 bytes, owned by the scene handle and sized for the launch (max_depth + 2 levels).
   PendingRec* __restrict__ ray_stack;

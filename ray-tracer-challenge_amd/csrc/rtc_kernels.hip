@@ -1216,6 +1216,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // wave-uniform cursor: the packet the wave pulled last (lane i < 16 holds its item i), the item that is
   // open, and the run of pixels of one 8x8 chunk that item names
   uint32_t items = RTC_NO_ITEM, item_next = RTC_PACKET_ITEMS;
+  // schedule feedback: how long the wave took for the packet it holds (meaningful because a wave finishes one
+  // packet before it pulls the next)
+  uint32_t pk_cur = RTC_NO_ITEM;
+  unsigned long long pk_t0 = 0ull;
   uint32_t chunk_pos = 64u, chunk_end = 64u;
   uint32_t chunk_rx0 = 0u, chunk_ry0 = 0u, chunk_px0 = 0u, chunk_py0 = 0u, chunk_w = 0u, chunk_h = 0u;
   size_t chunk_out0 = 0;
@@ -1350,6 +1354,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           // wave to a whole packet more than its neighbours (when a frame is split over GPUs a wave's fair share is
           // one or two packets): those lanes wait, or take over a sub-tree (step 2a), until enough of them are free.
           if (static_cast<uint32_t>(__builtin_popcountll(wmask)) < map.pull_min_idle && __any(have_cur || got_pixel)) break;
+          if (map.packet_time != nullptr && pk_cur != RTC_NO_ITEM) {  // the packet this wave just finished took ...
+            if (lane == 0u) map.packet_time[pk_cur] = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - pk_t0) >> 4);
+            pk_cur = RTC_NO_ITEM;
+          }
           uint32_t c = 0u;
           if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
           c = __builtin_amdgcn_readfirstlane(c);
@@ -1362,6 +1370,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           prof_first_unit = static_cast<unsigned>((__builtin_amdgcn_s_memtime() - prof_start) >> 8);  // time of the last fetch
           prof_units += 1ull;
 #endif
+          pk_cur = c;
+          pk_t0 = __builtin_amdgcn_s_memtime();
           if (map.order != nullptr) {
             items = lane < RTC_PACKET_ITEMS ? map.order[static_cast<size_t>(c) * RTC_PACKET_ITEMS + lane] : RTC_NO_ITEM;
           } else {  // unscheduled: packet c is chunk c, whole
@@ -1755,6 +1765,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     }
   }
 
+  if (map.packet_time != nullptr && pk_cur != RTC_NO_ITEM && lane == 0u)
+    map.packet_time[pk_cur] = static_cast<uint32_t>((__builtin_amdgcn_s_memtime() - pk_t0) >> 4);
 #ifdef RTC_PROFILE
   RTC_STAMP(7);
   prof_acc[7] = prof_iters;  // slot 7 reports main-loop iterations (wave-level), not cycles

@@ -34,6 +34,46 @@ int uploadSchedule(rtc_scene* s, hipStream_t stream) {
 // busy and the cheap pixels' lanes become free just as the expensive pixels' ray trees fan out (the
 // kernel's intra-wave sharing moves the sub-trees over).  Every other chunk stays whole: neighbouring
 // pixels in one wave is what keeps the traversal coherent.  Packets go out most expensive first.
+// Per-chunk wave time from the per-packet times of a measured launch (DevPixelMap::packet_time): a packet's time is
+// shared among its items in proportion to their cost (a partial item: its share of the chunk's cost by pixel count).
+// Chunks that were not timed (time 0: e.g. a launch that measured nothing) fall back to their cost.
+std::vector<uint32_t> chunkTimes(const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost,
+                                 const std::vector<uint32_t>& packet_time, const std::vector<uint32_t>& measured_order) {
+  std::vector<double> t(map.n_chunks, 0.0);
+  if (measured_order.empty()) {
+    for (uint32_t c = 0; c < map.n_chunks && c < packet_time.size(); ++c) t[c] = packet_time[c];
+  } else {
+    const size_t n_packets = measured_order.size() / RTC_PACKET_ITEMS;
+    for (size_t p = 0; p < n_packets && p < packet_time.size(); ++p) {
+      double w[RTC_PACKET_ITEMS], sum = 0.0;
+      uint32_t chunk[RTC_PACKET_ITEMS], n = 0;
+      for (uint32_t i = 0; i < RTC_PACKET_ITEMS; ++i) {
+        const uint32_t it = measured_order[p * RTC_PACKET_ITEMS + i];
+        if (it == RTC_NO_ITEM) continue;
+        const uint32_t c = it & 0xFFFFFu, len = (it >> 26) + 1u;
+        if (c >= map.n_chunks) continue;
+        chunk[n] = c;
+        w[n] = (static_cast<double>(chunk_cost[c]) + 1.0) * len / 64.0;
+        sum += w[n];
+        ++n;
+      }
+      for (uint32_t i = 0; i < n; ++i) t[chunk[i]] += packet_time[p] * w[i] / sum;
+    }
+  }
+  double total_t = 0.0, total_c = 0.0;
+  for (uint32_t c = 0; c < map.n_chunks; ++c) {
+    total_t += t[c];
+    total_c += chunk_cost[c];
+  }
+  const double per_cost = total_c > 0.0 && total_t > 0.0 ? total_t / total_c : 1.0;
+  std::vector<uint32_t> out(map.n_chunks);
+  for (uint32_t c = 0; c < map.n_chunks; ++c) {
+    const double v = t[c] > 0.0 ? t[c] : chunk_cost[c] * per_cost;
+    out[c] = static_cast<uint32_t>(std::min(v, 4.0e9));
+  }
+  return out;
+}
+
 // The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,
 // so every packet is one whole chunk, most expensive first.  Returns false if some chunk has to be split.
 bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost, double n_waves) {
@@ -56,7 +96,8 @@ bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uin
   return true;
 }
 
-void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost, double n_waves) {
+void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost,
+                  const std::vector<uint32_t>& chunk_cost_sum, const std::vector<uint32_t>& chunk_time, double n_waves) {
   static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
   static const double fill = getenv("RTC_SPLIT_FILL") ? atof(getenv("RTC_SPLIT_FILL")) : 1.0;
   struct Item { uint32_t cost, code, npx; };
@@ -72,7 +113,9 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
     for (uint32_t k = 0; k < 64u; ++k) {
       const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
-      const uint32_t v = (rx < w && ry < h) ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
+      // a pixel's share of the chunk's measured TIME, by its share of the chunk's cost
+      const double scale = chunk_cost_sum[c] ? static_cast<double>(chunk_time[c]) / chunk_cost_sum[c] : 0.0;
+      const uint32_t v = (rx < w && ry < h) ? static_cast<uint32_t>(cost[out0 + static_cast<size_t>(ry) * w + rx] * scale) : 0u;
       pc[static_cast<size_t>(c) * 64u + k] = v;
       chunk_cost[c] += v;
     }
