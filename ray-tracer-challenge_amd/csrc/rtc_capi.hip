@@ -187,6 +187,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       // what every chunk really took: a packet's time, shared among its items by their cost
       std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
       if (getenv("RTC_SCHED_BY_COST")) chunk_time = s->h_chunk_cost;  // experiment knob: ignore the measured times
+      s->h_chunk_time_dbg = chunk_time;
       const auto t_c = std::chrono::steady_clock::now();
       const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                         s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
@@ -220,8 +221,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     // interactive mode); a static view keeps its schedule and pays nothing.  The successor of a collecting
     // launch re-packs (one stream sync, a 4-byte-per-pixel copy, O(pixels) on the host: ~0.7 ms at 1080p).
     const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
-    const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed));
-    s->cost_pending = collect;
+    static const bool always_time = getenv("RTC_TIME_ALWAYS") != nullptr;  // diagnostic: time the packets of every launch
+    const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed) || always_time);
+    s->cost_pending = collect && !(always_time && s->launches_with_key > 0);
     map.packet_time = nullptr;
     if (collect) {
       map.cost = s->d_cost;
@@ -1094,6 +1096,40 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   out->shadow_calls = h.shadow_calls;
   out->shadow_traced = h.shadow_traced;
   out->overflow = h.overflow;
+  if (getenv("RTC_TIME_ALWAYS") && s->d_packet_time && !s->measured_order.empty()) {  // diagnostic: predicted vs actual packet times
+    const size_t n = s->measured_order.size() / RTC_PACKET_ITEMS;
+    std::vector<uint32_t> t(n);
+    HIP_TRY(hipMemcpy(t.data(), s->d_packet_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "rtc packet times (position: now / when the schedule was packed):");
+    for (double f : {0.0, 0.1, 0.5, 0.9, 0.97, 0.98, 0.985, 0.99, 0.995, 0.999}) {
+      const size_t i = std::min(n - 1, static_cast<size_t>(f * n));
+      const uint32_t it = s->measured_order[i * RTC_PACKET_ITEMS];
+      const uint32_t c = it & 0xFFFFFu;
+      std::fprintf(stderr, " %.3f:%u/%u", f, t[i], c < s->h_chunk_time_dbg.size() ? s->h_chunk_time_dbg[c] : 0u);
+    }
+    if (const char* path = getenv("RTC_TIME_DUMP")) {
+      if (FILE* f = std::fopen(path, "w")) {
+        for (size_t i = 0; i < n; ++i) {
+          const uint32_t c = s->measured_order[i * RTC_PACKET_ITEMS] & 0xFFFFFu;
+          std::fprintf(f, "%zu %u %u %u\n", i, c, t[i], c < s->h_chunk_time_dbg.size() ? s->h_chunk_time_dbg[c] : 0u);
+        }
+        std::fclose(f);
+      }
+    }
+    unsigned long long tail_now = 0, tail_pred = 0, all_now = 0, all_pred = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t c = s->measured_order[i * RTC_PACKET_ITEMS] & 0xFFFFFu;
+      const uint32_t pr = c < s->h_chunk_time_dbg.size() ? s->h_chunk_time_dbg[c] : 0u;
+      all_now += t[i];
+      all_pred += pr;
+      if (i >= n - n / 50) {
+        tail_now += t[i];
+        tail_pred += pr;
+      }
+    }
+    std::fprintf(stderr, "\nrtc packet times: all %llu now / %llu predicted; last 2%% of the schedule %llu now / %llu predicted\n", all_now,
+                 all_pred, tail_now, tail_pred);
+  }
 #ifdef RTC_PROFILE
   if (getenv("RTC_PROFILE_DUMP")) {
     std::fprintf(stderr, "rtc prof:");

@@ -110,6 +110,7 @@ struct rtc_scene {
   uint32_t* d_packet_time = nullptr;  // per packet of the measured schedule: the time its wave needed (DevPixelMap::packet_time)
   size_t packet_time_capacity = 0;
   std::vector<uint32_t> h_packet_time;
+  std::vector<uint32_t> h_chunk_time_dbg;  // per-chunk times the schedule in use was packed from (diagnostics)
   std::vector<uint32_t> measured_order;  // the schedule (h_order) of the measuring launch; empty: packet i was chunk i
   uint64_t launches_with_key = 0;
   bool order_from_cost = false;

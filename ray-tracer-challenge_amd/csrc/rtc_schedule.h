@@ -88,11 +88,45 @@ bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uin
   if (static_cast<double>(heaviest) > cap) return false;
   std::vector<uint32_t> order(map.n_chunks);
   for (uint32_t i = 0; i < map.n_chunks; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return chunk_cost[a] > chunk_cost[b]; });
-  s->h_order.assign(static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
-  for (uint32_t i = 0; i < map.n_chunks; ++i) s->h_order[static_cast<size_t>(i) * RTC_PACKET_ITEMS] = scheduleItem(order[i], 0, 64);
+  // Longest first, but in classes of about equal length (a quarter octave) that keep the chunks' image order: waves
+  // that run at the same moment then work on neighbouring chunks (measured: sorting strictly by time scatters the
+  // cheap chunks of the tail over the image and they take 2-8 times longer each than in image order).
+  static const bool strict = getenv("RTC_SCHED_STRICT") != nullptr;  // experiment knob
+  auto klass = [&](uint32_t c) { return strict ? static_cast<int>(chunk_cost[c]) : static_cast<int>(4.0 * std::log2(1.0 + chunk_cost[c])); };
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return klass(a) > klass(b); });
+  // Cheap chunks travel several to a packet (up to 16, up to 1/`group` of a wave's fair share): when every wave
+  // reaches the cheap end of the list at the same moment, one-chunk packets of a few microseconds each turn the
+  // work counter and the memory system into the bottleneck (measured: the last 2 % of the schedule took 8 times
+  // longer per chunk than the same chunks took when only a few waves were pulling them).
+  static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 16.0;
+  static const double t_min = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 8000.0;  // s_memtime ticks / 16 (~50 us)
+  const double group_cap = group > 0.0 ? std::max(total / std::max(1.0, n_waves) / group, t_min) : 0.0;
+  s->h_order.clear();
+  s->h_order.reserve(static_cast<size_t>(map.n_chunks) * 4u);
+  uint32_t n_packets = 0;
+  for (uint32_t i = 0; i < map.n_chunks;) {
+    double sum = 0.0;
+    uint32_t n = 0;
+    while (i < map.n_chunks && n < RTC_PACKET_ITEMS && (n == 0 || sum + chunk_cost[order[i]] <= group_cap)) {
+      sum += chunk_cost[order[i]];
+      s->h_order.push_back(scheduleItem(order[i], 0, 64));
+      ++i;
+      ++n;
+    }
+    for (; n < RTC_PACKET_ITEMS; ++n) s->h_order.push_back(RTC_NO_ITEM);
+    ++n_packets;
+  }
   if (getenv("RTC_PROFILE_DUMP"))
-    std::fprintf(stderr, "rtc schedule: %u whole-chunk packets, heaviest %u, cap %.0f, total %.0f\n", map.n_chunks, heaviest, cap, total);
+    std::fprintf(stderr, "rtc schedule: %u whole chunks in %u packets, heaviest %u, cap %.0f, total %.0f\n", map.n_chunks, n_packets,
+                 heaviest, cap, total);
+  if (getenv("RTC_PROFILE_DUMP")) {
+    std::fprintf(stderr, "rtc schedule times by position:");
+    for (double f : {0.0, 0.1, 0.25, 0.5, 0.75, 0.9, 0.97, 0.98, 0.99, 0.995, 1.0}) {
+      const uint32_t i = std::min<uint32_t>(map.n_chunks - 1, static_cast<uint32_t>(f * map.n_chunks));
+      std::fprintf(stderr, " %.3f:%u(c%u)", f, chunk_cost[order[i]], order[i]);
+    }
+    std::fprintf(stderr, "\n");
+  }
   return true;
 }
 
@@ -225,10 +259,20 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
       packets.push_back(P);
     }
   }
-  for (size_t i = 0; i < light_end; ++i) {
-    Packet P{whole[i].cost, 64u, 1, {}};
-    P.items[0] = whole[i].code;
-    packets.push_back(P);
+  {  // the chunks that stay whole: cheap ones several to a packet, as in packWholeChunks
+    static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 16.0;
+    static const double t_min = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 8000.0;
+    const double group_cap = group > 0.0 ? std::max(total / std::max(1.0, n_waves) / group, t_min) : 0.0;
+    for (size_t i = 0; i < light_end;) {
+      Packet P{0, 0u, 0, {}};
+      while (i < light_end && P.n_items < RTC_PACKET_ITEMS && (P.n_items == 0 || static_cast<double>(P.cost + whole[i].cost) <= group_cap)) {
+        P.items[P.n_items++] = whole[i].code;
+        P.cost += whole[i].cost;
+        P.npx += 64u;
+        ++i;
+      }
+      packets.push_back(P);
+    }
   }
   packets.erase(std::remove_if(packets.begin(), packets.end(), [](const Packet& P) { return P.n_items == 0; }), packets.end());
   std::stable_sort(packets.begin(), packets.end(), [](const Packet& a, const Packet& b) { return a.cost > b.cost; });

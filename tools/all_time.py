@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""GPU-only frame time of the five BASELINE configs (no oracle): for scheduling experiments."""
+"""GPU-only frame time of the five BASELINE configs (no oracle), three scene handles each (every handle measures its
+own first frame and packs its own schedule): mean [min..max] ms.  For scheduling experiments."""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 rtc = importlib.import_module("ray-tracer-challenge_amd")
 CASES = [("fresnel.json", 300, 300, 5), ("cover.json", 1920, 1080, 5), ("reflection_and_refraction.json", 1920, 1080, 8),
          ("teapot.json", 1920, 1080, 5), ("dragons.json", 3840, 2160, 5)]
+only = sys.argv[1:]
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 out = []
 for name, w, h, depth in CASES:
-    hs = rtc.HostScene.from_file(name); gpu = rtc.GpuScene(hs.desc); cam = hs.camera(w, h)
+    if only and name.split(".")[0] not in only:
+        continue
+    hs = rtc.HostScene.from_file(name); cam = hs.camera(w, h)
     canvas = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
-    for _ in range(4): gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20 if h < 2000 else 8
-    a.record(stream)
-    for _ in range(n): gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
-    b.record(stream); torch.cuda.synchronize()
-    out.append(f"{name.split('.')[0][:10]} {a.elapsed_time(b)/n:.3f}")
+    ts = []
+    for rep in range(3):
+        gpu = rtc.GpuScene(hs.desc)
+        for _ in range(4): gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 15 if h < 2000 else 6
+        a.record(stream)
+        for _ in range(n): gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
+        b.record(stream); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / n)
+        gpu.close()
+    out.append(f"{name.split('.')[0][:10]} {sum(ts)/3:.3f} [{min(ts):.3f}..{max(ts):.3f}]")
 print(" | ".join(out), flush=True)

@@ -37,6 +37,7 @@ for name, v in (("lifetime_us", life), ("iterations", iters), ("packets", units)
     print(f"{name:14s} min {v.min():8.1f} p10 {np.percentile(v,10):8.1f} med {np.median(v):8.1f} p90 {np.percentile(v,90):8.1f} max {v.max():8.1f} sum {v.sum():12.0f}")
 print("us per iteration (lifetime/iterations): med", np.median(life / np.maximum(iters, 1)))
 o = np.argsort(-life)[:8]
-print("longest waves: life, iters, packets, last_fetch_us")
+print("longest waves: life, iters, packets, last_fetch_us, last packet index")
 for i in o:
-    print("  ", life[i], iters[i], units[i], last_fetch[i])
+    print("  ", life[i], iters[i], units[i], last_fetch[i], int(rows[i, 5]))
+print("last packet index of all waves: min", int(rows[:, 5].min()), "median", int(np.median(rows[:, 5])), "max", int(rows[:, 5].max()))
