@@ -230,6 +230,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       s->cost_cam = cam;
       s->cost_depth = max_depth;
       HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
+      if (always_time && s->launches_with_key > 0) map.cost = nullptr;  // diagnostic launches only time the packets
       if (map.n_units > s->packet_time_capacity) {
         HIP_TRY(hipStreamSynchronize(s->last_stream));
         if (s->d_packet_time) (void)hipFree(s->d_packet_time);
@@ -1110,8 +1111,16 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
     if (const char* path = getenv("RTC_TIME_DUMP")) {
       if (FILE* f = std::fopen(path, "w")) {
         for (size_t i = 0; i < n; ++i) {
-          const uint32_t c = s->measured_order[i * RTC_PACKET_ITEMS] & 0xFFFFFu;
-          std::fprintf(f, "%zu %u %u %u\n", i, c, t[i], c < s->h_chunk_time_dbg.size() ? s->h_chunk_time_dbg[c] : 0u);
+          unsigned long long pred = 0;
+          uint32_t items = 0;
+          for (uint32_t j = 0; j < RTC_PACKET_ITEMS; ++j) {
+            const uint32_t it = s->measured_order[i * RTC_PACKET_ITEMS + j];
+            if (it == RTC_NO_ITEM) continue;
+            const uint32_t c = it & 0xFFFFFu, len = (it >> 26) + 1u;
+            if (c < s->h_chunk_time_dbg.size()) pred += static_cast<unsigned long long>(s->h_chunk_time_dbg[c]) * len / 64u;
+            ++items;
+          }
+          std::fprintf(f, "%zu %u %u %llu\n", i, items, t[i], pred);
         }
         std::fclose(f);
       }
