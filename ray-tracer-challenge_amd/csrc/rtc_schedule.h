@@ -98,7 +98,7 @@ bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uin
   // reaches the cheap end of the list at the same moment, one-chunk packets of a few microseconds each turn the
   // work counter and the memory system into the bottleneck (measured: the last 2 % of the schedule took 8 times
   // longer per chunk than the same chunks took when only a few waves were pulling them).
-  static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 16.0;
+  static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 32.0;
   static const double t_min = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 8000.0;  // s_memtime ticks / 16 (~50 us)
   const double group_cap = group > 0.0 ? std::max(total / std::max(1.0, n_waves) / group, t_min) : 0.0;
   s->h_order.clear();
@@ -260,7 +260,7 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     }
   }
   {  // the chunks that stay whole: cheap ones several to a packet, as in packWholeChunks
-    static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 16.0;
+    static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 32.0;
     static const double t_min = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 8000.0;
     const double group_cap = group > 0.0 ? std::max(total / std::max(1.0, n_waves) / group, t_min) : 0.0;
     for (size_t i = 0; i < light_end;) {
