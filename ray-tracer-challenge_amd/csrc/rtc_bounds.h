@@ -276,10 +276,10 @@ struct BvhBuilder {
   // returns the child reference for prims[first, first+count)
   uint32_t build(size_t first, size_t count, uint32_t depth = 1) {
     max_depth = std::max(max_depth, depth);
-    // Up to three leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64
-    // leaf tests together) measured at 1 / 2 / 3 / 4 leaves per node: dragons 4K 8.26 / 8.14 / 8.30 / 8.55 ms,
-    // teapot 0.79 / 0.75 / 0.71 / 0.70 ms, nefertiti 1.67 / 1.57 / 1.55 / 1.60 ms.
-    static const size_t max_leaf = getenv("RTC_BVH_LEAF") ? std::min<size_t>(8, std::max<size_t>(1, atoi(getenv("RTC_BVH_LEAF")))) : 3;
+    // Up to two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
+    // tests together) and the final schedule, measured at 1 / 2 / 3 / 4 / 6 leaves per node: dragons 4K
+    // 5.59 / 5.54 / 5.69 / 5.85 / 6.14 ms, teapot 0.476 / 0.449 / 0.444 / 0.445 / 0.454 ms.
+    static const size_t max_leaf = getenv("RTC_BVH_LEAF") ? std::min<size_t>(8, std::max<size_t>(1, atoi(getenv("RTC_BVH_LEAF")))) : 2;
     if (count <= max_leaf) {
       const uint32_t at = static_cast<uint32_t>(leaves.size());
       for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
