@@ -411,15 +411,26 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   if (order.size() + trivial.size() == 0 || order.size() == map.n_chunks || medium.size() == map.n_chunks) return RTC_OK;
   if (getenv("RTC_PROFILE_DUMP"))
     std::fprintf(stderr, "rtc schedule: %zu heavy, %zu medium, %zu trivial chunks\n", order.size(), medium.size(), trivial.size());
-  order.insert(order.end(), medium.begin(), medium.end());
-  order.insert(order.end(), trivial.begin(), trivial.end());
-  s->h_order.assign(order.size() * RTC_PACKET_ITEMS, RTC_NO_ITEM);  // one whole chunk per packet
-  for (size_t i = 0; i < order.size(); ++i) s->h_order[i * RTC_PACKET_ITEMS] = scheduleItem(order[i], 0, 64);
+  // Packets: a chunk that may branch the ray tree travels alone, the others several to a packet (neighbours in
+  // image order): a one-chunk packet of a few microseconds costs a pull of the work counter and a drain of the wave.
+  s->h_order.assign(static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
+  uint32_t n_packets = 0;
+  auto emit = [&](const std::vector<uint32_t>& chunks, uint32_t per_packet) {
+    for (size_t i = 0; i < chunks.size(); i += per_packet, ++n_packets)
+      for (uint32_t n = 0; n < per_packet && i + n < chunks.size(); ++n)
+        s->h_order[static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS + n] = scheduleItem(chunks[i + n], 0, 64);
+  };
+  static const uint32_t per_medium = getenv("RTC_FIRST_MEDIUM") ? std::max(1, std::min(16, atoi(getenv("RTC_FIRST_MEDIUM")))) : 1u;
+  static const uint32_t per_trivial = getenv("RTC_FIRST_TRIVIAL") ? std::max(1, std::min(16, atoi(getenv("RTC_FIRST_TRIVIAL")))) : 16u;
+  emit(order, 1);
+  emit(medium, per_medium);
+  emit(trivial, per_trivial);
+  s->h_order.resize(static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS);
   const int st = uploadSchedule(s, stream);
   if (st != RTC_OK) return st;
   s->order_key = key;
   map.order = s->d_order;
-  map.n_units = static_cast<uint32_t>(order.size());
+  map.n_units = n_packets;
   return RTC_OK;
 }
 

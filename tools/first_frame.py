@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""One-shot use (the reference CLI renders one frame and exits): GPU time of the FIRST launch on a fresh scene handle
+(geometric heuristic schedule, measures costs), the second (packs the schedule) and the third (steady state)."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+for name, w, h, depth in (("cover.json", 1920, 1080, 5), ("teapot.json", 1920, 1080, 5), ("dragons.json", 3840, 2160, 5)):
+    hs = rtc.HostScene.from_file(name); cam = hs.camera(w, h)
+    canvas = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+    res = []
+    for rep in range(3):
+        gpu = rtc.GpuScene(hs.desc)
+        torch.cuda.synchronize()
+        row = []
+        for i in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            a.record(stream)
+            gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
+            b.record(stream); torch.cuda.synchronize()
+            row.append((a.elapsed_time(b), (time.perf_counter() - t0) * 1e3))
+        res.append(row)
+        gpu.close()
+    best = min(res, key=lambda r: r[0][0])
+    print(name, " | ".join(f"launch {i}: gpu {g:.3f} ms, wall {wl:.3f} ms" for i, (g, wl) in enumerate(best)), flush=True)
