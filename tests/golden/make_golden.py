@@ -35,6 +35,7 @@ CASES = [
     ("align_check.json", 80, 40, 5),
     ("earth.json", 80, 40, 5),
     ("texture_demo.json", 80, 45, 5),
+    ("skybox_demo.json", 80, 40, 5),
 ]
 
 

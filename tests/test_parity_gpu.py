@@ -38,6 +38,7 @@ CASES = [
     ("align_check.json", 200, 100, 5),                  # cubic texture maps, align-check uv patterns
     ("earth.json", 200, 100, 5),                        # spherical map of a PNG, bilinear
     ("texture_demo.json", 160, 90, 5),                  # all four mappings, uv checkers / images, maps under other patterns
+    ("skybox_demo.json", 200, 100, 5),                  # skybox.json's structure: camera inside a 1000x cube of image faces
     ("cover.json", 33, 17, 0),                          # depth 0: no secondary rays at all
     ("fresnel.json", 17, 33, 1),
 ]
