@@ -229,7 +229,6 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       map.cost = s->d_cost;
       s->cost_cam = cam;
       s->cost_depth = max_depth;
-      HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
       if (always_time && s->launches_with_key > 0) map.cost = nullptr;  // diagnostic launches only time the packets
       if (map.n_units > s->packet_time_capacity) {
         HIP_TRY(hipStreamSynchronize(s->last_stream));
@@ -297,10 +296,8 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   HIP_TRY(hipMemsetAsync(st_now, 0, sizeof(DevStats), stream));
   HIP_TRY(hipMemsetAsync(&st_now->prof_t0, 0xFF, sizeof(unsigned long long), stream));
 #endif
-  // the kernel ADDS each lane's share of a pixel (shares of one ray tree may finish in several lanes)
-#ifndef RTC_EXP_NOMEMSET
-  HIP_TRY(hipMemsetAsync(d_out, 0, out_pixels * 3 * sizeof(double), stream));
-#endif
+  // No clear of the canvas: every pixel of the rectangle is either stored once or zeroed by the lane that first
+  // hands part of its ray tree to a neighbour (render_body step 2a).
   auto* const kernel = s->ext_kernel ? (lds ? rtc_render_kernel_ext : rtc_render_kernel_bigworld_ext)
                                      : (lds ? (s->simple_kernel ? rtc_render_kernel_simple : rtc_render_kernel) : rtc_render_kernel_bigworld);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,

@@ -1261,8 +1261,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   for (;;) {
     RTC_STAMP(0);
     // ---- 1. a lane without a ray pops its stack; an empty stack means its share of the pixel is done.
-    // Shares of one pixel may finish in several lanes (step 2a): those are ADDED to the zeroed canvas; a
-    // pixel whose whole ray tree stayed in one lane (most of them) is stored once.
+    // Shares of one pixel may finish in several lanes (step 2a): those are ADDED to the pixel, which the
+    // first hand-out zeroed; a pixel whose whole ray tree stayed in one lane (most of them) is stored once.
     if (!have_cur) {
       if (sp > base) {
         cur = load_pending(stack + static_cast<size_t>(--sp) * 64u);
@@ -1323,6 +1323,17 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (donor && drank < pairs) {
           mailbox[drank].p = load_pending(stack + static_cast<size_t>(base++) * 64u);
           mailbox[drank].out_index = out_index;
+          if (!shared) {
+            // First hand-out of this pixel: from here on its shares are ADDED, so it starts from zero.  The canvas is
+            // not cleared per launch (a pixel nobody shares is stored once); the store is at L2 before the taker —
+            // a lane of this wave — can issue its first atomic.
+            double* __restrict__ o = out + 3 * out_index;
+            o[0] = 0.0;
+            o[1] = 0.0;
+            o[2] = 0.0;
+            if (map.cost != nullptr) map.cost[out_index] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          }
           shared = true;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

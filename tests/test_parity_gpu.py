@@ -132,6 +132,44 @@ def test_repeat_renders_agree(rtc):
     assert np.array_equal(gpu2.render(cam2, 5), gpu2.render(cam2, 5))
 
 
+def test_canvas_is_fully_written(rtc):
+    """The library never clears the caller's canvas: every pixel is stored once, or zeroed by the lane that first
+    shares its ray tree and then added to.  Rendering over NaNs must give the same image, launch after launch
+    (first launch: heuristic schedule; second: re-packed; third: steady state)."""
+    torch = pytest.importorskip("torch")
+    for scene, w, h, depth in (("reflection_and_refraction.json", 320, 180, 5), ("fresnel.json", 150, 150, 5),
+                               ("cover.json", 97, 61, 5)):
+        hs = rtc.HostScene.from_file(scene)
+        cam = hs.camera(w, h)
+        gpu = rtc.GpuScene(hs.desc)
+        want, _ = ob.OracleScene(hs.desc).render(cam, depth)
+        for launch in range(3):
+            canvas = torch.full((h, w, 3), float("nan"), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            gpu.render_device(cam, canvas.data_ptr(), depth, None, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = canvas.cpu().numpy()
+            assert np.isfinite(got).all(), (scene, launch, int(np.isnan(got).sum()))
+            assert np.abs(got - want).max() < TOL, (scene, launch)
+    # tile mode: the pixels of the rank's tiles inside the image are all written; the padding is left alone
+    hs = rtc.HostScene.from_file("fresnel.json")
+    cam = hs.camera(100, 70)
+    gpu = rtc.GpuScene(hs.desc)
+    full = gpu.render(cam, 5)
+    tw = th = 32
+    tx, ty = rtc.tile_grid(cam.hsize, cam.vsize, tw, th)
+    buf = torch.full((tx * ty, th, tw, 3), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    gpu.render_tiles_device(cam, buf.data_ptr(), tw, th, 0, 1, tx * ty, 5, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    tiles = buf.cpu().numpy()
+    for t in range(tx * ty):
+        y0, x0 = (t // tx) * th, (t % tx) * tw
+        hh, ww = min(th, cam.vsize - y0), min(tw, cam.hsize - x0)
+        assert np.abs(tiles[t, :hh, :ww] - full[y0:y0 + hh, x0:x0 + ww]).max() < REPEAT_TOL, t
+        assert np.isnan(tiles[t, hh:]).all() and np.isnan(tiles[t, :, ww:]).all()
+
+
 def test_default_world_kat_through_the_abi(rtc):
     """camera.zig:171-187: default world, 11x11, fov pi/2, from (0,0,-5): pixel (5,5) = (0.38066, 0.47583, 0.2855)."""
     scene = """{"camera":{"width":11,"height":11,"field-of-view":1.5707963267948966,"from":[0,0,-5],"to":[0,0,0],"up":[0,1,0]},
