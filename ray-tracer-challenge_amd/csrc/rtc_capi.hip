@@ -1144,6 +1144,12 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
                  h.prof_t1 >> 24, h.prof_t1 & 0xFFFFFFull, h.prof_busy, h.stolen);
     std::fprintf(stderr, "rtc traces (invocations, lanes): closest %llu %llu | shadow %llu %llu | behind %llu %llu\n", h.prof2[0],
                  h.prof2[1], h.prof2[2], h.prof2[3], h.prof2[4], h.prof2[5]);
+    std::fprintf(stderr, "rtc trace cycles by lanes with a ray (1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64):");
+    for (int k = 0; k < 3; ++k) {
+      std::fprintf(stderr, " %s", k == 0 ? "closest" : k == 1 ? "| shadow" : "| behind");
+      for (int i = 0; i < 7; ++i) std::fprintf(stderr, " %llu", h.prof3[k * 7 + i]);
+    }
+    std::fprintf(stderr, "\n");
     if (const char* path = getenv("RTC_PROFILE_LOG")) {
       if (FILE* f = std::fopen(path, "w")) {
         for (int i = 0; i < 4096; ++i)

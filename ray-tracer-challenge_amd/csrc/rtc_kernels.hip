@@ -55,9 +55,18 @@
     prof2[slot] += 1ull;                                                                \
     prof2[(slot) + 1] += static_cast<unsigned long long>(__builtin_popcountll(__ballot(true))); \
   } while (0)
+// wave cycles spent in traces, by how many lanes had a ray: [kind 0 closest / 1 shadow / 2 behind][1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64]
+#define RTC_HIST_BEGIN()                                                                      \
+  const unsigned hist_n_ = static_cast<unsigned>(__builtin_popcountll(__ballot(true)));        \
+  const unsigned long long hist_t_ = __builtin_amdgcn_s_memtime()
+#define RTC_HIST_END(kind)                                                                                          \
+  prof3[(kind) * 7 + (hist_n_ <= 2 ? 0 : hist_n_ <= 4 ? 1 : hist_n_ <= 8 ? 2 : hist_n_ <= 16 ? 3 : hist_n_ <= 32 ? 4 : hist_n_ <= 48 ? 5 : 6)] += \
+      __builtin_amdgcn_s_memtime() - hist_t_
 #else
 #define RTC_STAMP(sec) do { } while (0)
 #define RTC_COUNT(slot) do { } while (0)
+#define RTC_HIST_BEGIN() do { } while (0)
+#define RTC_HIST_END(kind) do { } while (0)
 #endif
 
 #ifndef RTC_LB2
@@ -1256,6 +1265,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   unsigned prof_sec = 0;
   unsigned long long prof_iters = 0, prof_units = 0;
   unsigned long long prof2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof3[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned prof_last_unit = 0, prof_first_unit = 0;
 #endif
   for (;;) {
@@ -1480,7 +1490,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 #endif
     ClosestVisitor hv;
     RTC_COUNT(0);
-    trace<CSG, SIMPLE>(S, recs, cull, ray, hv, overflow);
+    {
+      RTC_HIST_BEGIN();
+      trace<CSG, SIMPLE>(S, recs, cull, ray, hv, overflow);
+      RTC_HIST_END(0);
+    }
     RTC_STAMP(2);
     if (hv.leaf == RTC_NO_LEAF) continue;  // black (world.zig:119)
 
@@ -1521,7 +1535,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
       RTC_COUNT(4);
-      trace<CSG, SIMPLE>(S, recs, cull, ray, bv, overflow);
+      {
+        RTC_HIST_BEGIN();
+        trace<CSG, SIMPLE>(S, recs, cull, ray, bv, overflow);
+        RTC_HIST_END(2);
+      }
       RTC_STAMP(6);
       bv.flush();
       const double hit_ior = mats[mat_index].ior;
@@ -1664,7 +1682,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
           RTC_STAMP(3);
           RTC_COUNT(2);
-          trace<CSG, SIMPLE>(S, recs, cull, sray, sv, overflow);
+          {
+            RTC_HIST_BEGIN();
+            trace<CSG, SIMPLE>(S, recs, cull, sray, sv, overflow);
+            RTC_HIST_END(1);
+          }
           RTC_STAMP(4);
           shadowed = sv.shadowed;
         }
@@ -1787,6 +1809,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     atomicMax(&stats->prof_t1, ((prof_t - prof_start) << 24) | (prof_last_unit & 0xFFFFFFull));  // longest wave + its last unit
     atomicAdd(&stats->prof_busy, prof_t - prof_start);
     for (int i = 0; i < 8; ++i) atomicAdd(&stats->prof2[i], prof2[i]);
+    for (int i = 0; i < 21; ++i) atomicAdd(&stats->prof3[i], prof3[i]);
     const unsigned wid = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 4095u;
     stats->prof_log[wid][0] = prof_t - prof_start;
     stats->prof_log[wid][1] = prof_iters;
