@@ -1153,9 +1153,12 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
     if (const char* path = getenv("RTC_PROFILE_LOG")) {
       if (FILE* f = std::fopen(path, "w")) {
         for (int i = 0; i < 4096; ++i)
-          if (h.prof_log[i][0])
-            std::fprintf(f, "%d %llu %llu %llu %llu %llu\n", i, h.prof_log[i][0], h.prof_log[i][1], h.prof_log[i][2],
+          if (h.prof_log[i][0]) {
+            std::fprintf(f, "%d %llu %llu %llu %llu %llu", i, h.prof_log[i][0], h.prof_log[i][1], h.prof_log[i][2],
                          h.prof_log[i][3] >> 32, h.prof_log[i][3] & 0xFFFFFFFFull);
+            for (int k = 0; k < 16; ++k) std::fprintf(f, " %llu", h.prof_last[i][k]);
+            std::fprintf(f, "\n");
+          }
         std::fclose(f);
       }
     }

@@ -211,5 +211,6 @@ struct DevStats {
   unsigned long long prof3[21]; // wave cycles in traces by lanes with a ray: [closest, shadow, behind][1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64]
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
   unsigned long long prof_log[4096][4];            // per wave: lifetime, iterations, units, first<<32|last unit
+  unsigned long long prof_last[4096][16];          // per wave: prof[] of its last packet only
 #endif
 };

@@ -1265,6 +1265,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   unsigned prof_sec = 0;
   unsigned long long prof_iters = 0, prof_units = 0;
   unsigned long long prof2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_snap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // prof_acc at the wave's last packet fetch
   unsigned long long prof3[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned prof_last_unit = 0, prof_first_unit = 0;
 #endif
@@ -1369,6 +1370,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       if (chunk_pos >= chunk_end) {
         uint32_t unit = RTC_NO_ITEM;
         if (item_next < RTC_PACKET_ITEMS) unit = __builtin_amdgcn_readlane(items, item_next);
+        RTC_STAMP(9);  // (diagnostic builds: section 15 ends when the items of a fresh packet have arrived)
         if (unit == RTC_NO_ITEM) {  // the packet is used up: pull the next one
           if (drained) break;
           // A wave owns every pixel of a packet it pulls.  Pulling one for a couple of idle lanes would commit the
@@ -1380,8 +1382,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             pk_cur = RTC_NO_ITEM;
           }
           uint32_t c = 0u;
+          RTC_STAMP(14);  // (diagnostic builds: section 14 = the round trip of the work counter)
           if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
           c = __builtin_amdgcn_readfirstlane(c);
+          RTC_STAMP(15);
           if (c >= map.n_units) {
             drained = true;
             break;
@@ -1390,6 +1394,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           prof_last_unit = c;
           prof_first_unit = static_cast<unsigned>((__builtin_amdgcn_s_memtime() - prof_start) >> 8);  // time of the last fetch
           prof_units += 1ull;
+          for (int i = 0; i < 16; ++i) prof_snap[i] = prof_acc[i];
+          prof_snap[7] = prof_iters;
 #endif
           pk_cur = c;
           pk_t0 = __builtin_amdgcn_s_memtime();
@@ -1815,6 +1821,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     stats->prof_log[wid][1] = prof_iters;
     stats->prof_log[wid][2] = prof_units;
     stats->prof_log[wid][3] = (static_cast<unsigned long long>(prof_first_unit) << 32) | prof_last_unit;
+    for (int i = 0; i < 16; ++i) stats->prof_last[wid][i] = prof_acc[i] - prof_snap[i];  // sections of the last packet
   }
 #endif
   // one atomic per counter per wave

@@ -41,3 +41,12 @@ print("longest waves: life, iters, packets, last_fetch_us, last packet index")
 for i in o:
     print("  ", life[i], iters[i], units[i], last_fetch[i], int(rows[i, 5]))
 print("last packet index of all waves: min", int(rows[:, 5].min()), "median", int(np.median(rows[:, 5])), "max", int(rows[:, 5].max()))
+if rows.shape[1] >= 22:
+    # sections of each wave's LAST packet (prof[] deltas since its last fetch; slot 7 = iterations)
+    last = rows[:, 6:22] / 100.0
+    names = ["pop/store", "closest", "after-closest", "shadow", "lighting", "behind", "after-behind", "iters*100", "share", "deal/pull",
+             "precomp", "pattern", "lights-setup", "spawn", "counter", "items"]
+    tail = life - last_fetch
+    for label, sel in (("all waves", np.arange(len(rows))), ("the 5 % of waves that end last", np.argsort(-life)[:len(rows) // 20])):
+        print(f"last packet of {label}: time after the last fetch mean {tail[sel].mean():.0f}, iterations {last[sel, 7].mean() * 100:.1f}")
+        print("   " + " | ".join(f"{n} {last[sel, k].mean():.0f}" for k, n in enumerate(names) if n != "-" and k != 7))
