@@ -669,6 +669,9 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   bool branching_everywhere = false, unbounded_nonplane = false;
   std::vector<RootRec> root_recs(d.n_roots);
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
+  struct RootCull {
+    float cx, cy, cz, r2;
+  };
   std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
   float cull_cmax = 0.0f;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
@@ -853,7 +856,15 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(s->roots.upload(roots));
   HIP_TRY(s->root_recs.upload(root_recs));
-  HIP_TRY(s->root_cull.upload(root_cull));
+  std::vector<RootCullPair> root_cull_pairs(root_cull.size() / 2u);
+  for (size_t i = 0; i < root_cull_pairs.size(); ++i) {
+    const RootCull &a = root_cull[2 * i], &b = root_cull[2 * i + 1];
+    root_cull_pairs[i].cx = {a.cx, b.cx};
+    root_cull_pairs[i].cy = {a.cy, b.cy};
+    root_cull_pairs[i].cz = {a.cz, b.cz};
+    root_cull_pairs[i].r2 = {a.r2, b.r2};
+  }
+  HIP_TRY(s->root_cull.upload(root_cull_pairs));
   HIP_TRY(s->kids.upload(kids));
   HIP_TRY(s->leaf_meta.upload(leaf_meta));
   HIP_TRY(s->xf.upload(xf));

@@ -50,10 +50,12 @@ struct DevCyl {
 
 // One record per World.objects entry, flattened so the wave-uniform root loop needs no dependent
 // (pointer-chasing) loads.  Split in two tables, both staged once per work-group into LDS:
-//   RootCull  16 B  conservative world-space bounding sphere in FP32 (r2 == +inf: no finite bound)
-//   RootRec  144 B  what the exact test needs
-struct RootCull {
-  float cx, cy, cz, r2;  // centre rounded to nearest, r2 rounded UP; phase 1 of the root loop is FP32
+//   RootCullPair 32 B  conservative world-space bounding spheres of TWO roots in FP32 (r2 == +inf: no finite bound),
+//                      component by component: the two roots are the two lanes of packed-FP32 instructions
+//   RootRec     144 B  what the exact test needs
+struct RootCullPair {
+  typedef float Pair __attribute__((ext_vector_type(2)));
+  Pair cx, cy, cz, r2;  // centre rounded to nearest, r2 rounded UP; phase 1 of the root loop is FP32
 };
 struct RootRec {
   double inv[12];        // rows 0..2 of the leaf's inverse (unused for groups)
@@ -127,7 +129,7 @@ struct __attribute__((aligned(32))) CsgRec {
 
 struct DevScene {
   const RootRec* __restrict__ root_recs;
-  const RootCull* __restrict__ root_cull;
+  const RootCullPair* __restrict__ root_cull;  // (n_roots + 3) / 4 * 2 pairs, padded with never-kept spheres
   const uint32_t* __restrict__ roots;
   const uint4* __restrict__ leaf_meta;
   const double* __restrict__ xf;        // [n_xforms][12]

@@ -69,7 +69,7 @@ struct rtc_scene {
   size_t frame_capacity = 0;  // in doubles
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
-  DevBuf<RootCull> root_cull;
+  DevBuf<RootCullPair> root_cull;
   DevBuf<uint4> leaf_meta;
   DevBuf<double> xf, tri, trin, node_box, light;
   DevBuf<DevPattern> pat;

@@ -601,25 +601,35 @@ __device__ __forceinline__ RayF ray_f32(const Ray& r, float cmax) {
   return f;
 }
 
+typedef float Float2 __attribute__((ext_vector_type(2)));
+
+// Phase 1 of the root loop for TWO roots: the arithmetic runs as packed FP32 (v_pk_fma_f32 & co: one instruction per
+// pair of roots), only the comparisons are per root.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.
 template <class V>
-__device__ __forceinline__ bool root_culled(const RootCull& R, const RayF& ray) {
+__device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF& ray) {
   // explicit FMAs: this file is compiled with contraction off for the FP64 path, but nothing here has
   // to round like the reference
-  const float ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
-  const float b = __builtin_fmaf(ocx, ray.dx, __builtin_fmaf(ocy, ray.dy, ocz * ray.dz));
-  const float oc2 = __builtin_fmaf(ocx, ocx, __builtin_fmaf(ocy, ocy, ocz * ocz));
-  const float T = ray.t_scale * (oc2 + ray.s2);       // 8e-6 * a * (oc^2 + S^2)
-  const float ac = ray.a * (oc2 - R.r2);
-  const float bb = b * b;
-  const float disc = bb - ac;
-  const bool miss = disc < -T;                          // the line misses the sphere
-  const bool sided = (ac > T) & (bb > T);               // origin outside, sphere clearly on one side of it
-  const bool behind = sided & (b < 0.0f);               // entirely at t < 0
-  const bool front = sided & (b > 0.0f);                // entirely at t > 0
+  const Float2 ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
+  const Float2 b = __builtin_elementwise_fma(ocx, Float2(ray.dx), __builtin_elementwise_fma(ocy, Float2(ray.dy), ocz * ray.dz));
+  const Float2 oc2 = __builtin_elementwise_fma(ocx, ocx, __builtin_elementwise_fma(ocy, ocy, ocz * ocz));
+  const Float2 T = (oc2 + ray.s2) * ray.t_scale;       // 8e-6 * a * (oc^2 + S^2)
+  const Float2 ac = (oc2 - R.r2) * ray.a;
+  const Float2 bb = b * b;
+  const Float2 disc = bb - ac;
 #ifdef RTC_EXP_NOROOTCULL  // diagnostic: keep every root
-  return false;
+  return 3u;
 #endif
-  return miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly);
+  uint32_t kept = 0u;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const bool miss = disc[e] < -T[e];                    // the line misses the sphere
+    const bool sided = (ac[e] > T[e]) & (bb[e] > T[e]);   // origin outside, sphere clearly on one side of it
+    const bool behind = sided & (b[e] < 0.0f);            // entirely at t < 0
+    const bool front = sided & (b[e] > 0.0f);             // entirely at t > 0
+    const bool culled = miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly);
+    kept |= culled ? 0u : (1u << e);
+  }
+  return kept;
 }
 
 // World.intersect's loop over World.objects (world.zig:74), two-phase so that no load depends on a
@@ -632,18 +642,18 @@ __device__ __forceinline__ bool root_culled(const RootCull& R, const RayF& ray) 
 // survivors is most of the world while each lane's own list is 2-4 roots long.
 template <bool CSG, bool SIMPLE, class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
-                                      const RootCull* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow) {
+                                      const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow) {
   const RayF rf = ray_f32(ray, S.cull_cmax);
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
     unsigned long long mine = 0ull;
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
     for (uint32_t i = 0; i < n; i += 4u) {
-      const RootCull c0 = cull[base + i], c1 = cull[base + i + 1u], c2 = cull[base + i + 2u], c3 = cull[base + i + 3u];
-      const unsigned long long k0 = !root_culled<V>(c0, rf), k1 = !root_culled<V>(c1, rf);
-      const unsigned long long k2 = !root_culled<V>(c2, rf), k3 = !root_culled<V>(c3, rf);
-      mine |= (k0 | (k1 << 1) | (k2 << 2) | (k3 << 3)) << i;
+      const RootCullPair p0 = cull[(base + i) >> 1], p1 = cull[((base + i) >> 1) + 1u];
+      const unsigned long long k = roots_kept<V>(p0, rf) | (roots_kept<V>(p1, rf) << 2);
+      mine |= k << i;
     }
+    if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
     while (mine != 0ull && !vis.done()) {
       const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mine));
       mine &= mine - 1ull;
@@ -1191,13 +1201,13 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
   // chases pointers through memory.  Larger worlds run the same code on the tables in memory.
   __shared__ RootRec lds_recs[LDS ? RTC_LDS_ROOTS : 1];
-  __shared__ RootCull lds_cull[LDS ? RTC_LDS_ROOTS : 1];
+  __shared__ RootCullPair lds_cull[LDS ? RTC_LDS_ROOTS / 2 : 1];
   __shared__ DevMaterial lds_mat[LDS ? RTC_LDS_MATERIALS : 1];
   __shared__ DevPattern lds_pat[LDS ? RTC_LDS_PATTERNS : 1];
   __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
   __shared__ Mail lds_mail[4][64];  // per wave: rays handed from busy lanes to idle ones
   const RootRec* __restrict__ recs = S.root_recs;
-  const RootCull* __restrict__ cull = S.root_cull;
+  const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
   const DevPattern* __restrict__ pats = S.pat;
   const double* __restrict__ lights = S.light;
@@ -1208,7 +1218,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
     };
     stage(lds_recs, S.root_recs, S.n_roots * (sizeof(RootRec) / 8u));
-    stage(lds_cull, S.root_cull, ((S.n_roots + 3u) & ~3u) * (sizeof(RootCull) / 8u));
+    stage(lds_cull, S.root_cull, ((S.n_roots + 3u) & ~3u) / 2u * (sizeof(RootCullPair) / 8u));
     stage(lds_mat, S.mat, S.n_materials * (sizeof(DevMaterial) / 8u));
     stage(lds_pat, S.pat, S.n_patterns * (sizeof(DevPattern) / 8u));
     stage(lds_light, S.light, S.n_lights * 6u);
