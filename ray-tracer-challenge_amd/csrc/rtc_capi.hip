@@ -186,6 +186,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       HIP_TRY(hipStreamSynchronize(s->last_stream));
       // what every chunk really took: a packet's time, shared among its items by their cost
       std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
+      // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
+      if (s->measured_inflation.size() == chunk_time.size())
+        for (size_t c = 0; c < chunk_time.size(); ++c) chunk_time[c] = static_cast<uint32_t>(chunk_time[c] / s->measured_inflation[c]);
       if (getenv("RTC_SCHED_BY_COST")) chunk_time = s->h_chunk_cost;  // experiment knob: ignore the measured times
       s->h_chunk_time_dbg = chunk_time;
       const auto t_c = std::chrono::steady_clock::now();
@@ -195,7 +198,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       if (!packWholeChunks(s, map, chunk_time, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
         s->h_cost.resize(out_pixels);
         HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        packSchedule(s, map, s->h_cost, s->h_chunk_cost, chunk_time, n_waves);
+        packSchedule(s, map, s->h_cost, s->h_chunk_cost, chunk_time, n_waves, s->cost_depth);
       }
       const auto t_d = std::chrono::steady_clock::now();
       const int st = uploadSchedule(s, stream);
@@ -242,8 +245,10 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       map.packet_time = s->d_packet_time;
       if (map.order != nullptr) {
         s->measured_order = s->h_order;  // the schedule this launch runs (and times)
+        s->measured_inflation = s->order_from_cost ? s->h_split_inflation : std::vector<float>();
       } else {
         s->measured_order.clear();
+        s->measured_inflation.clear();
       }
     } else {
       map.cost = nullptr;

@@ -96,6 +96,8 @@ struct rtc_scene {
   std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
   bool branching_everywhere = false;  // such a root without a finite bound
   std::vector<uint32_t> h_order;
+  std::vector<float> h_split_inflation;   // per chunk: modelled time of its parts / its time whole, for the schedule in h_order (empty: nothing is cut)
+  std::vector<float> measured_inflation;  // ... for the schedule the last measuring launch ran
   uint32_t* d_order = nullptr;
   size_t order_capacity = 0;
   std::vector<double> order_key;   // camera + map the cached (heuristic) order was built for

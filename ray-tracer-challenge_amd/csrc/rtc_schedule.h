@@ -86,6 +86,7 @@ bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uin
   }
   const double cap = std::max(1.0, alpha * total / std::max(1.0, n_waves));
   if (static_cast<double>(heaviest) > cap) return false;
+  s->h_split_inflation.clear();
   std::vector<uint32_t> order(map.n_chunks);
   for (uint32_t i = 0; i < map.n_chunks; ++i) order[i] = i;
   // Longest first, but in classes of about equal length (a quarter octave) that keep the chunks' image order: waves
@@ -131,12 +132,13 @@ bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uin
 }
 
 void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost,
-                  const std::vector<uint32_t>& chunk_cost_sum, const std::vector<uint32_t>& chunk_time, double n_waves) {
+                  const std::vector<uint32_t>& chunk_cost_sum, const std::vector<uint32_t>& chunk_time, double n_waves,
+                  uint32_t max_depth) {
   static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
-  static const double fill = getenv("RTC_SPLIT_FILL") ? atof(getenv("RTC_SPLIT_FILL")) : 1.0;
-  struct Item { uint32_t cost, code, npx; };
+  struct Item { uint32_t cost, code; };
   const uint32_t n_chunks = map.n_chunks;
-  std::vector<uint32_t> pc(static_cast<size_t>(n_chunks) * 64u);  // per chunk, its pixels' costs
+  std::vector<uint32_t> pc(static_cast<size_t>(n_chunks) * 64u);  // per chunk, its pixels' shares of the chunk's time
+  std::vector<float> rays(static_cast<size_t>(n_chunks) * 64u);   // per chunk, the rays of its pixels' trees (about)
   std::vector<uint64_t> chunk_cost(n_chunks, 0);
   double total = 0.0;
   for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -145,36 +147,82 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     const uint32_t rx0 = (cr - ccy * map.chunks_x) * 8u, ry0 = ccy * 8u;
     const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
     const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
+    // a pixel's share of the chunk's measured TIME, by its share of the chunk's cost
+    const double scale = chunk_cost_sum[c] ? static_cast<double>(chunk_time[c]) / chunk_cost_sum[c] : 0.0;
     for (uint32_t k = 0; k < 64u; ++k) {
       const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
-      // a pixel's share of the chunk's measured TIME, by its share of the chunk's cost
-      const double scale = chunk_cost_sum[c] ? static_cast<double>(chunk_time[c]) / chunk_cost_sum[c] : 0.0;
-      const uint32_t v = (rx < w && ry < h) ? static_cast<uint32_t>(cost[out0 + static_cast<size_t>(ry) * w + rx] * scale) : 0u;
+      if (rx >= w || ry >= h) continue;
+      const uint32_t px_cost = cost[out0 + static_cast<size_t>(ry) * w + rx];
+      const uint32_t v = static_cast<uint32_t>(px_cost * scale);
       pc[static_cast<size_t>(c) * 64u + k] = v;
       chunk_cost[c] += v;
+      rays[static_cast<size_t>(c) * 64u + k] = std::max(1.0f, px_cost / 5.0f);  // cost: 2 per closest-hit or containers trace, 1 per shadow ray
     }
     total += static_cast<double>(chunk_cost[c]);
   }
-  const double cap = std::max(1.0, alpha * total / std::max(1.0, n_waves));
-  std::vector<Item> whole, runs;
+  // Depth-aware splitting.  A wave renders one ray per lane per iteration, and the rays of one pixel's tree depend on
+  // each other level by level: pixels [a, b) of a chunk take about L + S iterations, L = the deepest tree among them
+  // (at most max_depth + 1 levels, at most the rays it has), S = their rays / 64.  A chunk measured at T > F (a wave's
+  // fair share) is cut into r parts of S / r each; every part pays L again, so r stops where a part's S would fall
+  // under L / 2 (a chunk that is all depth stays whole), and F includes what the cuts add (fixed point, a few rounds).
+  const double level_cap = static_cast<double>(max_depth) + 1.0;
+  auto iterations = [&](uint32_t c, uint32_t a, uint32_t b, double* depth = nullptr) {
+    double L = 0.0, S = 0.0;
+    for (uint32_t i = a; i < b; ++i) {
+      const double r = rays[static_cast<size_t>(c) * 64u + i];
+      L = std::max(L, std::min(r, level_cap));
+      S += r / 64.0;
+    }
+    if (depth) *depth = L;
+    return L + S;
+  };
+  std::vector<uint8_t> parts(n_chunks, 1);
+  double fair = total / std::max(1.0, n_waves);
+  for (int round = 0; round < 6; ++round) {
+    double extra = 0.0;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      const double T = static_cast<double>(chunk_cost[c]);
+      uint32_t r = 1;
+      if (T > alpha * fair) {
+        double L = 0.0;
+        const double it = iterations(c, 0, 64, &L), per_iteration = T / std::max(it, 1e-9), S = it - L;
+        const double room = std::max(alpha * fair / per_iteration - L, std::max(0.5 * L, 0.5));
+        r = std::max(1u, std::min(16u, static_cast<uint32_t>(std::ceil(S / room))));
+        extra += (r - 1u) * L * per_iteration;
+      }
+      parts[c] = static_cast<uint8_t>(r);
+    }
+    fair = (total + extra) / std::max(1.0, n_waves);
+  }
+  const double cap = std::max(1.0, alpha * fair);
+  std::vector<float>& inflation = s->h_split_inflation;
+  inflation.assign(n_chunks, 1.0f);
+  std::vector<Item> whole;
+  struct Part { uint64_t est; uint32_t code, npx; };
+  std::vector<Part> split_parts;
   for (uint32_t c = 0; c < n_chunks; ++c) {
-    if (static_cast<double>(chunk_cost[c]) <= cap) {
-      whole.push_back({static_cast<uint32_t>(chunk_cost[c]), scheduleItem(c, 0, 64), 64u});
+    if (parts[c] == 1u) {
+      whole.push_back({static_cast<uint32_t>(chunk_cost[c]), scheduleItem(c, 0, 64)});
       continue;
     }
-    const uint32_t* k = &pc[static_cast<size_t>(c) * 64u];
-    for (uint32_t r = 0; r < 8u; ++r) {
-      uint32_t start = r * 8u, acc = 0u;
-      for (uint32_t i = r * 8u; i < r * 8u + 8u; ++i) {
-        if (i > start && static_cast<double>(acc + k[i]) > cap) {
-          runs.push_back({acc, scheduleItem(c, start, i - start), i - start});
-          start = i;
-          acc = 0u;
-        }
-        acc += k[i];
+    // r contiguous pixel ranges of about equal ray counts, in the chunk's row-major order: one item each
+    const float* k = &rays[static_cast<size_t>(c) * 64u];
+    const double T = static_cast<double>(chunk_cost[c]), per_iteration = T / std::max(iterations(c, 0, 64), 1e-9);
+    double S = 0.0;
+    for (uint32_t i = 0; i < 64u; ++i) S += k[i];
+    double done = 0.0, est_sum = 0.0;
+    uint32_t start = 0, made = 0;
+    for (uint32_t i = 0; i < 64u; ++i) {
+      done += k[i];
+      if (i == 63u || (made + 1u < parts[c] && done >= S * (made + 1u) / parts[c])) {
+        const double est = per_iteration * iterations(c, start, i + 1u);
+        split_parts.push_back({static_cast<uint64_t>(est), scheduleItem(c, start, i + 1u - start), i + 1u - start});
+        est_sum += est;
+        start = i + 1u;
+        ++made;
       }
-      runs.push_back({acc, scheduleItem(c, start, r * 8u + 8u - start), r * 8u + 8u - start});
     }
+    inflation[c] = static_cast<float>(std::max(1.0, est_sum / std::max(T, 1.0)));
   }
   std::vector<uint32_t>& out = s->h_order;
   out.clear();
@@ -182,55 +230,15 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
   std::vector<Packet> packets;
   std::sort(whole.begin(), whole.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
   size_t light_end = whole.size();  // whole[light_end..] have been cut up as filler
-  if (!runs.empty()) {
-    std::sort(runs.begin(), runs.end(), [](const Item& a, const Item& b) { return a.cost > b.cost; });
-    uint64_t run_cost = 0, run_px = 0;
-    for (const Item& it : runs) run_cost += it.cost, run_px += it.npx;
-    const size_t n_bins = std::max<size_t>({1, static_cast<size_t>((run_px + 63) / 64),
-                                            static_cast<size_t>(static_cast<double>(run_cost) / (fill * cap)) + 1});
-    packets.assign(n_bins, Packet{0, 0, 0, {}});
-    const uint32_t kRunItems = RTC_PACKET_ITEMS - 4u;  // slots kept free for filler rows
-    // longest-first into the cheapest bin that still has room (a heap of bins by cost)
-    auto cmp = [&](uint32_t a, uint32_t b) { return packets[a].cost > packets[b].cost; };
-    std::vector<uint32_t> heap(n_bins);
-    for (size_t i = 0; i < n_bins; ++i) heap[i] = static_cast<uint32_t>(i);
-    std::make_heap(heap.begin(), heap.end(), cmp);
-    std::vector<uint32_t> skipped;
-    for (const Item& it : runs) {
-      skipped.clear();
-      bool placed = false;
-      while (!heap.empty()) {
-        std::pop_heap(heap.begin(), heap.end(), cmp);
-        const uint32_t b = heap.back();
-        heap.pop_back();
-        Packet& P = packets[b];
-        if (P.npx + it.npx <= 64u && P.n_items < kRunItems) {
-          P.items[P.n_items++] = it.code;
-          P.npx += it.npx;
-          P.cost += it.cost;
-          placed = true;
-          if (P.npx < 64u && P.n_items < kRunItems) skipped.push_back(b);
-          break;
-        }
-        skipped.push_back(b);
-        if (skipped.size() > 32) break;  // bounded search; a fresh packet takes the run
-      }
-      for (uint32_t b : skipped) {
-        heap.push_back(b);
-        std::push_heap(heap.begin(), heap.end(), cmp);
-      }
-      if (!placed) {
-        Packet P{it.cost, it.npx, 1, {}};
-        P.items[0] = it.code;
-        packets.push_back(P);  // not in the heap: it stays as it is
-      }
-    }
-    // top up with rows of the cheapest whole chunks
-    uint32_t filler_chunk = 0, filler_row = 8;  // rows of whole[light_end] still unused
+  {
+    // one part per packet, topped up with rows of the cheapest chunks: their pixels are done after an iteration or
+    // two, just when the part's ray trees fan out and need the lanes
     static const bool no_fill = getenv("RTC_SPLIT_NOFILL") != nullptr;  // experiment knob
-    for (Packet& P : packets) {
-      if (no_fill) break;
-      while (P.npx + 8u <= 64u && P.n_items < RTC_PACKET_ITEMS) {
+    uint32_t filler_chunk = 0, filler_row = 8;
+    for (const Part& pt : split_parts) {
+      Packet P{pt.est, pt.npx, 1, {}};
+      P.items[0] = pt.code;
+      while (!no_fill && P.npx + 8u <= 64u && P.n_items < RTC_PACKET_ITEMS) {
         if (filler_row == 8u) {
           if (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap) break;
           --light_end;
@@ -245,10 +253,9 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
         P.cost += rc;
         ++filler_row;
       }
-      if (filler_row == 8u && (light_end == 0 || static_cast<double>(whole[light_end - 1].cost) > 0.25 * cap)) break;
+      packets.push_back(P);
     }
-    // rows of a filler chunk that no packet took
-    if (filler_row < 8u) {
+    if (filler_row < 8u) {  // rows of a filler chunk that no packet took
       Packet P{0, 0, 0, {}};
       for (; filler_row < 8u; ++filler_row) {
         P.items[P.n_items++] = scheduleItem(filler_chunk, filler_row * 8u, 8);
@@ -307,7 +314,7 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     uint64_t hpx[5] = {0, 0, 0, 0, 0}, hit[5] = {0, 0, 0, 0, 0};
     for (const Packet& P : packets) {
       pcst.push_back(P.cost);
-      hpx[P.npx == 64 ? 4 : P.npx / 16]++;
+      hpx[std::min(4u, P.npx / 16u)]++;
       hit[P.n_items == 1 ? 0 : 1 + (P.n_items - 1) / 5]++;
     }
     std::sort(pcst.begin(), pcst.end());
@@ -317,8 +324,8 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
                  (unsigned long long)hit[0], (unsigned long long)hit[1], (unsigned long long)hit[2], (unsigned long long)hit[3], (unsigned long long)hit[4]);
   }
   if (getenv("RTC_PROFILE_DUMP"))
-    std::fprintf(stderr, "rtc schedule: %zu packets (%zu runs of %zu split chunks, %zu filler chunks), cap %.0f rays, total %.0f\n",
-                 packets.size(), runs.size(), static_cast<size_t>(n_chunks) - whole.size(), whole.size() - light_end, cap, total);
+    std::fprintf(stderr, "rtc schedule: %zu packets (%zu parts of %zu split chunks, %zu filler chunks), cap %.0f, total %.0f\n",
+                 packets.size(), split_parts.size(), static_cast<size_t>(n_chunks) - whole.size(), whole.size() - light_end, cap, total);
 }
 
 // Heavy-first chunk order (DevPixelMap::order): chunks whose pixels may look straight at an object with a

@@ -31,7 +31,7 @@ def main():
     sptr = stream.cuda_stream
 
     def timed(fn):
-        for _ in range(3):
+        for _ in range(8):
             fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
