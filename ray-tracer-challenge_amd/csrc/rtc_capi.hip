@@ -332,15 +332,54 @@ const char* rtc_status_name(int status) {
   }
 }
 
-int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
-  g_error.clear();
-  if (!desc || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  *out = nullptr;
-  const rtc_scene_desc& d = *desc;
-  if (d.abi_version != RTC_ABI_VERSION)
-    return fail(RTC_ERR_INVALID_ARGUMENT, "abi_version %u, library speaks %u", d.abi_version, RTC_ABI_VERSION);
+}  // extern "C"
 
-  // ---- validate (host only; nothing touches the GPU until the scene is known to be sound)
+namespace {
+
+struct RootCull {  // host form of one bounding sphere; uploaded two to a RootCullPair
+  float cx, cy, cz, r2;
+};
+
+// What validateScene learns about a scene on the way.
+struct SceneTraits {
+  bool has_csg = false;     // some node is a csg operation
+  bool ext_kernel = false;  // csg or texture maps: the `_ext` kernels
+  uint32_t max_stack = 0;   // traversal stack the deepest group tree needs
+};
+
+// The device tables of a scene, on the host (buildTables fills them, uploadTables copies them).
+struct HostTables {
+  std::vector<uint4> leaf_meta;
+  std::vector<uint32_t> roots;
+  std::vector<uint32_t> kids;
+  std::vector<uint32_t> leaf_parent;
+  std::vector<uint32_t> node_parent;
+  std::vector<BvhNode> bvh_nodes;
+  std::vector<uint32_t> bvh_leaves;
+  std::vector<uint32_t> node_info;
+  std::vector<uint2> node_range;
+  std::vector<Sphere> branching_spheres;
+  std::vector<Sphere> occupied_spheres;
+  std::vector<RootRec> root_recs;
+  std::vector<RootCull> root_cull;
+  std::vector<double> xf;
+  std::vector<DevPattern> pat;
+  std::vector<DevCyl> cyl;
+  std::vector<double> tri;
+  std::vector<double> trin;
+  std::vector<DevMaterial> mat;
+  std::vector<uint2> node_kids;
+  std::vector<double> node_box;
+  std::vector<double> light;
+  uint32_t n_live = 0;
+  float bvh_mag = 0.0f;
+  float cull_cmax = 0.0f;
+  bool branching_everywhere = false;
+  bool unbounded_nonplane = false;
+};
+
+// Everything rtc_scene_create refuses, checked on the host before anything touches the GPU.
+int validateScene(const rtc_scene_desc& d, SceneTraits& traits) {
   for (uint32_t i = 0; i < d.n_xforms; ++i)
     if (!affineRow(d.xf_inv + 16ull * i)) return fail(RTC_ERR_NOT_AFFINE, "xform %u: last row is not (0,0,0,1)", i);
   for (uint32_t i = 0; i < d.n_patterns; ++i) {
@@ -394,18 +433,20 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     if (!ids.insert(d.leaf_id[i]).second)
       return fail(RTC_ERR_UNSUPPORTED, "leaf %u: Shape.id %u appears on more than one leaf", i, d.leaf_id[i]);
   }
-  bool has_csg = false;
+  bool& has_csg = traits.has_csg;
+  has_csg = false;
   for (uint32_t n = 0; n < d.n_nodes && d.node_op; ++n) {
     if (d.node_op[n] == RTC_CSG_NONE) continue;
     if (d.node_op[n] > RTC_CSG_DIFFERENCE) return fail(RTC_ERR_INVALID_ARGUMENT, "node %u: csg operation %u", n, d.node_op[n]);
     if (d.node_count[n] != 2) return fail(RTC_ERR_INVALID_ARGUMENT, "csg node %u has %u children, not left and right", n, d.node_count[n]);
     has_csg = true;
   }
-  auto opOf = [&](uint32_t n) -> uint32_t { return d.node_op ? d.node_op[n] : RTC_CSG_NONE; };
-  bool ext_kernel = has_csg;
+  bool& ext_kernel = traits.ext_kernel;
+  ext_kernel = has_csg;
   for (uint32_t i = 0; i < d.n_patterns; ++i) ext_kernel |= d.pat_kind[i] == RTC_PAT_TEXTURE_MAP;
   std::vector<uint8_t> leaf_seen(d.n_leaves, 0), node_seen(d.n_nodes, 0);
-  uint32_t max_stack = 0;
+  uint32_t& max_stack = traits.max_stack;
+  max_stack = 0;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     const uint32_t r = d.roots[i];
     if (r & RTC_CHILD_NODE_BIT) {
@@ -419,6 +460,224 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   if (max_stack > RTC_TRAV_STACK)
     return fail(RTC_ERR_OVERFLOW, "group tree needs a traversal stack of %u entries, kernel has %d", max_stack, RTC_TRAV_STACK);
 
+  return RTC_OK;
+}
+
+// One record and one bounding sphere per World.objects entry, and what the first-frame schedule wants to know about
+// them (where the branching materials are, what can be seen at all).
+void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_of, const std::vector<uint32_t>& bvh_root_of,
+                     HostTables& T) {
+  auto opOf = [&](uint32_t n) -> uint32_t { return d.node_op ? d.node_op[n] : RTC_CSG_NONE; };
+  auto& root_recs = T.root_recs;
+  auto& root_cull = T.root_cull;
+  auto& cull_cmax = T.cull_cmax;
+  auto& branching_spheres = T.branching_spheres;
+  auto& occupied_spheres = T.occupied_spheres;
+  auto& branching_everywhere = T.branching_everywhere;
+  auto& unbounded_nonplane = T.unbounded_nonplane;
+  branching_everywhere = false;
+  unbounded_nonplane = false;
+  root_recs.assign(d.n_roots, RootRec{});
+  // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
+  root_cull.assign((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  cull_cmax = 0.0f;
+  for (uint32_t i = 0; i < d.n_roots; ++i) {
+    RootRec& R = root_recs[i];
+    std::memset(&R, 0, sizeof R);
+    const uint32_t ref = d.roots[i];
+    Sphere sp;
+    if (ref & RTC_CHILD_NODE_BIT) {
+      const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
+      R.kind_flags = RTC_ROOT_IS_GROUP | (opOf(n) != RTC_CSG_NONE ? RTC_ROOT_IS_CSG : 0u);
+      R.index = n;
+      R.geom = bvh_root_of[i];
+      // every entry of the group lies on a line that passes the group's own box test
+      const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
+      const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
+      const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+      bool csg_below = false;
+      {
+        std::vector<uint32_t> todo{n};
+        while (!todo.empty() && !csg_below) {
+          const uint32_t m = todo.back();
+          todo.pop_back();
+          csg_below = opOf(m) != RTC_CSG_NONE;
+          for (uint32_t k = 0; k < d.node_count[m]; ++k)
+            if (d.children[d.node_first[m] + k] & RTC_CHILD_NODE_BIT) todo.push_back(d.children[d.node_first[m] + k] & ~RTC_CHILD_NODE_BIT);
+        }
+      }
+      if (!csg_below) {
+        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
+      } else if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+        // A csg keeps the box it was built with when a transform is pushed through it (shape.zig:298-302),
+        // so its leaves - and the entries they report - may lie outside it and outside the groups above.
+        // "The line misses the box => no entry" still holds; "the box is behind the origin => so is every
+        // entry" does not.  The sphere therefore covers the box AND the leaves' world boxes.
+        Aabb all;
+        all.add(lo);
+        all.add(hi);
+        bool bounded = true;
+        std::vector<uint32_t> todo{n};
+        while (!todo.empty() && bounded) {
+          const uint32_t m = todo.back();
+          todo.pop_back();
+          for (uint32_t k = 0; k < d.node_count[m] && bounded; ++k) {
+            const uint32_t c = d.children[d.node_first[m] + k];
+            if (c & RTC_CHILD_NODE_BIT) {
+              todo.push_back(c & ~RTC_CHILD_NODE_BIT);
+            } else {
+              const Aabb b = leafWorldBox(d, c);
+              if (b.finite()) {
+                all.merge(b);
+              } else {
+                bounded = false;
+              }
+            }
+          }
+        }
+        if (bounded && all.finite()) sp = sphereOfBox(I, all.lo, all.hi);
+      }
+    } else {
+      const uint8_t k = d.leaf_kind[ref];
+      const uint32_t g = d.leaf_geom[ref];
+      std::memcpy(R.inv, d.xf_inv + 16ull * d.leaf_xform[ref], sizeof R.inv);
+      R.kind_flags = static_cast<uint32_t>(k) | (d.leaf_shadow[ref] ? 0x100u : 0u);
+      if (k == RTC_CYLINDER || k == RTC_CONE) {
+        R.ymin = d.cyl_min[g];
+        R.ymax = d.cyl_max[g];
+        if (d.cyl_closed[g]) R.kind_flags |= 0x200u;
+      }
+      R.index = dfs_of[ref];
+      R.material = d.leaf_material[ref];
+      R.geom = (k == RTC_TRIANGLE || k == RTC_SMOOTH_TRIANGLE) ? g : 0u;
+      sp = leafSphere(d, ref);
+    }
+    sp = inflate(sp);
+    {
+      // does anything under this root branch the ray tree (reflective AND transparent, world.zig:101-102)?
+      bool branches = false;
+      std::vector<uint32_t> todo{ref};
+      while (!todo.empty() && !branches) {
+        const uint32_t r = todo.back();
+        todo.pop_back();
+        if (r & RTC_CHILD_NODE_BIT) {
+          const uint32_t n = r & ~RTC_CHILD_NODE_BIT;
+          for (uint32_t k = 0; k < d.node_count[n]; ++k) todo.push_back(d.children[d.node_first[n] + k]);
+        } else {
+          const double* mp = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * d.leaf_material[r];
+          branches = mp[4] != 0.0 && mp[5] != 0.0;
+        }
+      }
+      if (branches) {
+        if (sp.finite()) branching_spheres.push_back(sp);
+        else branching_everywhere = true;
+      }
+      if (sp.finite()) {
+        occupied_spheres.push_back(sp);
+      } else if ((ref & RTC_CHILD_NODE_BIT) || d.leaf_kind[ref] != RTC_PLANE) {
+        unbounded_nonplane = true;
+      }
+    }
+    RootCull& C = root_cull[i];
+    if (sp.finite()) {
+      // FP32 copy: centre to nearest (its rounding is covered by the kernel's margin, which scales with
+      // max|c|), r^2 rounded UP after a further 1e-5 relative inflation
+      C.cx = static_cast<float>(sp.cx);
+      C.cy = static_cast<float>(sp.cy);
+      C.cz = static_cast<float>(sp.cz);
+      const double r2 = sp.r * sp.r * (1.0 + 1e-5);
+      float r2f = static_cast<float>(r2);
+      if (static_cast<double>(r2f) < r2) r2f = std::nextafterf(r2f, INFINITY);
+      C.r2 = r2f;
+      const float cm = static_cast<float>(std::sqrt(sp.cx * sp.cx + sp.cy * sp.cy + sp.cz * sp.cz) * (1.0 + 1e-6));
+      cull_cmax = std::fmax(cull_cmax, std::isfinite(cm) ? cm : 0.0f);
+      if (!std::isfinite(C.cx) || !std::isfinite(C.cy) || !std::isfinite(C.cz) || !std::isfinite(C.r2) || !std::isfinite(cm))
+        C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};  // out of FP32 range: no bound
+    } else {
+      C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};
+    }
+  }
+}
+
+// The tables that are the caller's arrays in the kernel's element layout.
+void copyPlainTables(const rtc_scene_desc& d, HostTables& T) {
+  auto& xf = T.xf;
+  auto& pat = T.pat;
+  auto& cyl = T.cyl;
+  auto& tri = T.tri;
+  auto& trin = T.trin;
+  auto& mat = T.mat;
+  auto& node_kids = T.node_kids;
+  auto& node_box = T.node_box;
+  auto& light = T.light;
+  auto rows12 = [](const double* src, uint32_t n) {
+    std::vector<double> v(12ull * n);
+    for (uint32_t i = 0; i < n; ++i) std::memcpy(&v[12ull * i], src + 16ull * i, 12 * sizeof(double));
+    return v;
+  };
+  xf = rows12(d.xf_inv, d.n_xforms);
+  pat.assign(d.n_patterns, DevPattern{});
+  for (uint32_t i = 0; i < d.n_patterns; ++i) {
+    std::memset(&pat[i], 0, sizeof(DevPattern));
+    std::memcpy(pat[i].inv, d.pat_inv + 16ull * i, sizeof pat[i].inv);
+    for (int k = 0; k < 3; ++k) pat[i].rgb[k] = d.pat_rgb[3ull * i + k];
+    pat[i].kind = d.pat_kind[i];
+    pat[i].a = d.pat_a[i];
+    pat[i].b = d.pat_b[i];
+  }
+  cyl.assign(d.n_cyls, DevCyl{});
+  for (uint32_t i = 0; i < d.n_cyls; ++i) cyl[i] = {d.cyl_min[i], d.cyl_max[i], d.cyl_closed[i] ? 1u : 0u, 0u};
+  tri.assign(9ull * d.n_tris, 0.0);
+  trin.assign(9ull * d.n_tris, 0.0);
+  for (uint32_t i = 0; i < d.n_tris; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      tri[9ull * i + k] = d.tri_p1[3ull * i + k];
+      tri[9ull * i + 3 + k] = d.tri_e1[3ull * i + k];
+      tri[9ull * i + 6 + k] = d.tri_e2[3ull * i + k];
+      trin[9ull * i + k] = d.tri_n1[3ull * i + k];
+      trin[9ull * i + 3 + k] = d.tri_n2[3ull * i + k];
+      trin[9ull * i + 6 + k] = d.tri_n3[3ull * i + k];
+    }
+  }
+  mat.assign(d.n_materials, DevMaterial{});
+  for (uint32_t i = 0; i < d.n_materials; ++i) {
+    const double* p = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * i;
+    mat[i] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], d.mat_pattern[i], 0u};
+  }
+  node_kids.assign(d.n_nodes, uint2{0, 0});
+  node_box.assign(6ull * d.n_nodes, 0.0);
+  for (uint32_t i = 0; i < d.n_nodes; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      node_box[6ull * i + k] = d.node_min[3ull * i + k];
+      node_box[6ull * i + 3 + k] = d.node_max[3ull * i + k];
+    }
+    node_kids[i] = {d.node_first[i], d.node_count[i]};
+  }
+  light.assign(6ull * d.n_lights, 0.0);
+  for (uint32_t i = 0; i < d.n_lights; ++i) {
+    for (int k = 0; k < 3; ++k) {
+      light[6ull * i + k] = d.light_pos[3ull * i + k];
+      light[6ull * i + 3 + k] = d.light_rgb[3ull * i + k];
+    }
+  }
+
+}
+
+// The flat device tables of a validated scene.
+int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& T) {
+  (void)traits;
+  auto& leaf_meta = T.leaf_meta;
+  auto& roots = T.roots;
+  auto& kids = T.kids;
+  auto& leaf_parent = T.leaf_parent;
+  auto& node_parent = T.node_parent;
+  auto& bvh_nodes = T.bvh_nodes;
+  auto& bvh_leaves = T.bvh_leaves;
+  auto& node_info = T.node_info;
+  auto& node_range = T.node_range;
+  auto& n_live = T.n_live;
+  auto& bvh_mag = T.bvh_mag;
+  auto opOf = [&](uint32_t n) -> uint32_t { return d.node_op ? d.node_op[n] : RTC_CSG_NONE; };
   // ---- device tables.  Leaves are re-indexed to depth-first order: the leaf index IS the
   // equal-t tie-break (see ClosestVisitor), whatever order the caller's arrays are in.
   std::vector<uint32_t> dfs_of(d.n_leaves, RTC_NO_LEAF);
@@ -450,10 +709,10 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     }
     // leaves not reachable from any root keep RTC_NO_LEAF and are dropped
   }
-  uint32_t n_live = 0;
+  n_live = 0;
   for (uint32_t v : dfs_of) n_live += (v != RTC_NO_LEAF);
 
-  std::vector<uint4> leaf_meta(n_live);
+  leaf_meta.assign(n_live, uint4{0, 0, 0, 0});
   for (uint32_t i = 0; i < d.n_leaves; ++i) {
     if (dfs_of[i] == RTC_NO_LEAF) continue;
     uint4 m;
@@ -464,24 +723,24 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     leaf_meta[dfs_of[i]] = m;
   }
   auto remap = [&](uint32_t ref) { return (ref & RTC_CHILD_NODE_BIT) ? ref : dfs_of[ref]; };
-  std::vector<uint32_t> roots(d.n_roots), kids(d.n_children);
+  roots.assign(d.n_roots, 0u);
+  kids.assign(d.n_children, 0u);
   for (uint32_t i = 0; i < d.n_roots; ++i) roots[i] = remap(d.roots[i]);
   for (uint32_t i = 0; i < d.n_children; ++i) {
     const uint32_t c = d.children[i];
     kids[i] = (c & RTC_CHILD_NODE_BIT) ? c : (c < d.n_leaves && dfs_of[c] != RTC_NO_LEAF ? dfs_of[c] : 0u);
   }
   // reference-tree parents (for the box-chain re-check) and the candidate BVH of every group root
-  std::vector<uint32_t> leaf_parent(n_live, RTC_NO_LEAF), node_parent(d.n_nodes, RTC_NO_LEAF);
-  std::vector<BvhNode> bvh_nodes;
-  std::vector<uint32_t> bvh_leaves;
+  leaf_parent.assign(n_live, RTC_NO_LEAF);
+  node_parent.assign(d.n_nodes, RTC_NO_LEAF);
   std::vector<uint32_t> bvh_root_of(d.n_roots, 0);
-  float bvh_mag = 0.0f;
+  bvh_mag = 0.0f;
   // ---- reference-tree bookkeeping for every node: parent, which child of its parent it is (a csg's left
   // is child 0), the contiguous range of depth-first leaves below it, and the csg UNITS: a csg whose parent
   // is not a csg.  A unit is evaluated as a whole (its leaves' entries are merged, sorted and filtered by
   // every csg node on the way up, csg.zig:51-95), so the candidate BVH treats it as one primitive.
-  std::vector<uint32_t> node_info(d.n_nodes, 0);       // op | slot << 8 | side << 16 | is_unit << 17
-  std::vector<uint2> node_range(d.n_nodes, uint2{0, 0});
+  node_info.assign(d.n_nodes, 0u);       // op | slot << 8 | side << 16 | is_unit << 17
+  node_range.assign(d.n_nodes, uint2{0, 0});
   std::vector<uint8_t> leaf_side(n_live, 0);
   {
     struct Frame { uint32_t node, next, unit, first_leaf; };
@@ -670,193 +929,41 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
                  bvh_nodes.size(), in_groups, once, bad);
   }
   if (bvh_leaves.size() >= (1u << 28)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the BVH leaf-range encoding", bvh_leaves.size());
-  std::vector<Sphere> branching_spheres, occupied_spheres;
-  bool branching_everywhere = false, unbounded_nonplane = false;
-  std::vector<RootRec> root_recs(d.n_roots);
-  // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
-  struct RootCull {
-    float cx, cy, cz, r2;
-  };
-  std::vector<RootCull> root_cull((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
-  float cull_cmax = 0.0f;
-  for (uint32_t i = 0; i < d.n_roots; ++i) {
-    RootRec& R = root_recs[i];
-    std::memset(&R, 0, sizeof R);
-    const uint32_t ref = d.roots[i];
-    Sphere sp;
-    if (ref & RTC_CHILD_NODE_BIT) {
-      const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
-      R.kind_flags = RTC_ROOT_IS_GROUP | (opOf(n) != RTC_CSG_NONE ? RTC_ROOT_IS_CSG : 0u);
-      R.index = n;
-      R.geom = bvh_root_of[i];
-      // every entry of the group lies on a line that passes the group's own box test
-      const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
-      const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
-      const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-      bool csg_below = false;
-      {
-        std::vector<uint32_t> todo{n};
-        while (!todo.empty() && !csg_below) {
-          const uint32_t m = todo.back();
-          todo.pop_back();
-          csg_below = opOf(m) != RTC_CSG_NONE;
-          for (uint32_t k = 0; k < d.node_count[m]; ++k)
-            if (d.children[d.node_first[m] + k] & RTC_CHILD_NODE_BIT) todo.push_back(d.children[d.node_first[m] + k] & ~RTC_CHILD_NODE_BIT);
-        }
-      }
-      if (!csg_below) {
-        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
-      } else if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
-        // A csg keeps the box it was built with when a transform is pushed through it (shape.zig:298-302),
-        // so its leaves - and the entries they report - may lie outside it and outside the groups above.
-        // "The line misses the box => no entry" still holds; "the box is behind the origin => so is every
-        // entry" does not.  The sphere therefore covers the box AND the leaves' world boxes.
-        Aabb all;
-        all.add(lo);
-        all.add(hi);
-        bool bounded = true;
-        std::vector<uint32_t> todo{n};
-        while (!todo.empty() && bounded) {
-          const uint32_t m = todo.back();
-          todo.pop_back();
-          for (uint32_t k = 0; k < d.node_count[m] && bounded; ++k) {
-            const uint32_t c = d.children[d.node_first[m] + k];
-            if (c & RTC_CHILD_NODE_BIT) {
-              todo.push_back(c & ~RTC_CHILD_NODE_BIT);
-            } else {
-              const Aabb b = leafWorldBox(d, c);
-              if (b.finite()) {
-                all.merge(b);
-              } else {
-                bounded = false;
-              }
-            }
-          }
-        }
-        if (bounded && all.finite()) sp = sphereOfBox(I, all.lo, all.hi);
-      }
-    } else {
-      const uint8_t k = d.leaf_kind[ref];
-      const uint32_t g = d.leaf_geom[ref];
-      std::memcpy(R.inv, d.xf_inv + 16ull * d.leaf_xform[ref], sizeof R.inv);
-      R.kind_flags = static_cast<uint32_t>(k) | (d.leaf_shadow[ref] ? 0x100u : 0u);
-      if (k == RTC_CYLINDER || k == RTC_CONE) {
-        R.ymin = d.cyl_min[g];
-        R.ymax = d.cyl_max[g];
-        if (d.cyl_closed[g]) R.kind_flags |= 0x200u;
-      }
-      R.index = dfs_of[ref];
-      R.material = d.leaf_material[ref];
-      R.geom = (k == RTC_TRIANGLE || k == RTC_SMOOTH_TRIANGLE) ? g : 0u;
-      sp = leafSphere(d, ref);
-    }
-    sp = inflate(sp);
-    {
-      // does anything under this root branch the ray tree (reflective AND transparent, world.zig:101-102)?
-      bool branches = false;
-      std::vector<uint32_t> todo{ref};
-      while (!todo.empty() && !branches) {
-        const uint32_t r = todo.back();
-        todo.pop_back();
-        if (r & RTC_CHILD_NODE_BIT) {
-          const uint32_t n = r & ~RTC_CHILD_NODE_BIT;
-          for (uint32_t k = 0; k < d.node_count[n]; ++k) todo.push_back(d.children[d.node_first[n] + k]);
-        } else {
-          const double* mp = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * d.leaf_material[r];
-          branches = mp[4] != 0.0 && mp[5] != 0.0;
-        }
-      }
-      if (branches) {
-        if (sp.finite()) branching_spheres.push_back(sp);
-        else branching_everywhere = true;
-      }
-      if (sp.finite()) {
-        occupied_spheres.push_back(sp);
-      } else if ((ref & RTC_CHILD_NODE_BIT) || d.leaf_kind[ref] != RTC_PLANE) {
-        unbounded_nonplane = true;
-      }
-    }
-    RootCull& C = root_cull[i];
-    if (sp.finite()) {
-      // FP32 copy: centre to nearest (its rounding is covered by the kernel's margin, which scales with
-      // max|c|), r^2 rounded UP after a further 1e-5 relative inflation
-      C.cx = static_cast<float>(sp.cx);
-      C.cy = static_cast<float>(sp.cy);
-      C.cz = static_cast<float>(sp.cz);
-      const double r2 = sp.r * sp.r * (1.0 + 1e-5);
-      float r2f = static_cast<float>(r2);
-      if (static_cast<double>(r2f) < r2) r2f = std::nextafterf(r2f, INFINITY);
-      C.r2 = r2f;
-      const float cm = static_cast<float>(std::sqrt(sp.cx * sp.cx + sp.cy * sp.cy + sp.cz * sp.cz) * (1.0 + 1e-6));
-      cull_cmax = std::fmax(cull_cmax, std::isfinite(cm) ? cm : 0.0f);
-      if (!std::isfinite(C.cx) || !std::isfinite(C.cy) || !std::isfinite(C.cz) || !std::isfinite(C.r2) || !std::isfinite(cm))
-        C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};  // out of FP32 range: no bound
-    } else {
-      C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};
-    }
-  }
-  auto rows12 = [](const double* src, uint32_t n) {
-    std::vector<double> v(12ull * n);
-    for (uint32_t i = 0; i < n; ++i) std::memcpy(&v[12ull * i], src + 16ull * i, 12 * sizeof(double));
-    return v;
-  };
-  std::vector<double> xf = rows12(d.xf_inv, d.n_xforms);
-  std::vector<DevPattern> pat(d.n_patterns);
-  for (uint32_t i = 0; i < d.n_patterns; ++i) {
-    std::memset(&pat[i], 0, sizeof(DevPattern));
-    std::memcpy(pat[i].inv, d.pat_inv + 16ull * i, sizeof pat[i].inv);
-    for (int k = 0; k < 3; ++k) pat[i].rgb[k] = d.pat_rgb[3ull * i + k];
-    pat[i].kind = d.pat_kind[i];
-    pat[i].a = d.pat_a[i];
-    pat[i].b = d.pat_b[i];
-  }
-  std::vector<DevCyl> cyl(d.n_cyls);
-  for (uint32_t i = 0; i < d.n_cyls; ++i) cyl[i] = {d.cyl_min[i], d.cyl_max[i], d.cyl_closed[i] ? 1u : 0u, 0u};
-  std::vector<double> tri(9ull * d.n_tris), trin(9ull * d.n_tris);
-  for (uint32_t i = 0; i < d.n_tris; ++i) {
-    for (int k = 0; k < 3; ++k) {
-      tri[9ull * i + k] = d.tri_p1[3ull * i + k];
-      tri[9ull * i + 3 + k] = d.tri_e1[3ull * i + k];
-      tri[9ull * i + 6 + k] = d.tri_e2[3ull * i + k];
-      trin[9ull * i + k] = d.tri_n1[3ull * i + k];
-      trin[9ull * i + 3 + k] = d.tri_n2[3ull * i + k];
-      trin[9ull * i + 6 + k] = d.tri_n3[3ull * i + k];
-    }
-  }
-  std::vector<DevMaterial> mat(d.n_materials);
-  for (uint32_t i = 0; i < d.n_materials; ++i) {
-    const double* p = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * i;
-    mat[i] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], d.mat_pattern[i], 0u};
-  }
-  std::vector<uint2> node_kids(d.n_nodes);
-  std::vector<double> node_box(6ull * d.n_nodes);
-  for (uint32_t i = 0; i < d.n_nodes; ++i) {
-    for (int k = 0; k < 3; ++k) {
-      node_box[6ull * i + k] = d.node_min[3ull * i + k];
-      node_box[6ull * i + 3 + k] = d.node_max[3ull * i + k];
-    }
-    node_kids[i] = {d.node_first[i], d.node_count[i]};
-  }
-  std::vector<double> light(6ull * d.n_lights);
-  for (uint32_t i = 0; i < d.n_lights; ++i) {
-    for (int k = 0; k < 3; ++k) {
-      light[6ull * i + k] = d.light_pos[3ull * i + k];
-      light[6ull * i + 3 + k] = d.light_rgb[3ull * i + k];
-    }
-  }
+  buildRootTables(d, dfs_of, bvh_root_of, T);
+  copyPlainTables(d, T);
 
-  // ---- upload
-  int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
-    return fail(RTC_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
-  auto s = new (std::nothrow) rtc_scene();
-  if (!s) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation");
-  struct Guard {
-    rtc_scene* s;
-    ~Guard() {
-      if (s) rtc_scene_destroy(s);
-    }
-  } guard{s};
+  return RTC_OK;
+}
+
+// Copies the tables into HBM and fills in the scene handle.
+int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostTables& T, rtc_scene* s) {
+  const auto& leaf_meta = T.leaf_meta;
+  const auto& roots = T.roots;
+  const auto& kids = T.kids;
+  const auto& leaf_parent = T.leaf_parent;
+  const auto& node_parent = T.node_parent;
+  const auto& bvh_nodes = T.bvh_nodes;
+  const auto& bvh_leaves = T.bvh_leaves;
+  const auto& node_info = T.node_info;
+  const auto& node_range = T.node_range;
+  const auto& branching_spheres = T.branching_spheres;
+  const auto& occupied_spheres = T.occupied_spheres;
+  const auto& root_recs = T.root_recs;
+  const auto& root_cull = T.root_cull;
+  const auto& xf = T.xf;
+  const auto& pat = T.pat;
+  const auto& cyl = T.cyl;
+  const auto& tri = T.tri;
+  const auto& trin = T.trin;
+  const auto& mat = T.mat;
+  const auto& node_kids = T.node_kids;
+  const auto& node_box = T.node_box;
+  const auto& light = T.light;
+  const auto& n_live = T.n_live;
+  const auto& bvh_mag = T.bvh_mag;
+  const auto& cull_cmax = T.cull_cmax;
+  const auto& branching_everywhere = T.branching_everywhere;
+  const auto& unbounded_nonplane = T.unbounded_nonplane;
   HIP_TRY(hipGetDevice(&s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(s->roots.upload(roots));
@@ -915,6 +1022,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   }
   HIP_TRY(s->node_info.upload(node_info));
   HIP_TRY(s->node_range.upload(node_range));
+  const bool has_csg = traits.has_csg, ext_kernel = traits.ext_kernel;
   s->has_csg = has_csg;
   s->ext_kernel = ext_kernel;
   // spheres, planes and cubes at top level only, small enough for the LDS tables: the `simple` kernel
@@ -926,7 +1034,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
   HIP_TRY(hipDeviceSynchronize());  // launches may come on any stream: the zeroes must be there by then
-  s->max_trav_stack = max_stack;
+  s->max_trav_stack = traits.max_stack;
   s->branching = branching_spheres;
   s->branching_everywhere = branching_everywhere;
   s->occupied = occupied_spheres;
@@ -980,6 +1088,37 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   D.n_materials = d.n_materials;
   D.n_patterns = d.n_patterns;
   D.cull_cmax = cull_cmax;
+  return RTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
+  g_error.clear();
+  if (!desc || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  const rtc_scene_desc& d = *desc;
+  if (d.abi_version != RTC_ABI_VERSION)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "abi_version %u, library speaks %u", d.abi_version, RTC_ABI_VERSION);
+
+  SceneTraits traits;
+  if (const int st = validateScene(d, traits); st != RTC_OK) return st;
+  HostTables tables;
+  if (const int st = buildTables(d, traits, tables); st != RTC_OK) return st;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+    return fail(RTC_ERR_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+  auto s = new (std::nothrow) rtc_scene();
+  if (!s) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation");
+  struct Guard {
+    rtc_scene* s;
+    ~Guard() {
+      if (s) rtc_scene_destroy(s);
+    }
+  } guard{s};
+  if (const int st = uploadTables(d, traits, tables, s); st != RTC_OK) return st;
   guard.s = nullptr;
   *out = s;
   return RTC_OK;
