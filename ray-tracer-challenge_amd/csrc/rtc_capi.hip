@@ -129,6 +129,168 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
+// The schedule of one launch (results never depend on it).  First launch with a pixel map: the geometric heuristic of
+// chunkOrder().  The launch after a measuring launch packs from what that one measured.  Fills map.order / n_units /
+// cost / packet_time.
+int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, size_t out_pixels,
+                   hipStream_t stream) {
+  // Schedule.  First launch with a pixel map: the geometric heuristic of chunkOrder().  From the second
+  // launch on: longest job first by the MEASURED per-chunk ray counts of the previous frame (refreshed on
+  // launch 2 and then every 64 launches: one stream sync, a 4-byte-per-chunk copy and a sort).  Frames
+  // of an interactive session (lib.zig's move/rotateCamera) change little from one to the next.
+  const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
+  std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
+  if (mkey != s->cost_key) {
+    s->cost_key = mkey;
+    s->launches_with_key = 0;
+    s->order_from_cost = false;
+    s->cost_pending = false;
+  }
+  if (out_pixels > s->cost_capacity) {
+    if (s->d_cost) (void)hipFree(s->d_cost);
+    s->d_cost = nullptr;
+    s->cost_capacity = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
+    s->cost_capacity = out_pixels;
+    s->launches_with_key = 0;
+    s->cost_pending = false;
+  }
+  const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
+  if (schedulable && s->cost_pending) {
+    s->sched_cam = s->cost_cam;
+    s->sched_depth = s->cost_depth;
+    const auto t_a = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    const auto t_b = std::chrono::steady_clock::now();
+    // per-chunk sums first (a tiny kernel, 4 bytes per chunk to copy); the per-pixel costs only if a chunk must be split
+    if (map.n_chunks > s->chunk_cost_capacity) {
+      if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
+      s->d_chunk_cost = nullptr;
+      s->chunk_cost_capacity = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+      s->chunk_cost_capacity = map.n_chunks;
+    }
+    hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, s->last_stream, s->d_cost, map,
+                       s->d_chunk_cost);
+    HIP_TRY(hipGetLastError());
+    s->h_chunk_cost.resize(map.n_chunks);
+    HIP_TRY(hipMemcpyAsync(s->h_chunk_cost.data(), s->d_chunk_cost, s->h_chunk_cost.size() * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, s->last_stream));
+    const size_t n_measured = s->measured_order.empty() ? map.n_chunks : s->measured_order.size() / RTC_PACKET_ITEMS;
+    s->h_packet_time.resize(n_measured);
+    HIP_TRY(hipMemcpyAsync(s->h_packet_time.data(), s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           s->last_stream));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    // what every chunk really took: a packet's time, shared among its items by their cost
+    std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
+    // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
+    if (s->measured_inflation.size() == chunk_time.size())
+      for (size_t c = 0; c < chunk_time.size(); ++c) chunk_time[c] = static_cast<uint32_t>(chunk_time[c] / s->measured_inflation[c]);
+    if (getenv("RTC_SCHED_BY_COST")) chunk_time = s->h_chunk_cost;  // experiment knob: ignore the measured times
+    s->h_chunk_time_dbg = chunk_time;
+    const auto t_c = std::chrono::steady_clock::now();
+    const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
+                      s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
+    const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+    if (!packWholeChunks(s, map, chunk_time, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
+      s->h_cost.resize(out_pixels);
+      HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      packSchedule(s, map, s->h_cost, s->h_chunk_cost, chunk_time, n_waves, s->cost_depth);
+    }
+    const auto t_d = std::chrono::steady_clock::now();
+    const int st = uploadSchedule(s, stream);
+    if (st != RTC_OK) return st;
+    if (getenv("RTC_PROFILE_DUMP")) {
+      const auto t_e = std::chrono::steady_clock::now();
+      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      std::fprintf(stderr, "rtc re-pack: sync %.2f ms, cost copy %.2f ms, packing %.2f ms, upload %.2f ms\n", ms(t_a, t_b),
+                   ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e));
+    }
+    s->order_from_cost = true;
+    s->order_key.clear();  // the heuristic cache no longer describes d_order
+  }
+  if (s->order_from_cost) {
+    map.order = s->d_order;
+    map.n_units = static_cast<uint32_t>(s->h_order.size() / RTC_PACKET_ITEMS);
+  } else {
+    const int st = chunkOrder(s, cam, map, stream);
+    if (st != RTC_OK) return st;
+  }
+  // Per-pixel ray counts are collected by the first launch with a pixel map, and after that by every 64th
+  // launch IF the view has changed since the schedule in use was measured (an orbiting camera, lib.zig's
+  // interactive mode); a static view keeps its schedule and pays nothing.  The successor of a collecting
+  // launch re-packs (one stream sync, a 4-byte-per-pixel copy, O(pixels) on the host: ~0.7 ms at 1080p).
+  const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
+  static const bool always_time = getenv("RTC_TIME_ALWAYS") != nullptr;  // diagnostic: time the packets of every launch
+  const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed) || always_time);
+  s->cost_pending = collect && !(always_time && s->launches_with_key > 0);
+  map.packet_time = nullptr;
+  if (collect) {
+    map.cost = s->d_cost;
+    s->cost_cam = cam;
+    s->cost_depth = max_depth;
+    if (always_time && s->launches_with_key > 0) map.cost = nullptr;  // diagnostic launches only time the packets
+    if (map.n_units > s->packet_time_capacity) {
+      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      if (s->d_packet_time) (void)hipFree(s->d_packet_time);
+      s->d_packet_time = nullptr;
+      s->packet_time_capacity = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), static_cast<size_t>(map.n_units) * sizeof(uint32_t)));
+      s->packet_time_capacity = map.n_units;
+    }
+    HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
+    map.packet_time = s->d_packet_time;
+    if (map.order != nullptr) {
+      s->measured_order = s->h_order;  // the schedule this launch runs (and times)
+      s->measured_inflation = s->order_from_cost ? s->h_split_inflation : std::vector<float>();
+    } else {
+      s->measured_order.clear();
+      s->measured_inflation.clear();
+    }
+  } else {
+    map.cost = nullptr;
+  }
+  s->launches_with_key++;
+  s->last_stream = stream;
+  return RTC_OK;
+}
+
+// Per-launch scratch in HBM, grown on demand: the lanes' pending-ray stacks ([wave][level][lane], 64 B each) and,
+// for scenes with csg, the lanes' intersection lists.
+int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_depth) {
+  const size_t need = static_cast<size_t>(blocks) * 4u * (max_depth + 2u) * 64u * 64u;
+  if (need > s->ray_stack_capacity) {
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
+    s->d_ray_stack = nullptr;
+    s->ray_stack_capacity = 0;
+    HIP_TRY(hipMalloc(&s->d_ray_stack, need));
+    s->ray_stack_capacity = need;
+  }
+  map.ray_stack = static_cast<PendingRec*>(s->d_ray_stack);
+  map.ray_stack_levels = max_depth + 2u;
+  // Measured with 1 / 16 / 32 / 48 / 64: cover 0.96 / 0.93 / 0.92 / 0.90 / 0.88 ms, reflection_and_refraction depth 8
+  // 3.29 / 3.24 / 3.16 / 3.05 / 2.84 ms, dragons 4K 8.33 / 7.99 / 7.59 / 7.18 / 6.60 ms: a wave that finishes its
+  // packet before it starts the next keeps neighbouring pixels (the same objects, materials, BVH paths) together;
+  // the lanes that run out early are fed by the work sharing of step 2a, not by pixels of another chunk.
+  static const uint32_t pull_min = getenv("RTC_PULL_MIN_IDLE") ? static_cast<uint32_t>(atoi(getenv("RTC_PULL_MIN_IDLE"))) : 64u;
+  map.pull_min_idle = std::max(1u, std::min(64u, pull_min));
+  s->dev.csg_buf = nullptr;
+  if (s->has_csg) {
+    const size_t need_csg = static_cast<size_t>(blocks) * 4u * RTC_CSG_ENTRIES * 64u * sizeof(CsgRec);
+    if (need_csg > s->csg_buf_capacity) {
+      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
+      s->d_csg_buf = nullptr;
+      s->csg_buf_capacity = 0;
+      HIP_TRY(hipMalloc(&s->d_csg_buf, need_csg));
+      s->csg_buf_capacity = need_csg;
+    }
+    s->dev.csg_buf = static_cast<CsgRec*>(s->d_csg_buf);
+  }
+  return RTC_OK;
+}
+
 int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
            size_t out_pixels, hipStream_t stream) {
   DevPixelMap map = map_in;
@@ -136,164 +298,14 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
   HIP_TRY(hipSetDevice(s->device));
-  {
-    // Schedule.  First launch with a pixel map: the geometric heuristic of chunkOrder().  From the second
-    // launch on: longest job first by the MEASURED per-chunk ray counts of the previous frame (refreshed on
-    // launch 2 and then every 64 launches: one stream sync, a 4-byte-per-chunk copy and a sort).  Frames
-    // of an interactive session (lib.zig's move/rotateCamera) change little from one to the next.
-    const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
-    std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
-    if (mkey != s->cost_key) {
-      s->cost_key = mkey;
-      s->launches_with_key = 0;
-      s->order_from_cost = false;
-      s->cost_pending = false;
-    }
-    if (out_pixels > s->cost_capacity) {
-      if (s->d_cost) (void)hipFree(s->d_cost);
-      s->d_cost = nullptr;
-      s->cost_capacity = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
-      s->cost_capacity = out_pixels;
-      s->launches_with_key = 0;
-      s->cost_pending = false;
-    }
-    const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
-    if (schedulable && s->cost_pending) {
-      s->sched_cam = s->cost_cam;
-      s->sched_depth = s->cost_depth;
-      const auto t_a = std::chrono::steady_clock::now();
-      HIP_TRY(hipStreamSynchronize(s->last_stream));
-      const auto t_b = std::chrono::steady_clock::now();
-      // per-chunk sums first (a tiny kernel, 4 bytes per chunk to copy); the per-pixel costs only if a chunk must be split
-      if (map.n_chunks > s->chunk_cost_capacity) {
-        if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
-        s->d_chunk_cost = nullptr;
-        s->chunk_cost_capacity = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
-        s->chunk_cost_capacity = map.n_chunks;
-      }
-      hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, s->last_stream, s->d_cost, map,
-                         s->d_chunk_cost);
-      HIP_TRY(hipGetLastError());
-      s->h_chunk_cost.resize(map.n_chunks);
-      HIP_TRY(hipMemcpyAsync(s->h_chunk_cost.data(), s->d_chunk_cost, s->h_chunk_cost.size() * sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, s->last_stream));
-      const size_t n_measured = s->measured_order.empty() ? map.n_chunks : s->measured_order.size() / RTC_PACKET_ITEMS;
-      s->h_packet_time.resize(n_measured);
-      HIP_TRY(hipMemcpyAsync(s->h_packet_time.data(), s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                             s->last_stream));
-      HIP_TRY(hipStreamSynchronize(s->last_stream));
-      // what every chunk really took: a packet's time, shared among its items by their cost
-      std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
-      // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
-      if (s->measured_inflation.size() == chunk_time.size())
-        for (size_t c = 0; c < chunk_time.size(); ++c) chunk_time[c] = static_cast<uint32_t>(chunk_time[c] / s->measured_inflation[c]);
-      if (getenv("RTC_SCHED_BY_COST")) chunk_time = s->h_chunk_cost;  // experiment knob: ignore the measured times
-      s->h_chunk_time_dbg = chunk_time;
-      const auto t_c = std::chrono::steady_clock::now();
-      const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
-                        s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
-      const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
-      if (!packWholeChunks(s, map, chunk_time, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
-        s->h_cost.resize(out_pixels);
-        HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        packSchedule(s, map, s->h_cost, s->h_chunk_cost, chunk_time, n_waves, s->cost_depth);
-      }
-      const auto t_d = std::chrono::steady_clock::now();
-      const int st = uploadSchedule(s, stream);
-      if (st != RTC_OK) return st;
-      if (getenv("RTC_PROFILE_DUMP")) {
-        const auto t_e = std::chrono::steady_clock::now();
-        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "rtc re-pack: sync %.2f ms, cost copy %.2f ms, packing %.2f ms, upload %.2f ms\n", ms(t_a, t_b),
-                     ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e));
-      }
-      s->order_from_cost = true;
-      s->order_key.clear();  // the heuristic cache no longer describes d_order
-    }
-    if (s->order_from_cost) {
-      map.order = s->d_order;
-      map.n_units = static_cast<uint32_t>(s->h_order.size() / RTC_PACKET_ITEMS);
-    } else {
-      const int st = chunkOrder(s, cam, map, stream);
-      if (st != RTC_OK) return st;
-    }
-    // Per-pixel ray counts are collected by the first launch with a pixel map, and after that by every 64th
-    // launch IF the view has changed since the schedule in use was measured (an orbiting camera, lib.zig's
-    // interactive mode); a static view keeps its schedule and pays nothing.  The successor of a collecting
-    // launch re-packs (one stream sync, a 4-byte-per-pixel copy, O(pixels) on the host: ~0.7 ms at 1080p).
-    const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
-    static const bool always_time = getenv("RTC_TIME_ALWAYS") != nullptr;  // diagnostic: time the packets of every launch
-    const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed) || always_time);
-    s->cost_pending = collect && !(always_time && s->launches_with_key > 0);
-    map.packet_time = nullptr;
-    if (collect) {
-      map.cost = s->d_cost;
-      s->cost_cam = cam;
-      s->cost_depth = max_depth;
-      if (always_time && s->launches_with_key > 0) map.cost = nullptr;  // diagnostic launches only time the packets
-      if (map.n_units > s->packet_time_capacity) {
-        HIP_TRY(hipStreamSynchronize(s->last_stream));
-        if (s->d_packet_time) (void)hipFree(s->d_packet_time);
-        s->d_packet_time = nullptr;
-        s->packet_time_capacity = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), static_cast<size_t>(map.n_units) * sizeof(uint32_t)));
-        s->packet_time_capacity = map.n_units;
-      }
-      HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
-      map.packet_time = s->d_packet_time;
-      if (map.order != nullptr) {
-        s->measured_order = s->h_order;  // the schedule this launch runs (and times)
-        s->measured_inflation = s->order_from_cost ? s->h_split_inflation : std::vector<float>();
-      } else {
-        s->measured_order.clear();
-        s->measured_inflation.clear();
-      }
-    } else {
-      map.cost = nullptr;
-    }
-    s->launches_with_key++;
-    s->last_stream = stream;
-  }
+  if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream); st != RTC_OK) return st;
   const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
   // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
   // chunks to hand out, 4 waves each); the waves pull chunks until the counter runs out.
   const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   const uint32_t blocks = std::max(1u, std::min(resident, (map.n_units + 3u) / 4u));
-  {
-    const size_t need = static_cast<size_t>(blocks) * 4u * (max_depth + 2u) * 64u * 64u;
-    if (need > s->ray_stack_capacity) {
-      HIP_TRY(hipStreamSynchronize(s->last_stream));
-      if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
-      s->d_ray_stack = nullptr;
-      s->ray_stack_capacity = 0;
-      HIP_TRY(hipMalloc(&s->d_ray_stack, need));
-      s->ray_stack_capacity = need;
-    }
-    map.ray_stack = static_cast<PendingRec*>(s->d_ray_stack);
-    map.ray_stack_levels = max_depth + 2u;
-    // Measured with 1 / 16 / 32 / 48 / 64: cover 0.96 / 0.93 / 0.92 / 0.90 / 0.88 ms, reflection_and_refraction depth 8
-    // 3.29 / 3.24 / 3.16 / 3.05 / 2.84 ms, dragons 4K 8.33 / 7.99 / 7.59 / 7.18 / 6.60 ms: a wave that finishes its
-    // packet before it starts the next keeps neighbouring pixels (the same objects, materials, BVH paths) together;
-    // the lanes that run out early are fed by the work sharing of step 2a, not by pixels of another chunk.
-    static const uint32_t pull_min = getenv("RTC_PULL_MIN_IDLE") ? static_cast<uint32_t>(atoi(getenv("RTC_PULL_MIN_IDLE"))) : 64u;
-    map.pull_min_idle = std::max(1u, std::min(64u, pull_min));
-    s->dev.csg_buf = nullptr;
-    if (s->has_csg) {
-      const size_t need_csg = static_cast<size_t>(blocks) * 4u * RTC_CSG_ENTRIES * 64u * sizeof(CsgRec);
-      if (need_csg > s->csg_buf_capacity) {
-        HIP_TRY(hipStreamSynchronize(s->last_stream));
-        if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
-        s->d_csg_buf = nullptr;
-        s->csg_buf_capacity = 0;
-        HIP_TRY(hipMalloc(&s->d_csg_buf, need_csg));
-        s->csg_buf_capacity = need_csg;
-      }
-      s->dev.csg_buf = static_cast<CsgRec*>(s->d_csg_buf);
-    }
-  }
+  if (const int st = ensureScratch(s, map, blocks, max_depth); st != RTC_OK) return st;
   s->stats_parity ^= 1u;
   DevStats* const st_now = s->d_stats + s->stats_parity;
   DevStats* const st_next = s->d_stats + (s->stats_parity ^ 1u);
