@@ -224,6 +224,8 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   static const bool always_time = getenv("RTC_TIME_ALWAYS") != nullptr;  // diagnostic: time the packets of every launch
   const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed) || always_time);
   s->cost_pending = collect && !(always_time && s->launches_with_key > 0);
+  static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: keep the first launch's schedule
+  if (sched_off) s->cost_pending = false;
   map.packet_time = nullptr;
   if (collect) {
     map.cost = s->d_cost;
@@ -1261,6 +1263,16 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   out->shadow_calls = h.shadow_calls;
   out->shadow_traced = h.shadow_traced;
   out->overflow = h.overflow;
+  if (getenv("RTC_TIME_ALWAYS") && getenv("RTC_TIME_DUMP") && s->d_packet_time && s->measured_order.empty()) {
+    // diagnostic, unscheduled launches (packet c is chunk c): the same columns as below
+    const size_t n = s->packet_time_capacity;
+    std::vector<uint32_t> t(n);
+    HIP_TRY(hipMemcpy(t.data(), s->d_packet_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(getenv("RTC_TIME_DUMP"), "w")) {
+      for (size_t i = 0; i < n; ++i) std::fprintf(f, "%zu 1 %u 0 %zu\n", i, t[i], i);
+      std::fclose(f);
+    }
+  }
   if (getenv("RTC_TIME_ALWAYS") && s->d_packet_time && !s->measured_order.empty()) {  // diagnostic: predicted vs actual packet times
     const size_t n = s->measured_order.size() / RTC_PACKET_ITEMS;
     std::vector<uint32_t> t(n);
@@ -1284,7 +1296,7 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
             if (c < s->h_chunk_time_dbg.size()) pred += static_cast<unsigned long long>(s->h_chunk_time_dbg[c]) * len / 64u;
             ++items;
           }
-          std::fprintf(f, "%zu %u %u %llu\n", i, items, t[i], pred);
+          std::fprintf(f, "%zu %u %u %llu %u\n", i, items, t[i], pred, s->measured_order[i * RTC_PACKET_ITEMS] & 0xFFFFFu);
         }
         std::fclose(f);
       }

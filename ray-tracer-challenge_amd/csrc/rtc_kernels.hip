@@ -1305,8 +1305,15 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             Double2 rg;
             rg.x = acc_r;
             rg.y = acc_g;
+#ifdef RTC_EXP_TEMPORAL_STORE
             *reinterpret_cast<Double2*>(o) = rg;
             o[2] = acc_b;
+#else
+            // streaming stores: a finished pixel is not read again, and the canvas (50 MB at 1080p) must not push the
+            // BVH nodes and triangles of a mesh scene out of the 4 MB L2s
+            __builtin_nontemporal_store(rg, reinterpret_cast<Double2*>(o));
+            __builtin_nontemporal_store(acc_b, o + 2);
+#endif
           } else
 #ifdef RTC_EXP_NOWRITE
           if (acc_r == 12345.678)

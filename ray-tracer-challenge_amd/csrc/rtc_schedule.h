@@ -74,6 +74,15 @@ std::vector<uint32_t> chunkTimes(const DevPixelMap& map, const std::vector<uint3
   return out;
 }
 
+// Cheap chunks are handed out several to a packet, up to this much measured time (s_memtime ticks / 16: 8000 is about
+// 50 us).  Scenes with meshes get three times as much: the chunks of a packet are image neighbours, and a wave that
+// walks the same BVH nodes for all of them finds them in its CU's L1 (teapot 0.42 -> 0.40 ms; 98 % of the kernel's
+// loads hit L1, a chunk among strangers at the end of the list takes four times what it takes among neighbours).
+inline double groupFloor(const rtc_scene* s) {
+  static const double forced = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 0.0;
+  return forced > 0.0 ? forced : (s->simple_kernel ? 8000.0 : 24000.0);
+}
+
 // The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,
 // so every packet is one whole chunk, most expensive first.  Returns false if some chunk has to be split.
 bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost, double n_waves) {
@@ -93,14 +102,21 @@ bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uin
   // that run at the same moment then work on neighbouring chunks (measured: sorting strictly by time scatters the
   // cheap chunks of the tail over the image and they take 2-8 times longer each than in image order).
   static const bool strict = getenv("RTC_SCHED_STRICT") != nullptr;  // experiment knob
-  auto klass = [&](uint32_t c) { return strict ? static_cast<int>(chunk_cost[c]) : static_cast<int>(4.0 * std::log2(1.0 + chunk_cost[c])); };
+  // Below `flat` of a wave's fair share the order no longer matters for the balance of the frame, but the neighbourhood
+  // does (mesh scenes: a chunk among its image neighbours finds its BVH nodes and triangles in cache): one class.
+  static const double flat = getenv("RTC_SCHED_FLAT") ? atof(getenv("RTC_SCHED_FLAT")) : 0.0;
+  const double flat_below = flat * total / std::max(1.0, n_waves);
+  auto klass = [&](uint32_t c) {
+    if (strict) return static_cast<int>(chunk_cost[c]);
+    return static_cast<int>(4.0 * std::log2(1.0 + std::max(static_cast<double>(chunk_cost[c]), flat_below)));
+  };
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return klass(a) > klass(b); });
   // Cheap chunks travel several to a packet (up to 16, up to 1/`group` of a wave's fair share): when every wave
   // reaches the cheap end of the list at the same moment, one-chunk packets of a few microseconds each turn the
   // work counter and the memory system into the bottleneck (measured: the last 2 % of the schedule took 8 times
   // longer per chunk than the same chunks took when only a few waves were pulling them).
   static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 32.0;
-  static const double t_min = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 8000.0;  // s_memtime ticks / 16 (~50 us)
+  const double t_min = groupFloor(s);
   const double group_cap = group > 0.0 ? std::max(total / std::max(1.0, n_waves) / group, t_min) : 0.0;
   s->h_order.clear();
   s->h_order.reserve(static_cast<size_t>(map.n_chunks) * 4u);
@@ -268,7 +284,7 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
   }
   {  // the chunks that stay whole: cheap ones several to a packet, as in packWholeChunks
     static const double group = getenv("RTC_SCHED_GROUP") ? atof(getenv("RTC_SCHED_GROUP")) : 32.0;
-    static const double t_min = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 8000.0;
+    const double t_min = groupFloor(s);
     const double group_cap = group > 0.0 ? std::max(total / std::max(1.0, n_waves) / group, t_min) : 0.0;
     for (size_t i = 0; i < light_end;) {
       Packet P{0, 0u, 0, {}};

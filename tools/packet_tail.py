@@ -21,3 +21,8 @@ late = np.argsort(-(now * (idx > 0.9 * n)))[:8]
 print("longest packets of the last 10 % of the order:")
 for i in late:
     print(f"  {int(idx[i]):6d} {int(items[i]):3d} {now[i]:9.0f} {pred[i]:9.0f} {now[i] / fair:5.2f}")
+if rows.shape[1] >= 5 and len(sys.argv) > 2:
+    chunks_x = int(sys.argv[2])   # chunks per image row (width / 8): where the slow packets of the cheap end are
+    print("slowest packets of the last 10 %: chunk column, row (of the first item), now, predicted")
+    for i in late:
+        c = int(rows[i, 4]); print(f"  x {c % chunks_x:4d} y {c // chunks_x:4d}  {now[i]:8.0f} {pred[i]:8.0f}")
