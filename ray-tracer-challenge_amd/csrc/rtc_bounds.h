@@ -389,6 +389,75 @@ struct BvhBuilder {
   }
 };
 
+// Collapses a binary tree of BvhBuilder into four-wide nodes: the children of a node are its two children, the larger
+// (by surface area) inner one of which is replaced by ITS two children until there are four or none is left to open.
+// Boxes are copied, never recomputed: whatever the binary tree visits, this one visits.
+struct Bvh4Collapse {
+  const std::vector<BvhNode>& in;
+  std::vector<Bvh4Node>& out;
+  struct Kid {
+    const float* lo;
+    const float* hi;
+    uint32_t ref;
+  };
+  static bool inner(uint32_t ref) { return ref != RTC_NO_LEAF && !(ref & RTC_NODE_BIT); }
+  static double area(const Kid& k) {
+    const double x = static_cast<double>(k.hi[0]) - k.lo[0], y = static_cast<double>(k.hi[1]) - k.lo[1], z = static_cast<double>(k.hi[2]) - k.lo[2];
+    return (x < 0.0 || y < 0.0 || z < 0.0) ? 0.0 : 2.0 * (x * y + y * z + z * x);
+  }
+  // Returns the index of the four-wide node for binary node `n`; `need` = traversal stack entries its subtree can
+  // occupy after it has been popped (the kernel pushes every child it enters and pops the nearest).
+  uint32_t convert(uint32_t n, uint32_t& need) {
+    std::vector<Kid> kids;
+    auto add = [&](const BvhNode& N, int which) {
+      const uint32_t ref = which == 0 ? N.c0 : N.c1;
+      if (ref != RTC_NO_LEAF) kids.push_back({which == 0 ? N.lo0 : N.lo1, which == 0 ? N.hi0 : N.hi1, ref});
+    };
+    add(in[n], 0);
+    add(in[n], 1);
+    while (kids.size() < 4) {
+      int open = -1;
+      for (size_t i = 0; i < kids.size(); ++i)
+        if (inner(kids[i].ref) && (open < 0 || area(kids[i]) > area(kids[open]))) open = static_cast<int>(i);
+      if (open < 0) break;
+      const BvhNode& C = in[kids[open].ref];
+      kids.erase(kids.begin() + open);
+      add(C, 0);
+      add(C, 1);
+    }
+    const uint32_t me = static_cast<uint32_t>(out.size());
+    out.emplace_back();
+    Bvh4Node N;
+    std::memset(&N, 0, sizeof N);
+    uint32_t deepest = 0;
+    for (size_t i = 0; i < 4; ++i) {
+      if (i < kids.size()) {
+        for (int a = 0; a < 3; ++a) {
+          N.lo[a][i] = kids[i].lo[a];
+          N.hi[a][i] = kids[i].hi[a];
+        }
+        if (inner(kids[i].ref)) {
+          uint32_t below = 0;
+          N.c[i] = convert(kids[i].ref, below);
+          deepest = std::max(deepest, below);
+        } else {
+          N.c[i] = kids[i].ref;
+        }
+      } else {
+        for (int a = 0; a < 3; ++a) {
+          N.lo[a][i] = kHuge;
+          N.hi[a][i] = -kHuge;
+        }
+        N.c[i] = RTC_NO_LEAF;
+      }
+    }
+    const uint32_t k = static_cast<uint32_t>(kids.size());
+    need = std::max(k, (k ? k - 1u : 0u) + deepest);
+    out[me] = N;
+    return me;
+  }
+};
+
 bool affineRow(const double* m16) {  // last row must be exactly (0,0,0,1); -0 is accepted
   return m16[12] == 0.0 && m16[13] == 0.0 && m16[14] == 0.0 && m16[15] == 1.0;
 }

@@ -368,7 +368,8 @@ struct HostTables {
   std::vector<uint32_t> kids;
   std::vector<uint32_t> leaf_parent;
   std::vector<uint32_t> node_parent;
-  std::vector<BvhNode> bvh_nodes;
+  std::vector<BvhNode> bvh_nodes;      // the binary SAH trees (host only)
+  std::vector<Bvh4Node> bvh4_nodes;    // ... collapsed to four children per node: what the kernel walks
   std::vector<uint32_t> bvh_leaves;
   std::vector<uint32_t> node_info;
   std::vector<uint2> node_range;
@@ -686,6 +687,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
   auto& leaf_parent = T.leaf_parent;
   auto& node_parent = T.node_parent;
   auto& bvh_nodes = T.bvh_nodes;
+  auto& bvh4_nodes = T.bvh4_nodes;
   auto& bvh_leaves = T.bvh_leaves;
   auto& node_info = T.node_info;
   auto& node_range = T.node_range;
@@ -748,6 +750,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
   leaf_parent.assign(n_live, RTC_NO_LEAF);
   node_parent.assign(d.n_nodes, RTC_NO_LEAF);
   std::vector<uint32_t> bvh_root_of(d.n_roots, 0);
+  std::vector<uint32_t> bvh2_root_of(d.n_roots, 0);
   bvh_mag = 0.0f;
   // ---- reference-tree bookkeeping for every node: parent, which child of its parent it is (a csg's left
   // is child 0), the contiguous range of depth-first leaves below it, and the csg UNITS: a csg whose parent
@@ -872,9 +875,12 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
     BvhBuilder builder{bvh_nodes, bvh_leaves};
     bvh_root_of[i] = builder.buildRoot(std::move(items));
     bvh_mag = std::fmax(bvh_mag, builder.mag);
-    if (builder.max_depth + 1 > RTC_TRAV_STACK)
-      return fail(RTC_ERR_OVERFLOW, "root %u: candidate BVH is %u levels deep, the kernel's traversal stack holds %d", i,
-                  builder.max_depth, RTC_TRAV_STACK);
+    bvh2_root_of[i] = bvh_root_of[i];
+    uint32_t stack_need = 0;
+    bvh_root_of[i] = Bvh4Collapse{bvh_nodes, bvh4_nodes}.convert(bvh_root_of[i], stack_need);
+    if (stack_need + 1 > RTC_TRAV_STACK)
+      return fail(RTC_ERR_OVERFLOW, "root %u: walking its candidate BVH can take %u stack entries, the kernel's traversal stack holds %d", i,
+                  stack_need + 1, RTC_TRAV_STACK);
   }
   if (getenv("RTC_BVH_CHECK")) {
     // diagnostic: every leaf once, every stored child box contains the world boxes below it
@@ -887,7 +893,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
       if (!(d.roots[i] & RTC_CHILD_NODE_BIT)) continue;
       struct Item { uint32_t ref; const float* lo; const float* hi; };
       std::vector<Item> todo;
-      const BvhNode& R0 = bvh_nodes[bvh_root_of[i]];
+      const BvhNode& R0 = bvh_nodes[bvh2_root_of[i]];  // (the binary tree: the four-wide one copies its boxes)
       todo.push_back({R0.c0, R0.lo0, R0.hi0});
       todo.push_back({R0.c1, R0.lo1, R0.hi1});
       while (!todo.empty()) {
@@ -956,7 +962,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const auto& kids = T.kids;
   const auto& leaf_parent = T.leaf_parent;
   const auto& node_parent = T.node_parent;
-  const auto& bvh_nodes = T.bvh_nodes;
+  const auto& bvh4_nodes = T.bvh4_nodes;
   const auto& bvh_leaves = T.bvh_leaves;
   const auto& node_info = T.node_info;
   const auto& node_range = T.node_range;
@@ -1001,7 +1007,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(s->pat.upload(pat));
   HIP_TRY(s->node_box.upload(node_box));
   HIP_TRY(s->node_kids.upload(node_kids));
-  HIP_TRY(s->bvh.upload(bvh_nodes));
+  HIP_TRY(s->bvh.upload(bvh4_nodes));
   HIP_TRY(s->bvh_leaf.upload(bvh_leaves));
   HIP_TRY(s->leaf_parent.upload(leaf_parent));
   HIP_TRY(s->node_parent.upload(node_parent));

@@ -94,6 +94,15 @@ struct BvhNode {
   uint32_t pad_[2];
 };
 
+// What the kernel walks: the binary SAH tree collapsed to four children per node (half the dependent fetches per ray;
+// the walk waits on memory latency, not on box tests).  Child boxes component by component, so that two children are
+// the two lanes of packed FP32 instructions.  128 B.
+struct Bvh4Node {
+  float lo[3][4], hi[3][4];  // [axis][child]; an unused slot has lo = +huge, hi = -huge (never entered)
+  uint32_t c[4];             // as BvhNode::c0
+  uint32_t pad_[4];
+};
+
 // One pending secondary ray on a lane's stack (see DevPixelMap::ray_stack): origin, direction, weight,
 // remaining depth; exactly one 64-byte line.
 struct __attribute__((aligned(64))) PendingRec {
@@ -138,7 +147,7 @@ struct DevScene {
   const double* __restrict__ trin;      // [n_tris][9]
   const DevMaterial* __restrict__ mat;
   const DevPattern* __restrict__ pat;
-  const BvhNode* __restrict__ bvh;      // all groups' BVHs; RootRec::geom = root node of a group's BVH
+  const Bvh4Node* __restrict__ bvh;     // all groups' BVHs; RootRec::geom = root node of a group's BVH
   const uint32_t* __restrict__ bvh_leaf;   // leaf indices referenced by BvhNode leaf ranges
   const uint32_t* __restrict__ leaf_parent;  // reference Group node directly above each leaf (RTC_NO_LEAF: none)
   const uint32_t* __restrict__ node_parent;  // reference Group above each Group node (RTC_NO_LEAF: none)

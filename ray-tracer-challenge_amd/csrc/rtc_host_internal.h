@@ -76,7 +76,7 @@ struct rtc_scene {
   DevBuf<DevCyl> cyl;
   DevBuf<DevMaterial> mat;
   DevBuf<uint2> node_kids;
-  DevBuf<BvhNode> bvh;
+  DevBuf<Bvh4Node> bvh;
   DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent, node_info;
   DevBuf<uint2> node_range;
   DevBuf<DevTexMap> tex;

@@ -522,41 +522,59 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
         leaf_ref = ref;
         break;
       }
-      const BvhNode& N = S.bvh[ref];
-      auto interval = [&](const float* lo, const float* hi, float& tn, float& tf) {
-        const float tnx = ((px ? lo[0] : hi[0]) - onx) * ix, tfx = ((px ? hi[0] : lo[0]) - ofx) * ix;
-        const float tny = ((py ? lo[1] : hi[1]) - ony) * iy, tfy = ((py ? hi[1] : lo[1]) - ofy) * iy;
-        const float tnz = ((pz ? lo[2] : hi[2]) - onz) * iz, tfz = ((pz ? hi[2] : lo[2]) - ofz) * iz;
-        tn = fmaxf(fmaxf(tnx, tny), tnz);  // fmaxf/fminf drop the NaN of 0 * inf (ray inside a slab, parallel to it)
-        tf = fminf(fminf(tfx, tfy), tfz);
-      };
-      float tn0, tf0, tn1, tf1;
-      interval(N.lo0, N.hi0, tn0, tf0);
-      interval(N.lo1, N.hi1, tn1, tf1);
+      // One 128-byte node: four child boxes, component by component.
+      typedef float Float4 __attribute__((ext_vector_type(4)));
+      const Bvh4Node& N = S.bvh[ref];
+      const Float4 lox = *reinterpret_cast<const Float4*>(N.lo[0]), loy = *reinterpret_cast<const Float4*>(N.lo[1]);
+      const Float4 loz = *reinterpret_cast<const Float4*>(N.lo[2]), hix = *reinterpret_cast<const Float4*>(N.hi[0]);
+      const Float4 hiy = *reinterpret_cast<const Float4*>(N.hi[1]), hiz = *reinterpret_cast<const Float4*>(N.hi[2]);
+      const uint4 kids = *reinterpret_cast<const uint4*>(N.c);
+      const Float4 tnx = ((px ? lox : hix) - onx) * ix, tfx = ((px ? hix : lox) - ofx) * ix;
+      const Float4 tny = ((py ? loy : hiy) - ony) * iy, tfy = ((py ? hiy : loy) - ofy) * iy;
+      const Float4 tnz = ((pz ? loz : hiz) - onz) * iz, tfz = ((pz ? hiz : loz) - ofz) * iz;
+      // max / min drop the NaN of 0 * inf (ray inside a slab, parallel to it)
+      const Float4 tn = __builtin_elementwise_max(__builtin_elementwise_max(tnx, tny), tnz);
+      const Float4 tf = __builtin_elementwise_min(__builtin_elementwise_min(tfx, tfy), tfz);
+      const uint32_t c4[4] = {kids.x, kids.y, kids.z, kids.w};
+      float key[4];
+      uint32_t refs[4];
+      int entered = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
 #if defined(RTC_EXP_NOBVHCULL)  // diagnostic: visit every node
-      const bool h0 = (N.c0 != RTC_NO_LEAF), h1 = (N.c1 != RTC_NO_LEAF);
+        const bool h = c4[k] != RTC_NO_LEAF;
 #elif defined(RTC_EXP_NOCULLF)  // diagnostic: box test only, no t-interval pruning
-      const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0);
-      const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1);
+        const bool h = (c4[k] != RTC_NO_LEAF) & (tn[k] <= tf[k]);
 #else
-      const bool h0 = (N.c0 != RTC_NO_LEAF) & (tn0 <= tf0) & !vis.cullf(tn0, tf0);
-      const bool h1 = (N.c1 != RTC_NO_LEAF) & (tn1 <= tf1) & !vis.cullf(tn1, tf1);
+        const bool h = (c4[k] != RTC_NO_LEAF) & (tn[k] <= tf[k]) & (tn[k] < __builtin_inff()) & !vis.cullf(tn[k], tf[k]);
 #endif
-      if (h0 & h1) {
-        if (sp + 2 > RTC_TRAV_STACK) {
-          overflow = 1u;
-          continue;
-        }
-        const bool first0 = tn0 <= tn1;  // nearer child on top of the stack
-        stack[sp++] = first0 ? N.c1 : N.c0;
-        stack[sp++] = first0 ? N.c0 : N.c1;
-      } else if (h0 | h1) {
-        if (sp + 1 > RTC_TRAV_STACK) {
-          overflow = 1u;
-          continue;
-        }
-        stack[sp++] = h0 ? N.c0 : N.c1;
+        key[k] = h ? tn[k] : __builtin_inff();
+        refs[k] = c4[k];
+        entered += h ? 1 : 0;
       }
+      if (entered == 0) continue;
+      if (sp + entered > RTC_TRAV_STACK) {
+        overflow = 1u;
+        continue;
+      }
+      // farthest first, so that the nearest child is popped first (children not entered carry +inf and sort to the front)
+      auto order = [&](int a, int b) {
+        const bool swap = key[a] < key[b];
+        const float ka = swap ? key[b] : key[a], kb = swap ? key[a] : key[b];
+        const uint32_t ra = swap ? refs[b] : refs[a], rb = swap ? refs[a] : refs[b];
+        key[a] = ka;
+        key[b] = kb;
+        refs[a] = ra;
+        refs[b] = rb;
+      };
+      order(0, 1);
+      order(2, 3);
+      order(0, 2);
+      order(1, 3);
+      order(1, 2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (key[k] < __builtin_inff()) stack[sp++] = refs[k];
     }
     if (leaf_ref == RTC_NO_LEAF) break;  // nothing left (or the visitor is done)
     const uint32_t first = (leaf_ref & ~RTC_NODE_BIT) >> 3, count = (leaf_ref & 7u) + 1u;
