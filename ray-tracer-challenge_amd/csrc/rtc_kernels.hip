@@ -567,11 +567,15 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
         refs[a] = ra;
         refs[b] = rb;
       };
-      order(0, 1);
-      order(2, 3);
-      order(0, 2);
-      order(1, 3);
-      order(1, 2);
+      // (a shadow ray stops at any entry that counts: sorting its children - fully, or only the nearest to the top -
+      // cost more than it saved: dragons 4K 4.43 -> 4.25 ms, nefertiti 0.88 -> 0.85 ms, teapot 0.382 -> 0.384 ms without)
+      if constexpr (!V::kAnyHit) {
+        order(0, 1);
+        order(2, 3);
+        order(0, 2);
+        order(1, 3);
+        order(1, 2);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (key[k] < __builtin_inff()) stack[sp++] = refs[k];
@@ -701,6 +705,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
 // hit(): first entry with t >= 0 of the stably sorted list (shape.zig:71-80) ==
 // lexicographic min of (t, depth-first leaf index) over entries with t >= 0.
 struct ClosestVisitor {
+  static constexpr bool kAnyHit = false;  // the first entry that counts ends the trace: visiting order is free
   double t = kInf;
   uint32_t leaf = RTC_NO_LEAF;
   uint32_t root = RTC_NO_LEAF;      // World.objects index when the hit leaf IS a top-level object
@@ -736,6 +741,7 @@ struct ClosestVisitor {
 
 // isShadowed (world.zig:126-154): any entry with 0 <= t < distance on a casts_shadow leaf.
 struct ShadowVisitor {
+  static constexpr bool kAnyHit = true;  // the first entry that counts ends the trace: visiting order is free
   double distance;
   bool shadowed = false;
   __device__ __forceinline__ void set_root(uint32_t) {}
@@ -770,6 +776,7 @@ struct ShadowVisitor {
 //        entry at exactly t_hit: the reference does not `break` on an empty list).
 // Identity is the leaf index; rtc_scene_create rejects scenes whose leaves share a Shape.id.
 struct BehindVisitor {
+  static constexpr bool kAnyHit = false;  // the first entry that counts ends the trace: visiting order is free
   uint32_t hit_leaf;
   double hit_t;
   // running state of the leaf currently being visited (entries of one leaf arrive together)
