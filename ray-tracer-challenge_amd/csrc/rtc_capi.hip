@@ -1008,7 +1008,21 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(s->node_box.upload(node_box));
   HIP_TRY(s->node_kids.upload(node_kids));
   HIP_TRY(s->bvh.upload(bvh4_nodes));
-  HIP_TRY(s->bvh_leaf.upload(bvh_leaves));
+  std::vector<BvhLeafRec> leaf_recs(bvh_leaves.size());
+  for (size_t i = 0; i < leaf_recs.size(); ++i) {
+    BvhLeafRec& L = leaf_recs[i];
+    std::memset(&L, 0, sizeof L);
+    L.leaf = bvh_leaves[i];
+    if (L.leaf & RTC_NODE_BIT) continue;  // a csg unit
+    const uint4 m = leaf_meta[L.leaf];
+    L.kind_flags = m.x;
+    L.xform = m.y;
+    L.material = m.z;
+    L.geom = m.w;
+    const uint32_t kind = m.x & 0xFFu;
+    if (kind == RTC_TRIANGLE || kind == RTC_SMOOTH_TRIANGLE) std::memcpy(L.tri, &tri[9ull * m.w], sizeof L.tri);
+  }
+  HIP_TRY(s->bvh_leaf.upload(leaf_recs));
   HIP_TRY(s->leaf_parent.upload(leaf_parent));
   HIP_TRY(s->node_parent.upload(node_parent));
   {

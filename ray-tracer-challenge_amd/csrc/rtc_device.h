@@ -103,6 +103,18 @@ struct Bvh4Node {
   uint32_t pad_[4];
 };
 
+// Everything a visit of one BVH leaf needs, in BVH order: one fetch where leaf index -> leaf_meta -> tri would be three
+// dependent ones (the walk waits on memory latency).
+struct BvhLeafRec {
+  uint32_t leaf;        // depth-first leaf index, or RTC_NODE_BIT | node of a csg unit
+  uint32_t kind_flags;  // leaf_meta.x
+  uint32_t xform;       // leaf_meta.y
+  uint32_t material;    // leaf_meta.z
+  uint32_t geom;        // leaf_meta.w
+  uint32_t pad_[3];
+  double tri[9];        // p1, e1, e2 of a (smooth) triangle
+};
+
 // One pending secondary ray on a lane's stack (see DevPixelMap::ray_stack): origin, direction, weight,
 // remaining depth; exactly one 64-byte line.
 struct __attribute__((aligned(64))) PendingRec {
@@ -148,7 +160,7 @@ struct DevScene {
   const DevMaterial* __restrict__ mat;
   const DevPattern* __restrict__ pat;
   const Bvh4Node* __restrict__ bvh;     // all groups' BVHs; RootRec::geom = root node of a group's BVH
-  const uint32_t* __restrict__ bvh_leaf;   // leaf indices referenced by BvhNode leaf ranges
+  const BvhLeafRec* __restrict__ bvh_leaf; // the leaves referenced by the nodes' leaf ranges
   const uint32_t* __restrict__ leaf_parent;  // reference Group node directly above each leaf (RTC_NO_LEAF: none)
   const uint32_t* __restrict__ node_parent;  // reference Group above each Group node (RTC_NO_LEAF: none)
   // csg (csg.zig): per node  op (RTC_CSG_*, bits 0..1) | slot << 8 (index of a csg node inside its unit, < 32)

@@ -77,7 +77,8 @@ struct rtc_scene {
   DevBuf<DevMaterial> mat;
   DevBuf<uint2> node_kids;
   DevBuf<Bvh4Node> bvh;
-  DevBuf<uint32_t> bvh_leaf, leaf_parent, node_parent, node_info;
+  DevBuf<BvhLeafRec> bvh_leaf;
+  DevBuf<uint32_t> leaf_parent, node_parent, node_info;
   DevBuf<uint2> node_range;
   DevBuf<DevTexMap> tex;
   DevBuf<DevUv> uv;

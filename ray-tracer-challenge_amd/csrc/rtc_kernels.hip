@@ -330,9 +330,10 @@ __device__ __forceinline__ bool chain_ok(const DevScene& S, uint32_t leaf, const
 // A leaf proposed by the BVH: run the exact reference test; if one of its entries could change the
 // visitor's state, replay the reference box chain, then hand the entries over.
 template <class V>
-__device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, const Ray& ray, bool degenerate,
+__device__ __forceinline__ void visit_leaf(const DevScene& S, const BvhLeafRec& L, const Ray& ray, bool degenerate,
                                            uint32_t& cur_xf, Ray& lr, V& vis) {
-  const uint4 meta = S.leaf_meta[leaf];
+  const uint32_t leaf = L.leaf;
+  const uint4 meta{L.kind_flags, L.xform, L.material, L.geom};
   if (meta.y != cur_xf) {  // Shape.intersect: ray.transform(_inverse_transform), shape.zig:314-318
     lr = xform_ray(S.xf + 12ull * meta.y, ray);
     cur_xf = meta.y;
@@ -346,7 +347,7 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
   const uint32_t shadow = (meta.x >> 8) & 1u;
   bool relevant = false;
   double t_rel = 0.0;
-  leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr, [&](double t, double, double) {
+  leaf_entries(kind, cy, L.tri, lr, [&](double t, double, double) {
     if (!relevant && vis.relevant(leaf, shadow, t)) {
       relevant = true;
       t_rel = t;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, uint32_t leaf, con
 #else
   if (!chain_ok(S, leaf, ray, t_rel, degenerate)) return;
 #endif
-  leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr,
+  leaf_entries(kind, cy, L.tri, lr,
                [&](double t, double u, double v) { vis.entry(leaf, shadow, meta.z, t, u, v); });
 }
 
@@ -583,11 +584,11 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
     if (leaf_ref == RTC_NO_LEAF) break;  // nothing left (or the visitor is done)
     const uint32_t first = (leaf_ref & ~RTC_NODE_BIT) >> 3, count = (leaf_ref & 7u) + 1u;
     for (uint32_t i = 0; i < count; ++i) {
-      const uint32_t e = S.bvh_leaf[first + i];
-      if (CSG && (e & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
-        if constexpr (CSG) visit_csg(S, e & ~RTC_NODE_BIT, ray, vis, overflow);
+      const BvhLeafRec& L = S.bvh_leaf[first + i];
+      if (CSG && (L.leaf & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
+        if constexpr (CSG) visit_csg(S, L.leaf & ~RTC_NODE_BIT, ray, vis, overflow);
       } else {
-        visit_leaf(S, e, ray, degenerate, cur_xf, lr, vis);
+        visit_leaf(S, L, ray, degenerate, cur_xf, lr, vis);
       }
     }
   }
