@@ -370,6 +370,7 @@ struct HostTables {
   std::vector<uint32_t> node_parent;
   std::vector<BvhNode> bvh_nodes;      // the binary SAH trees (host only)
   std::vector<Bvh4Node> bvh4_nodes;    // ... collapsed to four children per node: what the kernel walks
+  bool chain_nested = false;           // every reference node box lies inside its parent's box
   std::vector<uint32_t> bvh_leaves;
   std::vector<uint32_t> node_info;
   std::vector<uint2> node_range;
@@ -951,6 +952,17 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
   if (bvh_leaves.size() >= (1u << 28)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the BVH leaf-range encoding", bvh_leaves.size());
   buildRootTables(d, dfs_of, bvh_root_of, T);
   copyPlainTables(d, T);
+  // Group boxes are unions of their children's boxes (group.zig:23-37), so they nest - unless a csg kept a stale box
+  // (shape.zig:298-302) or the caller's tables are not the reference's.  Checked, not assumed: the kernel's chain
+  // replay stops at the innermost box only if they do.
+  T.chain_nested = true;
+  for (uint32_t n = 0; n < d.n_nodes && T.chain_nested; ++n) {
+    const uint32_t p = node_parent[n];
+    if (p == RTC_NO_LEAF) continue;
+    for (int k = 0; k < 3; ++k)
+      if (!(d.node_min[3ull * n + k] >= d.node_min[3ull * p + k] && d.node_max[3ull * n + k] <= d.node_max[3ull * p + k]))
+        T.chain_nested = false;
+  }
 
   return RTC_OK;
 }
@@ -1111,6 +1123,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   D.img_rgb = s->img_rgb.p;
   D.node_range = s->node_range.p;
   D.bvh_mag = bvh_mag;
+  D.chain_nested = T.chain_nested ? 1u : 0u;
   D.node_box = s->node_box.p;
   D.node_kids = s->node_kids.p;
   D.kids = s->kids.p;

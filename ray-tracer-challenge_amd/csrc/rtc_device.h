@@ -180,6 +180,7 @@ struct DevScene {
   uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
   float cull_cmax;  // max over bounded roots of |centre|: scale of the FP32 rounding margin
   float bvh_mag;    // max |coordinate| of any finite BVH box: scale of the FP32 traversal margin
+  uint32_t chain_nested;  // every reference Group box lies inside its parent's: a ray that passes the innermost passes all
 };
 
 struct DevCamera {
