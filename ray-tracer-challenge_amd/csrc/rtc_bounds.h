@@ -276,12 +276,10 @@ struct BvhBuilder {
   // returns the child reference for prims[first, first+count)
   uint32_t build(size_t first, size_t count, uint32_t depth = 1) {
     max_depth = std::max(max_depth, depth);
-    // One or two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
-    // tests together), the four-wide nodes and the final schedule, measured at 1 / 2 / 3 / 4 leaves per node:
-    // dragons 4K 4.44 / 4.63 / 4.81 / 5.11 ms, nefertiti 0.88 / 0.89 / 0.92 / 0.94 ms, teapot (6 320 triangles)
-    // 0.397 / 0.385 / 0.386 / 0.411 ms: one for the large meshes, two for the small ones.
-    static const size_t forced_leaf = getenv("RTC_BVH_LEAF") ? std::min<size_t>(8, std::max<size_t>(1, atoi(getenv("RTC_BVH_LEAF")))) : 0;
-    const size_t max_leaf = forced_leaf ? forced_leaf : (prims.size() >= 20000 ? 1 : 2);
+    // Up to two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
+    // tests together), the four-wide nodes and the final schedule, measured at 1 / 2 / 3 leaves per node:
+    // dragons 4K 2.78 / 2.72 / 2.73 ms, nefertiti 0.728 / 0.713 / 0.719 ms, teapot 0.382 / 0.357 / 0.368 ms.
+    static const size_t max_leaf = getenv("RTC_BVH_LEAF") ? std::min<size_t>(8, std::max<size_t>(1, atoi(getenv("RTC_BVH_LEAF")))) : 2;
     if (count <= max_leaf) {
       const uint32_t at = static_cast<uint32_t>(leaves.size());
       for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);

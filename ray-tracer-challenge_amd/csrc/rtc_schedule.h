@@ -75,12 +75,14 @@ std::vector<uint32_t> chunkTimes(const DevPixelMap& map, const std::vector<uint3
 }
 
 // Cheap chunks are handed out several to a packet, up to this much measured time (s_memtime ticks / 16: 8000 is about
-// 50 us).  Scenes with meshes get three times as much: the chunks of a packet are image neighbours, and a wave that
-// walks the same BVH nodes for all of them finds them in its CU's L1 (teapot 0.42 -> 0.40 ms; 98 % of the kernel's
-// loads hit L1, a chunk among strangers at the end of the list takes four times what it takes among neighbours).
+// 50 us).  Scenes with meshes get twice as much: the chunks of a packet are image neighbours, and a wave that
+// walks the same BVH nodes for all of them finds them in its CU's L1 (98 % of the kernel's loads hit L1; a chunk among
+// strangers at the end of the list takes four times what it takes among neighbours).  Measured at 8000 / 16000 /
+// 24000 / 40000: teapot 0.370 / 0.362 / 0.356 / 0.361 ms, nefertiti 0.713 / 0.720 / 0.733 / 0.775 ms, dragons 4K
+// 2.79 / 2.78 / 2.79 / 2.91 ms.
 inline double groupFloor(const rtc_scene* s) {
   static const double forced = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 0.0;
-  return forced > 0.0 ? forced : (s->simple_kernel ? 8000.0 : 24000.0);
+  return forced > 0.0 ? forced : (s->simple_kernel ? 8000.0 : 16000.0);
 }
 
 // The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,
