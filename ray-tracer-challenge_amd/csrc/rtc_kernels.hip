@@ -518,11 +518,13 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
   // on dragons.json).
   uint32_t stack[RTC_TRAV_STACK];
   int sp = 0;
-  stack[sp++] = root;
+  uint32_t next = root;  // the node to visit next stays in a register: the stack (scratch memory) is one more dependent fetch
   for (;;) {
     uint32_t leaf_ref = RTC_NO_LEAF;
-    while (sp > 0 && !vis.done()) {
-      const uint32_t ref = stack[--sp];
+    while ((next != RTC_NO_LEAF || sp > 0) && !vis.done()) {
+      uint32_t ref = next;
+      next = RTC_NO_LEAF;
+      if (ref == RTC_NO_LEAF) ref = stack[--sp];
       if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
         leaf_ref = ref;
         break;
@@ -582,8 +584,12 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
         order(1, 2);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (key[k] < __builtin_inff()) stack[sp++] = refs[k];
+      for (int k = 0; k < 4; ++k) {
+        if (key[k] < __builtin_inff()) {
+          if (next != RTC_NO_LEAF) stack[sp++] = next;  // the last child entered (the nearest, where they are sorted) is not pushed
+          next = refs[k];
+        }
+      }
     }
     if (leaf_ref == RTC_NO_LEAF) break;  // nothing left (or the visitor is done)
     const uint32_t first = (leaf_ref & ~RTC_NODE_BIT) >> 3, count = (leaf_ref & 7u) + 1u;
