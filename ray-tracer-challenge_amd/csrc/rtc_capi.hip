@@ -1031,6 +1031,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     L.xform = m.y;
     L.material = m.z;
     L.geom = m.w;
+    L.parent = leaf_parent[L.leaf];
     const uint32_t kind = m.x & 0xFFu;
     if (kind == RTC_TRIANGLE || kind == RTC_SMOOTH_TRIANGLE) std::memcpy(L.tri, &tri[9ull * m.w], sizeof L.tri);
   }

@@ -111,7 +111,8 @@ struct BvhLeafRec {
   uint32_t xform;       // leaf_meta.y
   uint32_t material;    // leaf_meta.z
   uint32_t geom;        // leaf_meta.w
-  uint32_t pad_[3];
+  uint32_t parent;      // leaf_parent[leaf]: where the replay of the reference's box chain starts
+  uint32_t pad_[2];
   double tri[9];        // p1, e1, e2 of a (smooth) triangle
 };
 

@@ -307,12 +307,12 @@ __device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy,
 // rounding, the line passes through that box and every slab comparison of the reference test holds with
 // room to spare - unless a direction component is below the reference's 1e-5 "parallel" threshold, where
 // the reference test ignores the direction (bounding_box.zig:124-127); then the exact test is run.
-__device__ __forceinline__ bool chain_ok(const DevScene& S, uint32_t leaf, const Ray& ray, double t, bool degenerate) {
+__device__ __forceinline__ bool chain_ok(const DevScene& S, uint32_t first_parent, const Ray& ray, double t, bool degenerate) {
   const double px = ray.ox + ray.dx * t, py = ray.oy + ray.dy * t, pz = ray.oz + ray.dz * t;
   const double scale = zmax(zmax(__builtin_fabs(px), __builtin_fabs(py)), __builtin_fabs(pz)) +
                        zmax(zmax(__builtin_fabs(ray.ox), __builtin_fabs(ray.oy)), __builtin_fabs(ray.oz));
   const double m = 1e-9 * (1.0 + scale);
-  uint32_t n = S.leaf_parent[leaf];
+  uint32_t n = first_parent;  // leaf_parent[] of the leaf
   while (n != RTC_NO_LEAF) {
     const double* __restrict__ B = S.node_box + 6ull * n;
     const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4], b5 = B[5];
@@ -359,9 +359,9 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, const BvhLeafRec& 
   });
   if (!relevant) return;
 #ifdef RTC_EXP_EXACTCHAIN  // diagnostic: always run the exact reference box tests
-  if (!chain_ok(S, leaf, ray, t_rel, true)) return;
+  if (!chain_ok(S, L.parent, ray, t_rel, true)) return;
 #else
-  if (!chain_ok(S, leaf, ray, t_rel, degenerate)) return;
+  if (!chain_ok(S, L.parent, ray, t_rel, degenerate)) return;
 #endif
   leaf_entries(kind, cy, L.tri, lr,
                [&](double t, double u, double v) { vis.entry(leaf, shadow, meta.z, t, u, v); });
@@ -410,7 +410,7 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
     leaf_entries(kind, cy, S.tri + 9ull * meta.w, lr, [&](double t, double u, double v) {
       if (!any) {
         any = true;
-        boxes = chain_ok(S, leaf, ray, t, degenerate);
+        boxes = chain_ok(S, S.leaf_parent[leaf], ray, t, degenerate);
       }
       if (!boxes) return;
       if (n >= RTC_CSG_ENTRIES) {
