@@ -349,6 +349,20 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, const BvhLeafRec& 
     cy = {c.ymin, c.ymax, c.closed != 0u};
   }
   const uint32_t shadow = (meta.x >> 8) & 1u;
+  if (kind == 4u || kind == 5u) {  // a triangle has at most one entry: evaluate it once
+    bool hit = false;
+    double ht = 0.0, hu = 0.0, hv = 0.0;
+    leaf_entries(kind, cy, L.tri, lr, [&](double t, double u, double v) {
+      hit = true;
+      ht = t;
+      hu = u;
+      hv = v;
+    });
+    if (!hit || !vis.relevant(leaf, shadow, ht)) return;
+    if (!chain_ok(S, L.parent, ray, ht, degenerate)) return;
+    vis.entry(leaf, shadow, meta.z, ht, hu, hv);
+    return;
+  }
   bool relevant = false;
   double t_rel = 0.0;
   leaf_entries(kind, cy, L.tri, lr, [&](double t, double, double) {
