@@ -1,0 +1,121 @@
+// ASan/UBSan fuzz of the schedule packers (rtc_schedule.h) on the CPU: random per-pixel costs and per-chunk times,
+// rectangle and tile pixel maps, few and many waves.  Every packed schedule must hand out every pixel of every chunk
+// exactly once (checked here, independently of packSchedule's own self-check), and chunkTimes must account for the
+// whole measured time.  Includes the library's translation unit to reach its file-local functions.
+#include "../../ray-tracer-challenge_amd/csrc/rtc_capi.hip"
+
+#include <random>
+
+namespace {
+
+bool coversOnce(const std::vector<uint32_t>& order, uint32_t n_chunks, const char* what) {
+  std::vector<uint8_t> seen(static_cast<size_t>(n_chunks) * 64u, 0);
+  size_t covered = 0;
+  if (order.size() % RTC_PACKET_ITEMS) {
+    std::printf("FAIL %s: order size %zu\n", what, order.size());
+    return false;
+  }
+  for (uint32_t it : order) {
+    if (it == RTC_NO_ITEM) continue;
+    const uint32_t c = it & 0xFFFFFu, start = (it >> 20) & 63u, len = (it >> 26) + 1u;
+    if (c >= n_chunks || start + len > 64u) {
+      std::printf("FAIL %s: item %08x out of range\n", what, it);
+      return false;
+    }
+    for (uint32_t k = start; k < start + len; ++k, ++covered)
+      if (seen[static_cast<size_t>(c) * 64u + k]++) {
+        std::printf("FAIL %s: chunk %u pixel %u twice\n", what, c, k);
+        return false;
+      }
+  }
+  if (covered != seen.size()) {
+    std::printf("FAIL %s: %zu of %zu pixels\n", what, covered, seen.size());
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+int main() {
+  std::mt19937 rng(12345);
+  int failures = 0, cases = 0;
+  for (int rep = 0; rep < 60; ++rep) {
+    DevPixelMap map;
+    std::memset(&map, 0, sizeof map);
+    rtc_camera cam;
+    std::memset(&cam, 0, sizeof cam);
+    cam.hsize = 64 + rng() % 900;
+    cam.vsize = 64 + rng() % 500;
+    size_t out_pixels = 0;
+    if (rep % 2 == 0) {
+      const uint32_t w = 8 + rng() % (cam.hsize - 8), h = 8 + rng() % (cam.vsize - 8);
+      if (buildPixelMapRect(cam, rng() % (cam.hsize - w + 1), rng() % (cam.vsize - h + 1), w, h, map) != RTC_OK) return 2;
+      out_pixels = static_cast<size_t>(w) * h;
+    } else {  // as rtc_render_tiles_device sets it up
+      map.mode = 1;
+      map.tile_w = 8u * (1 + rng() % 8) + (rng() % 3 == 0 ? 4 : 0);
+      map.tile_h = 8u * (1 + rng() % 8);
+      map.tiles_x = (cam.hsize + map.tile_w - 1) / map.tile_w;
+      const uint32_t tiles_y = (cam.vsize + map.tile_h - 1) / map.tile_h, n_tiles = map.tiles_x * tiles_y;
+      map.tile_stride = 1 + rng() % 8;
+      map.first_tile = rng() % map.tile_stride;
+      map.n_my_tiles = map.first_tile < n_tiles ? (n_tiles - map.first_tile + map.tile_stride - 1) / map.tile_stride : 0;
+      if (map.n_my_tiles == 0) continue;
+      map.chunks_x = (map.tile_w + 7) / 8;
+      map.chunks_per_region = map.chunks_x * ((map.tile_h + 7) / 8);
+      map.n_chunks = map.chunks_per_region * map.n_my_tiles;
+      out_pixels = static_cast<size_t>(map.n_my_tiles) * map.tile_w * map.tile_h;
+    }
+    if (map.n_chunks < 64 || map.n_chunks >= RTC_ITEM_MAX_CHUNKS) continue;
+    // a "scene": mostly cheap pixels, blobs of deep ray trees, a few absurd values
+    std::vector<uint32_t> cost(out_pixels);
+    const int style = rng() % 4;
+    for (size_t i = 0; i < out_pixels; ++i) {
+      uint32_t c = 2 + rng() % 4;
+      if (style >= 1 && (i / 97) % 11 == 0) c = 40 + rng() % 200;
+      if (style == 2 && rng() % 5000 == 0) c = 100000;
+      if (style == 3) c = 3;
+      cost[i] = c;
+    }
+    // per-chunk sums the way rtc_chunk_cost_kernel produces them, and measured times loosely tied to them
+    std::vector<uint32_t> chunk_cost(map.n_chunks, 0), chunk_time(map.n_chunks, 0);
+    for (uint32_t c = 0; c < map.n_chunks; ++c) {
+      const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region, ccy = cr / map.chunks_x;
+      const uint32_t rx0 = (cr - ccy * map.chunks_x) * 8u, ry0 = ccy * 8u;
+      const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
+      const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
+      for (uint32_t k = 0; k < 64u; ++k) {
+        const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
+        if (rx < w && ry < h) chunk_cost[c] += cost[out0 + static_cast<size_t>(ry) * w + rx];
+      }
+      chunk_time[c] = rng() % 50 == 0 ? 0u : static_cast<uint32_t>(chunk_cost[c] * (8.0 + rng() % 8));
+    }
+    for (double n_waves : {4.0, 256.0, 2048.0}) {
+      rtc_scene s;
+      s.simple_kernel = rep % 3 == 0;
+      char what[128];
+      std::snprintf(what, sizeof what, "rep %d mode %u chunks %u waves %.0f", rep, map.mode, map.n_chunks, n_waves);
+      ++cases;
+      if (!packWholeChunks(&s, map, chunk_time, n_waves)) packSchedule(&s, map, cost, chunk_cost, chunk_time, n_waves, 1 + rng() % 8);
+      if (!coversOnce(s.h_order, map.n_chunks, what)) {
+        ++failures;
+        continue;
+      }
+      // a measuring launch under that schedule: every packet reports a time; the chunks must get all of it back
+      const size_t n_packets = s.h_order.size() / RTC_PACKET_ITEMS;
+      std::vector<uint32_t> packet_time(n_packets);
+      double total = 0.0;
+      for (uint32_t& t : packet_time) total += (t = 100 + rng() % 100000);
+      const std::vector<uint32_t> back = chunkTimes(map, chunk_cost, packet_time, s.h_order);
+      double sum = 0.0;
+      for (uint32_t t : back) sum += t;
+      if (back.size() != map.n_chunks || std::fabs(sum - total) > 1.0 * map.n_chunks + 1e-6 * total) {
+        std::printf("FAIL %s: chunkTimes returns %.0f of %.0f\n", what, sum, total);
+        ++failures;
+      }
+    }
+  }
+  std::printf("pack_fuzz: %d cases, %d failures\n", cases, failures);
+  return failures ? 1 : 0;
+}
