@@ -653,7 +653,7 @@ typedef float Float2 __attribute__((ext_vector_type(2)));
 // Phase 1 of the root loop for TWO roots: the arithmetic runs as packed FP32 (v_pk_fma_f32 & co: one instruction per
 // pair of roots), only the comparisons are per root.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.
 template <class V>
-__device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF& ray) {
+__device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF ray) {  // by value: by reference, three fields went through scratch memory
   // explicit FMAs: this file is compiled with contraction off for the FP64 path, but nothing here has
   // to round like the reference
   const Float2 ocx = R.cx - ray.ox, ocy = R.cy - ray.oy, ocz = R.cz - ray.oz;
