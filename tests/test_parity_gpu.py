@@ -170,6 +170,40 @@ def test_canvas_is_fully_written(rtc):
         assert np.isnan(tiles[t, hh:]).all() and np.isnan(tiles[t, :, ww:]).all()
 
 
+def test_group_boxes_that_do_not_nest(rtc):
+    """The chain replay stops at the innermost Group box only if rtc_scene_create finds every box inside its
+    parent's.  A description whose tables break that (here: inner boxes of groups.json and teapot.json blown up or
+    parents shrunk, so that rays pass an inner box and miss an outer one) must take the full replay and still match
+    the oracle, which tests every box on the way down like the reference (group.zig:46-50)."""
+    import ctypes as C
+    for scene, w, h in (("groups.json", 150, 50), ("teapot.json", 96, 54)):
+        hs = rtc.HostScene.from_file(scene)
+        d = type(hs.desc)()  # a shallow copy: same arrays, except the two replaced below
+        C.memmove(C.byref(d), C.byref(hs.desc), C.sizeof(d))
+        n = d.n_nodes
+        assert n > 3
+        lo = np.ctypeslib.as_array(d.node_min, (n, 3)).copy()
+        hi = np.ctypeslib.as_array(d.node_max, (n, 3)).copy()
+        rng = np.random.default_rng(7)
+        finite = np.isfinite(lo).all(axis=1) & np.isfinite(hi).all(axis=1)
+        picks = rng.choice(np.flatnonzero(finite), size=max(2, int(finite.sum()) // 3), replace=False)
+        for k in picks:  # shrink some boxes towards their centre: their children now stick out
+            c = 0.5 * (lo[k] + hi[k])
+            lo[k] = c + 0.6 * (lo[k] - c)
+            hi[k] = c + 0.6 * (hi[k] - c)
+        d.node_min = lo.ctypes.data_as(C.POINTER(C.c_double))
+        d.node_max = hi.ctypes.data_as(C.POINTER(C.c_double))
+        cam = hs.camera(w, h)
+        gpu = rtc.GpuScene(d)
+        got = gpu.render(cam, 5)
+        want, counters = ob.OracleScene(d).render(cam, 5)
+        base, _ = ob.OracleScene(hs.desc).render(cam, 5)
+        assert np.abs(want - base).max() > 1e-3, "the doctored boxes must change the image, or the test tests nothing"
+        assert np.abs(got - want).max() < TOL, scene
+        st = gpu.stats()
+        assert st["overflow"] == 0 and st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"]
+
+
 def test_default_world_kat_through_the_abi(rtc):
     """camera.zig:171-187: default world, 11x11, fov pi/2, from (0,0,-5): pixel (5,5) = (0.38066, 0.47583, 0.2855)."""
     scene = """{"camera":{"width":11,"height":11,"field-of-view":1.5707963267948966,"from":[0,0,-5],"to":[0,0,0],"up":[0,1,0]},
