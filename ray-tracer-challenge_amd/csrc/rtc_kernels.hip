@@ -1256,6 +1256,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   __shared__ DevPattern lds_pat[LDS ? RTC_LDS_PATTERNS : 1];
   __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
   __shared__ Mail lds_mail[4][64];  // per wave: rays handed from busy lanes to idle ones
+  // The colour a lane has accumulated for its pixel: touched once per iteration and when the pixel is finished, live
+  // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
+  // six VGPRs of a kernel at the 256-register limit.
+  __shared__ double lds_acc[4][64][3];
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -1301,7 +1305,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // cost feedback: traces this lane spent on its share of the pixel (closest-hit 2, containers 2, shadow 1 each:
   // roughly their shares of an iteration's time; a pixel behind glass costs several times a pixel on a wall per ray)
   uint32_t share_rays = 0u;
-  double acc_r = 0.0, acc_g = 0.0, acc_b = 0.0;
+  double* const acc = lds_acc[threadIdx.x >> 6][threadIdx.x & 63u];
+  acc[0] = acc[1] = acc[2] = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
   cur.ray = {0, 0, 0, 0, 0, 0};
@@ -1342,6 +1347,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sp = base = 0;
         if (has_pixel) {
           double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
+          const double acc_r = acc[0], acc_g = acc[1], acc_b = acc[2];
 #ifdef RTC_EXP_NOWRITE  // traffic experiment only: the canvas is never written
           if (acc_r == 12345.678) {
 #elif defined(RTC_EXP_STORE)  // traffic experiment only (wrong for shared pixels)
@@ -1423,7 +1429,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           have_cur = true;
           has_pixel = true;
           shared = true;
-          acc_r = acc_g = acc_b = 0.0;
+          acc[0] = acc[1] = acc[2] = 0.0;
           n_stolen++;
         }
       }
@@ -1546,7 +1552,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       have_cur = true;
       has_pixel = true;
       shared = false;
-      acc_r = acc_g = acc_b = 0.0;
+      acc[0] = acc[1] = acc[2] = 0.0;
       n_primary++;
     }
     if (!__any(have_cur)) break;
@@ -1793,9 +1799,9 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sb = sb + lb_;
       }
     }
-    acc_r += cur.weight * sr;
-    acc_g += cur.weight * sg;
-    acc_b += cur.weight * sb;
+    acc[0] += cur.weight * sr;
+    acc[1] += cur.weight * sg;
+    acc[2] += cur.weight * sb;
 
     RTC_STAMP(6);
     // ---- reflectedColor / refractedColor / schlick (world.zig:98-107, 157-189, 272-289)
