@@ -31,6 +31,9 @@
 #ifndef RTC_TRAV_STACK
 #define RTC_TRAV_STACK 64
 #endif
+#ifndef RTC_LDS_TRAV
+#define RTC_LDS_TRAV 8  // entries of the BVH walk's stack kept in LDS (the rest in scratch memory)
+#endif
 #ifndef RTC_MAX_DEPTH
 #define RTC_MAX_DEPTH 16
 #endif

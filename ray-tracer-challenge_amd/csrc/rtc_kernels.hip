@@ -509,7 +509,7 @@ __device__ __forceinline__ void visit_csg(const DevScene& S, uint32_t unit, cons
 // skipped; visitors prune by t-interval with their own slack.
 template <bool CSG, class V>
 __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, const Ray& ray, V& vis,
-                                             unsigned& overflow) {
+                                             unsigned& overflow, uint32_t* lds_stack) {
   const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
   const float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
 #ifdef RTC_EXP_BIGDELTA
@@ -530,15 +530,29 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
   // 64-byte fetch per step), then all lanes that hold one run the expensive exact FP64 leaf test TOGETHER.  With
   // one loop that does either per iteration, lanes at leaves and lanes at nodes take turns (33 % of lanes active
   // on dragons.json).
-  uint32_t stack[RTC_TRAV_STACK];
+  // The first RTC_LDS_TRAV entries of the stack live in LDS ([entry][lane]: conflict-free), the rest in scratch: a pop
+  // sits between two dependent fetches, and LDS answers sooner than the vector memory path.
+  uint32_t stack[RTC_TRAV_STACK - RTC_LDS_TRAV];
   int sp = 0;
+  auto push = [&](uint32_t v) {
+    if (sp < RTC_LDS_TRAV) {
+      lds_stack[sp * 64] = v;
+    } else {
+      stack[sp - RTC_LDS_TRAV] = v;
+    }
+    ++sp;
+  };
+  auto pop = [&]() {
+    --sp;
+    return sp < RTC_LDS_TRAV ? lds_stack[sp * 64] : stack[sp - RTC_LDS_TRAV];
+  };
   uint32_t next = root;  // the node to visit next stays in a register: the stack (scratch memory) is one more dependent fetch
   for (;;) {
     uint32_t leaf_ref = RTC_NO_LEAF;
     while ((next != RTC_NO_LEAF || sp > 0) && !vis.done()) {
       uint32_t ref = next;
       next = RTC_NO_LEAF;
-      if (ref == RTC_NO_LEAF) ref = stack[--sp];
+      if (ref == RTC_NO_LEAF) ref = pop();
       if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
         leaf_ref = ref;
         break;
@@ -600,7 +614,7 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (key[k] < __builtin_inff()) {
-          if (next != RTC_NO_LEAF) stack[sp++] = next;  // the last child entered (the nearest, where they are sorted) is not pushed
+          if (next != RTC_NO_LEAF) push(next);  // the last child entered (the nearest, where they are sorted) is not pushed
           next = refs[k];
         }
       }
@@ -689,7 +703,8 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 // survivors is most of the world while each lane's own list is 2-4 roots long.
 template <bool CSG, bool SIMPLE, class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
-                                      const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow) {
+                                      const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow,
+                                      uint32_t* lds_stack) {
   const RayF rf = ray_f32(ray, S.cull_cmax);
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
@@ -720,7 +735,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         if (CSG && (kf & RTC_ROOT_IS_CSG)) {
           if constexpr (CSG) visit_csg(S, R.index, ray, vis, overflow);
         } else {
-          traverse_bvh<CSG>(S, R.geom, ray, vis, overflow);
+          traverse_bvh<CSG>(S, R.geom, ray, vis, overflow, lds_stack);
         }
       }
     }  // while (mine)
@@ -1260,6 +1275,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
   // six VGPRs of a kernel at the 256-register limit.
   __shared__ double lds_acc[4][64][3];
+  __shared__ uint32_t lds_trav[SIMPLE ? 1 : 4][SIMPLE ? 1 : RTC_LDS_TRAV][64];  // per lane: the top of the BVH walk's stack
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -1306,6 +1322,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // roughly their shares of an iteration's time; a pixel behind glass costs several times a pixel on a wall per ray)
   uint32_t share_rays = 0u;
   double* const acc = lds_acc[threadIdx.x >> 6][threadIdx.x & 63u];
+  uint32_t* const trav_stack = SIMPLE ? nullptr : &lds_trav[threadIdx.x >> 6][0][threadIdx.x & 63u];
   acc[0] = acc[1] = acc[2] = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
@@ -1571,7 +1588,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_COUNT(0);
     {
       RTC_HIST_BEGIN();
-      trace<CSG, SIMPLE>(S, recs, cull, ray, hv, overflow);
+      trace<CSG, SIMPLE>(S, recs, cull, ray, hv, overflow, trav_stack);
       RTC_HIST_END(0);
     }
     RTC_STAMP(2);
@@ -1616,7 +1633,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       RTC_COUNT(4);
       {
         RTC_HIST_BEGIN();
-        trace<CSG, SIMPLE>(S, recs, cull, ray, bv, overflow);
+        trace<CSG, SIMPLE>(S, recs, cull, ray, bv, overflow, trav_stack);
         RTC_HIST_END(2);
       }
       RTC_STAMP(6);
@@ -1763,7 +1780,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, SIMPLE>(S, recs, cull, sray, sv, overflow);
+            trace<CSG, SIMPLE>(S, recs, cull, sray, sv, overflow, trav_stack);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
