@@ -87,3 +87,17 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
     ops[0] = 9
     assert lib.rtc_scene_create(C.byref(d2), C.byref(out)) == 1
     ops[0] = 3
+
+
+def test_zig_binding_in_integration_md_matches_the_header():
+    """INTEGRATION.md shows the extern struct a Zig maintainer would declare; its fields must be rtc.h's, in order."""
+    import re
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(repo, "include", "rtc.h")).read()
+    i = header.index("typedef struct rtc_scene_desc")
+    body = re.sub(r"/\*.*?\*/", "", header[i:header.index("} rtc_scene_desc;", i)], flags=re.S)
+    c_fields = re.findall(r"(?:const\s+)?(?:uint\d+_t|double|float)\s*\*?\s*(\w+)\s*;", body)
+    md = open(os.path.join(repo, "INTEGRATION.md")).read()
+    i = md.index("pub const RtcSceneDesc = extern struct {")
+    zig_fields = re.findall(r"(\w+):", md[i:md.index("};", i)])
+    assert len(c_fields) > 50 and c_fields == zig_fields
