@@ -145,6 +145,8 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->launches_with_key = 0;
     s->order_from_cost = false;
     s->cost_pending = false;
+    if (s->readback_enqueued) HIP_TRY(hipEventSynchronize(s->measure_done));  // (its copies must not land in a later read-back's buffers)
+    s->readback_enqueued = false;
   }
   if (out_pixels > s->cost_capacity) {
     if (s->d_cost) (void)hipFree(s->d_cost);
@@ -154,33 +156,37 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->cost_capacity = out_pixels;
     s->launches_with_key = 0;
     s->cost_pending = false;
+    s->readback_enqueued = false;
   }
   const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
-  if (schedulable && s->cost_pending) {
+  bool pack_now = false;
+  if (schedulable && s->cost_pending && s->readback_enqueued) {
+    // The measurements of an earlier launch are on their way to the host (enqueueReadback).  The launch right after the
+    // FIRST measuring launch waits for them: the heuristic schedule is worth replacing at once.  Later re-measurements
+    // (a moving camera) are picked up by whichever launch finds them complete; frames queued meanwhile are not drained.
+    // A caller that enqueues frames faster than the GPU renders them is held back here once it is eight launches past
+    // the measuring one: the wait is for the event, i.e. until the GPU is within eight queued frames of the host, so the
+    // GPU never runs dry, and no schedule is used for more than 16 + 8 frames of a moving view.
+    hipError_t ready = hipEventQuery(s->measure_done);
+    if (ready == hipErrorNotReady && (!s->order_from_cost || s->launches_since_measure >= 8u)) {
+      HIP_TRY(hipEventSynchronize(s->measure_done));
+      ready = hipSuccess;
+    }
+    if (ready == hipSuccess) {
+      pack_now = true;
+    } else if (ready != hipErrorNotReady) {
+      HIP_TRY(ready);
+    }
+  }
+  if (pack_now) {
+    s->cost_pending = false;
+    s->readback_enqueued = false;
     s->sched_cam = s->cost_cam;
     s->sched_depth = s->cost_depth;
     const auto t_a = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
-    const auto t_b = std::chrono::steady_clock::now();
-    // per-chunk sums first (a tiny kernel, 4 bytes per chunk to copy); the per-pixel costs only if a chunk must be split
-    if (map.n_chunks > s->chunk_cost_capacity) {
-      if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
-      s->d_chunk_cost = nullptr;
-      s->chunk_cost_capacity = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
-      s->chunk_cost_capacity = map.n_chunks;
-    }
-    hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, s->last_stream, s->d_cost, map,
-                       s->d_chunk_cost);
-    HIP_TRY(hipGetLastError());
-    s->h_chunk_cost.resize(map.n_chunks);
-    HIP_TRY(hipMemcpyAsync(s->h_chunk_cost.data(), s->d_chunk_cost, s->h_chunk_cost.size() * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, s->last_stream));
-    const size_t n_measured = s->measured_order.empty() ? map.n_chunks : s->measured_order.size() / RTC_PACKET_ITEMS;
-    s->h_packet_time.resize(n_measured);
-    HIP_TRY(hipMemcpyAsync(s->h_packet_time.data(), s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                           s->last_stream));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    const auto t_b = t_a;
+    s->h_chunk_cost.assign(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
+    s->h_packet_time.assign(s->pin_packet_time, s->pin_packet_time + s->readback_packets);
     // what every chunk really took: a packet's time, shared among its items by their cost
     std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
     // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
@@ -216,22 +222,29 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     const int st = chunkOrder(s, cam, map, stream);
     if (st != RTC_OK) return st;
   }
-  // Per-pixel ray counts are collected by the first launch with a pixel map, and after that by every 64th
-  // launch IF the view has changed since the schedule in use was measured (an orbiting camera, lib.zig's
-  // interactive mode); a static view keeps its schedule and pays nothing.  The successor of a collecting
-  // launch re-packs (one stream sync, a 4-byte-per-pixel copy, O(pixels) on the host: ~0.7 ms at 1080p).
+  // Per-pixel ray counts and packet times are collected by the first launch with a pixel map, and after that by every
+  // 16th launch IF the view has changed since the schedule in use was measured (an orbiting camera, lib.zig's
+  // interactive mode: a schedule packed for a view 40 degrees away doubles the frame time); a static view keeps its
+  // schedule and pays nothing.  Packing costs the host 1.4 ms at 1080p and no stream synchronisation.
   const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
   static const bool always_time = getenv("RTC_TIME_ALWAYS") != nullptr;  // diagnostic: time the packets of every launch
-  const bool collect = schedulable && (s->launches_with_key == 0 || (s->launches_with_key % 64 == 63 && view_changed) || always_time);
-  s->cost_pending = collect && !(always_time && s->launches_with_key > 0);
   static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: keep the first launch's schedule
-  if (sched_off) s->cost_pending = false;
+  // (no new measurement while one is still on its way to the host)
+  const bool measure = schedulable && !s->cost_pending && !sched_off &&
+                       (s->launches_with_key == 0 || (s->launches_with_key % 16 == 15 && view_changed));
+  const bool collect = measure || (schedulable && always_time && !s->cost_pending);
+  if (measure) {
+    s->cost_pending = true;
+    s->launches_since_measure = 0;
+  } else {
+    s->launches_since_measure++;
+  }
   map.packet_time = nullptr;
   if (collect) {
     map.cost = s->d_cost;
     s->cost_cam = cam;
     s->cost_depth = max_depth;
-    if (always_time && s->launches_with_key > 0) map.cost = nullptr;  // diagnostic launches only time the packets
+    if (!measure) map.cost = nullptr;  // diagnostic launches only time the packets
     if (map.n_units > s->packet_time_capacity) {
       HIP_TRY(hipStreamSynchronize(s->last_stream));
       if (s->d_packet_time) (void)hipFree(s->d_packet_time);
@@ -254,6 +267,39 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   }
   s->launches_with_key++;
   s->last_stream = stream;
+  return RTC_OK;
+}
+
+// Right after a measuring launch, on its stream: per-chunk sums of the per-pixel costs, both tables to pinned host
+// memory, an event.  Nothing here waits.
+int enqueueReadback(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
+  if (map.n_chunks > s->chunk_cost_capacity) {
+    if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
+    s->d_chunk_cost = nullptr;
+    s->chunk_cost_capacity = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+    s->chunk_cost_capacity = map.n_chunks;
+  }
+  auto pinned = [](uint32_t*& p, size_t& capacity, size_t n) -> hipError_t {
+    if (n <= capacity) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    capacity = 0;
+    const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) capacity = n;
+    return e;
+  };
+  const size_t n_measured = s->measured_order.empty() ? map.n_chunks : s->measured_order.size() / RTC_PACKET_ITEMS;
+  HIP_TRY(pinned(s->pin_chunk_cost, s->pin_chunk_cost_capacity, map.n_chunks));
+  HIP_TRY(pinned(s->pin_packet_time, s->pin_packet_time_capacity, n_measured));
+  if (!s->measure_done) HIP_TRY(hipEventCreateWithFlags(&s->measure_done, hipEventDisableTiming));
+  hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s->pin_chunk_cost, s->d_chunk_cost, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(s->pin_packet_time, s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(s->measure_done, stream));
+  s->readback_packets = n_measured;
+  s->readback_enqueued = true;
   return RTC_OK;
 }
 
@@ -322,6 +368,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
+  if (map.cost != nullptr && s->cost_pending && !s->readback_enqueued) return enqueueReadback(s, map, stream);
   return RTC_OK;
 }
 
@@ -1185,6 +1232,9 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_cost) (void)hipFree(s->d_cost);
   if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
   if (s->d_packet_time) (void)hipFree(s->d_packet_time);
+  if (s->pin_chunk_cost) (void)hipHostFree(s->pin_chunk_cost);
+  if (s->pin_packet_time) (void)hipHostFree(s->pin_packet_time);
+  if (s->measure_done) (void)hipEventDestroy(s->measure_done);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
   delete s;

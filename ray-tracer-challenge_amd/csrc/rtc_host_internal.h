@@ -111,6 +111,16 @@ struct rtc_scene {
   size_t chunk_cost_capacity = 0;
   std::vector<uint32_t> h_chunk_cost;
   uint32_t* d_packet_time = nullptr;  // per packet of the measured schedule: the time its wave needed (DevPixelMap::packet_time)
+  // A measuring launch is followed, on its stream, by the per-chunk sums, two copies into pinned host memory and this
+  // event: the launch that finds the event complete packs the new schedule without waiting for anything.
+  hipEvent_t measure_done = nullptr;
+  bool readback_enqueued = false;
+  uint32_t launches_since_measure = 0;
+  size_t readback_packets = 0;
+  uint32_t* pin_chunk_cost = nullptr;
+  size_t pin_chunk_cost_capacity = 0;
+  uint32_t* pin_packet_time = nullptr;
+  size_t pin_packet_time_capacity = 0;
   size_t packet_time_capacity = 0;
   std::vector<uint32_t> h_packet_time;
   std::vector<uint32_t> h_chunk_time_dbg;  // per-chunk times the schedule in use was packed from (diagnostics)

@@ -4,7 +4,8 @@ import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 rtc = importlib.import_module("ray-tracer-challenge_amd")
-hs = rtc.HostScene.from_file("cover.json"); gpu = rtc.GpuScene(hs.desc)
+name = sys.argv[1] if len(sys.argv) > 1 else "cover.json"
+hs = rtc.HostScene.from_file(name); gpu = rtc.GpuScene(hs.desc)
 canvas = torch.empty((1080, 1920, 3), dtype=torch.float64, device="cuda")
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 times = []
