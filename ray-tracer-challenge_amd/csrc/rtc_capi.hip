@@ -418,6 +418,7 @@ struct HostTables {
   std::vector<BvhNode> bvh_nodes;      // the binary SAH trees (host only)
   std::vector<Bvh4Node> bvh4_nodes;    // ... collapsed to four children per node: what the kernel walks
   bool chain_nested = false;           // every reference node box lies inside its parent's box
+  bool plane_spawns_rays = false;      // some top-level plane is reflective or transparent
   std::vector<uint32_t> bvh_leaves;
   std::vector<uint32_t> node_info;
   std::vector<uint2> node_range;
@@ -639,6 +640,10 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
         occupied_spheres.push_back(sp);
       } else if ((ref & RTC_CHILD_NODE_BIT) || d.leaf_kind[ref] != RTC_PLANE) {
         unbounded_nonplane = true;
+      } else {
+        // a plane that reflects or refracts: a pixel that sees "only planes" can still cost a whole ray tree
+        const double* mp = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * d.leaf_material[ref];
+        if (mp[4] != 0.0 || mp[5] != 0.0) T.plane_spawns_rays = true;
       }
     }
     RootCull& C = root_cull[i];
@@ -1133,6 +1138,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   s->branching_everywhere = branching_everywhere;
   s->occupied = occupied_spheres;
   s->unbounded_nonplane = unbounded_nonplane;
+  s->plane_spawns_rays = T.plane_spawns_rays;
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));

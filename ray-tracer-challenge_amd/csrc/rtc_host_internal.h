@@ -94,6 +94,7 @@ struct rtc_scene {
   // heavy-first scheduling hint (see DevPixelMap::order)
   std::vector<Sphere> occupied;    // bounding spheres of every bounded root
   bool unbounded_nonplane = false; // a root other than a plane without a finite bound (cannot be projected)
+  bool plane_spawns_rays = false;  // a top-level plane reflects or refracts: "sees only planes" does not mean cheap
   std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
   bool branching_everywhere = false;  // such a root without a finite bound
   std::vector<uint32_t> h_order;

@@ -449,7 +449,9 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   static const uint32_t per_trivial = getenv("RTC_FIRST_TRIVIAL") ? std::max(1, std::min(16, atoi(getenv("RTC_FIRST_TRIVIAL")))) : 16u;
   emit(order, 1);
   emit(medium, per_medium);
-  emit(trivial, per_trivial);
+  // (chunks that see only planes are cheap only if no plane spawns rays: reflection_and_refraction's mirror floor made
+  // sixteen-chunk packets of 16 ms at the very end of its first frame)
+  emit(trivial, s->plane_spawns_rays ? 1u : per_trivial);
   s->h_order.resize(static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS);
   const int st = uploadSchedule(s, stream);
   if (st != RTC_OK) return st;
