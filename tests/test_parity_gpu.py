@@ -440,7 +440,8 @@ def _random_scene(seed):
                                   "to": [0, 0.5, 0], "up": [0, 1, 0]}, "lights": lights, "objects": objs})
 
 
-@pytest.mark.parametrize("seed", list(range(1, 31)))
+# 410: a cone inside a group reports an entry outside the group's box (found by tools/fuzz_more.py)
+@pytest.mark.parametrize("seed", list(range(1, 31)) + [410])
 def test_random_scenes(rtc, seed):
     hs = rtc.HostScene(_random_scene(seed))
     cam = hs.camera()
