@@ -550,6 +550,7 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
     std::memset(&R, 0, sizeof R);
     const uint32_t ref = d.roots[i];
     Sphere sp;
+    bool line_only = false;  // entries may lie outside the bound: only "the line misses it" may cull
     if (ref & RTC_CHILD_NODE_BIT) {
       const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
       R.kind_flags = RTC_ROOT_IS_GROUP | (opOf(n) != RTC_CSG_NONE ? RTC_ROOT_IS_CSG : 0u);
@@ -559,7 +560,7 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
       const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
       const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-      bool csg_below = false;
+      bool csg_below = false, cone_below = false;
       {
         std::vector<uint32_t> todo{n};
         while (!todo.empty() && !csg_below) {
@@ -573,13 +574,15 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
             } else if (d.leaf_kind[c] == RTC_CONE) {
               // A cone reports the root of a ray parallel to one of its halves without the min < y < max filter
               // (cone.zig): an entry OUTSIDE its own box, hence outside this group's.  Same consequence as a csg
-              // below: the sphere must cover the leaves' own (for a cone: unbounded) boxes, or "the box is behind
-              // the origin" would drop that entry (found by widening the random-scene fuzz to 400 more seeds).
-              csg_below = true;
+              // below, except that the box itself stays a valid bound for "the line misses it": the sphere of the box
+              // is kept and flagged, and the cull then skips its "entirely behind / in front of the origin" rules
+              // (found by widening the random-scene fuzz to 400 more seeds).
+              cone_below = true;
             }
           }
         }
       }
+      line_only = cone_below;
       if (!csg_below) {
         if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
       } else if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
@@ -666,6 +669,10 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       const double r2 = sp.r * sp.r * (1.0 + 1e-5);
       float r2f = static_cast<float>(r2);
       if (static_cast<double>(r2f) < r2) r2f = std::nextafterf(r2f, INFINITY);
+      // the lowest mantissa bit carries `line_only` (set by rounding up once more where it has the wrong value)
+      uint32_t bits;
+      std::memcpy(&bits, &r2f, sizeof bits);
+      if ((bits & 1u) != (line_only ? 1u : 0u)) r2f = std::nextafterf(r2f, INFINITY);
       C.r2 = r2f;
       const float cm = static_cast<float>(std::sqrt(sp.cx * sp.cx + sp.cy * sp.cy + sp.cz * sp.cz) * (1.0 + 1e-6));
       cull_cmax = std::fmax(cull_cmax, std::isfinite(cm) ? cm : 0.0f);

@@ -666,7 +666,7 @@ typedef float Float2 __attribute__((ext_vector_type(2)));
 
 // Phase 1 of the root loop for TWO roots: the arithmetic runs as packed FP32 (v_pk_fma_f32 & co: one instruction per
 // pair of roots), only the comparisons are per root.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.
-template <class V>
+template <class V, bool GROUPS>
 __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF ray) {  // by value: by reference, three fields went through scratch memory
   // explicit FMAs: this file is compiled with contraction off for the FP64 path, but nothing here has
   // to round like the reference
@@ -684,7 +684,10 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     const bool miss = disc[e] < -T[e];                    // the line misses the sphere
-    const bool sided = (ac[e] > T[e]) & (bb[e] > T[e]);   // origin outside, sphere clearly on one side of it
+    // (lowest bit of r2 set: entries of this root may lie outside its bound - a cone in a group - and only `miss` holds)
+    // (a world without groups - the simple kernel - has no such root and does not look)
+    const bool line_only = GROUPS && (__builtin_bit_cast(uint32_t, static_cast<float>(R.r2[e])) & 1u) != 0u;
+    const bool sided = (ac[e] > T[e]) & (bb[e] > T[e]) & !line_only;  // origin outside, sphere clearly on one side of it
     const bool behind = sided & (b[e] < 0.0f);            // entirely at t < 0
     const bool front = sided & (b[e] > 0.0f);             // entirely at t > 0
     const bool culled = miss | (behind & V::kFrontOnly) | (front & V::kBehindOnly);
@@ -712,7 +715,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
     for (uint32_t i = 0; i < n; i += 4u) {
       const RootCullPair p0 = cull[(base + i) >> 1], p1 = cull[((base + i) >> 1) + 1u];
-      const unsigned long long k = roots_kept<V>(p0, rf) | (roots_kept<V>(p1, rf) << 2);
+      const unsigned long long k = roots_kept<V, !SIMPLE>(p0, rf) | (roots_kept<V, !SIMPLE>(p1, rf) << 2);
       mine |= k << i;
     }
     if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
