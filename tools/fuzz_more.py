@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off widening of tests/test_parity_gpu.py::test_random_scenes: the same generator over many more seeds
-(python tools/fuzz_more.py [first] [count]); prints the seeds that break parity or the ray counters."""
+(python tools/fuzz_more.py [first] [count] [depth]); prints the seeds that break parity or the ray counters."""
 import importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -12,12 +12,13 @@ import oracle_binding as ob
 from test_parity_gpu import _random_scene, TOL
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 bad, worst = [], 0.0
 for seed in range(first, first + count):
     hs = rtc.HostScene(_random_scene(seed)); cam = hs.camera()
     gpu = rtc.GpuScene(hs.desc)
-    got = gpu.render(cam, 5)
-    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    got = gpu.render(cam, depth)
+    want, counters = ob.OracleScene(hs.desc).render(cam, depth)
     st = gpu.stats()
     d = float(np.abs(got - want).max())
     worst = max(worst, d)
