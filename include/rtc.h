@@ -25,7 +25,31 @@
  *   - every function returns an rtc_status; the message/name of the last
  *     failure on the calling thread is available from rtc_last_error();
  *   - a handle may be used from one thread at a time; distinct handles are
- *     independent.
+ *     independent;
+ *   - renders on ONE handle run one after the other, whatever streams they are
+ *     enqueued on: a handle owns one set of counters, work counter and per-lane
+ *     scratch, so every launch records an event and a launch on a different
+ *     stream makes that stream wait for it first (no host synchronisation).
+ *     Two handles on two streams overlap freely.
+ *
+ * Limits (a scene beyond them is refused or reported, never rendered differently):
+ *   - a gradient / radial-gradient / blend pattern nested inside another one:
+ *     rtc_scene_create returns RTC_ERR_UNSUPPORTED;
+ *   - pattern select-chains (stripes / checkers / rings / perturb / texture map)
+ *     deeper than 64: RTC_ERR_UNSUPPORTED at create;
+ *   - more than 32 csg nodes under one csg: RTC_ERR_UNSUPPORTED at create; more
+ *     than RTC_CSG_ENTRIES (32) intersections of one ray with one csg unit, or a
+ *     group tree deeper than the traversal stack: the render counts the lane in
+ *     rtc_stats::overflow, rtc_render returns RTC_ERR_OVERFLOW, and callers of the
+ *     asynchronous entry points must check rtc_get_stats;
+ *   - two leaves with the same Shape.id: RTC_ERR_UNSUPPORTED (identity in the
+ *     containers walk is the leaf);
+ *   - reproducibility: geometry and every branch are bit-identical from run to
+ *     run; the colour of a pixel whose ray tree was shared between lanes is the
+ *     sum of the lanes' shares in completion order (f64 atomic adds), so two
+ *     renders of one frame agree to ~1e-15, not bitwise.  A pixel whose tree
+ *     stayed in one lane (every pixel of a scene without transparent
+ *     reflective materials) is bitwise reproducible.
  */
 #ifndef RTC_H
 #define RTC_H
@@ -237,7 +261,9 @@ int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, uint32_t max_dept
  * numbered row-major; this call renders tiles first_tile, first_tile+stride,
  * ... (n_my_tiles of them) into the compact buffer
  * d_rgb_out[k][tile_h][tile_w][3]; pixels of edge tiles that fall outside the
- * image are written as 0.  Asynchronous on `hip_stream` like rtc_render_device.
+ * image are NOT written (the library never clears the caller's buffer: zero it
+ * once if the padding is read, e.g. by a gather).  Asynchronous on `hip_stream`
+ * like rtc_render_device.
  */
 int rtc_render_tiles_device(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
                             uint32_t tile_w, uint32_t tile_h, uint32_t first_tile,

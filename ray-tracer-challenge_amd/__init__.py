@@ -309,8 +309,9 @@ def tile_grid(hsize, vsize, tile_w, tile_h):
 
 
 def tiles_of_rank(n_tiles, rank, world):
-    """Tiles rank, rank+world, ... ; every rank renders the same COUNT (padded by wrapping) so one
-    equal-count gather suffices.  Returns (first_tile, stride, count, padded_count)."""
+    """Tiles rank, rank+world, ... of the row-major tiling.  Returns (first_tile, stride, count, padded_count):
+    `count` tiles are rendered, `padded_count` = ceil(n_tiles / world) is the size of every rank's buffer so that one
+    equal-count gather suffices; slots count..padded_count-1 are never written (allocate the buffer zeroed)."""
     count = (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
     padded = (n_tiles + world - 1) // world
     return rank, world, count, padded

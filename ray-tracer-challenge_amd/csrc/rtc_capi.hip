@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -246,7 +247,7 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->cost_depth = max_depth;
     if (!measure) map.cost = nullptr;  // diagnostic launches only time the packets
     if (map.n_units > s->packet_time_capacity) {
-      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
       if (s->d_packet_time) (void)hipFree(s->d_packet_time);
       s->d_packet_time = nullptr;
       s->packet_time_capacity = 0;
@@ -266,7 +267,6 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     map.cost = nullptr;
   }
   s->launches_with_key++;
-  s->last_stream = stream;
   return RTC_OK;
 }
 
@@ -308,7 +308,7 @@ int enqueueReadback(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
 int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_depth) {
   const size_t need = static_cast<size_t>(blocks) * 4u * (max_depth + 2u) * 64u * 64u;
   if (need > s->ray_stack_capacity) {
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
     if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
     s->d_ray_stack = nullptr;
     s->ray_stack_capacity = 0;
@@ -327,7 +327,7 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   if (s->has_csg) {
     const size_t need_csg = static_cast<size_t>(blocks) * 4u * RTC_CSG_ENTRIES * 64u * sizeof(CsgRec);
     if (need_csg > s->csg_buf_capacity) {
-      HIP_TRY(hipStreamSynchronize(s->last_stream));
+      HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
       if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
       s->d_csg_buf = nullptr;
       s->csg_buf_capacity = 0;
@@ -346,6 +346,11 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
   HIP_TRY(hipSetDevice(s->device));
+  // Launches on one handle share its counters, work counter, pending-ray stacks, csg lists and schedule buffers, and
+  // launch N + 1 clears the counters of launch N + 2: they must run one after the other.  Stream order gives that on
+  // one stream; when the caller changes streams (rtc_render_device on its own stream, then rtc_render on the handle's),
+  // the new stream first waits for everything the handle enqueued before (the event recorded at the end of launch()).
+  if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream); st != RTC_OK) return st;
   const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
@@ -368,7 +373,10 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
-  if (map.cost != nullptr && s->cost_pending && !s->readback_enqueued) return enqueueReadback(s, map, stream);
+  if (map.cost != nullptr && s->cost_pending && !s->readback_enqueued)
+    if (const int st = enqueueReadback(s, map, stream); st != RTC_OK) return st;
+  HIP_TRY(hipEventRecord(s->launch_done, stream));
+  s->last_stream = stream;
   return RTC_OK;
 }
 
@@ -480,6 +488,53 @@ int validateScene(const rtc_scene_desc& d, SceneTraits& traits) {
     if (k == RTC_PAT_GRADIENT || k == RTC_PAT_RADIAL_GRADIENT || k == RTC_PAT_BLEND) {
       if (!selectChainOnly(d, d.pat_a[i]) || !selectChainOnly(d, d.pat_b[i]))
         return fail(RTC_ERR_UNSUPPORTED, "pattern %u: a gradient/blend nested inside a gradient/blend", i);
+    }
+  }
+  {
+    // Depth of the deepest chain of patterns below each pattern (itself included): the device follows a chain for at
+    // most 64 steps (pattern_chain), so a deeper one - or a cycle - is refused here rather than cut short there.
+    std::vector<uint32_t> depth(d.n_patterns, 0u);  // 0: not visited, 0xFFFFFFFF: on the current path
+    std::vector<std::pair<uint32_t, uint32_t>> stack;  // (pattern, next child)
+    auto kidsOf = [&](uint32_t i, uint32_t out[32]) -> uint32_t {
+      switch (d.pat_kind[i]) {
+        case RTC_PAT_STRIPES: case RTC_PAT_RINGS: case RTC_PAT_CHECKERS: case RTC_PAT_GRADIENT: case RTC_PAT_RADIAL_GRADIENT:
+        case RTC_PAT_BLEND: out[0] = d.pat_a[i]; out[1] = d.pat_b[i]; return 2u;
+        case RTC_PAT_PERTURB: out[0] = d.pat_a[i]; return 1u;
+        case RTC_PAT_TEXTURE_MAP: {
+          uint32_t n = 0;
+          for (int f = 0; f < 6; ++f) {
+            const uint32_t u = d.tex_uv[6ull * d.pat_a[i] + f];
+            const uint32_t n_sub = d.uv_kind[u] == RTC_UV_ALIGN_CHECK ? 5u : (d.uv_kind[u] == RTC_UV_CHECKERS ? 2u : 0u);
+            for (uint32_t k = 0; k < n_sub; ++k) out[n++] = d.uv_sub[5ull * u + k];
+          }
+          return n;
+        }
+        default: return 0u;
+      }
+    };
+    for (uint32_t root = 0; root < d.n_patterns; ++root) {
+      if (depth[root] != 0u) continue;
+      stack.push_back({root, 0u});
+      depth[root] = 0xFFFFFFFFu;
+      while (!stack.empty()) {
+        const uint32_t i = stack.back().first;
+        uint32_t kids[32];
+        const uint32_t nk = kidsOf(i, kids);
+        if (stack.back().second < nk) {
+          const uint32_t c = kids[stack.back().second++];
+          if (depth[c] == 0xFFFFFFFFu) return fail(RTC_ERR_UNSUPPORTED, "pattern %u: the pattern graph has a cycle", c);
+          if (depth[c] == 0u) {
+            depth[c] = 0xFFFFFFFFu;
+            stack.push_back({c, 0u});
+          }
+          continue;
+        }
+        uint32_t deepest = 0u;
+        for (uint32_t k = 0; k < nk; ++k) deepest = std::max(deepest, depth[kids[k]]);
+        depth[i] = deepest + 1u;
+        if (depth[i] > 64u) return fail(RTC_ERR_UNSUPPORTED, "pattern %u: a chain of more than 64 nested patterns", i);
+        stack.pop_back();
+      }
     }
   }
   for (uint32_t i = 0; i < d.n_materials; ++i)
@@ -1148,8 +1203,13 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     s->simple_kernel = !(d.roots[i] & RTC_CHILD_NODE_BIT) && d.leaf_kind[d.roots[i]] <= RTC_CUBE;
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
-  HIP_TRY(hipMemset(s->d_stats, 0, 2 * sizeof(DevStats)));
-  HIP_TRY(hipDeviceSynchronize());  // launches may come on any stream: the zeroes must be there by then
+  // Zeroed ON THE HANDLE'S STREAM, followed by the event every launch on another stream waits for (launch()): the
+  // first launch, whatever stream it comes on, finds the work counter at zero.  (A hipMemset here runs on the legacy
+  // stream, which a hipStreamNonBlocking stream does not wait for.)
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
+  HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(s->launch_done, s->stream));
+  s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
   s->branching = branching_spheres;
   s->branching_everywhere = branching_everywhere;
@@ -1245,6 +1305,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
 void rtc_scene_destroy(rtc_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  if (s->launch_done) (void)hipEventSynchronize(s->launch_done);  // the last launch, whatever stream it ran on
   if (s->stream) {
     (void)hipStreamSynchronize(s->stream);
     (void)hipStreamDestroy(s->stream);
@@ -1258,6 +1319,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->pin_chunk_cost) (void)hipHostFree(s->pin_chunk_cost);
   if (s->pin_packet_time) (void)hipHostFree(s->pin_packet_time);
   if (s->measure_done) (void)hipEventDestroy(s->measure_done);
+  if (s->launch_done) (void)hipEventDestroy(s->launch_done);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
   delete s;
@@ -1362,8 +1424,9 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   g_error.clear();
   if (!s || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipDeviceSynchronize());
-  static DevStats h;  // large in diagnostic layouts: keep it off the stack
+  HIP_TRY(hipEventSynchronize(s->launch_done));  // the last launch on this handle, whatever stream it ran on
+  const std::unique_ptr<DevStats> hp(new DevStats);  // large in diagnostic layouts: off the stack, and not shared between handles
+  DevStats& h = *hp;
   HIP_TRY(hipMemcpy(&h, s->d_stats + s->stats_parity, sizeof h, hipMemcpyDeviceToHost));
   out->primary = h.primary;
   out->secondary = h.secondary;

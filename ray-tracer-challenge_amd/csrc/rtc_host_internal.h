@@ -133,7 +133,8 @@ struct rtc_scene {
   uint32_t cost_depth = 0;
   rtc_camera sched_cam{};          // ... and of the measurement the current schedule was packed from
   uint32_t sched_depth = 0;
-  hipStream_t last_stream = nullptr;
+  hipStream_t last_stream = nullptr;  // the stream of the last launch (or the handle's own, after create)
+  hipEvent_t launch_done = nullptr;   // recorded behind everything a launch enqueues; a launch on ANOTHER stream waits for it
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack
   size_t ray_stack_capacity = 0;   // bytes
 };

@@ -1540,7 +1540,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           got_pixel = true;
           want = false;
           out_index = chunk_out0 + static_cast<size_t>(ry) * chunk_w + rx;
-        }  // pixels of an edge tile outside the image stay 0 (the canvas is zeroed before the launch)
+        }  // pixels of an edge tile outside the image are not written (rtc.h: the caller's padding is left alone)
       }
       chunk_pos += min(avail, static_cast<uint32_t>(__builtin_popcountll(wmask)));
       wmask = __ballot(want);

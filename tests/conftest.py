@@ -44,15 +44,20 @@ def build_everything():
 
 @pytest.fixture(scope="session")
 def rtc():
-    mod = importlib.import_module("ray-tracer-challenge_amd")
-    # On a GPU box, let PyTorch bring up its HIP context BEFORE this library launches anything (the order bench.py
-    # and smoke() have always used).  Twice a GPU test run hung at the first torch.cuda call made after the
-    # library had already rendered in the same process; the cause was never found, this order never hung.
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.zeros(1, device="cuda")
-            torch.cuda.synchronize()
-    except ImportError:
-        pass
-    return mod
+    """The package (ctypes binding of librtc_hip.so / librtc_host.so).
+
+    Round 1 saw two GPU test runs hang at the first torch.cuda call made after the library had already rendered in
+    the same process.  Cause, established in round 2 from the link maps (tests/test_abi.py::test_one_hip_runtime...
+    reproduces it on the CPU, without a GPU and without a hang): PyTorch's wheel bundles its own libamdhip64.so /
+    libhsa-runtime64.so WITHOUT a SONAME, librtc_hip.so asks for ROCm's `libamdhip64.so.7`.  When this package's
+    library was loaded first, the process ended up with both HIP runtimes (and both HSA runtimes) mapped, ROCm's copy
+    first in the global symbol scope: libc10_hip / libtorch_hip then bound hipMalloc & co. to ROCm's copy while
+    other torch libraries kept calling the bundled one -- two runtimes driving one GPU from one process.  With torch
+    imported first there is only the bundled copy (ours resolves to it).  The fix is in the package, where the
+    fault is (a Python host with torch is the only host that has two copies to choose from): hip_lib() maps torch's
+    copy before librtc_hip.so, so every load order ends with ONE runtime.  The other two things commit dad4b36 added
+    at the same time were not it and are gone: the torch-first warm-up that used to sit here, and the
+    hipDeviceSynchronize after the counters' hipMemset in rtc_scene_create (replaced by stream-ordered
+    initialisation: hipMemsetAsync on the handle's stream + the event every launch on another stream waits for).
+    """
+    return importlib.import_module("ray-tracer-challenge_amd")

@@ -132,6 +132,17 @@ static void boxKats() {
   cyl.ymax = 3;
   report("cylinder.zig:341", "cylinder_bounds",
          cyl.bounds().min.bitEqual(Tuple::point(-1, -5, -1)) && cyl.bounds().max.bitEqual(Tuple::point(1, 3, 1)));
+  {  // cone.zig:241-260 (the reference's second test is named "A bounded cylinder ..." but builds a cone)
+    const Shape unbounded = Shape::cone();
+    report("cone.zig:241", "cone_unbounded_bounds",
+           unbounded.bounds().min.x == -kInf && unbounded.bounds().min.y == -kInf && unbounded.bounds().min.z == -kInf &&
+               unbounded.bounds().max.x == kInf && unbounded.bounds().max.y == kInf && unbounded.bounds().max.z == kInf);
+    Shape cone = Shape::cone();
+    cone.ymin = -5;
+    cone.ymax = 3;
+    report("cone.zig:249", "cone_bounds",
+           cone.bounds().min.bitEqual(Tuple::point(-5, -5, -5)) && cone.bounds().max.bitEqual(Tuple::point(5, 3, 5)));
+  }
   const Shape pl = Shape::plane();
   report("plane.zig:109", "plane_bounds", pl.bounds().min.x == -kInf && pl.bounds().min.y == 0 && pl.bounds().max.z == kInf);
   const Shape tri = Shape::triangle(Tuple::point(-3, 7, 2), Tuple::point(6, 2, -4), Tuple::point(2, -1, -1));

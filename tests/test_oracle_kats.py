@@ -26,7 +26,7 @@ def test_oracle_kats_all_pass():
     assert rc == 0 and summary and "failed=0" in summary[0]
     # every area of the SURVEY §4 table is represented
     areas = {l[1].split(":")[0] for l in lines}
-    for area in ["tuple.zig", "matrix.zig", "ray.zig", "sphere.zig", "plane.zig", "cube.zig", "cylinder.zig",
+    for area in ["tuple.zig", "matrix.zig", "ray.zig", "sphere.zig", "plane.zig", "cube.zig", "cylinder.zig", "cone.zig", "blend.zig", "csg.zig",
                  "triangle.zig", "group.zig", "bounding_box.zig", "shape.zig", "material.zig", "pattern.zig",
                  "checkers.zig", "stripes.zig", "world.zig", "camera.zig"]:
         assert area in areas, area
@@ -39,7 +39,7 @@ def test_host_kats_all_pass():
     assert not failed, failed
     assert rc == 0 and summary and "failed=0" in summary[0]
     areas = {l[1].split(":")[0] for l in lines}
-    for area in ["matrix.zig", "bounding_box.zig", "group.zig", "scene.zig", "obj.zig", "canvas.zig", "camera.zig"]:
+    for area in ["matrix.zig", "bounding_box.zig", "group.zig", "scene.zig", "obj.zig", "canvas.zig", "camera.zig", "cone.zig"]:
         assert area in areas, area
 
 

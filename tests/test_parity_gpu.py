@@ -259,6 +259,157 @@ def test_full_size_cover_properties(rtc):
     assert np.abs(full[rows] - want[rows]).max() < TOL
 
 
+# ---------------------------------------------------------------- the launches the bench times
+# One handle renders a frame three times: launch 1 runs the geometric heuristic schedule and measures, launch 2 runs
+# the schedule packed from those measurements (whole chunks, or runs of pixels where a chunk exceeds a wave's share),
+# launch 3 is the steady state bench.py times.  Then the camera moves: the schedule is kept for a while, re-measured at
+# launch 16 of the pixel map and re-packed by whichever launch finds the measurements on the host.  Pixels are
+# independent (camera.zig:116-121), so EVERY one of these launches must give the oracle's image and ray counts.
+SCHEDULE_CASES = [
+    ("cover.json", 640, 360, 5),                        # rtc_render_kernel_simple, enough chunks for whole-chunk packing
+    ("fresnel.json", 150, 150, 5),                      # simple kernel, fewer chunks than waves: chunks cut into runs
+    ("reflection_and_refraction.json", 192, 108, 8),    # simple kernel, depth 8
+    ("teapot.json", 192, 108, 5),                       # rtc_render_kernel (BVH)
+    ("dragons.json", 192, 108, 5),                      # rtc_render_kernel, deep reference tree
+    ("groups.json", 150, 50, 5),                        # cones in divided groups
+    ("csg_demo.json", 160, 90, 5),                      # rtc_render_kernel_ext (csg)
+    ("texture_demo.json", 160, 90, 5),                  # rtc_render_kernel_ext (texture maps)
+]
+
+
+def _check_launch(gpu, cam, depth, want, counters, what):
+    got = gpu.render(cam, depth)
+    st = gpu.stats()
+    assert np.isfinite(got).all(), what
+    assert np.abs(got - want).max() < TOL, (what, float(np.abs(got - want).max()))
+    assert st["overflow"] == 0, what
+    assert [st["primary"], st["secondary"], st["shadow_calls"]] == [counters["primary"], counters["secondary"], counters["shadow"]], what
+
+
+@pytest.mark.parametrize("scene,w,h,depth", SCHEDULE_CASES)
+def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth):
+    hs = rtc.HostScene.from_file(scene)
+    gpu = rtc.GpuScene(hs.desc)
+    osc = ob.OracleScene(hs.desc)
+    cam = hs.camera(w, h)
+    want, counters = osc.render(cam, depth)
+    for launch in range(1, 4):          # heuristic + measuring, packed, steady state
+        _check_launch(gpu, cam, depth, want, counters, (scene, "launch", launch))
+    hs.rotate_camera(0.3)               # lib.zig:166-178; the schedule in use now belongs to another view
+    cam2 = hs.camera(w, h)
+    want2, counters2 = osc.render(cam2, depth)
+    assert np.abs(want2 - want).max() > 1e-3
+    for launch in range(4, 30):         # launch 16 re-measures, a later one re-packs (at the latest 8 launches on)
+        _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
+
+
+def test_every_schedule_big_world_kernels(rtc):
+    """The table-in-memory variants (rtc_render_kernel_bigworld and its _ext form) under packed schedules."""
+    import json
+    base = json.loads(_many_objects_scene(150))
+    ext = json.loads(_many_objects_scene(150))
+    ext["objects"].append({"type": {"csg": {"operation": "difference",
+                                            "left": {"type": {"cube": {}}, "transform": [{"translate": [0, 1.2, 0]}]},
+                                            "right": {"type": {"sphere": {}}, "transform": [{"scale": [1.3, 1.3, 1.3]}, {"translate": [0, 1.2, 0]}]}}}})
+    for scene in (base, ext):
+        hs = rtc.HostScene(json.dumps(scene))
+        cam = hs.camera()
+        gpu = rtc.GpuScene(hs.desc)
+        want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+        for launch in range(1, 4):
+            _check_launch(gpu, cam, 5, want, counters, ("big world", len(scene["objects"]), launch))
+
+
+# BASELINE configs[2..4] at their full sizes (configs[1]: test_full_size_cover_properties): launches 1-3 on one handle,
+# every k-th row of each against the oracle, and the packed launches against the first bit for bit where nothing is
+# shared between lanes.
+FULL_SIZE = [
+    ("reflection_and_refraction.json", 1920, 1080, 8, 40),
+    ("teapot.json", 1920, 1080, 5, 40),
+    ("dragons.json", 3840, 2160, 5, 90),
+]
+
+
+@pytest.mark.parametrize("scene,w,h,depth,row_step", FULL_SIZE)
+def test_full_size_configs(rtc, scene, w, h, depth, row_step):
+    hs = rtc.HostScene.from_file(scene)
+    cam = hs.camera(w, h)
+    gpu = rtc.GpuScene(hs.desc)
+    rows = np.arange(0, h, row_step)
+    want, _ = ob.OracleScene(hs.desc).render(cam, depth, row_step=row_step)
+    frames = []
+    for launch in range(1, 4):
+        got = gpu.render(cam, depth)
+        st = gpu.stats()
+        assert st["primary"] == w * h and st["overflow"] == 0
+        assert np.isfinite(got).all() and got.min() >= 0.0
+        assert np.abs(got[rows] - want[rows]).max() < TOL, (scene, launch)
+        frames.append((got, st))
+    for got, st in frames[1:]:          # the schedule changes nothing: same image, same ray counts
+        assert np.abs(got - frames[0][0]).max() < REPEAT_TOL
+        assert st == frames[0][1]
+    # a tile of the frame equals the frame
+    x0, y0, tw, th = w // 3, h // 2, 257, 129
+    assert np.abs(gpu.render(cam, depth, (x0, y0, tw, th)) - frames[0][0][y0:y0 + th, x0:x0 + tw]).max() < REPEAT_TOL
+
+
+def test_full_size_tile_path(rtc):
+    """The multi-GPU partition at the headline size on one GPU: cover 1920x1080 cut into 64x64 tiles dealt to 4 "ranks",
+    each rank's tiles rendered three times (heuristic, packed, steady state), un-permuted on the device, compared with
+    the plain render and with sampled oracle rows."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file("cover.json")
+    W, H, T, world = 1920, 1080, 64, 4
+    cam = hs.camera(W, H)
+    plain = rtc.GpuScene(hs.desc).render(cam, 5)
+    tx, ty = rtc.tile_grid(W, H, T, T)
+    n_tiles = tx * ty
+    padded = (n_tiles + world - 1) // world
+    stream = torch.cuda.Stream()
+    for launch in range(3):
+        gathered = torch.zeros((world, padded, T, T, 3), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        if launch == 0:
+            scenes = [rtc.GpuScene(hs.desc) for _ in range(world)]   # one handle per rank, as in bench.py
+        for rank in range(world):
+            first, stride, count, _ = rtc.tiles_of_rank(n_tiles, rank, world)
+            scenes[rank].render_tiles_device(cam, gathered[rank].data_ptr(), T, T, first, stride, count, 5, stream.cuda_stream)
+        canvas = torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda")
+        rtc.assemble_tiles_device(gathered.data_ptr(), world, padded, T, T, W, H, canvas.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        got = canvas.cpu().numpy()
+        assert np.abs(got - plain).max() < REPEAT_TOL, launch
+    want, _ = ob.OracleScene(hs.desc).render(cam, 5, row_step=60)
+    rows = np.arange(0, H, 60)
+    assert np.abs(got[rows] - want[rows]).max() < TOL
+
+
+def test_launches_on_different_streams_are_ordered(rtc):
+    """One handle, launches enqueued back to back on three different streams (a caller's, the handle's own through
+    rtc_render, another caller's) without any host synchronisation in between: they share the handle's counters and
+    scratch, so the library must order them (event + hipStreamWaitEvent); every canvas must be the oracle's image."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file("reflection_and_refraction.json")
+    w, h, depth = 320, 180, 5
+    cam = hs.camera(w, h)
+    want, counters = ob.OracleScene(hs.desc).render(cam, depth)
+    gpu = rtc.GpuScene(hs.desc)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for round_ in range(4):
+        a = torch.full((h, w, 3), float("nan"), dtype=torch.float64, device="cuda")
+        b = torch.full((h, w, 3), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        gpu.render_device(cam, a.data_ptr(), depth, None, s1.cuda_stream)
+        gpu.render_device(cam, b.data_ptr(), depth, None, s2.cuda_stream)
+        c = gpu.render(cam, depth)                       # the handle's own stream, synchronous
+        st = gpu.stats()
+        torch.cuda.synchronize()
+        for name, img in (("a", a.cpu().numpy()), ("b", b.cpu().numpy()), ("c", c)):
+            assert np.isfinite(img).all(), (round_, name)
+            assert np.abs(img - want).max() < TOL, (round_, name)
+        assert [st["primary"], st["secondary"], st["shadow_calls"]] == [counters["primary"], counters["secondary"], counters["shadow"]]
+
+
 def test_errors_through_the_abi(rtc):
     hs = rtc.HostScene.from_file("fresnel.json")
     gpu = rtc.GpuScene(hs.desc)
