@@ -63,6 +63,68 @@ def measured_traffic(scene, width, height, depth):
     return 2 * 1024 * t["fetch_size_kb"] + 1024 * t["write_size_kb"]
 
 
+def executed_flops(scene, width, height, depth):
+    """FP64 flops the kernel EXECUTES per launch, from the committed SQ PMC pass of this workload (profiles/traffic.json,
+    "pmc"): wave-level instruction counts x 64 lanes x the mean fraction of active lanes, an FMA counted as 2."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+    except OSError:
+        return None
+    c = t.get("pmc") or {}
+    if [t.get("scene"), t.get("width"), t.get("height"), t.get("depth")] != [scene, width, height, depth]:
+        return None
+    need = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+            "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"]
+    if any(k not in c for k in need):
+        return None
+    lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+    wave_instr = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
+    return {"flops": wave_instr * 64.0 * lanes, "lanes_active": lanes, "valu_instructions": c["SQ_INSTS_VALU"],
+            "fp64_instructions": c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"],
+            "source": t.get("source")}
+
+
+def one_shot_and_moving_view(rtc, torch, hs, args, stream):
+    """What the steady-state figure leaves out (the reference renders a scene ONCE, main.zig:92, and its interactive mode
+    moves the camera every frame, lib.zig:166-190): the first frame of a fresh scene handle (heuristic schedule + the
+    host's share), the second (re-pack), a frame with host output (rtc_render: + D2H), and an orbit of 64 frames at
+    0.01 rad per frame (enqueued back to back, as an interactive host would)."""
+    W, H = args.width, args.height
+    sptr = stream.cuda_stream
+    cam = hs.camera(W, H)
+    canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+    g = rtc.GpuScene(hs.desc)
+    torch.cuda.synchronize()
+    out = {}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for name in ("first_frame", "second_frame"):
+        t0 = time.perf_counter()
+        ev[0].record(stream)
+        g.render_device(cam, canvas.data_ptr(), args.depth, None, sptr)
+        ev[1].record(stream)
+        stream.synchronize()
+        out[name + "_ms"] = (time.perf_counter() - t0) * 1e3
+        out[name + "_kernel_ms"] = ev[0].elapsed_time(ev[1])
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        g.render(cam, args.depth)
+        times.append((time.perf_counter() - t0) * 1e3)
+    out["host_output_ms"] = sorted(times)[len(times) // 2]
+    frames, angle = 64, 0.01
+    for rep in range(2):                                  # the second orbit goes on from where the first stopped
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            hs.rotate_camera(angle)
+            g.render_device(hs.camera(W, H), canvas.data_ptr(), args.depth, None, sptr)
+        stream.synchronize()
+        out["orbit_ms" if rep == 1 else "orbit_first_pass_ms"] = (time.perf_counter() - t0) * 1e3 / frames
+    hs.rotate_camera(-2 * frames * angle)
+    out["orbit"] = "%d frames, %.2f rad per frame, one handle, frames enqueued back to back; wall time / frames" % (frames, angle)
+    return out
+
+
 def kernel_name(hs):
     """Which variant of the render kernel rtc_capi.hip's launch() picks for this scene (rocprof shows the same name)."""
     d = hs.desc
@@ -89,35 +151,75 @@ def algorithmic_flops(desc, hs, stats):
     return rays * per_ray + hits * 120 + stats["shadow_calls"] * 120 if desc.n_nodes == 0 else None
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup's CFS quota (cpu.max / cfs_quota_us) caps a container far below
+    os.cpu_count() - the GPU boxes show 256 logical CPUs and grant 16 (cpu.max = "1600000 100000"); threads beyond the
+    quota only get throttled (measured there: 16 threads 14.6 Mrays/s, 256 threads 6-10)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    cores = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return cores, n, quota
+
+
 def cpu_baseline(rtc, hs, cam, depth, target_seconds=12.0):
-    """Times the oracle on every k-th row of the frame, k chosen from a short calibration so the sample
-    takes about `target_seconds` on this host's cores."""
+    """Times the oracle (C++ restatement of the reference's CPU path, one job per row on a thread pool like
+    camera.zig:88-97, per-thread arena like camera.zig:113-120) on every k-th row of the frame, k chosen from a short
+    calibration so that a pass takes a few seconds on the cores this process may use."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_binding as ob
     osc = ob.OracleScene(hs.desc)
-    cores = os.cpu_count() or 1
+    cores, logical, quota = cpu_quota()
     t0 = time.perf_counter()
     _, c = osc.render(cam, depth, row_step=90, threads=cores)   # calibration: 12 rows
     cal = time.perf_counter() - t0
     rows_cal = (cam.vsize + 89) // 90
     per_row = cal / rows_cal
-    rows_target = max(rows_cal, min(cam.vsize, int(target_seconds / max(per_row, 1e-9))))
+    rows_target = max(rows_cal, min(cam.vsize, int(target_seconds / 3.0 / max(per_row, 1e-9))))
     step = max(1, cam.vsize // rows_target)
     rows = (cam.vsize + step - 1) // step
     times = []
     spent = 0.0
-    while len(times) < 3 or (spent < target_seconds and len(times) < 9):   # median of >= 3 passes
+    while len(times) < 3 or (spent < target_seconds and len(times) < 5):   # median of >= 3 passes
         t0 = time.perf_counter()
         _, c = osc.render(cam, depth, row_step=step, threads=cores)
         times.append(time.perf_counter() - t0)
         spent += times[-1]
     dt = sorted(times)[len(times) // 2]
     rays = c["primary"] + c["secondary"]
+    # Thread scaling on ONE fixed sample (every 8th row), so that the figures compare: with the per-thread arena the
+    # oracle scales with the cores it is given; beyond the cgroup quota more threads only get throttled.
+    scaling = {}
+    for th in sorted({1, 4, cores, min(logical, 4 * cores), logical}):
+        t0 = time.perf_counter()
+        _, cs = osc.render(cam, depth, row_step=8, threads=th)
+        dts = time.perf_counter() - t0
+        scaling[str(th)] = {"mrays_per_s": (cs["primary"] + cs["secondary"]) / dts / 1e6, "seconds": dts}
+    one = scaling["1"]["mrays_per_s"]
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"every {step}th row ({rows} of {cam.vsize} rows) of the same frame, median of {len(times)} "
                   f"passes of {dt:.2f} s, {cores} threads, one job per row (camera.zig:88-97)",
         "ms_per_frame_extrapolated": dt * 1e3 * cam.vsize / rows,
+        "host": {"logical_cpus": logical, "cgroup_cpu_quota": quota,
+                 "note": "threads = the CPUs the container may use (cgroup quota), not os.cpu_count(): threads beyond the "
+                         "quota are throttled and lower the throughput (thread_scaling; samples shorter than one 100 ms "
+                         "quota period can burst above it)"},
+        "thread_scaling": scaling,
+        "parallel_efficiency": scaling[str(cores)]["mrays_per_s"] / (one * cores),
+        "build": "oracle/ (C++ restatement of the reference's CPU path), -O3 -ffp-contract=off, per-thread bump arena "
+                 "reset after every pixel like camera.zig:113-120",
     }
 
 
@@ -131,6 +233,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the first-frame / host-output / orbit timings")
     ap.add_argument("--tile-path", action="store_true",
                     help="run the multi-GPU code path (tiles + gather + un-permute) even with one rank")
     ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
@@ -294,7 +397,9 @@ def main():
                                     "none (1 GPU)" if world == 1 else f"{TILE}x{TILE} round-robin over {world} GPUs + 1 RCCL gather/frame"),
                        "rays_per_frame": {"primary": stats["primary"], "secondary": stats["secondary"],
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
-                       "mrays_per_s_incl_shadow": (rays + stats["shadow_calls"]) * args.steps / elapsed / 1e6},
+                       "mrays_per_s_incl_shadow_traced": (rays + stats["shadow_traced"]) * args.steps / elapsed / 1e6,
+                       "timed_frames": "steady state of a STATIC view: the schedule was measured on this same frame by the two "
+                                       "untimed setup launches; first_frame_ms / orbit_ms below are the other cases"},
         }
         if world == 1 and not args.tile_path:
             ab = algorithmic_bytes(hs.desc, W, H)
@@ -303,6 +408,7 @@ def main():
             result["roofline"] = {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.scene, W, H, args.depth),
+                "traffic_source": "committed profile (profiles/traffic.json), not measured in this run",
                 "kernel": kernel_name(hs), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
                 "note": "HBM is NOT what binds this kernel: the compulsory traffic is the canvas (24*W*H B) plus "
@@ -321,6 +427,19 @@ def main():
                             "kernel skips most of them by bounding-sphere rejection.  Peak counts an FMA as 2 "
                             "flops; the path runs with FMA contraction OFF to round like the reference.",
                 }
+                ex = executed_flops(args.scene, W, H, args.depth)
+                if ex is not None:
+                    etf = ex["flops"] / (kernel_ms * 1e-3) / 1e12
+                    result["roofline_valu"].update({
+                        "executed_flops": ex["flops"], "executed_tflops": etf, "executed_frac": etf / FP64_VECTOR_PEAK_TF,
+                        "executed_note": "FP64 flops the kernel executes per launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
+                                         "lanes x %.2f lanes active; %d of %d VALU wave-instructions are FP64 arithmetic), from "
+                                         "the committed PMC pass %s over this run's kernel time: THIS is the hardware "
+                                         "utilisation, `frac` above prices the reference's brute-force flop count"
+                                         % (ex["lanes_active"], ex["fp64_instructions"], ex["valu_instructions"], ex["source"]),
+                    })
+            if not args.no_extras:
+                result["config"].update(one_shot_and_moving_view(rtc, torch, hs, args, stream))
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)
                 result["config"]["gpu_vs_cpu_frame_time"] = result["cpu_baseline"]["ms_per_frame_extrapolated"] / ms_per_step

@@ -227,6 +227,7 @@ int orc_render(void* scene, const rtc_camera* cam, uint32_t max_depth, uint32_t 
             px[0] = c.r;
             px[1] = c.g;
             px[2] = c.b;
+            orc::Arena::mine().reset();  // arena.reset(.retain_capacity) after every pixel, camera.zig:119
           }
         }
       } catch (const std::exception& e) {

@@ -23,7 +23,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <limits>
+#include <new>
 #include <memory>
 #include <stdexcept>
 #include <vector>
@@ -46,6 +48,73 @@ inline Counters& counters() {
   static thread_local Counters c;
   return c;
 }
+
+// ------------------------------------------------------------------ allocation
+// The reference gives every row job one ArenaAllocator and resets it after every pixel with
+// `.retain_capacity` (camera.zig:113-120): all the intersection lists of a pixel's ray tree are bump allocations
+// that are never freed one by one, and from the second pixel on the arena asks the system for nothing.  Same here:
+// a per-thread bump arena behind a stateless std allocator (deallocate is a no-op), reset by the render loop after
+// every pixel.  (With std::allocator the oracle spent its time in glibc malloc: 256 threads ran 18 times slower per
+// thread than one.)  Users that never reset (the KAT binary) just keep bumping.
+class Arena {
+ public:
+  ~Arena() {
+    for (Block& b : blocks_) std::free(b.p);
+  }
+  void* allocate(size_t bytes, size_t align) {
+    for (;;) {
+      if (!blocks_.empty()) {
+        Block& b = blocks_.back();
+        const size_t at = (b.used + align - 1) & ~(align - 1);
+        if (at + bytes <= b.size) {
+          b.used = at + bytes;
+          return b.p + at;
+        }
+      }
+      const size_t size = std::max<size_t>(std::max<size_t>(bytes + align, 1u << 16), 2 * total_);
+      char* p = static_cast<char*>(std::malloc(size));
+      if (!p) throw std::bad_alloc();
+      blocks_.push_back({p, size, 0});
+      total_ += size;
+    }
+  }
+  void reset() {  // ArenaAllocator.reset(.retain_capacity): one block of the whole capacity, nothing returned
+    if (blocks_.size() > 1) {
+      for (Block& b : blocks_) std::free(b.p);
+      blocks_.clear();
+      char* p = static_cast<char*>(std::malloc(total_));
+      if (!p) throw std::bad_alloc();
+      blocks_.push_back({p, total_, 0});
+    } else if (!blocks_.empty()) {
+      blocks_.back().used = 0;
+    }
+  }
+  static Arena& mine() {
+    static thread_local Arena a;
+    return a;
+  }
+
+ private:
+  struct Block {
+    char* p;
+    size_t size, used;
+  };
+  std::vector<Block> blocks_;
+  size_t total_ = 0;
+};
+template <class T>
+struct ArenaAlloc {
+  using value_type = T;
+  ArenaAlloc() = default;
+  template <class U>
+  ArenaAlloc(const ArenaAlloc<U>&) {}
+  T* allocate(size_t n) { return static_cast<T*>(Arena::mine().allocate(n * sizeof(T), alignof(T) < 8 ? 8 : alignof(T))); }
+  void deallocate(T*, size_t) {}
+  template <class U>
+  bool operator==(const ArenaAlloc<U>&) const { return true; }
+  template <class U>
+  bool operator!=(const ArenaAlloc<U>&) const { return false; }
+};
 
 // ------------------------------------------------------------------ tuple.zig
 struct Tuple {
@@ -471,10 +540,24 @@ struct Intersection {  // shape.zig:23-47
   const Shape* object;
   double u = 0.0, v = 0.0;
 };
-using Intersections = std::vector<Intersection>;
+using Intersections = std::vector<Intersection, ArenaAlloc<Intersection>>;
 
-// shape.zig:64-66 — std.mem.sort is a stable sort (SURVEY assumption A1).
+// shape.zig:64-66 — std.mem.sort is a stable, in-place sort that allocates nothing (SURVEY assumption A1).  Any stable
+// sort yields the same order; short lists (all but pathological ones) take the in-place insertion sort, because
+// std::stable_sort asks the heap for a merge buffer on every call.
 inline void sortIntersections(Intersections& xs) {
+  if (xs.size() <= 64) {
+    for (size_t i = 1; i < xs.size(); ++i) {
+      const Intersection v = xs[i];
+      size_t j = i;
+      while (j > 0 && v.t < xs[j - 1].t) {
+        xs[j] = xs[j - 1];
+        --j;
+      }
+      xs[j] = v;
+    }
+    return;
+  }
   std::stable_sort(xs.begin(), xs.end(), [](const Intersection& a, const Intersection& b) { return a.t < b.t; });
 }
 // shape.zig:71-80
@@ -944,7 +1027,7 @@ struct PreComputations {  // world.zig:194-210
     const Tuple under_point = sub(pt, mul(normal, epsilon));
     const Tuple reflectv = reflect(ray.direction, normal);
 
-    std::vector<const Shape*> containers;
+    std::vector<const Shape*, ArenaAlloc<const Shape*>> containers;  // (allocator.alloc in world.zig:229)
     containers.reserve(xs.size());
     double n1 = 1.0, n2 = 1.0;
     for (const Intersection& item : xs) {

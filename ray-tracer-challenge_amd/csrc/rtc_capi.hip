@@ -31,6 +31,11 @@ extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCame
 extern "C" __global__ void rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                           const uint32_t max_depth, double* __restrict__ out,
                                                           DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_pack_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
+                                           const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
+                                           const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, const float n_waves,
+                                           const float t_min, uint32_t* __restrict__ chunk_time, uint32_t* __restrict__ sorted,
+                                           uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info);
 extern "C" __global__ void rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map,
                                                  uint32_t* __restrict__ chunk_cost);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
@@ -130,176 +135,162 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
-// The schedule of one launch (results never depend on it).  First launch with a pixel map: the geometric heuristic of
-// chunkOrder().  The launch after a measuring launch packs from what that one measured.  Fills map.order / n_units /
-// cost / packet_time.
+// The schedule of one launch (results never depend on it).
+//   * first launch of a pixel map: the geometric heuristic of chunkOrder() (host), and the launch MEASURES: per-pixel
+//     ray counts and the time every packet took in the wave that pulled it;
+//   * a measuring launch is followed on its stream by rtc_chunk_cost_kernel and rtc_pack_kernel: the next launch runs a
+//     schedule packed on the device from those measurements.  Nothing waits for the host;
+//   * a view (camera, depth) other than the one the schedule in use was measured with measures again: an orbiting
+//     camera (lib.zig:166-190) renders every frame with the schedule of the frame before;  a static view keeps its
+//     schedule and measures nothing;
+//   * the first measurement is also read back: if the packer found a chunk above a wave's fair share (small images, one
+//     rank's share of a frame split over GPUs) the host cuts such chunks into runs of pixels (packSchedule) and the
+//     launch that finds the read-back complete switches to that schedule.
 int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, size_t out_pixels,
-                   hipStream_t stream) {
-  // Schedule.  First launch with a pixel map: the geometric heuristic of chunkOrder().  From the second
-  // launch on: longest job first by the MEASURED per-chunk ray counts of the previous frame (refreshed on
-  // launch 2 and then every 64 launches: one stream sync, a 4-byte-per-chunk copy and a sort).  Frames
-  // of an interactive session (lib.zig's move/rotateCamera) change little from one to the next.
+                   hipStream_t stream, bool& measure) {
+  measure = false;
   const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
   std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
   if (mkey != s->cost_key) {
     s->cost_key = mkey;
     s->launches_with_key = 0;
-    s->order_from_cost = false;
-    s->cost_pending = false;
+    s->sched_valid = false;
+    s->order_key.clear();
     if (s->readback_enqueued) HIP_TRY(hipEventSynchronize(s->measure_done));  // (its copies must not land in a later read-back's buffers)
     s->readback_enqueued = false;
   }
   if (out_pixels > s->cost_capacity) {
+    HIP_TRY(hipEventSynchronize(s->launch_done));
     if (s->d_cost) (void)hipFree(s->d_cost);
     s->d_cost = nullptr;
     s->cost_capacity = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
     s->cost_capacity = out_pixels;
-    s->launches_with_key = 0;
-    s->cost_pending = false;
     s->readback_enqueued = false;
   }
   const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
-  bool pack_now = false;
-  if (schedulable && s->cost_pending && s->readback_enqueued) {
-    // The measurements of an earlier launch are on their way to the host (enqueueReadback).  The launch right after the
-    // FIRST measuring launch waits for them: the heuristic schedule is worth replacing at once.  Later re-measurements
-    // (a moving camera) are picked up by whichever launch finds them complete; frames queued meanwhile are not drained.
-    // A caller that enqueues frames faster than the GPU renders them is held back here once it is eight launches past
-    // the measuring one: the wait is for the event, i.e. until the GPU is within eight queued frames of the host, so the
-    // GPU never runs dry, and no schedule is used for more than 16 + 8 frames of a moving view.
-    hipError_t ready = hipEventQuery(s->measure_done);
-    if (ready == hipErrorNotReady && (!s->order_from_cost || s->launches_since_measure >= 8u)) {
-      HIP_TRY(hipEventSynchronize(s->measure_done));
-      ready = hipSuccess;
-    }
+  const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
+                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
+  const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+  if (schedulable && s->readback_enqueued) {
+    const hipError_t ready = hipEventQuery(s->measure_done);
     if (ready == hipSuccess) {
-      pack_now = true;
+      s->readback_enqueued = false;
+      // (a later measuring launch has overwritten the per-pixel costs: that read-back describes a frame that is gone)
+      if (s->pin_info->needs_split && s->readback_gen == s->measure_gen) {
+        const std::vector<uint32_t> h_chunk_cost(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
+        const std::vector<uint32_t> h_packet_time(s->pin_packet_time, s->pin_packet_time + s->readback_packets);
+        // what every chunk really took: a packet's time, shared among its items by their cost
+        std::vector<uint32_t> chunk_time = chunkTimes(map, h_chunk_cost, h_packet_time, s->measured_order);
+        // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
+        if (s->measured_inflation.size() == chunk_time.size())
+          for (size_t c = 0; c < chunk_time.size(); ++c) chunk_time[c] = static_cast<uint32_t>(chunk_time[c] / s->measured_inflation[c]);
+        s->h_cost.resize(out_pixels);
+        HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        packSchedule(s, map, s->h_cost, h_chunk_cost, chunk_time, n_waves, s->readback_depth);
+        if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
+        s->sched_valid = true;
+        s->sched_cam = s->readback_cam;
+        s->sched_depth = s->readback_depth;
+        s->order_key.clear();  // the heuristic cache no longer describes the buffers
+      }
     } else if (ready != hipErrorNotReady) {
       HIP_TRY(ready);
     }
   }
-  if (pack_now) {
-    s->cost_pending = false;
-    s->readback_enqueued = false;
-    s->sched_cam = s->cost_cam;
-    s->sched_depth = s->cost_depth;
-    const auto t_a = std::chrono::steady_clock::now();
-    const auto t_b = t_a;
-    s->h_chunk_cost.assign(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
-    s->h_packet_time.assign(s->pin_packet_time, s->pin_packet_time + s->readback_packets);
-    // what every chunk really took: a packet's time, shared among its items by their cost
-    std::vector<uint32_t> chunk_time = chunkTimes(map, s->h_chunk_cost, s->h_packet_time, s->measured_order);
-    // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
-    if (s->measured_inflation.size() == chunk_time.size())
-      for (size_t c = 0; c < chunk_time.size(); ++c) chunk_time[c] = static_cast<uint32_t>(chunk_time[c] / s->measured_inflation[c]);
-    if (getenv("RTC_SCHED_BY_COST")) chunk_time = s->h_chunk_cost;  // experiment knob: ignore the measured times
-    s->h_chunk_time_dbg = chunk_time;
-    const auto t_c = std::chrono::steady_clock::now();
-    const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
-                      s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
-    const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
-    if (!packWholeChunks(s, map, chunk_time, n_waves)) {  // some chunk is above a wave's fair share: runs of pixels
-      s->h_cost.resize(out_pixels);
-      HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-      packSchedule(s, map, s->h_cost, s->h_chunk_cost, chunk_time, n_waves, s->cost_depth);
-    }
-    const auto t_d = std::chrono::steady_clock::now();
-    const int st = uploadSchedule(s, stream);
-    if (st != RTC_OK) return st;
-    if (getenv("RTC_PROFILE_DUMP")) {
-      const auto t_e = std::chrono::steady_clock::now();
-      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-      std::fprintf(stderr, "rtc re-pack: sync %.2f ms, cost copy %.2f ms, packing %.2f ms, upload %.2f ms\n", ms(t_a, t_b),
-                   ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e));
-    }
-    s->order_from_cost = true;
-    s->order_key.clear();  // the heuristic cache no longer describes d_order
-  }
-  if (s->order_from_cost) {
-    map.order = s->d_order;
-    map.n_units = static_cast<uint32_t>(s->h_order.size() / RTC_PACKET_ITEMS);
+  if (s->sched_valid) {
+    map.order = s->d_sched[s->sched_cur];
+    map.n_units_dev = s->sched_on_device ? &s->d_sched_info[s->sched_cur].n_units : nullptr;
+    map.n_units = s->sched_on_device ? map.n_chunks : s->sched_n_units;  // (device-packed: an upper bound, for the grid)
   } else {
-    const int st = chunkOrder(s, cam, map, stream);
-    if (st != RTC_OK) return st;
+    if (const int st = chunkOrder(s, cam, map, stream); st != RTC_OK) return st;
+    if (map.order == nullptr) s->h_order.clear();  // unscheduled: packet i is chunk i
   }
-  // Per-pixel ray counts and packet times are collected by the first launch with a pixel map, and after that by every
-  // 16th launch IF the view has changed since the schedule in use was measured (an orbiting camera, lib.zig's
-  // interactive mode: a schedule packed for a view 40 degrees away doubles the frame time); a static view keeps its
-  // schedule and pays nothing.  Packing costs the host 1.4 ms at 1080p and no stream synchronisation.
-  const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
-  static const bool always_time = getenv("RTC_TIME_ALWAYS") != nullptr;  // diagnostic: time the packets of every launch
   static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: keep the first launch's schedule
-  // (no new measurement while one is still on its way to the host)
-  const bool measure = schedulable && !s->cost_pending && !sched_off &&
-                       (s->launches_with_key == 0 || (s->launches_with_key % 16 == 15 && view_changed));
-  const bool collect = measure || (schedulable && always_time && !s->cost_pending);
-  if (measure) {
-    s->cost_pending = true;
-    s->launches_since_measure = 0;
-  } else {
-    s->launches_since_measure++;
-  }
+  const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
+  measure = schedulable && !sched_off && (!s->sched_valid || view_changed);
+  map.cost = nullptr;
   map.packet_time = nullptr;
-  if (collect) {
-    map.cost = s->d_cost;
-    s->cost_cam = cam;
-    s->cost_depth = max_depth;
-    if (!measure) map.cost = nullptr;  // diagnostic launches only time the packets
-    if (map.n_units > s->packet_time_capacity) {
-      HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
+  if (measure) {
+    if (const int st = ensureScheduleBuffers(s, static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
+    if (!s->sched_valid && map.order != nullptr) map.order = s->d_sched[s->sched_cur];  // (the buffers may just have been allocated ... by chunkOrder's upload: same pointer)
+    const size_t need_pt = std::max<size_t>(map.n_units, map.n_chunks);
+    if (need_pt > s->packet_time_capacity) {
+      HIP_TRY(hipEventSynchronize(s->launch_done));
       if (s->d_packet_time) (void)hipFree(s->d_packet_time);
       s->d_packet_time = nullptr;
       s->packet_time_capacity = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), static_cast<size_t>(map.n_units) * sizeof(uint32_t)));
-      s->packet_time_capacity = map.n_units;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), need_pt * sizeof(uint32_t)));
+      s->packet_time_capacity = need_pt;
+    }
+    if (map.n_chunks > s->pack_capacity) {
+      HIP_TRY(hipEventSynchronize(s->launch_done));
+      for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+      }
+      s->pack_capacity = 0;
+      for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost})
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+      s->pack_capacity = map.n_chunks;
     }
     HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
+    map.cost = s->d_cost;
     map.packet_time = s->d_packet_time;
-    if (map.order != nullptr) {
-      s->measured_order = s->h_order;  // the schedule this launch runs (and times)
-      s->measured_inflation = s->order_from_cost ? s->h_split_inflation : std::vector<float>();
-    } else {
-      s->measured_order.clear();
-      s->measured_inflation.clear();
-    }
-  } else {
-    map.cost = nullptr;
   }
   s->launches_with_key++;
   return RTC_OK;
 }
 
-// Right after a measuring launch, on its stream: per-chunk sums of the per-pixel costs, both tables to pinned host
-// memory, an event.  Nothing here waits.
-int enqueueReadback(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
-  if (map.n_chunks > s->chunk_cost_capacity) {
-    if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
-    s->d_chunk_cost = nullptr;
-    s->chunk_cost_capacity = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_cost), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
-    s->chunk_cost_capacity = map.n_chunks;
-  }
-  auto pinned = [](uint32_t*& p, size_t& capacity, size_t n) -> hipError_t {
-    if (n <= capacity) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-    capacity = 0;
-    const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(uint32_t), hipHostMallocDefault);
-    if (e == hipSuccess) capacity = n;
-    return e;
-  };
-  const size_t n_measured = s->measured_order.empty() ? map.n_chunks : s->measured_order.size() / RTC_PACKET_ITEMS;
-  HIP_TRY(pinned(s->pin_chunk_cost, s->pin_chunk_cost_capacity, map.n_chunks));
-  HIP_TRY(pinned(s->pin_packet_time, s->pin_packet_time_capacity, n_measured));
-  if (!s->measure_done) HIP_TRY(hipEventCreateWithFlags(&s->measure_done, hipEventDisableTiming));
+// Right after a measuring launch, on its stream: per-chunk sums of the per-pixel costs, then the next frame's schedule
+// packed into the buffer that is not in use; the buffers swap.  The first measurement of a pixel map also goes to pinned
+// host memory behind an event (see updateSchedule).  Nothing here waits.
+int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, hipStream_t stream) {
+  const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
+                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
+  const float n_waves = 4.0f * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(s->pin_chunk_cost, s->d_chunk_cost, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(s->pin_packet_time, s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipEventRecord(s->measure_done, stream));
-  s->readback_packets = n_measured;
-  s->readback_enqueued = true;
+  const uint32_t target = s->sched_cur ^ 1u;
+  hipLaunchKernelGGL(rtc_pack_kernel, dim3(1), dim3(1024), 0, stream, map.order, map.n_units_dev, map.n_units, s->d_packet_time,
+                     s->d_chunk_cost, map.n_chunks, n_waves, static_cast<float>(groupFloor(s)), s->d_chunk_time, s->d_sorted,
+                     s->d_sched[target], s->d_sched_info + target);
+  HIP_TRY(hipGetLastError());
+  s->measure_gen++;
+  const bool host_knows_the_schedule = map.n_units_dev == nullptr;
+  if (!s->sched_valid && host_knows_the_schedule && !s->readback_enqueued) {  // the first measurement of this pixel map
+    auto pinned = [](auto*& p, size_t& capacity, size_t n) -> hipError_t {
+      if (n <= capacity) return hipSuccess;
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+      capacity = 0;
+      const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(*p), hipHostMallocDefault);
+      if (e == hipSuccess) capacity = n;
+      return e;
+    };
+    const size_t n_measured = map.order == nullptr ? map.n_chunks : map.n_units;
+    HIP_TRY(pinned(s->pin_chunk_cost, s->pin_chunk_cost_capacity, map.n_chunks));
+    HIP_TRY(pinned(s->pin_packet_time, s->pin_packet_time_capacity, n_measured));
+    if (!s->pin_info) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_info), sizeof(DevSchedInfo), hipHostMallocDefault));
+    if (!s->measure_done) HIP_TRY(hipEventCreateWithFlags(&s->measure_done, hipEventDisableTiming));
+    HIP_TRY(hipMemcpyAsync(s->pin_chunk_cost, s->d_chunk_cost, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(s->pin_packet_time, s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(s->pin_info, s->d_sched_info + target, sizeof(DevSchedInfo), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(s->measure_done, stream));
+    s->readback_packets = n_measured;
+    s->readback_enqueued = true;
+    s->readback_gen = s->measure_gen;
+    s->readback_cam = cam;
+    s->readback_depth = max_depth;
+    s->measured_order = map.order == nullptr ? std::vector<uint32_t>() : s->h_order;
+    s->measured_inflation = s->h_split_inflation;
+  }
+  s->sched_cur = target;
+  s->sched_valid = true;
+  s->sched_on_device = true;
+  s->sched_cam = cam;
+  s->sched_depth = max_depth;
+  s->order_key.clear();
   return RTC_OK;
 }
 
@@ -351,7 +342,8 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   // one stream; when the caller changes streams (rtc_render_device on its own stream, then rtc_render on the handle's),
   // the new stream first waits for everything the handle enqueued before (the event recorded at the end of launch()).
   if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
-  if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream); st != RTC_OK) return st;
+  bool measure = false;
+  if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, measure); st != RTC_OK) return st;
   const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
   // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
@@ -373,8 +365,8 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
-  if (map.cost != nullptr && s->cost_pending && !s->readback_enqueued)
-    if (const int st = enqueueReadback(s, map, stream); st != RTC_OK) return st;
+  if (measure)
+    if (const int st = packNextSchedule(s, cam, map, max_depth, stream); st != RTC_OK) return st;
   HIP_TRY(hipEventRecord(s->launch_done, stream));
   s->last_stream = stream;
   return RTC_OK;
@@ -1312,7 +1304,12 @@ void rtc_scene_destroy(rtc_scene* s) {
   }
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
-  if (s->d_order) (void)hipFree(s->d_order);
+  for (int b = 0; b < 2; ++b)
+    if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
+  if (s->d_sched_info) (void)hipFree(s->d_sched_info);
+  if (s->d_chunk_time) (void)hipFree(s->d_chunk_time);
+  if (s->d_sorted) (void)hipFree(s->d_sorted);
+  if (s->pin_info) (void)hipHostFree(s->pin_info);
   if (s->d_cost) (void)hipFree(s->d_cost);
   if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
   if (s->d_packet_time) (void)hipFree(s->d_packet_time);
@@ -1433,58 +1430,6 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   out->shadow_calls = h.shadow_calls;
   out->shadow_traced = h.shadow_traced;
   out->overflow = h.overflow;
-  if (getenv("RTC_TIME_ALWAYS") && getenv("RTC_TIME_DUMP") && s->d_packet_time && s->measured_order.empty()) {
-    // diagnostic, unscheduled launches (packet c is chunk c): the same columns as below
-    const size_t n = s->packet_time_capacity;
-    std::vector<uint32_t> t(n);
-    HIP_TRY(hipMemcpy(t.data(), s->d_packet_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (FILE* f = std::fopen(getenv("RTC_TIME_DUMP"), "w")) {
-      for (size_t i = 0; i < n; ++i) std::fprintf(f, "%zu 1 %u 0 %zu\n", i, t[i], i);
-      std::fclose(f);
-    }
-  }
-  if (getenv("RTC_TIME_ALWAYS") && s->d_packet_time && !s->measured_order.empty()) {  // diagnostic: predicted vs actual packet times
-    const size_t n = s->measured_order.size() / RTC_PACKET_ITEMS;
-    std::vector<uint32_t> t(n);
-    HIP_TRY(hipMemcpy(t.data(), s->d_packet_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "rtc packet times (position: now / when the schedule was packed):");
-    for (double f : {0.0, 0.1, 0.5, 0.9, 0.97, 0.98, 0.985, 0.99, 0.995, 0.999}) {
-      const size_t i = std::min(n - 1, static_cast<size_t>(f * n));
-      const uint32_t it = s->measured_order[i * RTC_PACKET_ITEMS];
-      const uint32_t c = it & 0xFFFFFu;
-      std::fprintf(stderr, " %.3f:%u/%u", f, t[i], c < s->h_chunk_time_dbg.size() ? s->h_chunk_time_dbg[c] : 0u);
-    }
-    if (const char* path = getenv("RTC_TIME_DUMP")) {
-      if (FILE* f = std::fopen(path, "w")) {
-        for (size_t i = 0; i < n; ++i) {
-          unsigned long long pred = 0;
-          uint32_t items = 0;
-          for (uint32_t j = 0; j < RTC_PACKET_ITEMS; ++j) {
-            const uint32_t it = s->measured_order[i * RTC_PACKET_ITEMS + j];
-            if (it == RTC_NO_ITEM) continue;
-            const uint32_t c = it & 0xFFFFFu, len = (it >> 26) + 1u;
-            if (c < s->h_chunk_time_dbg.size()) pred += static_cast<unsigned long long>(s->h_chunk_time_dbg[c]) * len / 64u;
-            ++items;
-          }
-          std::fprintf(f, "%zu %u %u %llu %u\n", i, items, t[i], pred, s->measured_order[i * RTC_PACKET_ITEMS] & 0xFFFFFu);
-        }
-        std::fclose(f);
-      }
-    }
-    unsigned long long tail_now = 0, tail_pred = 0, all_now = 0, all_pred = 0;
-    for (size_t i = 0; i < n; ++i) {
-      const uint32_t c = s->measured_order[i * RTC_PACKET_ITEMS] & 0xFFFFFu;
-      const uint32_t pr = c < s->h_chunk_time_dbg.size() ? s->h_chunk_time_dbg[c] : 0u;
-      all_now += t[i];
-      all_pred += pr;
-      if (i >= n - n / 50) {
-        tail_now += t[i];
-        tail_pred += pr;
-      }
-    }
-    std::fprintf(stderr, "\nrtc packet times: all %llu now / %llu predicted; last 2%% of the schedule %llu now / %llu predicted\n", all_now,
-                 all_pred, tail_now, tail_pred);
-  }
 #ifdef RTC_PROFILE
   if (getenv("RTC_PROFILE_DUMP")) {
     std::fprintf(stderr, "rtc prof:");

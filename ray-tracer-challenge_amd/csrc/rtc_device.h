@@ -213,6 +213,9 @@ struct DevPixelMap {
   // through glass - padded with cheap ones) and hands the most expensive packets out first.
   // Scheduling only: results do not depend on it.
   const uint32_t* __restrict__ order;
+  // With a schedule packed ON THE DEVICE (rtc_pack_kernel) the host does not know how many packets it has: the kernel
+  // then reads the count from here (DevSchedInfo::n_units of the schedule in use); null: n_units above is exact.
+  const uint32_t* __restrict__ n_units_dev;
   // Optional per-pixel cost output (rays traced for the pixel, indexed like the canvas), zeroed before
   // the launch; the host packs the next frames' schedule by it.
   uint32_t* __restrict__ cost;
@@ -224,6 +227,15 @@ struct DevPixelMap {
   PendingRec* __restrict__ ray_stack;
   uint32_t ray_stack_levels;
   uint32_t pull_min_idle;  // a wave pulls its next packet only when at least this many lanes are idle (or none has a ray)
+};
+
+// What rtc_pack_kernel leaves beside a schedule it packed.
+struct DevSchedInfo {
+  uint32_t n_units;      // packets in the schedule
+  uint32_t needs_split;  // some chunk took longer than a wave's fair share: the host may cut it into runs (packSchedule)
+  uint32_t heaviest;     // longest chunk time
+  uint32_t pad_;
+  unsigned long long total;  // sum of the chunk times
 };
 
 // Zero at the start of every launch; counters get one atomic per wave.  A scene owns TWO of these and

@@ -97,42 +97,52 @@ struct rtc_scene {
   bool plane_spawns_rays = false;  // a top-level plane reflects or refracts: "sees only planes" does not mean cheap
   std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
   bool branching_everywhere = false;  // such a root without a finite bound
-  std::vector<uint32_t> h_order;
+  // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next
+  // launch runs; a measuring launch is followed by rtc_pack_kernel, which packs the other buffer from what the launch
+  // measured, and the buffers swap - no host in the loop.  The host only writes a buffer for the first launch of a pixel
+  // map (the geometric heuristic, chunkOrder) and when some chunk has to be cut into runs (packSchedule).
+  std::vector<uint32_t> h_order;          // the last schedule the HOST built (heuristic or split)
   std::vector<float> h_split_inflation;   // per chunk: modelled time of its parts / its time whole, for the schedule in h_order (empty: nothing is cut)
-  std::vector<float> measured_inflation;  // ... for the schedule the last measuring launch ran
-  uint32_t* d_order = nullptr;
-  size_t order_capacity = 0;
-  std::vector<double> order_key;   // camera + map the cached (heuristic) order was built for
-  // measured-cost feedback: per-chunk ray counts of the previous launch with the same pixel map
+  uint32_t* d_sched[2] = {nullptr, nullptr};
+  size_t sched_capacity = 0;              // words per buffer
+  uint32_t sched_cur = 0;
+  DevSchedInfo* d_sched_info = nullptr;   // [2], beside the buffers
+  bool sched_valid = false;               // d_sched[sched_cur] holds a MEASURED schedule for the pixel map `cost_key`
+  bool sched_on_device = false;           // ... packed by rtc_pack_kernel: its packet count is in d_sched_info[sched_cur]
+  uint32_t sched_n_units = 0;             // ... packed by the host: its packet count
+  rtc_camera sched_cam{};                 // the view (and depth) that schedule was measured with: another view measures again
+  uint32_t sched_depth = 0;
+  std::vector<double> order_key;          // camera + map the heuristic order in h_order was built for
+  uint32_t* d_chunk_time = nullptr;       // rtc_pack_kernel scratch: per-chunk times, sorted chunks
+  uint32_t* d_sorted = nullptr;
+  size_t pack_capacity = 0;               // chunks
+  // ---- measurements: per-pixel ray counts and per-packet times of a measuring launch
   uint32_t* d_cost = nullptr;
   size_t cost_capacity = 0;
-  std::vector<uint32_t> cost_key;  // pixel map the costs / the cost-sorted order belong to
+  std::vector<uint32_t> cost_key;  // pixel map the costs / the schedule belong to
   std::vector<uint32_t> h_cost;
   uint32_t* d_chunk_cost = nullptr;  // per-chunk sums of d_cost (rtc_chunk_cost_kernel)
   size_t chunk_cost_capacity = 0;
-  std::vector<uint32_t> h_chunk_cost;
   uint32_t* d_packet_time = nullptr;  // per packet of the measured schedule: the time its wave needed (DevPixelMap::packet_time)
-  // A measuring launch is followed, on its stream, by the per-chunk sums, two copies into pinned host memory and this
-  // event: the launch that finds the event complete packs the new schedule without waiting for anything.
+  size_t packet_time_capacity = 0;
+  uint64_t launches_with_key = 0;
+  uint64_t measure_gen = 0;        // measuring launches so far (a read-back belongs to one of them)
+  // The FIRST measuring launch of a pixel map (it ran a schedule the host knows) is also read back: per-chunk sums,
+  // packet times and the packer's verdict go to pinned host memory behind an event; a later launch that finds the event
+  // complete cuts the chunks that exceed a wave's fair share into runs (packSchedule) if the packer asked for it.
   hipEvent_t measure_done = nullptr;
   bool readback_enqueued = false;
-  uint32_t launches_since_measure = 0;
+  uint64_t readback_gen = 0;
   size_t readback_packets = 0;
+  rtc_camera readback_cam{};
+  uint32_t readback_depth = 0;
   uint32_t* pin_chunk_cost = nullptr;
   size_t pin_chunk_cost_capacity = 0;
   uint32_t* pin_packet_time = nullptr;
   size_t pin_packet_time_capacity = 0;
-  size_t packet_time_capacity = 0;
-  std::vector<uint32_t> h_packet_time;
-  std::vector<uint32_t> h_chunk_time_dbg;  // per-chunk times the schedule in use was packed from (diagnostics)
-  std::vector<uint32_t> measured_order;  // the schedule (h_order) of the measuring launch; empty: packet i was chunk i
-  uint64_t launches_with_key = 0;
-  bool order_from_cost = false;
-  bool cost_pending = false;       // the previous launch measured per-pixel costs: the next one packs from them
-  rtc_camera cost_cam{};           // camera (and depth) of that measurement ...
-  uint32_t cost_depth = 0;
-  rtc_camera sched_cam{};          // ... and of the measurement the current schedule was packed from
-  uint32_t sched_depth = 0;
+  DevSchedInfo* pin_info = nullptr;
+  std::vector<uint32_t> measured_order;   // the (host-built) schedule the read-back launch ran; empty: packet i was chunk i
+  std::vector<float> measured_inflation;  // ... and its h_split_inflation
   hipStream_t last_stream = nullptr;  // the stream of the last launch (or the handle's own, after create)
   hipEvent_t launch_done = nullptr;   // recorded behind everything a launch enqueues; a launch on ANOTHER stream waits for it
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack

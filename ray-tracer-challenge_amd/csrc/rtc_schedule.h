@@ -10,16 +10,34 @@ inline uint32_t scheduleItem(uint32_t chunk, uint32_t start, uint32_t len) {
   return chunk | (start << 20) | ((len - 1u) << 26);
 }
 
-int uploadSchedule(rtc_scene* s, hipStream_t stream) {
-  const std::vector<uint32_t>& order = s->h_order;
-  if (order.size() > s->order_capacity) {
-    if (s->d_order) (void)hipFree(s->d_order);
-    s->d_order = nullptr;
-    s->order_capacity = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_order), order.size() * sizeof(uint32_t)));
-    s->order_capacity = order.size();
+// Both schedule buffers hold at least `words` words (a device-packed schedule needs 16 per chunk; a host schedule with
+// chunks cut into runs can be longer).  Growing drops what the buffers held.
+int ensureScheduleBuffers(rtc_scene* s, size_t words) {
+  if (words <= s->sched_capacity) return RTC_OK;
+  HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be reading a buffer)
+  for (int b = 0; b < 2; ++b) {
+    if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
+    s->d_sched[b] = nullptr;
   }
-  HIP_TRY(hipMemcpyAsync(s->d_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  s->sched_capacity = 0;
+  s->sched_valid = false;
+  s->order_key.clear();
+  for (int b = 0; b < 2; ++b) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched[b]), words * sizeof(uint32_t)));
+  if (!s->d_sched_info) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched_info), 2 * sizeof(DevSchedInfo)));
+  s->sched_capacity = words;
+  return RTC_OK;
+}
+
+// Copies s->h_order into the buffer that is not in use and makes it the current one (stream order: launches already
+// enqueued keep reading the other buffer).
+int uploadSchedule(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
+  const std::vector<uint32_t>& order = s->h_order;
+  if (const int st = ensureScheduleBuffers(s, std::max(order.size(), static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS)); st != RTC_OK) return st;
+  const uint32_t target = s->sched_cur ^ 1u;
+  HIP_TRY(hipMemcpyAsync(s->d_sched[target], order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  s->sched_cur = target;
+  s->sched_on_device = false;
+  s->sched_n_units = static_cast<uint32_t>(order.size() / RTC_PACKET_ITEMS);
   return RTC_OK;
 }
 
@@ -87,7 +105,10 @@ inline double groupFloor(const rtc_scene* s) {
 
 // The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,
 // so every packet is one whole chunk, most expensive first.  Returns false if some chunk has to be split.
-bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost, double n_waves) {
+// The library itself packs this case ON THE DEVICE (rtc_pack_kernel, same policy: classes of a quarter octave, image
+// order inside a class, cheap chunks several to a packet); this host statement of it is what the packer fuzz
+// (tools/sanitize/pack_fuzz.hip) and packSchedule's readers go by.
+[[maybe_unused]] bool packWholeChunks(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost, double n_waves) {
   static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
   double total = 0.0;
   uint32_t heaviest = 0;
@@ -350,6 +371,7 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
 // branching material come first.  A heuristic on the host, cached per (camera, map); never affects results.
 int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_t stream) {
   map.order = nullptr;
+  map.n_units_dev = nullptr;
   map.n_units = map.n_chunks;
   if (map.n_chunks >= RTC_ITEM_MAX_CHUNKS) return RTC_OK;  // chunk index must fit the item encoding
   if (map.n_chunks < 64) return RTC_OK;
@@ -361,9 +383,9 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   key.insert(key.end(), cam.inv_view, cam.inv_view + 16);
   const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
   for (size_t i = 0; i < offsetof(DevPixelMap, n_units) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
-  if (key == s->order_key && s->d_order) {
-    map.order = s->d_order;
-    map.n_units = static_cast<uint32_t>(s->h_order.size() / RTC_PACKET_ITEMS);
+  if (key == s->order_key && s->sched_capacity != 0 && !s->sched_on_device) {  // (the buffer in use still holds it)
+    map.order = s->d_sched[s->sched_cur];
+    map.n_units = s->sched_n_units;
     return RTC_OK;
   }
   // forward view matrix (world -> camera)
@@ -453,10 +475,10 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
   // sixteen-chunk packets of 16 ms at the very end of its first frame)
   emit(trivial, s->plane_spawns_rays ? 1u : per_trivial);
   s->h_order.resize(static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS);
-  const int st = uploadSchedule(s, stream);
+  const int st = uploadSchedule(s, map, stream);
   if (st != RTC_OK) return st;
   s->order_key = key;
-  map.order = s->d_order;
+  map.order = s->d_sched[s->sched_cur];
   map.n_units = n_packets;
   return RTC_OK;
 }

@@ -31,6 +31,7 @@ if os.path.exists(os.path.join(src, "scale_sim.txt")):
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 traffic = {"scene": "cover.json", "width": 1920, "height": 1080, "depth": 5,
            "fetch_size_kb": round(pmc["FETCH_SIZE"], 1), "write_size_kb": round(pmc["WRITE_SIZE"], 1),
+           "pmc": {k: round(v, 1) for k, v in sorted(pmc.items())},
            "source": f"profiles/{rnd}/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, per-launch mean)"}
 json.dump(traffic, open(os.path.join(repo, "profiles", "traffic.json"), "w"), indent=1)
 ks = open(os.path.join(dst, "kernel_stats.csv")).read().splitlines()
