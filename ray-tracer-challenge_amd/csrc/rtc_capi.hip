@@ -31,13 +31,22 @@ extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCame
 extern "C" __global__ void rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                           const uint32_t max_depth, double* __restrict__ out,
                                                           DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
-extern "C" __global__ void rtc_pack_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
-                                           const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
-                                           const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, const float n_waves,
-                                           const float t_min, uint32_t* __restrict__ chunk_time, uint32_t* __restrict__ sorted,
-                                           uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info);
 extern "C" __global__ void rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map,
-                                                 uint32_t* __restrict__ chunk_cost);
+                                                 uint32_t* __restrict__ chunk_cost, uint32_t* __restrict__ chunk_time,
+                                                 DevPackState* __restrict__ state);
+extern "C" __global__ void rtc_chunk_time_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
+                                                 const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
+                                                 const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks,
+                                                 uint32_t* __restrict__ chunk_time);
+extern "C" __global__ void rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks,
+                                                 const float cost_to_time, uint32_t* __restrict__ chunk_time,
+                                                 DevPackState* __restrict__ state);
+extern "C" __global__ void rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves,
+                                                const float t_min, DevPackState* __restrict__ state, uint32_t* __restrict__ sorted,
+                                                DevSchedInfo* __restrict__ info);
+extern "C" __global__ void rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves,
+                                                const float t_min, const DevPackState* __restrict__ state,
+                                                uint32_t* __restrict__ order_out);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
                                                const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
                                                const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
@@ -135,26 +144,78 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
+double residentWaves(const rtc_scene* s) {
+  const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
+                   s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
+  return 4.0 * s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+}
+
+// The measured schedule in use, into a launch's pixel map.
+void useSchedule(const rtc_scene* s, DevPixelMap& map) {
+  map.order = s->d_sched[s->sched_cur];
+  map.n_units_dev = s->sched_on_device ? &s->d_sched_info[s->sched_cur].n_units : nullptr;
+  map.n_units = s->sched_on_device ? map.n_chunks : s->sched_n_units;  // (device-packed: an upper bound, for the grid)
+}
+
+// Everything a measuring launch and the packer behind it write to.
+int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
+  if (const int st = ensureScheduleBuffers(s, static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
+  // (a host schedule with chunks cut into runs can have more packets than there are chunks: at most 16 parts each)
+  const size_t need_pt = static_cast<size_t>(map.n_chunks) * 16u;
+  if (need_pt > s->packet_time_capacity) {
+    HIP_TRY(hipEventSynchronize(s->launch_done));
+    if (s->d_packet_time) (void)hipFree(s->d_packet_time);
+    s->d_packet_time = nullptr;
+    s->packet_time_capacity = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), need_pt * sizeof(uint32_t)));
+    s->packet_time_capacity = need_pt;
+  }
+  if (map.n_chunks > s->pack_capacity) {
+    HIP_TRY(hipEventSynchronize(s->launch_done));
+    for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost}) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    s->pack_capacity = 0;
+    for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost})
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+    s->pack_capacity = map.n_chunks;
+  }
+  return RTC_OK;
+}
+
 // The schedule of one launch (results never depend on it).
-//   * first launch of a pixel map: the geometric heuristic of chunkOrder() (host), and the launch MEASURES: per-pixel
-//     ray counts and the time every packet took in the wave that pulled it;
-//   * a measuring launch is followed on its stream by rtc_chunk_cost_kernel and rtc_pack_kernel: the next launch runs a
-//     schedule packed on the device from those measurements.  Nothing waits for the host;
-//   * a view (camera, depth) other than the one the schedule in use was measured with measures again: an orbiting
-//     camera (lib.zig:166-190) renders every frame with the schedule of the frame before;  a static view keeps its
-//     schedule and measures nothing;
-//   * the first measurement is also read back: if the packer found a chunk above a wave's fair share (small images, one
-//     rank's share of a frame split over GPUs) the host cuts such chunks into runs of pixels (packSchedule) and the
-//     launch that finds the read-back complete switches to that schedule.
+//   * first launch of a pixel map: the geometric heuristic of chunkOrder() on the host - except for frames of 65 536
+//     chunks and more (4K), where that heuristic costs the host more than the frame takes (14 ms wall for the first
+//     frame of dragons.json at 4K): a PROBE launch renders one pixel of every 8x8 chunk (1/64 of the rays) and counts
+//     its rays, and the packer orders the frame's chunks by that.  Measured first frames, probe / heuristic, GPU time:
+//     cover 1080p 1.56 / 1.31 ms, reflection_and_refraction depth 8 4.88 / 4.41, teapot 1.35 / 0.70, dragons 4K
+//     4.45 / 5.10 (the probe launch itself takes 0.3 ms: one pixel's ray tree is a chain of dependent iterations);
+//   * a launch whose schedule was not measured on its own view MEASURES: per-pixel ray counts and the time every packet
+//     took in the wave that pulled it; it is followed on its stream by rtc_chunk_cost_kernel and rtc_pack_kernel: the
+//     next launch runs a schedule packed on the device from those measurements.  Nothing waits for the host;
+//   * so an orbiting camera (lib.zig:166-190) renders every frame with the schedule of the frame before, and a static
+//     view keeps the schedule of its first full frame and measures nothing more;
+//   * the first full measurement is also read back (per-chunk costs and times, the packer's verdict): if a chunk took
+//     longer than a wave's fair share (small images, one rank's share of a frame split over GPUs) the host cuts such
+//     chunks into runs of pixels (packSchedule) and the launch that finds the read-back complete switches to that.
+#define RTC_PROBE_MIN_CHUNKS 65536u
+
+struct SchedulePlan {
+  bool measure = false;  // this launch collects costs and packet times, and the next schedule is packed from them
+  bool probe = false;    // ... and is preceded by a probe launch that packs ITS schedule
+};
+
 int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, size_t out_pixels,
-                   hipStream_t stream, bool& measure) {
-  measure = false;
+                   hipStream_t stream, SchedulePlan& plan) {
+  plan = SchedulePlan{};
   const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
   std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
   if (mkey != s->cost_key) {
     s->cost_key = mkey;
     s->launches_with_key = 0;
     s->sched_valid = false;
+    s->split_checked = false;
     s->order_key.clear();
     if (s->readback_enqueued) HIP_TRY(hipEventSynchronize(s->measure_done));  // (its copies must not land in a later read-back's buffers)
     s->readback_enqueued = false;
@@ -169,9 +230,6 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->readback_enqueued = false;
   }
   const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
-  const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
-                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
-  const double n_waves = 4.0 * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   if (schedulable && s->readback_enqueued) {
     const hipError_t ready = hipEventQuery(s->measure_done);
     if (ready == hipSuccess) {
@@ -179,15 +237,10 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
       // (a later measuring launch has overwritten the per-pixel costs: that read-back describes a frame that is gone)
       if (s->pin_info->needs_split && s->readback_gen == s->measure_gen) {
         const std::vector<uint32_t> h_chunk_cost(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
-        const std::vector<uint32_t> h_packet_time(s->pin_packet_time, s->pin_packet_time + s->readback_packets);
-        // what every chunk really took: a packet's time, shared among its items by their cost
-        std::vector<uint32_t> chunk_time = chunkTimes(map, h_chunk_cost, h_packet_time, s->measured_order);
-        // a chunk that ran in parts paid for its deepest ray tree in each of them (packSchedule's model): undo that before packing again
-        if (s->measured_inflation.size() == chunk_time.size())
-          for (size_t c = 0; c < chunk_time.size(); ++c) chunk_time[c] = static_cast<uint32_t>(chunk_time[c] / s->measured_inflation[c]);
+        const std::vector<uint32_t> h_chunk_time(s->pin_chunk_time, s->pin_chunk_time + map.n_chunks);
         s->h_cost.resize(out_pixels);
         HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        packSchedule(s, map, s->h_cost, h_chunk_cost, chunk_time, n_waves, s->readback_depth);
+        packSchedule(s, map, s->h_cost, h_chunk_cost, h_chunk_time, residentWaves(s), s->readback_depth);
         if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
         s->sched_valid = true;
         s->sched_cam = s->readback_cam;
@@ -198,67 +251,54 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
       HIP_TRY(ready);
     }
   }
+  static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: never measure, keep the first launch's schedule
+  static const bool no_probe = getenv("RTC_NO_PROBE") != nullptr;    // diagnostic: the host heuristic for every first frame
+  if (schedulable && !sched_off)
+    if (const int st = ensureMeasureBuffers(s, map); st != RTC_OK) return st;
+  uint32_t probe_min = RTC_PROBE_MIN_CHUNKS;
+  if (!s->sched_valid)
+    if (const char* e = getenv("RTC_PROBE_MIN_CHUNKS")) probe_min = static_cast<uint32_t>(std::max(64, atoi(e)));  // tests: probe small frames too
+  plan.probe = schedulable && !sched_off && !no_probe && !s->sched_valid && map.n_chunks >= probe_min;
+  if (plan.probe) {
+    plan.measure = true;
+    return RTC_OK;  // (launch() runs the probe and then comes back through useSchedule)
+  }
   if (s->sched_valid) {
-    map.order = s->d_sched[s->sched_cur];
-    map.n_units_dev = s->sched_on_device ? &s->d_sched_info[s->sched_cur].n_units : nullptr;
-    map.n_units = s->sched_on_device ? map.n_chunks : s->sched_n_units;  // (device-packed: an upper bound, for the grid)
+    useSchedule(s, map);
   } else {
     if (const int st = chunkOrder(s, cam, map, stream); st != RTC_OK) return st;
     if (map.order == nullptr) s->h_order.clear();  // unscheduled: packet i is chunk i
   }
-  static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: keep the first launch's schedule
   const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
-  measure = schedulable && !sched_off && (!s->sched_valid || view_changed);
-  map.cost = nullptr;
-  map.packet_time = nullptr;
-  if (measure) {
-    if (const int st = ensureScheduleBuffers(s, static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
-    if (!s->sched_valid && map.order != nullptr) map.order = s->d_sched[s->sched_cur];  // (the buffers may just have been allocated ... by chunkOrder's upload: same pointer)
-    const size_t need_pt = std::max<size_t>(map.n_units, map.n_chunks);
-    if (need_pt > s->packet_time_capacity) {
-      HIP_TRY(hipEventSynchronize(s->launch_done));
-      if (s->d_packet_time) (void)hipFree(s->d_packet_time);
-      s->d_packet_time = nullptr;
-      s->packet_time_capacity = 0;
-      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_packet_time), need_pt * sizeof(uint32_t)));
-      s->packet_time_capacity = need_pt;
-    }
-    if (map.n_chunks > s->pack_capacity) {
-      HIP_TRY(hipEventSynchronize(s->launch_done));
-      for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost}) {
-        if (*p) (void)hipFree(*p);
-        *p = nullptr;
-      }
-      s->pack_capacity = 0;
-      for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost})
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
-      s->pack_capacity = map.n_chunks;
-    }
-    HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
-    map.cost = s->d_cost;
-    map.packet_time = s->d_packet_time;
-  }
-  s->launches_with_key++;
+  plan.measure = schedulable && !sched_off && (!s->sched_valid || view_changed);
   return RTC_OK;
 }
 
 // Right after a measuring launch, on its stream: per-chunk sums of the per-pixel costs, then the next frame's schedule
-// packed into the buffer that is not in use; the buffers swap.  The first measurement of a pixel map also goes to pinned
-// host memory behind an event (see updateSchedule).  Nothing here waits.
-int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, hipStream_t stream) {
-  const bool lds_ = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
-                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
-  const float n_waves = 4.0f * s->n_cus * (lds_ ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
-  hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((map.n_chunks + 255u) / 256u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost);
-  HIP_TRY(hipGetLastError());
-  const uint32_t target = s->sched_cur ^ 1u;
-  hipLaunchKernelGGL(rtc_pack_kernel, dim3(1), dim3(1024), 0, stream, map.order, map.n_units_dev, map.n_units, s->d_packet_time,
-                     s->d_chunk_cost, map.n_chunks, n_waves, static_cast<float>(groupFloor(s)), s->d_chunk_time, s->d_sorted,
-                     s->d_sched[target], s->d_sched_info + target);
+// packed into the buffer that is not in use; the buffers swap.  The first full measurement of a pixel map also goes to
+// pinned host memory behind an event (see updateSchedule).  Nothing here waits.
+int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, hipStream_t stream,
+                     bool is_probe) {
+  const uint32_t n = map.n_chunks, target = s->sched_cur ^ 1u;
+  const float n_waves = static_cast<float>(residentWaves(s)), t_min = static_cast<float>(groupFloor(s));
+  // A probe counted the rays of ONE pixel per chunk and timed nothing: 64 pixels x about 10 ticks (of 16 shader cycles)
+  // per unit of cost, twice that where rays walk a BVH (cover: a sky chunk 1 280 ticks = 8 us, the heaviest glass chunk
+  // 45 000 = 0.28 ms; measured 5 us and 0.37 ms).
+  const float per_cost = s->simple_kernel ? 10.0f : 20.0f, cost_to_time = is_probe ? 64.0f * per_cost : per_cost;
+  const uint32_t prev_packets = map.order == nullptr ? n : map.n_units;  // (device-packed: an upper bound)
+  hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost, s->d_chunk_time,
+                     s->d_pack_state);
+  hipLaunchKernelGGL(rtc_chunk_time_kernel, dim3((prev_packets + 255u) / 256u), dim3(256), 0, stream, map.order, map.n_units_dev,
+                     map.n_units, s->d_packet_time, s->d_chunk_cost, n, s->d_chunk_time);
+  hipLaunchKernelGGL(rtc_pack_class_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_cost, n, cost_to_time,
+                     s->d_chunk_time, s->d_pack_state);
+  hipLaunchKernelGGL(rtc_pack_sort_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, t_min,
+                     s->d_pack_state, s->d_sorted, s->d_sched_info + target);
+  hipLaunchKernelGGL(rtc_pack_emit_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_sorted, n, n_waves, t_min,
+                     s->d_pack_state, s->d_sched[target]);
   HIP_TRY(hipGetLastError());
   s->measure_gen++;
-  const bool host_knows_the_schedule = map.n_units_dev == nullptr;
-  if (!s->sched_valid && host_knows_the_schedule && !s->readback_enqueued) {  // the first measurement of this pixel map
+  if (!is_probe && !s->split_checked && !s->readback_enqueued) {  // the first full measurement of this pixel map
     auto pinned = [](auto*& p, size_t& capacity, size_t n) -> hipError_t {
       if (n <= capacity) return hipSuccess;
       if (p) (void)hipHostFree(p);
@@ -268,22 +308,19 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
       if (e == hipSuccess) capacity = n;
       return e;
     };
-    const size_t n_measured = map.order == nullptr ? map.n_chunks : map.n_units;
     HIP_TRY(pinned(s->pin_chunk_cost, s->pin_chunk_cost_capacity, map.n_chunks));
-    HIP_TRY(pinned(s->pin_packet_time, s->pin_packet_time_capacity, n_measured));
+    HIP_TRY(pinned(s->pin_chunk_time, s->pin_chunk_time_capacity, map.n_chunks));
     if (!s->pin_info) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_info), sizeof(DevSchedInfo), hipHostMallocDefault));
     if (!s->measure_done) HIP_TRY(hipEventCreateWithFlags(&s->measure_done, hipEventDisableTiming));
     HIP_TRY(hipMemcpyAsync(s->pin_chunk_cost, s->d_chunk_cost, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(s->pin_packet_time, s->d_packet_time, n_measured * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(s->pin_chunk_time, s->d_chunk_time, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(s->pin_info, s->d_sched_info + target, sizeof(DevSchedInfo), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(s->measure_done, stream));
-    s->readback_packets = n_measured;
     s->readback_enqueued = true;
+    s->split_checked = true;
     s->readback_gen = s->measure_gen;
     s->readback_cam = cam;
     s->readback_depth = max_depth;
-    s->measured_order = map.order == nullptr ? std::vector<uint32_t>() : s->h_order;
-    s->measured_inflation = s->h_split_inflation;
   }
   s->sched_cur = target;
   s->sched_valid = true;
@@ -330,27 +367,17 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   return RTC_OK;
 }
 
-int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
-           size_t out_pixels, hipStream_t stream) {
-  DevPixelMap map = map_in;
-  if (max_depth > RTC_MAX_DEPTH)
-    return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
-  if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
-  HIP_TRY(hipSetDevice(s->device));
-  // Launches on one handle share its counters, work counter, pending-ray stacks, csg lists and schedule buffers, and
-  // launch N + 1 clears the counters of launch N + 2: they must run one after the other.  Stream order gives that on
-  // one stream; when the caller changes streams (rtc_render_device on its own stream, then rtc_render on the handle's),
-  // the new stream first waits for everything the handle enqueued before (the event recorded at the end of launch()).
-  if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
-  bool measure = false;
-  if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, measure); st != RTC_OK) return st;
+// One launch of the render kernel for `map` (schedule and measurement buffers already chosen).
+int enqueueRender(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, double* d_out, hipStream_t stream) {
   const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
                    s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
   // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
-  // chunks to hand out, 4 waves each); the waves pull chunks until the counter runs out.
+  // packets to hand out, 4 waves each); the waves pull packets until the counter runs out.
   const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
   const uint32_t blocks = std::max(1u, std::min(resident, (map.n_units + 3u) / 4u));
   if (const int st = ensureScratch(s, map, blocks, max_depth); st != RTC_OK) return st;
+  if (map.packet_time != nullptr)
+    HIP_TRY(hipMemsetAsync(map.packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
   s->stats_parity ^= 1u;
   DevStats* const st_now = s->d_stats + s->stats_parity;
   DevStats* const st_next = s->d_stats + (s->stats_parity ^ 1u);
@@ -365,8 +392,55 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
-  if (measure)
-    if (const int st = packNextSchedule(s, cam, map, max_depth, stream); st != RTC_OK) return st;
+  return RTC_OK;
+}
+
+// The probe launch of a first frame: pixel 27 (row 3, column 3) of every chunk, sixteen chunks to a packet, with the
+// per-pixel ray counts switched on; the packer then orders the chunks by those counts (no packet was timed: a chunk's
+// time falls back to its cost).  The probe's pixels are real pixels of the frame - the frame renders them again.
+int probeAndPack(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
+                 size_t out_pixels, hipStream_t stream) {
+  DevPixelMap map = map_in;
+  const uint32_t n_packets = (map.n_chunks + RTC_PACKET_ITEMS - 1u) / RTC_PACKET_ITEMS;
+  s->h_order.assign(static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
+  for (uint32_t c = 0; c < map.n_chunks; ++c) s->h_order[c] = scheduleItem(c, 27u, 1u);
+  s->h_split_inflation.clear();
+  if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
+  s->order_key.clear();
+  map.order = s->d_sched[s->sched_cur];
+  map.n_units_dev = nullptr;
+  map.n_units = n_packets;
+  map.cost = s->d_cost;
+  map.packet_time = nullptr;  // (the probe's packets are not what the frame's will be: the packer sees zero times)
+  HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(n_packets) * sizeof(uint32_t), stream));
+  if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
+  return packNextSchedule(s, cam, map, max_depth, stream, true);
+}
+
+int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
+           size_t out_pixels, hipStream_t stream) {
+  DevPixelMap map = map_in;
+  if (max_depth > RTC_MAX_DEPTH)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
+  if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
+  HIP_TRY(hipSetDevice(s->device));
+  // Launches on one handle share its counters, work counter, pending-ray stacks, csg lists and schedule buffers, and
+  // launch N + 1 clears the counters of launch N + 2: they must run one after the other.  Stream order gives that on
+  // one stream; when the caller changes streams (rtc_render_device on its own stream, then rtc_render on the handle's),
+  // the new stream first waits for everything the handle enqueued before (the event recorded at the end of launch()).
+  if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
+  SchedulePlan plan;
+  if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
+  if (plan.probe) {
+    if (const int st = probeAndPack(s, cam, map_in, max_depth, d_out, out_pixels, stream); st != RTC_OK) return st;
+    useSchedule(s, map);
+  }
+  map.cost = plan.measure ? s->d_cost : nullptr;
+  map.packet_time = plan.measure ? s->d_packet_time : nullptr;
+  if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
+  if (plan.measure)
+    if (const int st = packNextSchedule(s, cam, map, max_depth, stream, false); st != RTC_OK) return st;
   HIP_TRY(hipEventRecord(s->launch_done, stream));
   s->last_stream = stream;
   return RTC_OK;
@@ -1307,6 +1381,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   for (int b = 0; b < 2; ++b)
     if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
   if (s->d_sched_info) (void)hipFree(s->d_sched_info);
+  if (s->d_pack_state) (void)hipFree(s->d_pack_state);
   if (s->d_chunk_time) (void)hipFree(s->d_chunk_time);
   if (s->d_sorted) (void)hipFree(s->d_sorted);
   if (s->pin_info) (void)hipHostFree(s->pin_info);
@@ -1314,7 +1389,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
   if (s->d_packet_time) (void)hipFree(s->d_packet_time);
   if (s->pin_chunk_cost) (void)hipHostFree(s->pin_chunk_cost);
-  if (s->pin_packet_time) (void)hipHostFree(s->pin_packet_time);
+  if (s->pin_chunk_time) (void)hipHostFree(s->pin_chunk_time);
   if (s->measure_done) (void)hipEventDestroy(s->measure_done);
   if (s->launch_done) (void)hipEventDestroy(s->launch_done);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);

@@ -238,6 +238,15 @@ struct DevSchedInfo {
   unsigned long long total;  // sum of the chunk times
 };
 
+// Scratch of the packer's launches (rtc_chunk_cost_kernel clears it).
+#define RTC_PACK_CLASSES 136  // 4 * log2(1 + t) of a 32-bit time is at most 128
+struct DevPackState {
+  uint32_t cnt[RTC_PACK_CLASSES];     // chunks per class
+  uint32_t cursor[RTC_PACK_CLASSES];  // chunks of the class already placed by the sort
+  unsigned long long total;           // sum of the chunk times
+  uint32_t heaviest, pad_;
+};
+
 // Zero at the start of every launch; counters get one atomic per wave.  A scene owns TWO of these and
 // alternates: launch n counts in [n & 1] and clears [(n + 1) & 1] for its successor (stream order makes
 // that safe), so no launch needs a memset of its own.

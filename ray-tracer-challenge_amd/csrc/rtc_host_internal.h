@@ -107,6 +107,7 @@ struct rtc_scene {
   size_t sched_capacity = 0;              // words per buffer
   uint32_t sched_cur = 0;
   DevSchedInfo* d_sched_info = nullptr;   // [2], beside the buffers
+  DevPackState* d_pack_state = nullptr;   // the packer's histogram and totals
   bool sched_valid = false;               // d_sched[sched_cur] holds a MEASURED schedule for the pixel map `cost_key`
   bool sched_on_device = false;           // ... packed by rtc_pack_kernel: its packet count is in d_sched_info[sched_cur]
   uint32_t sched_n_units = 0;             // ... packed by the host: its packet count
@@ -127,22 +128,20 @@ struct rtc_scene {
   size_t packet_time_capacity = 0;
   uint64_t launches_with_key = 0;
   uint64_t measure_gen = 0;        // measuring launches so far (a read-back belongs to one of them)
-  // The FIRST measuring launch of a pixel map (it ran a schedule the host knows) is also read back: per-chunk sums,
-  // packet times and the packer's verdict go to pinned host memory behind an event; a later launch that finds the event
-  // complete cuts the chunks that exceed a wave's fair share into runs (packSchedule) if the packer asked for it.
+  // The FIRST full measuring launch of a pixel map is also read back: per-chunk costs and times and the packer's verdict
+  // go to pinned host memory behind an event; a later launch that finds the event complete cuts the chunks that exceed a
+  // wave's fair share into runs (packSchedule) if the packer asked for it.
   hipEvent_t measure_done = nullptr;
   bool readback_enqueued = false;
   uint64_t readback_gen = 0;
-  size_t readback_packets = 0;
+  bool split_checked = false;      // that read-back has been enqueued for the pixel map in use
   rtc_camera readback_cam{};
   uint32_t readback_depth = 0;
   uint32_t* pin_chunk_cost = nullptr;
   size_t pin_chunk_cost_capacity = 0;
-  uint32_t* pin_packet_time = nullptr;
-  size_t pin_packet_time_capacity = 0;
+  uint32_t* pin_chunk_time = nullptr;
+  size_t pin_chunk_time_capacity = 0;
   DevSchedInfo* pin_info = nullptr;
-  std::vector<uint32_t> measured_order;   // the (host-built) schedule the read-back launch ran; empty: packet i was chunk i
-  std::vector<float> measured_inflation;  // ... and its h_split_inflation
   hipStream_t last_stream = nullptr;  // the stream of the last launch (or the handle's own, after create)
   hipEvent_t launch_done = nullptr;   // recorded behind everything a launch enqueues; a launch on ANOTHER stream waits for it
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack

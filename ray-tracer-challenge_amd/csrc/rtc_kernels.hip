@@ -1997,190 +1997,210 @@ rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world, c
 // The schedule of the NEXT frame, packed on the device from what THIS frame measured: no host in
 // the loop, so a moving camera (lib.zig:166-190) renders every frame with a schedule that is one frame old instead of
 // one that is 16-24 frames old.  Same policy as the host's packWholeChunks (rtc_schedule.h): whole chunks, longest
-// first in classes of a quarter octave of measured time, image order kept inside a class (neighbouring chunks run at
-// the same moment: same objects, same BVH nodes), cheap chunks several to a packet.
-//   1. per-chunk time: a packet's measured time shared among its items by their cost (chunkTimes);
-//   2. counting sort by class, in batches of 1024 consecutive chunks (order inside a batch is arrival order);
-//   3. packets: k chunks of one class per packet, k = group_cap / the class's upper time bound, 1..16.
-// One work-group: 32 400 chunks (1080p) take a few microseconds, 129 600 (4K) a few tens.
+// first in classes of a quarter octave of measured time, image order (about) kept inside a class - neighbouring chunks
+// run at the same moment: same objects, same BVH nodes -, cheap chunks several to a packet.  Five small launches on the
+// render's stream, every one a grid over chunks or packets (a single work-group doing all of it took 180 us at 1080p:
+// forty dependent round trips to memory; this takes about 20):
+//   rtc_chunk_cost_kernel  per-chunk sums of the per-pixel ray counts; clears what the next steps add into
+//   rtc_chunk_time_kernel  a packet's measured time, shared among its items by their cost (host twin: chunkTimes)
+//   rtc_pack_class_kernel  per chunk: final time (cost x `cost_to_time` if it was not timed), its class; histogram, totals
+//   rtc_pack_sort_kernel   counting sort by class, a block of 1024 consecutive chunks at a time
+//   rtc_pack_emit_kernel   packets: k chunks of one class each, k = group_cap / the class's upper time bound, 1..16
 // Results never depend on the schedule.
 // ------------------------------------------------------------------------------------------
-#define RTC_PACK_CLASSES 136  // 4 * log2(1 + t) of a 32-bit time is at most 128
 __device__ __forceinline__ uint32_t pack_class(uint32_t t) {
-  return static_cast<uint32_t>(4.0f * __builtin_log2f(1.0f + static_cast<float>(t)));
+  return static_cast<uint32_t>(4.0f * __builtin_log2f(1.0f + static_cast<float>(t)));  // < RTC_PACK_CLASSES for any 32-bit t
 }
 
-extern "C" __global__ void __launch_bounds__(1024)
-rtc_pack_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
-                const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
-                const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, const float n_waves, const float t_min,
-                uint32_t* __restrict__ chunk_time, uint32_t* __restrict__ sorted, uint32_t* __restrict__ order_out,
-                DevSchedInfo* __restrict__ info) {
-  __shared__ uint32_t cnt[RTC_PACK_CLASSES], cbase[RTC_PACK_CLASSES], cursor[RTC_PACK_CLASSES];
-  __shared__ uint32_t per_packet[RTC_PACK_CLASSES], pbase[RTC_PACK_CLASSES + 1];
-  __shared__ double red_a[16], red_b[16];
-  __shared__ uint32_t red_m[16];
-  __shared__ double sh_total_t, sh_total_c;
-  __shared__ uint32_t sh_heaviest, sh_n_packets;
-  const uint32_t tid = threadIdx.x, nth = blockDim.x;
-  const uint32_t prev_n = prev_order == nullptr ? n_chunks : (prev_n_units_dev != nullptr ? *prev_n_units_dev : prev_n_units_host);
-  for (uint32_t c = tid; c < n_chunks; c += nth) chunk_time[c] = 0u;
-  if (tid < RTC_PACK_CLASSES) cnt[tid] = 0u;
-  __syncthreads();
-  // ---- 1. chunk times (agent-scope atomics: a chunk cut into runs is timed in several packets)
-  for (uint32_t p = tid; p < prev_n; p += nth) {
-    const uint32_t pt = packet_time[p];
-    if (prev_order == nullptr) {  // unscheduled launch: packet p was chunk p
-      if (p < n_chunks && pt != 0u) atomicAdd(&chunk_time[p], pt);
-      continue;
-    }
-    float w[RTC_PACKET_ITEMS], sum = 0.0f;
-    uint32_t ch[RTC_PACKET_ITEMS], n = 0u;
-    const uint4* row = reinterpret_cast<const uint4*>(prev_order + static_cast<size_t>(p) * RTC_PACKET_ITEMS);
-#pragma unroll
-    for (uint32_t q = 0; q < RTC_PACKET_ITEMS / 4u; ++q) {
-      const uint4 v = row[q];
-      const uint32_t its[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t it = its[e];
-        const uint32_t c = it & 0xFFFFFu, len = (it >> 26) + 1u;
-        const bool ok = it != RTC_NO_ITEM && c < n_chunks;
-        ch[q * 4u + e] = ok ? c : RTC_NO_ITEM;
-        w[q * 4u + e] = ok ? (static_cast<float>(chunk_cost[c]) + 1.0f) * static_cast<float>(len) * (1.0f / 64.0f) : 0.0f;
-        sum += w[q * 4u + e];
-        n += ok ? 1u : 0u;
-      }
-    }
-    if (n == 0u || pt == 0u) continue;
-#pragma unroll
-    for (uint32_t i = 0; i < RTC_PACKET_ITEMS; ++i)
-      if (ch[i] != RTC_NO_ITEM) atomicAdd(&chunk_time[ch[i]], static_cast<uint32_t>(static_cast<float>(pt) * w[i] / sum));
-  }
-  __threadfence();
-  __syncthreads();
-  // ---- totals (chunks that were not timed fall back to their cost at the frame's mean time per cost)
-  auto block_sum2 = [&](double a, double b, double& out_a, double& out_b) {
-    for (int off = 32; off > 0; off >>= 1) {
-      a += __shfl_down(a, off, 64);
-      b += __shfl_down(b, off, 64);
-    }
-    if ((tid & 63u) == 0u) {
-      red_a[tid >> 6] = a;
-      red_b[tid >> 6] = b;
-    }
-    __syncthreads();
-    if (tid == 0u) {
-      double x = 0.0, y = 0.0;
-      for (uint32_t i = 0; i < (nth + 63u) / 64u; ++i) {
-        x += red_a[i];
-        y += red_b[i];
-      }
-      out_a = x;
-      out_b = y;
-    }
-    __syncthreads();
-  };
-  {
-    double tt = 0.0, tc = 0.0;
-    for (uint32_t c = tid; c < n_chunks; c += nth) {
-      tt += static_cast<double>(__hip_atomic_load(&chunk_time[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      tc += static_cast<double>(chunk_cost[c]);
-    }
-    block_sum2(tt, tc, sh_total_t, sh_total_c);
-  }
-  const double per_cost = (sh_total_c > 0.0 && sh_total_t > 0.0) ? sh_total_t / sh_total_c : 1.0;
-  {
-    double total = 0.0;
-    uint32_t heaviest = 0u;
-    for (uint32_t c = tid; c < n_chunks; c += nth) {
-      const uint32_t t = __hip_atomic_load(&chunk_time[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const double v = t != 0u ? static_cast<double>(t) : static_cast<double>(chunk_cost[c]) * per_cost;
-      const uint32_t tv = static_cast<uint32_t>(v < 4.0e9 ? v : 4.0e9);
-      chunk_time[c] = tv;  // read back below by this same thread only
-      total += tv;
-      heaviest = max(heaviest, tv);
-      atomicAdd(&cnt[pack_class(tv)], 1u);
-    }
-    for (int off = 32; off > 0; off >>= 1) heaviest = max(heaviest, static_cast<uint32_t>(__shfl_down(heaviest, off, 64)));
-    if ((tid & 63u) == 0u) red_m[tid >> 6] = heaviest;
-    double dummy = 0.0;
-    block_sum2(total, 0.0, sh_total_t, dummy);  // (the barrier inside also publishes red_m and cnt)
-    if (tid == 0u) {
-      uint32_t h = 0u;
-      for (uint32_t i = 0; i < (nth + 63u) / 64u; ++i) h = max(h, red_m[i]);
-      sh_heaviest = h;
-      // ---- 2./3. class bases (longest class first) and packets per class
-      const double fair = sh_total_t / fmax(1.0, static_cast<double>(n_waves));
-      const double group_cap = fmax(fair / 32.0, static_cast<double>(t_min));
-      uint32_t at = 0u, packets = 0u;
-      for (int k = RTC_PACK_CLASSES - 1; k >= 0; --k) {
-        cbase[k] = at;
-        cursor[k] = 0u;
-        at += cnt[k];
-        const double t_hi = static_cast<double>(__builtin_exp2f(static_cast<float>(k + 1) * 0.25f)) - 1.0;  // upper time bound of class k
-        const double per = group_cap / fmax(t_hi, 1.0);
-        const uint32_t kk = per >= 16.0 ? 16u : (per < 1.0 ? 1u : static_cast<uint32_t>(per));
-        per_packet[k] = kk;
-        pbase[k] = packets;  // (classes are laid out longest first: pbase grows as k falls)
-        packets += (cnt[k] + kk - 1u) / kk;
-      }
-      sh_n_packets = packets;
-    }
-    __syncthreads();
-  }
-  // ---- 2. counting sort, batch by batch so that a class keeps (about) the image order of its chunks
-  for (uint32_t base = 0; base < n_chunks; base += nth) {
-    const uint32_t c = base + tid;
-    if (c < n_chunks) {
-      const uint32_t k = pack_class(chunk_time[c]);
-      const uint32_t pos = atomicAdd(&cursor[k], 1u);
-      sorted[cbase[k] + pos] = c | (k << 20);  // RTC_ITEM_MAX_CHUNKS = 2^20 chunks; the class rides along
-    }
-    __syncthreads();
-  }
-  __threadfence_block();
-  __syncthreads();
-  // ---- 3. packets: the first chunk of each writes the whole row of 16 items
-  for (uint32_t i = tid; i < n_chunks; i += nth) {
-    const uint32_t e = sorted[i];
-    const uint32_t k = e >> 20;
-    const uint32_t j = i - cbase[k], kk = per_packet[k];
-    if (j % kk != 0u) continue;
-    const uint32_t p = pbase[k] + j / kk;
-    const uint32_t have = min(kk, cnt[k] - j);
-    uint32_t items[RTC_PACKET_ITEMS];
-#pragma unroll
-    for (uint32_t q = 0; q < RTC_PACKET_ITEMS; ++q)
-      items[q] = q < have ? ((sorted[i + q] & 0xFFFFFu) | (63u << 26)) : RTC_NO_ITEM;  // chunk | start 0 | (64 - 1) << 26
-    uint4* row = reinterpret_cast<uint4*>(order_out + static_cast<size_t>(p) * RTC_PACKET_ITEMS);
-#pragma unroll
-    for (uint32_t q = 0; q < RTC_PACKET_ITEMS / 4u; ++q) row[q] = uint4{items[q * 4u], items[q * 4u + 1u], items[q * 4u + 2u], items[q * 4u + 3u]};
-  }
-  if (tid == 0u) {
-    info->n_units = sh_n_packets;
-    info->heaviest = sh_heaviest;
-    info->needs_split = static_cast<double>(sh_heaviest) > sh_total_t / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
-    info->pad_ = 0u;
-    info->total = static_cast<unsigned long long>(sh_total_t);
-  }
-}
-
-// Per-chunk sums of the per-pixel cost array (DevPixelMap::cost), one thread per 8x8 chunk: what the host needs to
-// order whole chunks; the per-pixel values travel only if some chunk has to be split (rtc_schedule.h).
+// One wave per 8x8 chunk: coalesced rows of the cost array.
 extern "C" __global__ void __launch_bounds__(256)
-rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, uint32_t* __restrict__ chunk_cost) {
-  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, uint32_t* __restrict__ chunk_cost,
+                      uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state) {
+  if (blockIdx.x == 0u) {
+    uint32_t* z = reinterpret_cast<uint32_t*>(state);
+    for (uint32_t i = threadIdx.x; i < sizeof(DevPackState) / sizeof(uint32_t); i += blockDim.x) z[i] = 0u;
+  }
+  const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6), k = threadIdx.x & 63u;
   if (c >= map.n_chunks) return;
   const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
   const uint32_t ccy = cr / map.chunks_x;
-  const uint32_t rx0 = (cr - ccy * map.chunks_x) * 8u, ry0 = ccy * 8u;
+  const uint32_t rx = (cr - ccy * map.chunks_x) * 8u + (k & 7u), ry = ccy * 8u + (k >> 3);
   const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
   const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
-  uint32_t sum = 0u;
-  for (uint32_t k = 0; k < 64u; ++k) {
-    const uint32_t rx = rx0 + (k & 7u), ry = ry0 + (k >> 3);
-    if (rx < w && ry < h) sum += cost[out0 + static_cast<size_t>(ry) * w + rx];
+  uint32_t sum = (rx < w && ry < h) ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if (k == 0u) {
+    chunk_cost[c] = sum;
+    chunk_time[c] = 0u;
   }
-  chunk_cost[c] = sum;
+}
+
+// One thread per packet of the schedule the measured launch ran (prev_order == nullptr: packet p was chunk p).
+extern "C" __global__ void __launch_bounds__(256)
+rtc_chunk_time_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
+                      const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
+                      const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, uint32_t* __restrict__ chunk_time) {
+  const uint32_t prev_n = prev_order == nullptr ? n_chunks : (prev_n_units_dev != nullptr ? *prev_n_units_dev : prev_n_units_host);
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= prev_n) return;
+  const uint32_t pt = packet_time[p];
+  if (pt == 0u) return;
+  if (prev_order == nullptr) {
+    if (p < n_chunks) atomicAdd(&chunk_time[p], pt);
+    return;
+  }
+  float w[RTC_PACKET_ITEMS], sum = 0.0f;
+  uint32_t ch[RTC_PACKET_ITEMS];
+  const uint4* row = reinterpret_cast<const uint4*>(prev_order + static_cast<size_t>(p) * RTC_PACKET_ITEMS);
+#pragma unroll
+  for (uint32_t q = 0; q < RTC_PACKET_ITEMS / 4u; ++q) {
+    const uint4 v = row[q];
+    const uint32_t its[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t it = its[e];
+      const uint32_t c = it & 0xFFFFFu, len = (it >> 26) + 1u;
+      const bool ok = it != RTC_NO_ITEM && c < n_chunks;
+      ch[q * 4u + e] = ok ? c : RTC_NO_ITEM;
+      w[q * 4u + e] = ok ? (static_cast<float>(chunk_cost[ok ? c : 0u]) + 1.0f) * static_cast<float>(len) * (1.0f / 64.0f) : 0.0f;
+      sum += w[q * 4u + e];
+    }
+  }
+  if (!(sum > 0.0f)) return;
+  // (atomics: a chunk that was cut into runs is timed in several packets)
+#pragma unroll
+  for (uint32_t i = 0; i < RTC_PACKET_ITEMS; ++i)
+    if (ch[i] != RTC_NO_ITEM) atomicAdd(&chunk_time[ch[i]], static_cast<uint32_t>(static_cast<float>(pt) * w[i] / sum));
+}
+
+// One thread per chunk.
+extern "C" __global__ void __launch_bounds__(1024)
+rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, const float cost_to_time,
+                      uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state) {
+  __shared__ uint32_t cnt[RTC_PACK_CLASSES];
+  __shared__ unsigned long long sh_total;
+  __shared__ uint32_t sh_heaviest;
+  const uint32_t tid = threadIdx.x;
+  if (tid < RTC_PACK_CLASSES) cnt[tid] = 0u;
+  if (tid == 0u) {
+    sh_total = 0ull;
+    sh_heaviest = 0u;
+  }
+  __syncthreads();
+  const uint32_t c = blockIdx.x * blockDim.x + tid;
+  unsigned long long total = 0ull;
+  uint32_t heaviest = 0u;
+  if (c < n_chunks) {
+    const uint32_t t = chunk_time[c];
+    // a chunk that was not timed (a probe launch times nothing): its cost at the caller's estimate of ticks per unit
+    const float v = t != 0u ? static_cast<float>(t) : static_cast<float>(chunk_cost[c]) * cost_to_time;
+    const uint32_t tv = v < 4.0e9f ? static_cast<uint32_t>(v) : 4000000000u;
+    chunk_time[c] = tv;
+    total = tv;
+    heaviest = tv;
+    atomicAdd(&cnt[pack_class(tv)], 1u);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    total += __shfl_down(total, off, 64);
+    heaviest = max(heaviest, static_cast<uint32_t>(__shfl_down(heaviest, off, 64)));
+  }
+  if ((tid & 63u) == 0u) {
+    atomicAdd(&sh_total, total);
+    atomicMax(&sh_heaviest, heaviest);
+  }
+  __syncthreads();
+  if (tid < RTC_PACK_CLASSES && cnt[tid] != 0u) atomicAdd(&state->cnt[tid], cnt[tid]);
+  if (tid == 0u) {
+    atomicAdd(&state->total, sh_total);
+    atomicMax(&state->heaviest, sh_heaviest);
+  }
+}
+
+// Class bases (longest class first), chunks per packet and first packet of every class, from the histogram.
+struct PackLayout {
+  uint32_t cbase[RTC_PACK_CLASSES], per_packet[RTC_PACK_CLASSES], pbase[RTC_PACK_CLASSES], n_packets;
+};
+// Called by every thread of a work-group (at least RTC_PACK_CLASSES of them); ends with a barrier.
+__device__ __forceinline__ void pack_layout(const DevPackState* __restrict__ state, const float n_waves, const float t_min,
+                                            PackLayout& L) {
+  const uint32_t k = threadIdx.x;
+  if (k < RTC_PACK_CLASSES) {  // per class, in parallel: its size, chunks per packet, packets
+    const float fair = static_cast<float>(state->total) / fmaxf(1.0f, n_waves);
+    const float group_cap = fmaxf(fair * (1.0f / 32.0f), t_min);
+    const float t_hi = __builtin_exp2f(static_cast<float>(k + 1u) * 0.25f) - 1.0f;  // upper time bound of class k
+    const float per = group_cap / fmaxf(t_hi, 1.0f);
+    const uint32_t kk = per >= 16.0f ? 16u : (per < 1.0f ? 1u : static_cast<uint32_t>(per));
+    const uint32_t n = state->cnt[k];
+    L.per_packet[k] = kk;
+    L.cbase[k] = n;                   // (turned into the exclusive sums below)
+    L.pbase[k] = (n + kk - 1u) / kk;
+  }
+  __syncthreads();
+  if (k == 0u) {  // longest class first
+    uint32_t at = 0u, packets = 0u;
+    for (int c = RTC_PACK_CLASSES - 1; c >= 0; --c) {
+      const uint32_t n = L.cbase[c], np = L.pbase[c];
+      L.cbase[c] = at;
+      L.pbase[c] = packets;
+      at += n;
+      packets += np;
+    }
+    L.n_packets = packets;
+  }
+  __syncthreads();
+}
+
+// One work-group per block of 1024 consecutive chunks: a class keeps the image order of its chunks block by block
+// (inside a block and between blocks the order is arrival order).
+extern "C" __global__ void __launch_bounds__(1024)
+rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves, const float t_min,
+                     DevPackState* __restrict__ state, uint32_t* __restrict__ sorted, DevSchedInfo* __restrict__ info) {
+  __shared__ PackLayout L;
+  __shared__ uint32_t cnt[RTC_PACK_CLASSES], start[RTC_PACK_CLASSES], cursor[RTC_PACK_CLASSES];
+  const uint32_t tid = threadIdx.x;
+  if (tid < RTC_PACK_CLASSES) {
+    cnt[tid] = 0u;
+    cursor[tid] = 0u;
+  }
+  pack_layout(state, n_waves, t_min, L);
+  const uint32_t c = blockIdx.x * blockDim.x + tid;
+  uint32_t k = 0u;
+  if (c < n_chunks) {
+    k = pack_class(chunk_time[c]);
+    atomicAdd(&cnt[k], 1u);
+  }
+  __syncthreads();
+  if (tid < RTC_PACK_CLASSES && cnt[tid] != 0u) start[tid] = atomicAdd(&state->cursor[tid], cnt[tid]);
+  __syncthreads();
+  if (c < n_chunks) sorted[L.cbase[k] + start[k] + atomicAdd(&cursor[k], 1u)] = c | (k << 20);  // 2^20 chunks at most; the class rides along
+  if (blockIdx.x == 0u && tid == 0u) {
+    info->n_units = L.n_packets;
+    info->heaviest = state->heaviest;
+    info->needs_split = static_cast<double>(state->heaviest) > static_cast<double>(state->total) / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
+    info->pad_ = 0u;
+    info->total = state->total;
+  }
+}
+
+// One thread per sorted chunk; the first chunk of each packet writes the whole row of 16 items.
+extern "C" __global__ void __launch_bounds__(1024)
+rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves, const float t_min,
+                     const DevPackState* __restrict__ state, uint32_t* __restrict__ order_out) {
+  __shared__ PackLayout L;
+  pack_layout(state, n_waves, t_min, L);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_chunks) return;
+  const uint32_t e = sorted[i];
+  const uint32_t k = e >> 20;
+  const uint32_t j = i - L.cbase[k], kk = L.per_packet[k];
+  if (j % kk != 0u) return;
+  const uint32_t p = L.pbase[k] + j / kk;
+  const uint32_t have = min(kk, state->cnt[k] - j);
+  uint32_t items[RTC_PACKET_ITEMS];
+#pragma unroll
+  for (uint32_t q = 0; q < RTC_PACKET_ITEMS; ++q)
+    items[q] = q < have ? ((sorted[i + q] & 0xFFFFFu) | (63u << 26)) : RTC_NO_ITEM;  // chunk | start 0 | (64 - 1) << 26
+  uint4* row = reinterpret_cast<uint4*>(order_out + static_cast<size_t>(p) * RTC_PACKET_ITEMS);
+#pragma unroll
+  for (uint32_t q = 0; q < RTC_PACKET_ITEMS / 4u; ++q) row[q] = uint4{items[q * 4u], items[q * 4u + 1u], items[q * 4u + 2u], items[q * 4u + 3u]};
 }

@@ -24,6 +24,7 @@ int ensureScheduleBuffers(rtc_scene* s, size_t words) {
   s->order_key.clear();
   for (int b = 0; b < 2; ++b) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched[b]), words * sizeof(uint32_t)));
   if (!s->d_sched_info) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched_info), 2 * sizeof(DevSchedInfo)));
+  if (!s->d_pack_state) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pack_state), sizeof(DevPackState)));
   s->sched_capacity = words;
   return RTC_OK;
 }
@@ -52,10 +53,11 @@ int uploadSchedule(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
 // busy and the cheap pixels' lanes become free just as the expensive pixels' ray trees fan out (the
 // kernel's intra-wave sharing moves the sub-trees over).  Every other chunk stays whole: neighbouring
 // pixels in one wave is what keeps the traversal coherent.  Packets go out most expensive first.
+// (Host statement of step 1 of rtc_pack_kernel, which is what the library runs; the packer fuzz checks this one.)
 // Per-chunk wave time from the per-packet times of a measured launch (DevPixelMap::packet_time): a packet's time is
 // shared among its items in proportion to their cost (a partial item: its share of the chunk's cost by pixel count).
 // Chunks that were not timed (time 0: e.g. a launch that measured nothing) fall back to their cost.
-std::vector<uint32_t> chunkTimes(const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost,
+[[maybe_unused]] std::vector<uint32_t> chunkTimes(const DevPixelMap& map, const std::vector<uint32_t>& chunk_cost,
                                  const std::vector<uint32_t>& packet_time, const std::vector<uint32_t>& measured_order) {
   std::vector<double> t(map.n_chunks, 0.0);
   if (measured_order.empty()) {

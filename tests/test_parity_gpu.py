@@ -303,6 +303,47 @@ def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth):
         _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
 
 
+def test_probe_launch_at_small_sizes(rtc, monkeypatch):
+    """Frames of 8192 chunks and more start with a probe launch (one pixel per chunk, its ray count orders the chunks of
+    the first frame).  Here the threshold is lowered so that every kernel variant and the tile mode run it at sizes the
+    oracle renders whole; the probe's pixels are rendered twice (probe, frame) and must not be counted twice."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("RTC_PROBE_MIN_CHUNKS", "64")
+    for scene, w, h, depth in (("cover.json", 192, 108, 5), ("teapot.json", 96, 54, 5), ("csg_demo.json", 96, 54, 5),
+                               ("reflection_and_refraction.json", 150, 97, 8)):
+        hs = rtc.HostScene.from_file(scene)
+        cam = hs.camera(w, h)
+        gpu = rtc.GpuScene(hs.desc)
+        want, counters = ob.OracleScene(hs.desc).render(cam, depth)
+        for launch in range(1, 4):
+            canvas = torch.full((h, w, 3), float("nan"), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            gpu.render_device(cam, canvas.data_ptr(), depth, None, torch.cuda.current_stream().cuda_stream)
+            st = gpu.stats()
+            got = canvas.cpu().numpy()
+            assert np.isfinite(got).all(), (scene, launch)
+            assert np.abs(got - want).max() < TOL, (scene, launch)
+            assert [st["primary"], st["secondary"], st["shadow_calls"], st["overflow"]] == [counters["primary"], counters["secondary"], counters["shadow"], 0]
+    # tile mode (one rank's share of a frame): edge tiles stick out of the image, probe pixels outside it are skipped
+    hs = rtc.HostScene.from_file("fresnel.json")
+    cam = hs.camera(200, 140)
+    full = rtc.GpuScene(hs.desc).render(cam, 5)
+    tw = th = 32
+    tx, ty = rtc.tile_grid(cam.hsize, cam.vsize, tw, th)
+    gpu = rtc.GpuScene(hs.desc)
+    for launch in range(2):
+        buf = torch.full((tx * ty, th, tw, 3), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        gpu.render_tiles_device(cam, buf.data_ptr(), tw, th, 0, 1, tx * ty, 5, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert gpu.stats()["primary"] == 200 * 140
+        tiles = buf.cpu().numpy()
+        for t in range(tx * ty):
+            y0, x0 = (t // tx) * th, (t % tx) * tw
+            hh, ww = min(th, cam.vsize - y0), min(tw, cam.hsize - x0)
+            assert np.abs(tiles[t, :hh, :ww] - full[y0:y0 + hh, x0:x0 + ww]).max() < REPEAT_TOL, (launch, t)
+
+
 def test_every_schedule_big_world_kernels(rtc):
     """The table-in-memory variants (rtc_render_kernel_bigworld and its _ext form) under packed schedules."""
     import json
