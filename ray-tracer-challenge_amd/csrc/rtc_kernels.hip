@@ -138,6 +138,58 @@ __device__ __forceinline__ bool slab(const Ray& r, double mnx, double mny, doubl
   return !(tmin > tmax);
 }
 
+// Two quotients by the same divisor, as a cube axis needs them (cube.zig:28-33: tmin_numerator / direction and
+// tmax_numerator / direction).  The compiler expands x / d into v_div_scale x2, v_rcp_f64, four v_fma refining the
+// reciprocal, v_mul, v_fma, v_div_fmas, v_div_fixup: eleven instructions, seven of which depend on d alone.  Where
+// neither v_div_scale rescales its operands nor v_div_fixup overrides the result - |d| in [1e-5, 2^200], x == 0 or
+// |x| in [2^-53, 2^201]: far inside the hardware's conditions (quotient exponent within +-768, nothing denormal) - the
+// sequence below IS that expansion with the d-only part computed once, so both quotients are bit-identical to x / d
+// (checked against the plain division on 2^28 random and edge-case operand pairs: tests/hip/shared_divisor_check.hip).
+__device__ __forceinline__ double refined_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double quotient(double x, double d, double r) {
+  const double q = x * r;
+  return __builtin_fma(__builtin_fma(-d, q, x), r, q);
+}
+
+// Cube.localIntersect's three checkAxis calls (cube.zig:24-47) for the unit cube.  The numerators are -1 - o and 1 - o:
+// zero, or at least 2^-53 in magnitude; with every component of the ray below 2^200 the shared-divisor quotients above
+// are exact.  A ray outside that range (or with a NaN) takes the plain divisions of slab().
+__device__ __forceinline__ bool cube_slab(const Ray& r, double& tmin, double& tmax) {
+  const double big = 0x1p200;
+  const bool tame = (__builtin_fabs(r.ox) <= big) & (__builtin_fabs(r.oy) <= big) & (__builtin_fabs(r.oz) <= big) &
+                    (__builtin_fabs(r.dx) <= big) & (__builtin_fabs(r.dy) <= big) & (__builtin_fabs(r.dz) <= big);
+  if (!tame) return slab(r, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
+  auto axis = [&](double origin, double direction, double& lo, double& hi) {
+    const double tmin_numerator = -1.0 - origin;
+    const double tmax_numerator = 1.0 - origin;
+    const double rcp = refined_rcp(direction);
+    lo = quotient(tmin_numerator, direction, rcp);
+    hi = quotient(tmax_numerator, direction, rcp);
+    if (!(__builtin_fabs(direction) >= 1e-5)) {
+      lo = tmin_numerator * kInf;
+      hi = tmax_numerator * kInf;
+    }
+    if (lo > hi) {
+      const double save = hi;
+      hi = lo;
+      lo = save;
+    }
+  };
+  double xtmin, xtmax, ytmin, ytmax, ztmin, ztmax;
+  axis(r.ox, r.dx, xtmin, xtmax);
+  axis(r.oy, r.dy, ytmin, ytmax);
+  axis(r.oz, r.dz, ztmin, ztmax);
+  tmin = zmax(xtmin, zmax(ytmin, ztmin));
+  tmax = zmin(xtmax, zmin(ytmax, ztmax));
+  return !(tmin > tmax);
+}
+
 // Emits the entries a leaf's localIntersect appends, in the reference's order, as f(t, u, v).
 // `r` is the ray in the leaf's object space.
 struct CylParams {
@@ -176,7 +228,7 @@ __device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy,
     }
     case 2: {  // cube.zig:49-79
       double tmin, tmax;
-      if (slab(r, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax)) {
+      if (cube_slab(r, tmin, tmax)) {
         f(tmin, 0.0, 0.0);
         f(tmax, 0.0, 0.0);
       }

@@ -770,3 +770,17 @@ def test_edge_many_lights_and_materials(rtc):
                                               "transform": [{"scale": [0.1 + 0.01 * k] * 3}]},
                                   "shininess": 10 + k, "reflective": 0.1 if k % 7 == 0 else 0.0}})
     _parity(rtc, _json_scene(objs, lights, 40, 24))
+
+
+def test_shared_divisor_quotients_are_exact(tmp_path):
+    """cube_slab() divides a cube axis's two numerators by the same direction component with ONE refined reciprocal
+    (csrc/rtc_kernels.hip: refined_rcp / quotient).  tests/hip/shared_divisor_check.hip runs that sequence beside the
+    plain division on 2^28 operand pairs (random over the whole range cube_slab admits, and edge cases around the
+    1e-5 threshold and numerators of a few ulps): the quotients must be bit-identical."""
+    import subprocess
+    repo = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    exe = str(tmp_path / "shared_divisor_check")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O3", "-ffp-contract=off", "-o", exe,
+                    _os.path.join(repo, "tests", "hip", "shared_divisor_check.hip")], check=True, capture_output=True, timeout=600)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and " 0 mismatches" in run.stdout, run.stdout + run.stderr
