@@ -510,6 +510,7 @@ struct HostTables {
   std::vector<double> node_box;
   std::vector<double> light;
   uint32_t n_live = 0;
+  uint32_t n_root_kind[3] = {0, 0, 0};  // planes, spheres, cubes at the head of root_recs (in that order)
   float bvh_mag = 0.0f;
   float cull_cmax = 0.0f;
   bool branching_everywhere = false;
@@ -803,6 +804,32 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};
     }
   }
+  // Sorted by kind for the kernel's root loop (trace() phase 2 runs one kind at a time): planes, spheres, cubes, the
+  // rest; World.objects order inside a kind.  The record carries everything that depends on the object's identity
+  // (depth-first leaf index, material), so the table order is free.
+  auto klass = [&](const RootRec& R) -> int {
+    if (R.kind_flags & RTC_ROOT_IS_GROUP) return 3;
+    switch (R.kind_flags & 0xFFu) {
+      case RTC_PLANE: return 0;
+      case RTC_SPHERE: return 1;
+      case RTC_CUBE: return 2;
+      default: return 3;
+    }
+  };
+  std::vector<uint32_t> perm(d.n_roots);
+  for (uint32_t i = 0; i < d.n_roots; ++i) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return klass(root_recs[a]) < klass(root_recs[b]); });
+  std::vector<RootRec> recs2(d.n_roots);
+  std::vector<RootCull> cull2(root_cull.size(), RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  T.n_root_kind[0] = T.n_root_kind[1] = T.n_root_kind[2] = 0;
+  for (uint32_t i = 0; i < d.n_roots; ++i) {
+    recs2[i] = root_recs[perm[i]];
+    cull2[i] = root_cull[perm[i]];
+    const int k = klass(recs2[i]);
+    if (k < 3) T.n_root_kind[k]++;
+  }
+  root_recs.swap(recs2);
+  root_cull.swap(cull2);
 }
 
 // The tables that are the caller's arrays in the kernel's element layout.
@@ -1332,6 +1359,9 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   D.n_materials = d.n_materials;
   D.n_patterns = d.n_patterns;
   D.cull_cmax = cull_cmax;
+  D.n_root_planes = T.n_root_kind[0];
+  D.n_root_spheres = T.n_root_kind[1];
+  D.n_root_cubes = T.n_root_kind[2];
   return RTC_OK;
 }
 

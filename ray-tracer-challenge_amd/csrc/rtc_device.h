@@ -182,6 +182,9 @@ struct DevScene {
   const uint32_t* __restrict__ kids;
   const double* __restrict__ light;     // [n_lights][6]
   uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
+  // root_recs / root_cull are sorted by kind: [planes][spheres][cubes][every other leaf kind and the groups] (the
+  // order inside a kind is World.objects order; nothing depends on the table order, see trace())
+  uint32_t n_root_planes, n_root_spheres, n_root_cubes;
   float cull_cmax;  // max over bounded roots of |centre|: scale of the FP32 rounding margin
   float bvh_mag;    // max |coordinate| of any finite BVH box: scale of the FP32 traversal margin
   uint32_t chain_nested;  // every reference Group box lies inside its parent's: a ray that passes the innermost passes all
