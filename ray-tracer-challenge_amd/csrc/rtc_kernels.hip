@@ -1319,11 +1319,24 @@ __device__ __forceinline__ Pending load_pending(const PendingRec* src) {
   return p;
 }
 
-// One ray in flight between two lanes of a wave, with the canvas pixel its colour is added to.
-struct Mail {
+// The same record in LDS: the first levels of every lane's stack live there (render_body), four 16-byte quarters with
+// the lanes of a wave side by side in each, so that a wave's push or pop is four conflict-free 16-byte accesses.
+__device__ __forceinline__ void store_pending_lds(Quad2* dst, const Pending& p) {  // dst: quarter 0 of the lane's slot
+  Quad2 a, b, c, e;
+  a.x = dbits(p.ray.ox); a.y = dbits(p.ray.oy);
+  b.x = dbits(p.ray.oz); b.y = dbits(p.ray.dx);
+  c.x = dbits(p.ray.dy); c.y = dbits(p.ray.dz);
+  e.x = dbits(p.weight); e.y = p.remaining;
+  dst[0] = a; dst[64] = b; dst[128] = c; dst[192] = e;
+}
+__device__ __forceinline__ Pending load_pending_lds(const Quad2* src) {
+  const Quad2 a = src[0], b = src[64], c = src[128], e = src[192];
   Pending p;
-  size_t out_index;
-};
+  p.ray = {bitsd(a.x), bitsd(a.y), bitsd(b.x), bitsd(b.y), bitsd(c.x), bitsd(c.y)};
+  p.weight = bitsd(e.x);
+  p.remaining = static_cast<uint32_t>(e.y);
+  return p;
+}
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   unsigned long long s = v;
@@ -1362,7 +1375,14 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   __shared__ DevMaterial lds_mat[LDS ? RTC_LDS_MATERIALS : 1];
   __shared__ DevPattern lds_pat[LDS ? RTC_LDS_PATTERNS : 1];
   __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
-  __shared__ Mail lds_mail[4][64];  // per wave: rays handed from busy lanes to idle ones
+  // per wave: which pending ray (donor lane, level of its stack) an idle lane takes over, and the canvas pixel it belongs to
+  __shared__ uint4 lds_mail[4][64];
+  // The first LDS_LEVELS levels of every lane's stack of pending rays ([wave][level][quarter][lane], see
+  // store_pending_lds); deeper levels are in the buffer in memory (DevPixelMap::ray_stack).  A lane's stack is empty
+  // again after almost every pixel, so nearly every push and pop stays here: the pops no longer wait for memory and the
+  // 2048 resident waves no longer cycle 59 MB of stack lines through the L2s (142 MB written per cover frame).
+  constexpr int LDS_LEVELS = SIMPLE ? 2 : (LDS ? 1 : 2);  // (what fits beside the tables at two work-groups per CU)
+  __shared__ Quad2 lds_pend[4][LDS_LEVELS][4][64];
   // The colour a lane has accumulated for its pixel: touched once per iteration and when the pixel is finished, live
   // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
   // six VGPRs of a kernel at the 256-register limit.
@@ -1432,7 +1452,20 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * map.ray_stack_levels * 64u + lane;
   const int stack_cap = static_cast<int>(map.ray_stack_levels);
   int sp = 0, base = 0;
-  Mail* const mailbox = lds_mail[threadIdx.x >> 6];
+  uint4* const mailbox = lds_mail[threadIdx.x >> 6];
+  Quad2* const pend_wave = &lds_pend[threadIdx.x >> 6][0][0][0];  // level l of lane x: pend_wave + l * 256 + x
+  // (the buffer in memory keeps a slot for every level; the first LDS_LEVELS of them are never touched)
+  auto push_level = [&](int level, const Pending& p) {
+    if (level < LDS_LEVELS) {
+      store_pending_lds(pend_wave + level * 256 + lane, p);
+    } else {
+      store_pending(stack + static_cast<size_t>(level) * 64u, p);
+    }
+  };
+  auto load_level = [&](int level, uint32_t of_lane) -> Pending {
+    if (level < LDS_LEVELS) return load_pending_lds(pend_wave + level * 256 + of_lane);
+    return load_pending(stack + static_cast<size_t>(level) * 64u - lane + of_lane);
+  };
 
 #ifdef RTC_PROFILE
   unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1452,7 +1485,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     // first hand-out zeroed; a pixel whose whole ray tree stayed in one lane (most of them) is stored once.
     if (!have_cur) {
       if (sp > base) {
-        cur = load_pending(stack + static_cast<size_t>(--sp) * 64u);
+        cur = load_level(--sp, lane);
         have_cur = true;
       } else {
         sp = base = 0;
@@ -1516,8 +1549,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         const uint32_t irank = static_cast<uint32_t>(__builtin_popcountll(imask & lanes_below));
         const uint32_t drank = static_cast<uint32_t>(__builtin_popcountll(dmask & lanes_below));
         if (donor && drank < pairs) {
-          mailbox[drank].p = load_pending(stack + static_cast<size_t>(base++) * 64u);
-          mailbox[drank].out_index = out_index;
+          mailbox[drank] = uint4{lane, static_cast<uint32_t>(base++), static_cast<uint32_t>(out_index), static_cast<uint32_t>(out_index >> 32)};
           if (!shared) {
             // First hand-out of this pixel: from here on its shares are ADDED, so it starts from zero.  The canvas is
             // not cleared per launch (a pixel nobody shares is stored once); the store is at L2 before the taker —
@@ -1535,14 +1567,17 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (idle && irank < pairs) {
-          cur = mailbox[irank].p;
-          out_index = mailbox[irank].out_index;
+          // (the donor's slot is read here, in program order before any lane of the wave can push into it again)
+          const uint4 m = mailbox[irank];
+          cur = load_level(static_cast<int>(m.y), m.x);
+          out_index = static_cast<size_t>(m.z) | (static_cast<size_t>(m.w) << 32);
           have_cur = true;
           has_pixel = true;
           shared = true;
           acc[0] = acc[1] = acc[2] = 0.0;
           n_stolen++;
         }
+        if (sp == base) sp = base = 0;  // a donor whose stack is empty again starts over at level 0 (in LDS)
       }
     }
     RTC_STAMP(9);
@@ -1974,7 +2009,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       n_secondary++;
       if (do_reflect) {  // both children: the reflection continues in registers, the refraction waits
         if (sp < stack_cap) {
-          store_pending(stack + static_cast<size_t>(sp++) * 64u, p);
+          push_level(sp++, p);
         } else {
           overflow = 1u;
         }
