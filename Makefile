@@ -2,6 +2,7 @@
 # infrastructure) the CPU oracle.  __graft_entry__.build() drives this file.
 #
 #   ray-tracer-challenge_amd/lib/librtc_hip.so   product: HIP kernels + C ABI (include/rtc.h), gfx950
+#   ray-tracer-challenge_amd/lib/librtc_multi.so product: single-process multi-GPU render (include/rtc_multi.h): librtc_hip + RCCL
 #   ray-tracer-challenge_amd/lib/librtc_host.so  product: scene model, JSON/OBJ loaders, Camera/World/Canvas API
 #   ray-tracer-challenge_amd/lib/rtc_host_kat    product unit tests (reference KATs for the build-time helpers)
 #   oracle/build/liboracle.so, oracle_kat        test infrastructure only
@@ -23,7 +24,7 @@ HOST_HDR := $(wildcard $(PKG)/host/*.hpp) include/rtc.h include/rtc_host.h
 
 all: hip host oracle
 
-hip: $(LIB)/librtc_hip.so
+hip: $(LIB)/librtc_hip.so $(LIB)/librtc_multi.so
 host: $(LIB)/librtc_host.so $(LIB)/rtc_host_kat
 oracle:
 	$(MAKE) -C oracle
@@ -39,6 +40,9 @@ $(LIB)/rtc_capi.o: $(PKG)/csrc/rtc_capi.hip $(wildcard $(PKG)/csrc/*.h) include/
 
 $(LIB)/librtc_hip.so: $(LIB)/rtc_kernels.o $(LIB)/rtc_capi.o
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $^
+
+$(LIB)/librtc_multi.so: $(PKG)/csrc/rtc_multi.hip include/rtc_multi.h include/rtc.h $(LIB)/librtc_hip.so
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $< -L$(LIB) -lrtc_hip -L$(ROCM)/lib -lrccl -Wl,-rpath,'$$ORIGIN'
 
 $(LIB)/librtc_host.so: $(HOST_SRC) $(HOST_HDR) $(LIB)/librtc_hip.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(HOST_SRC) -L$(LIB) -lrtc_hip -lz -Wl,-rpath,'$$ORIGIN'

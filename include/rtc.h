@@ -271,6 +271,38 @@ int rtc_render_tiles_device(rtc_scene *scene, const rtc_camera *cam, uint32_t ma
                             double *d_rgb_out, void *hip_stream);
 
 /*
+ * The same with an explicit list of tiles (host memory, copied): region k of d_rgb_out is tile tiles[k].  This is
+ * what a cost-balanced split uses (rtc_assign_tiles below); a handle keeps the last list on the device, so
+ * rendering the same list again copies nothing.
+ */
+int rtc_render_tile_list_device(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
+                                uint32_t tile_w, uint32_t tile_h, const uint32_t *tiles,
+                                uint32_t n_my_tiles, double *d_rgb_out, void *hip_stream);
+
+/*
+ * What the regions (tiles) of the most recent MEASURING tile-mode render on this handle took, in the library's
+ * wave-time units (only ratios mean anything): cost_out[k] for region k.  A render measures when its schedule
+ * was not measured on its own view, i.e. the first frame of a tile list and every frame of a moving camera.
+ * Synchronises.  RTC_ERR_INVALID_ARGUMENT if there is no such measurement of n_regions regions.
+ */
+int rtc_get_tile_costs(rtc_scene *scene, double *cost_out, uint32_t n_regions);
+
+/*
+ * Cost-balanced split of the image's tiles over `world` ranks (host only, deterministic: every rank that calls it
+ * with the same costs gets the same table): longest tile first onto the least-loaded rank that still has a free
+ * slot, every rank holding at most padded = ceil(n_tiles / world) tiles so that one equal-count gather moves
+ * them.  rank_of_tile[t] = the rank that renders tile t; slot_of_tile[t] = rank * padded + k, the tile's place in
+ * the gathered buffer [world][padded][tile_h][tile_w][3] (a rank renders its tiles in increasing tile order).
+ */
+int rtc_assign_tiles(const double *tile_cost, uint32_t n_tiles, uint32_t world,
+                     uint32_t *rank_of_tile, uint32_t *slot_of_tile);
+
+/* rtc_assemble_tiles_device for such a split: d_slot_of_tile is rtc_assign_tiles' table in device memory. */
+int rtc_assemble_tile_list_device(const double *d_gathered, const uint32_t *d_slot_of_tile,
+                                  uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
+                                  double *d_canvas, void *hip_stream);
+
+/*
  * Rank 0 of the tile partition, after the gather: copies the ranks' compact tile
  * buffers d_gathered[world][padded_tiles][tile_h][tile_w][3] (rank r's k-th tile
  * is tile r + k * world of the row-major tiling) into the row-major canvas

@@ -1,0 +1,54 @@
+/*
+ * rtc_multi.h — C ABI of the single-process multi-GPU render (librtc_multi.so = librtc_hip.so + RCCL).
+ *
+ * The reference is ONE process that renders ONE image (src/main.zig:92: camera.render(allocator, world)).  A Zig or C
+ * host that wants the 8 GPUs of a node behind that one call binds this: the flat scene is replicated on every GPU,
+ * the image is cut into 64x64 tiles, every GPU renders its share into a compact buffer, ONE ncclGather per frame
+ * brings the shares to GPU 0 over xGMI, one kernel un-permutes them into the row-major Canvas (canvas.zig:132-137),
+ * which is copied to the caller.  The split starts round-robin; after the first frame (and, while the camera moves,
+ * every 16 frames) the tiles are re-dealt by their MEASURED cost (rtc_get_tile_costs + rtc_assign_tiles of rtc.h).
+ *
+ * (The multi-PROCESS form of the same path - one rank per GPU under torch.distributed, which is what bench.py's
+ * N > 1 mode runs - uses the per-rank entry points of rtc.h directly and the process group's gather.)
+ *
+ * Pixels are independent (camera.zig:116-121): the image is the one rtc_render gives, whatever the split.
+ */
+#ifndef RTC_MULTI_H
+#define RTC_MULTI_H
+
+#include "rtc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtc_multi rtc_multi; /* opaque: n scene handles, n streams, n RCCL communicators */
+
+/* All ranks on device 0, plain device copies instead of RCCL: lets a one-GPU box run the whole split / gather /
+ * un-permute / re-balance logic (tests).  Without it n_gpus must not exceed the visible devices. */
+#define RTC_MULTI_VIRTUAL 1u
+
+/* Replicates the scene on devices 0 .. n_gpus-1 of this process and creates the communicators (ncclCommInitAll). */
+int rtc_multi_create(const rtc_scene_desc *desc, uint32_t n_gpus, uint32_t flags, rtc_multi **out);
+void rtc_multi_destroy(rtc_multi *m);
+
+/*
+ * Camera.render (camera.zig:80-125) of the whole image on all GPUs: rgb_out[y * hsize + x][0..2], host memory,
+ * [vsize][hsize][3] doubles.  Synchronous.  Status codes and names as in rtc.h; RTC_ERR_NO_DEVICE carries RCCL
+ * failures too.
+ */
+int rtc_multi_render(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, double *rgb_out);
+
+/* Ray counters of the last frame, summed over the GPUs. */
+int rtc_multi_get_stats(rtc_multi *m, rtc_stats *out);
+
+/* The split in use: tiles per rank and the measured load share of the busiest rank over the mean (1.0 = even; 0 before
+ * the first re-balance). */
+int rtc_multi_balance(rtc_multi *m, uint32_t *tiles_per_rank /* [n_gpus] */, double *max_over_mean);
+
+const char *rtc_multi_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTC_MULTI_H */

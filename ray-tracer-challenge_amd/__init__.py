@@ -86,13 +86,19 @@ class Stats(C.Structure):
 
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_device",
-               "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
+               "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
                "rtc_status_name"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
+MULTI_SYMBOLS = ["rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_multi_get_stats", "rtc_multi_balance",
+                 "rtc_multi_last_error"]
+RTC_MULTI_VIRTUAL = 1
+
 _hip = None
 _host = None
+_multi = None
 
 
 def _one_hip_runtime():
@@ -137,6 +143,11 @@ def hip_lib():
         lib.rtc_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 5 + [C.c_void_p, C.c_void_p]
         lib.rtc_assemble_tiles_device.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
+        lib.rtc_render_tile_list_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, _u32p, C.c_uint32,
+                                                    C.c_void_p, C.c_void_p]
+        lib.rtc_get_tile_costs.argtypes = [C.c_void_p, _dp, C.c_uint32]
+        lib.rtc_assign_tiles.argtypes = [_dp, C.c_uint32, C.c_uint32, _u32p, _u32p]
+        lib.rtc_assemble_tile_list_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_scene_synchronize.argtypes = [C.c_void_p]
         lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         _hip = lib
@@ -169,6 +180,67 @@ def host_lib():
         lib.rtch_scene_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _host = lib
     return _host
+
+
+def multi_lib():
+    """librtc_multi.so (links librtc_hip.so and RCCL): the single-process multi-GPU render of include/rtc_multi.h."""
+    global _multi
+    if _multi is None:
+        hip_lib()
+        path = os.path.join(LIB_DIR, "librtc_multi.so")
+        if not os.path.exists(path):
+            raise RtcError("LibraryMissing", f"{path} not built: run `make` or __graft_entry__.build()")
+        lib = C.CDLL(path)
+        lib.rtc_multi_last_error.restype = C.c_char_p
+        lib.rtc_multi_create.argtypes = [C.POINTER(SceneDesc), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.rtc_multi_destroy.argtypes = [C.c_void_p]
+        lib.rtc_multi_destroy.restype = None
+        lib.rtc_multi_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
+        lib.rtc_multi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        lib.rtc_multi_balance.argtypes = [C.c_void_p, _u32p, _dp]
+        _multi = lib
+    return _multi
+
+
+class MultiGpu:
+    """rtc_multi: one process, n GPUs, one gather per frame (include/rtc_multi.h)."""
+
+    def __init__(self, desc, n_gpus, virtual=False):
+        self.n = n_gpus
+        self._m = C.c_void_p()
+        self._check(multi_lib().rtc_multi_create(C.byref(desc), n_gpus, RTC_MULTI_VIRTUAL if virtual else 0, C.byref(self._m)))
+
+    @staticmethod
+    def _check(status):
+        if status != 0:
+            raise RtcError(hip_lib().rtc_status_name(status).decode(), multi_lib().rtc_multi_last_error().decode())
+
+    def render(self, cam, max_depth=REFERENCE_DEPTH):
+        out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
+        self._check(multi_lib().rtc_multi_render(self._m, C.byref(cam), max_depth, out.ctypes.data))
+        return out
+
+    def stats(self):
+        st = Stats()
+        self._check(multi_lib().rtc_multi_get_stats(self._m, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def balance(self):
+        tiles = np.zeros(self.n, dtype=np.uint32)
+        ratio = C.c_double()
+        self._check(multi_lib().rtc_multi_balance(self._m, tiles.ctypes.data_as(_u32p), C.byref(ratio)))
+        return tiles, ratio.value
+
+    def close(self):
+        if self._m:
+            multi_lib().rtc_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _check_host(status):
@@ -264,6 +336,18 @@ class GpuScene:
         _check_hip(hip_lib().rtc_render_tiles_device(self._s, C.byref(cam), max_depth, tile_w, tile_h, first_tile,
                                                      tile_stride, n_my_tiles, d_out_ptr, stream))
 
+    def render_tile_list_device(self, cam, d_out_ptr, tile_w, tile_h, tiles, max_depth=REFERENCE_DEPTH, stream=None):
+        """A rank's share of a cost-balanced split: region k of the buffer is tile tiles[k]."""
+        tiles = np.ascontiguousarray(tiles, dtype=np.uint32)
+        _check_hip(hip_lib().rtc_render_tile_list_device(self._s, C.byref(cam), max_depth, tile_w, tile_h,
+                                                         tiles.ctypes.data_as(_u32p), len(tiles), d_out_ptr, stream))
+
+    def tile_costs(self, n_regions):
+        """Measured cost of every region (tile) of the last measuring tile-mode render on this handle."""
+        out = np.empty(n_regions, dtype=np.float64)
+        _check_hip(hip_lib().rtc_get_tile_costs(self._s, out.ctypes.data_as(_dp), n_regions))
+        return out
+
     def synchronize(self):
         _check_hip(hip_lib().rtc_scene_synchronize(self._s))
 
@@ -315,6 +399,21 @@ def tiles_of_rank(n_tiles, rank, world):
     count = (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
     padded = (n_tiles + world - 1) // world
     return rank, world, count, padded
+
+
+def assign_tiles(tile_cost, world):
+    """rtc_assign_tiles: (rank_of_tile, slot_of_tile) of a cost-balanced split; slot = rank * ceil(n / world) + k."""
+    cost = np.ascontiguousarray(tile_cost, dtype=np.float64)
+    rank_of = np.empty(len(cost), dtype=np.uint32)
+    slot_of = np.empty(len(cost), dtype=np.uint32)
+    _check_hip(hip_lib().rtc_assign_tiles(cost.ctypes.data_as(_dp), len(cost), world, rank_of.ctypes.data_as(_u32p),
+                                          slot_of.ctypes.data_as(_u32p)))
+    return rank_of, slot_of
+
+
+def assemble_tile_list_device(d_gathered_ptr, d_slot_of_tile_ptr, tile_w, tile_h, hsize, vsize, d_canvas_ptr, stream):
+    _check_hip(hip_lib().rtc_assemble_tile_list_device(d_gathered_ptr, d_slot_of_tile_ptr, tile_w, tile_h, hsize, vsize,
+                                                       d_canvas_ptr, stream))
 
 
 def assemble_tiles_device(d_gathered_ptr, world, padded, tile_w, tile_h, hsize, vsize, d_canvas_ptr, stream):

@@ -47,6 +47,9 @@ extern "C" __global__ void rtc_pack_sort_kernel(const uint32_t* __restrict__ chu
 extern "C" __global__ void rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves,
                                                 const float t_min, const DevPackState* __restrict__ state,
                                                 uint32_t* __restrict__ order_out);
+extern "C" __global__ void rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
+                                                    const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
+                                                    const uint32_t vsize, double* __restrict__ canvas);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
                                                const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
                                                const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
@@ -298,6 +301,10 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
                      s->d_pack_state, s->d_sched[target]);
   HIP_TRY(hipGetLastError());
   s->measure_gen++;
+  if (!is_probe) {
+    s->measured_regions = map.mode == 0u ? 1u : map.n_my_tiles;
+    s->measured_chunks_per_region = map.chunks_per_region;
+  }
   if (!is_probe && !s->split_checked && !s->readback_enqueued) {  // the first full measurement of this pixel map
     auto pinned = [](auto*& p, size_t& capacity, size_t n) -> hipError_t {
       if (n <= capacity) return hipSuccess;
@@ -1412,6 +1419,7 @@ void rtc_scene_destroy(rtc_scene* s) {
     if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
   if (s->d_sched_info) (void)hipFree(s->d_sched_info);
   if (s->d_pack_state) (void)hipFree(s->d_pack_state);
+  if (s->d_tile_list) (void)hipFree(s->d_tile_list);
   if (s->d_chunk_time) (void)hipFree(s->d_chunk_time);
   if (s->d_sorted) (void)hipFree(s->d_sorted);
   if (s->pin_info) (void)hipHostFree(s->pin_info);
@@ -1469,6 +1477,117 @@ int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_de
   map.n_chunks = static_cast<uint32_t>(total_chunks);
   return launch(s, *cam, map, max_depth, d_rgb_out, static_cast<size_t>(n_my_tiles) * tile_w * tile_h,
                 hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
+}
+
+int rtc_render_tile_list_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t tile_w, uint32_t tile_h,
+                                const uint32_t* tiles, uint32_t n_my_tiles, double* d_rgb_out, void* hip_stream) {
+  g_error.clear();
+  if (!s || !d_rgb_out || !tiles) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  int st = checkCamera(cam);
+  if (st != RTC_OK) return st;
+  if (tile_w == 0 || tile_h == 0 || n_my_tiles == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "tile %ux%u count %u", tile_w, tile_h, n_my_tiles);
+  DevPixelMap map;
+  std::memset(&map, 0, sizeof map);
+  map.mode = 2;
+  map.tile_w = tile_w;
+  map.tile_h = tile_h;
+  map.n_my_tiles = n_my_tiles;
+  map.tiles_x = (cam->hsize + tile_w - 1) / tile_w;
+  const uint64_t n_tiles = static_cast<uint64_t>(map.tiles_x) * ((cam->vsize + tile_h - 1) / tile_h);
+  {
+    std::vector<uint8_t> seen(n_tiles, 0);
+    for (uint32_t i = 0; i < n_my_tiles; ++i) {
+      if (tiles[i] >= n_tiles) return fail(RTC_ERR_INVALID_ARGUMENT, "tile %u outside the %llu tiles of the image", tiles[i], (unsigned long long)n_tiles);
+      if (seen[tiles[i]]++) return fail(RTC_ERR_INVALID_ARGUMENT, "tile %u appears twice in the list", tiles[i]);
+    }
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
+  if (s->h_tile_list.size() != n_my_tiles || std::memcmp(s->h_tile_list.data(), tiles, n_my_tiles * sizeof(uint32_t)) != 0) {
+    if (n_my_tiles > s->tile_list_capacity) {
+      HIP_TRY(hipEventSynchronize(s->launch_done));
+      if (s->d_tile_list) (void)hipFree(s->d_tile_list);
+      s->d_tile_list = nullptr;
+      s->tile_list_capacity = 0;
+      HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_tile_list), n_my_tiles * sizeof(uint32_t)));
+      s->tile_list_capacity = n_my_tiles;
+    }
+    // (launches of the old list may still be running on another stream: the copy is ordered like a launch)
+    if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
+    s->h_tile_list.assign(tiles, tiles + n_my_tiles);
+    HIP_TRY(hipMemcpyAsync(s->d_tile_list, s->h_tile_list.data(), n_my_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(s->launch_done, stream));
+    s->last_stream = stream;
+    s->tile_list_gen++;
+  }
+  map.first_tile = s->tile_list_gen;  // a new list is a new pixel map: its schedule is measured afresh
+  map.tile_list = s->d_tile_list;
+  map.chunks_x = (tile_w + 7) / 8;
+  map.chunks_per_region = map.chunks_x * ((tile_h + 7) / 8);
+  const uint64_t total_chunks = static_cast<uint64_t>(map.chunks_per_region) * n_my_tiles;
+  if (total_chunks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "%llu chunks", (unsigned long long)total_chunks);
+  map.n_chunks = static_cast<uint32_t>(total_chunks);
+  return launch(s, *cam, map, max_depth, d_rgb_out, static_cast<size_t>(n_my_tiles) * tile_w * tile_h, stream);
+}
+
+int rtc_get_tile_costs(rtc_scene* s, double* cost_out, uint32_t n_regions) {
+  g_error.clear();
+  if (!s || !cost_out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (s->measured_regions == 0 || n_regions != s->measured_regions || !s->d_chunk_time)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "no measured launch with %u regions on this handle (the last one had %u)", n_regions,
+                s->measured_regions);
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->launch_done));
+  const size_t n = static_cast<size_t>(s->measured_regions) * s->measured_chunks_per_region;
+  std::vector<uint32_t> t(n);
+  HIP_TRY(hipMemcpy(t.data(), s->d_chunk_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t r = 0; r < n_regions; ++r) {
+    double sum = 0.0;
+    for (uint32_t c = 0; c < s->measured_chunks_per_region; ++c) sum += t[static_cast<size_t>(r) * s->measured_chunks_per_region + c];
+    cost_out[r] = sum;
+  }
+  return RTC_OK;
+}
+
+int rtc_assign_tiles(const double* tile_cost, uint32_t n_tiles, uint32_t world, uint32_t* rank_of_tile, uint32_t* slot_of_tile) {
+  g_error.clear();
+  if (!tile_cost || !rank_of_tile || !slot_of_tile || n_tiles == 0 || world == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "null or empty argument");
+  // Longest job first onto the rank with the least work so far - among the ranks that still have a free slot: every
+  // rank's buffer holds ceil(n_tiles / world) tiles (one equal-count gather).  Ties go to the lower tile / lower rank,
+  // so every rank that computes this from the same costs gets the same table.
+  const uint32_t padded = (n_tiles + world - 1u) / world;
+  std::vector<uint32_t> order(n_tiles);
+  for (uint32_t t = 0; t < n_tiles; ++t) order[t] = t;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return tile_cost[a] > tile_cost[b]; });
+  std::vector<double> load(world, 0.0);
+  std::vector<uint32_t> count(world, 0u);
+  for (uint32_t t : order) {
+    uint32_t best = world;
+    for (uint32_t r = 0; r < world; ++r)
+      if (count[r] < padded && (best == world || load[r] < load[best])) best = r;
+    rank_of_tile[t] = best;
+    load[best] += tile_cost[t] > 0.0 ? tile_cost[t] : 0.0;
+    count[best]++;
+  }
+  // slots in tile order inside a rank (the rank renders its list in that order: image neighbours stay neighbours)
+  std::fill(count.begin(), count.end(), 0u);
+  for (uint32_t t = 0; t < n_tiles; ++t) slot_of_tile[t] = rank_of_tile[t] * padded + count[rank_of_tile[t]]++;
+  return RTC_OK;
+}
+
+int rtc_assemble_tile_list_device(const double* d_gathered, const uint32_t* d_slot_of_tile, uint32_t tile_w, uint32_t tile_h,
+                                  uint32_t hsize, uint32_t vsize, double* d_canvas, void* hip_stream) {
+  g_error.clear();
+  if (!d_gathered || !d_slot_of_tile || !d_canvas || !hip_stream) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (tile_w == 0 || tile_h == 0 || hsize == 0 || vsize == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "tile %ux%u image %ux%u", tile_w, tile_h, hsize, vsize);
+  const size_t n = static_cast<size_t>(hsize) * vsize * 3u;
+  const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
+  hipLaunchKernelGGL(rtc_assemble_list_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_gathered,
+                     d_slot_of_tile, tile_w, tile_h, hsize, vsize, d_canvas);
+  HIP_TRY(hipGetLastError());
+  return RTC_OK;
 }
 
 int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,

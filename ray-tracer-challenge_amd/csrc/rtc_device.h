@@ -201,6 +201,8 @@ struct DevCamera {
 //   mode 0: rectangle [x0,x0+w) x [y0,y0+h) -> out[(y-y0)*w + (x-x0)]
 //   mode 1: interleaved tiles (multi-GPU): region i is tile first_tile + i*tile_stride of a
 //           tile_w x tile_h tiling of the image -> out[(i*tile_h + ly)*tile_w + lx]
+//   mode 2: the same with an explicit list: region i is tile tile_list[i] (a rank's share of a cost-balanced split;
+//           first_tile carries the generation of the list, so that a new list is a new map for the schedule)
 struct DevPixelMap {
   uint32_t mode;
   uint32_t x0, y0, w, h;
@@ -209,6 +211,7 @@ struct DevPixelMap {
   uint32_t chunks_x;            // chunks per row of the rectangle / of one tile
   uint32_t chunks_per_region;   // chunks in the rectangle / in one tile
   uint32_t n_chunks;            // total
+  const uint32_t* __restrict__ tile_list;  // mode 2 (device memory, owned by the scene handle)
   uint32_t n_units;             // what the work counter runs over: n_chunks, or the number of packets in `order`
   // Optional schedule: PACKETS of RTC_PACKET_ITEMS items, one packet per pull of the work counter.  An item
   // names a run of pixels of one chunk: chunk | start << 20 | (len - 1) << 26, RTC_NO_ITEM = unused slot.

@@ -142,6 +142,12 @@ struct rtc_scene {
   uint32_t* pin_chunk_time = nullptr;
   size_t pin_chunk_time_capacity = 0;
   DevSchedInfo* pin_info = nullptr;
+  // mode-2 pixel maps (rtc_render_tile_list_device): the list of the last such launch, on both sides
+  std::vector<uint32_t> h_tile_list;
+  uint32_t* d_tile_list = nullptr;
+  size_t tile_list_capacity = 0;
+  uint32_t tile_list_gen = 0;
+  uint32_t measured_regions = 0, measured_chunks_per_region = 0;  // what d_chunk_time describes (rtc_get_tile_costs)
   hipStream_t last_stream = nullptr;  // the stream of the last launch (or the handle's own, after create)
   hipEvent_t launch_done = nullptr;   // recorded behind everything a launch enqueues; a launch on ANOTHER stream waits for it
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack

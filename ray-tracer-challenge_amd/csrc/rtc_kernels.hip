@@ -1644,7 +1644,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           chunk_h = map.h;
           chunk_out0 = 0;
         } else {
-          const uint32_t tile = map.first_tile + region * map.tile_stride;
+          const uint32_t tile = map.mode == 1u ? map.first_tile + region * map.tile_stride : map.tile_list[region];
           const uint32_t ty = tile / map.tiles_x;
           chunk_px0 = (tile - ty * map.tiles_x) * map.tile_w;
           chunk_py0 = ty * map.tile_h;
@@ -2113,6 +2113,24 @@ rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world, c
     const uint32_t tile = (y / tile_h) * tiles_x + x / tile_w;
     const uint32_t r = tile % world, k = tile / world;
     const size_t src = (((static_cast<size_t>(r) * padded + k) * tile_h + y % tile_h) * tile_w + x % tile_w) * 3u + ch;
+    canvas[i] = gathered[src];
+  }
+}
+
+// The same for a cost-balanced split: tile t sits in slot slot_of_tile[t] (rank * padded + k) of the gathered buffer.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
+                         const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize, const uint32_t vsize,
+                         double* __restrict__ canvas) {
+  const size_t n = static_cast<size_t>(hsize) * vsize * 3u;
+  const uint32_t tiles_x = (hsize + tile_w - 1u) / tile_w;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t pixel = i / 3u;
+    const uint32_t ch = static_cast<uint32_t>(i - pixel * 3u);
+    const uint32_t y = static_cast<uint32_t>(pixel / hsize), x = static_cast<uint32_t>(pixel - static_cast<size_t>(y) * hsize);
+    const uint32_t slot = slot_of_tile[(y / tile_h) * tiles_x + x / tile_w];
+    const size_t src = ((static_cast<size_t>(slot) * tile_h + y % tile_h) * tile_w + x % tile_w) * 3u + ch;
     canvas[i] = gathered[src];
   }
 }

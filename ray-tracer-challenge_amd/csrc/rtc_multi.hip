@@ -1,0 +1,300 @@
+// rtc_multi.hip — librtc_multi.so: the single-process multi-GPU render of include/rtc_multi.h on top of the per-rank
+// entry points of librtc_hip.so and RCCL (one ncclGather per frame; no other collective).  Host code only.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rtc_multi.h"
+
+namespace {
+
+thread_local std::string g_multi_error;
+
+int mfail(int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_multi_error = std::string(rtc_status_name(status)) + ": " + buf;
+  return status;
+}
+
+#define M_HIP(expr)                                                                                        \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return mfail(e_ == hipErrorOutOfMemory ? RTC_ERR_OUT_OF_MEMORY : RTC_ERR_NO_DEVICE, "%s -> %s", #expr, \
+                   hipGetErrorString(e_));                                                                 \
+  } while (0)
+#define M_NCCL(expr)                                                                                \
+  do {                                                                                              \
+    ncclResult_t r_ = (expr);                                                                       \
+    if (r_ != ncclSuccess) return mfail(RTC_ERR_NO_DEVICE, "%s -> %s", #expr, ncclGetErrorString(r_)); \
+  } while (0)
+#define M_RTC(expr)                                                          \
+  do {                                                                       \
+    const int s_ = (expr);                                                   \
+    if (s_ != RTC_OK) {                                                      \
+      g_multi_error = rtc_last_error();                                      \
+      return s_;                                                             \
+    }                                                                        \
+  } while (0)
+
+constexpr uint32_t kTile = 64;
+
+}  // namespace
+
+struct rtc_multi {
+  uint32_t n = 0;
+  bool virt = false;
+  std::vector<int> dev;
+  std::vector<rtc_scene*> scene;
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> shared;  // virtual mode: rank r's share has been copied into the gathered buffer
+  std::vector<ncclComm_t> comm;
+  // sized for one image size
+  uint32_t hsize = 0, vsize = 0, n_tiles = 0, padded = 0;
+  std::vector<double*> d_buf;  // [n] a rank's compact tiles [padded][64][64][3], on its device
+  double* d_gathered = nullptr;  // device 0: [n][padded][64][64][3]
+  double* d_canvas = nullptr;    // device 0
+  uint32_t* d_slot = nullptr;    // device 0: rtc_assign_tiles' slot_of_tile
+  std::vector<uint32_t> rank_of, slot_of;
+  std::vector<std::vector<uint32_t>> tiles_of;
+  bool balanced = false;
+  uint32_t frames_since_balance = 0;
+  rtc_camera balance_cam{};
+  double max_over_mean = 0.0;
+};
+
+namespace {
+
+size_t slabDoubles(const rtc_multi* m) { return static_cast<size_t>(m->padded) * kTile * kTile * 3u; }
+
+void setLists(rtc_multi* m) {
+  m->tiles_of.assign(m->n, {});
+  for (uint32_t t = 0; t < m->n_tiles; ++t) m->tiles_of[m->rank_of[t]].push_back(t);  // increasing tile order = slot order
+}
+
+void freeFrameBuffers(rtc_multi* m) {
+  for (uint32_t r = 0; r < m->d_buf.size(); ++r)
+    if (m->d_buf[r]) {
+      (void)hipSetDevice(m->dev[r]);
+      (void)hipFree(m->d_buf[r]);
+    }
+  m->d_buf.clear();
+  if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+  if (m->d_gathered) (void)hipFree(m->d_gathered);
+  if (m->d_canvas) (void)hipFree(m->d_canvas);
+  if (m->d_slot) (void)hipFree(m->d_slot);
+  m->d_gathered = m->d_canvas = nullptr;
+  m->d_slot = nullptr;
+}
+
+int sizeFor(rtc_multi* m, const rtc_camera& cam) {
+  if (cam.hsize == m->hsize && cam.vsize == m->vsize && !m->d_buf.empty()) return RTC_OK;
+  for (uint32_t r = 0; r < m->n; ++r) {
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_HIP(hipStreamSynchronize(m->stream[r]));
+  }
+  freeFrameBuffers(m);
+  m->hsize = cam.hsize;
+  m->vsize = cam.vsize;
+  const uint32_t tx = (cam.hsize + kTile - 1) / kTile, ty = (cam.vsize + kTile - 1) / kTile;
+  m->n_tiles = tx * ty;
+  m->padded = (m->n_tiles + m->n - 1) / m->n;
+  m->d_buf.assign(m->n, nullptr);
+  for (uint32_t r = 0; r < m->n; ++r) {
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_buf[r]), slabDoubles(m) * sizeof(double)));
+    M_HIP(hipMemset(m->d_buf[r], 0, slabDoubles(m) * sizeof(double)));  // slots and edge pixels nobody renders stay 0
+  }
+  M_HIP(hipSetDevice(m->dev[0]));
+  M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_gathered), slabDoubles(m) * m->n * sizeof(double)));
+  M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_canvas), static_cast<size_t>(cam.hsize) * cam.vsize * 3u * sizeof(double)));
+  M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_slot), m->n_tiles * sizeof(uint32_t)));
+  // the first frame: tiles dealt round-robin (nothing has been measured yet)
+  m->rank_of.resize(m->n_tiles);
+  m->slot_of.resize(m->n_tiles);
+  for (uint32_t t = 0; t < m->n_tiles; ++t) {
+    m->rank_of[t] = t % m->n;
+    m->slot_of[t] = (t % m->n) * m->padded + t / m->n;
+  }
+  setLists(m);
+  M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+  m->balanced = false;
+  m->frames_since_balance = 0;
+  m->max_over_mean = 0.0;
+  return RTC_OK;
+}
+
+// Re-deal the tiles by what the ranks measured for them in the frame just rendered.
+int rebalance(rtc_multi* m, const rtc_camera& cam) {
+  std::vector<double> cost(m->n_tiles, 0.0);
+  for (uint32_t r = 0; r < m->n; ++r) {
+    const std::vector<uint32_t>& mine = m->tiles_of[r];
+    if (mine.empty()) continue;
+    std::vector<double> c(mine.size());
+    M_HIP(hipSetDevice(m->dev[r]));
+    if (rtc_get_tile_costs(m->scene[r], c.data(), static_cast<uint32_t>(mine.size())) != RTC_OK) return RTC_OK;  // nothing measured: keep the split
+    for (size_t k = 0; k < mine.size(); ++k) cost[mine[k]] = c[k];
+  }
+  M_RTC(rtc_assign_tiles(cost.data(), m->n_tiles, m->n, m->rank_of.data(), m->slot_of.data()));
+  setLists(m);
+  M_HIP(hipSetDevice(m->dev[0]));
+  M_HIP(hipStreamSynchronize(m->stream[0]));  // (the frame that used the old table is done: rtc_multi_render is synchronous)
+  M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+  std::vector<double> load(m->n, 0.0);
+  double total = 0.0;
+  for (uint32_t t = 0; t < m->n_tiles; ++t) {
+    load[m->rank_of[t]] += cost[t];
+    total += cost[t];
+  }
+  m->max_over_mean = total > 0.0 ? *std::max_element(load.begin(), load.end()) / (total / m->n) : 0.0;
+  m->balanced = true;
+  m->frames_since_balance = 0;
+  m->balance_cam = cam;
+  return RTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtc_multi_last_error(void) { return g_multi_error.c_str(); }
+
+int rtc_multi_create(const rtc_scene_desc* desc, uint32_t n_gpus, uint32_t flags, rtc_multi** out) {
+  g_multi_error.clear();
+  if (!desc || !out || n_gpus == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument or no GPUs");
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return mfail(RTC_ERR_NO_DEVICE, "no HIP device is visible");
+  const bool virt = (flags & RTC_MULTI_VIRTUAL) != 0u;
+  if (!virt && n_gpus > static_cast<uint32_t>(n_dev))
+    return mfail(RTC_ERR_INVALID_ARGUMENT, "%u GPUs asked for, %d visible", n_gpus, n_dev);
+  rtc_multi* m = new (std::nothrow) rtc_multi();
+  if (!m) return mfail(RTC_ERR_OUT_OF_MEMORY, "host allocation");
+  struct Guard {
+    rtc_multi* m;
+    ~Guard() {
+      if (m) rtc_multi_destroy(m);
+    }
+  } guard{m};
+  m->n = n_gpus;
+  m->virt = virt;
+  m->dev.resize(n_gpus);
+  m->scene.assign(n_gpus, nullptr);
+  m->stream.assign(n_gpus, nullptr);
+  m->shared.assign(n_gpus, nullptr);
+  for (uint32_t r = 0; r < n_gpus; ++r) m->dev[r] = virt ? 0 : static_cast<int>(r);
+  for (uint32_t r = 0; r < n_gpus; ++r) {
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_RTC(rtc_scene_create(desc, &m->scene[r]));  // the scene (<= 30 MB) is replicated
+    M_HIP(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking));
+    M_HIP(hipEventCreateWithFlags(&m->shared[r], hipEventDisableTiming));
+  }
+  if (!virt) {
+    m->comm.assign(n_gpus, nullptr);
+    M_NCCL(ncclCommInitAll(m->comm.data(), static_cast<int>(n_gpus), m->dev.data()));
+  }
+  guard.m = nullptr;
+  *out = m;
+  return RTC_OK;
+}
+
+void rtc_multi_destroy(rtc_multi* m) {
+  if (!m) return;
+  for (uint32_t r = 0; r < m->stream.size(); ++r) {
+    (void)hipSetDevice(m->dev[r]);
+    if (m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
+  }
+  for (ncclComm_t c : m->comm)
+    if (c) (void)ncclCommDestroy(c);
+  freeFrameBuffers(m);
+  for (uint32_t r = 0; r < m->scene.size(); ++r) {
+    (void)hipSetDevice(m->dev[r]);
+    if (m->scene[r]) rtc_scene_destroy(m->scene[r]);
+    if (m->shared[r]) (void)hipEventDestroy(m->shared[r]);
+    if (m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
+  }
+  delete m;
+}
+
+int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double* rgb_out) {
+  g_multi_error.clear();
+  if (!m || !cam || !rgb_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
+  if (const int st = sizeFor(m, *cam); st != RTC_OK) return st;
+  // every rank renders its tiles into its compact buffer ...
+  for (uint32_t r = 0; r < m->n; ++r) {
+    if (m->tiles_of[r].empty()) continue;
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_RTC(rtc_render_tile_list_device(m->scene[r], cam, max_depth, kTile, kTile, m->tiles_of[r].data(),
+                                      static_cast<uint32_t>(m->tiles_of[r].size()), m->d_buf[r], m->stream[r]));
+  }
+  // ... ONE gather brings them to rank 0 (each rank's send is ordered behind its render on its stream) ...
+  const size_t slab = slabDoubles(m);
+  if (!m->virt) {
+    M_NCCL(ncclGroupStart());
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipSetDevice(m->dev[r]));
+      M_NCCL(ncclGather(m->d_buf[r], m->d_gathered, slab, ncclDouble, 0, m->comm[r], m->stream[r]));
+    }
+    M_NCCL(ncclGroupEnd());
+  } else {
+    M_HIP(hipSetDevice(m->dev[0]));
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipMemcpyAsync(m->d_gathered + slab * r, m->d_buf[r], slab * sizeof(double), hipMemcpyDeviceToDevice, m->stream[r]));
+      M_HIP(hipEventRecord(m->shared[r], m->stream[r]));
+      if (r != 0) M_HIP(hipStreamWaitEvent(m->stream[0], m->shared[r], 0));
+    }
+  }
+  // ... and one kernel un-permutes them into the row-major canvas
+  M_HIP(hipSetDevice(m->dev[0]));
+  M_RTC(rtc_assemble_tile_list_device(m->d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, m->d_canvas, m->stream[0]));
+  M_HIP(hipMemcpyAsync(rgb_out, m->d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
+                       hipMemcpyDeviceToHost, m->stream[0]));
+  M_HIP(hipStreamSynchronize(m->stream[0]));
+  rtc_stats st;
+  if (const int s = rtc_multi_get_stats(m, &st); s != RTC_OK) return s;
+  if (st.overflow) return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", (unsigned long long)st.overflow);
+  // Re-deal the tiles by measured cost: after the first frame of an image size, and every 16 frames while the camera
+  // is not where the split was measured (a moving camera measures every frame).
+  m->frames_since_balance++;
+  const bool moved = std::memcmp(cam, &m->balance_cam, sizeof *cam) != 0;
+  if (m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u)))
+    if (const int s = rebalance(m, *cam); s != RTC_OK) return s;
+  return RTC_OK;
+}
+
+int rtc_multi_get_stats(rtc_multi* m, rtc_stats* out) {
+  if (!m || !out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  std::memset(out, 0, sizeof *out);
+  for (uint32_t r = 0; r < m->n; ++r) {
+    if (m->tiles_of.size() > r && m->tiles_of[r].empty()) continue;
+    rtc_stats s;
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_RTC(rtc_get_stats(m->scene[r], &s));
+    out->primary += s.primary;
+    out->secondary += s.secondary;
+    out->shadow_calls += s.shadow_calls;
+    out->shadow_traced += s.shadow_traced;
+    out->overflow += s.overflow;
+  }
+  return RTC_OK;
+}
+
+int rtc_multi_balance(rtc_multi* m, uint32_t* tiles_per_rank, double* max_over_mean) {
+  if (!m || !tiles_per_rank || !max_over_mean) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  for (uint32_t r = 0; r < m->n; ++r) tiles_per_rank[r] = r < m->tiles_of.size() ? static_cast<uint32_t>(m->tiles_of[r].size()) : 0u;
+  *max_over_mean = m->max_over_mean;
+  return RTC_OK;
+}
+
+}  // extern "C"

@@ -440,7 +440,8 @@ int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_
       px0 += map.x0;
       py0 += map.y0;
     } else {
-      const uint32_t tile = map.first_tile + region * map.tile_stride, ty = tile / map.tiles_x;
+      const uint32_t tile = map.mode == 1u ? map.first_tile + region * map.tile_stride : s->h_tile_list[region];
+      const uint32_t ty = tile / map.tiles_x;
       px0 += static_cast<double>(tile - ty * map.tiles_x) * map.tile_w;
       py0 += static_cast<double>(ty) * map.tile_h;
     }

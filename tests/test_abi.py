@@ -29,6 +29,15 @@ def test_host_symbols_are_exported(rtc):
         assert getattr(lib, n) is not None
 
 
+def test_multi_symbols_are_exported(rtc):
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "rtc_multi.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(rtc_multi_[a-z_0-9]+)\s*\(", text)))
+    assert set(names) == set(rtc.MULTI_SYMBOLS), names
+    lib = rtc.multi_lib()
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
 def test_status_names(rtc):
     lib = rtc.hip_lib()
     assert lib.rtc_status_name(0) == b"Ok"
@@ -169,3 +178,30 @@ def test_create_rejects_pattern_chains_the_device_would_cut_short(rtc):
     a[stripes[0]] = stripes[0]                      # a pattern that is its own sub-pattern
     assert lib.rtc_scene_create(C.byref(d), C.byref(out)) == 4
     assert b"cycle" in lib.rtc_last_error()
+
+
+def test_assign_tiles_balances_and_fills_equal_buffers(rtc):
+    """rtc_assign_tiles (host only): every tile exactly once, no rank above ceil(n / world) tiles (one equal-count gather),
+    slots unique, deterministic, and on a skewed cost map far better balanced than dealing the tiles round-robin."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n_tiles, world in ((510, 8), (510, 4), (17, 3), (5, 8), (64, 1)):
+        cost = rng.uniform(1.0, 2.0, n_tiles)
+        blob = rng.choice(n_tiles, size=max(1, n_tiles // 20), replace=False)
+        cost[blob] *= 40.0                                   # a glass sphere: a few tiles cost forty times the rest
+        rank_of, slot_of = rtc.assign_tiles(cost, world)
+        padded = (n_tiles + world - 1) // world
+        assert rank_of.max() < world and len(set(slot_of.tolist())) == n_tiles
+        assert np.array_equal(slot_of // padded, rank_of) and (slot_of % padded).max() < padded
+        counts = np.bincount(rank_of, minlength=world)
+        assert counts.max() <= padded
+        for r in range(world):                               # a rank's slots follow increasing tile order
+            mine = np.flatnonzero(rank_of == r)
+            assert np.array_equal(slot_of[mine] - r * padded, np.arange(len(mine)))
+        again = rtc.assign_tiles(cost, world)
+        assert np.array_equal(again[0], rank_of) and np.array_equal(again[1], slot_of)
+        if world > 1 and n_tiles >= 8 * world:
+            load = np.bincount(rank_of, weights=cost, minlength=world)
+            rr = np.bincount(np.arange(n_tiles) % world, weights=cost, minlength=world)
+            assert load.max() <= rr.max() + 1e-9
+            assert load.max() / load.mean() < 1.10, (n_tiles, world, load)

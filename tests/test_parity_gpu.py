@@ -425,6 +425,75 @@ def test_full_size_tile_path(rtc):
     assert np.abs(got[rows] - want[rows]).max() < TOL
 
 
+def test_cost_balanced_tile_split(rtc):
+    """The multi-GPU split by measured cost on one GPU: frame 1 dealt round-robin and measured, rtc_get_tile_costs,
+    rtc_assign_tiles, then every "rank" renders its tile LIST; un-permuted by the table on the device; equal to the plain
+    render, and better balanced than round-robin by the tiles' own measured costs."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file("cover.json")
+    W, H, T, world = 960, 540, 64, 4
+    cam = hs.camera(W, H)
+    plain = rtc.GpuScene(hs.desc).render(cam, 5)
+    tx, ty = rtc.tile_grid(W, H, T, T)
+    n_tiles = tx * ty
+    padded = (n_tiles + world - 1) // world
+    stream = torch.cuda.Stream()
+    scenes = [rtc.GpuScene(hs.desc) for _ in range(world)]
+    cost = np.zeros(n_tiles)
+    for rank in range(world):                                # frame 1: round-robin, measured
+        first, stride, count, _ = rtc.tiles_of_rank(n_tiles, rank, world)
+        buf = torch.zeros((padded, T, T, 3), dtype=torch.float64, device="cuda")
+        scenes[rank].render_tiles_device(cam, buf.data_ptr(), T, T, first, stride, count, 5, stream.cuda_stream)
+        cost[first::stride] = scenes[rank].tile_costs(count)
+    assert (cost > 0).all()
+    rank_of, slot_of = rtc.assign_tiles(cost, world)
+    rr_load = np.bincount(np.arange(n_tiles) % world, weights=cost, minlength=world)
+    load = np.bincount(rank_of, weights=cost, minlength=world)
+    assert load.max() < rr_load.max()
+    d_slot = torch.from_numpy(slot_of.astype(np.int32)).cuda()
+    for launch in range(3):
+        gathered = torch.zeros((world, padded, T, T, 3), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for rank in range(world):
+            tiles = np.flatnonzero(rank_of == rank).astype(np.uint32)
+            scenes[rank].render_tile_list_device(cam, gathered[rank].data_ptr(), T, T, tiles, 5, stream.cuda_stream)
+        canvas = torch.full((H, W, 3), float("nan"), dtype=torch.float64, device="cuda")
+        rtc.assemble_tile_list_device(gathered.data_ptr(), d_slot.data_ptr(), T, T, W, H, canvas.data_ptr(), stream.cuda_stream)
+        stream.synchronize()
+        assert np.abs(canvas.cpu().numpy() - plain).max() < REPEAT_TOL, launch
+    with pytest.raises(rtc.RtcError):                        # a tile twice in a list
+        scenes[0].render_tile_list_device(cam, gathered[0].data_ptr(), T, T, np.array([1, 1], dtype=np.uint32), 5, stream.cuda_stream)
+    with pytest.raises(rtc.RtcError):                        # no measurement of that many regions
+        scenes[0].tile_costs(3)
+
+
+def test_single_process_multi_gpu_render(rtc):
+    """include/rtc_multi.h on this one-GPU box: four VIRTUAL ranks (all on device 0, device copies in place of RCCL: the
+    split, the gather layout, the un-permute and the re-balance by measured cost) and ONE real rank through RCCL
+    (ncclCommInitAll + ncclGather).  Every frame is the oracle's image; the camera moves in between."""
+    hs = rtc.HostScene.from_file("cover.json")
+    osc = ob.OracleScene(hs.desc)
+    for n, virtual in ((4, True), (3, True), (1, False)):
+        hs = rtc.HostScene.from_file("cover.json")
+        multi = rtc.MultiGpu(hs.desc, n, virtual)
+        for frame in range(4):
+            cam = hs.camera(400, 230)
+            want, counters = osc.render(cam, 5)
+            got = multi.render(cam, 5)
+            st = multi.stats()
+            assert np.abs(got - want).max() < TOL, (n, frame)
+            assert [st["primary"], st["secondary"], st["shadow_calls"], st["overflow"]] == [counters["primary"], counters["secondary"], counters["shadow"], 0]
+            tiles, ratio = multi.balance()
+            assert tiles.sum() == 7 * 4                      # 400x230 in 64x64 tiles
+            if n > 1 and frame >= 1:
+                assert 0.99 < ratio < 1.6, (n, frame, ratio)  # re-dealt by measured cost after the first frame
+            if frame == 1:
+                hs.rotate_camera(0.4)
+        other = hs.camera(130, 70)                           # another image size on the same object
+        assert np.abs(multi.render(other, 5) - osc.render(other, 5)[0]).max() < TOL
+        multi.close()
+
+
 def test_launches_on_different_streams_are_ordered(rtc):
     """One handle, launches enqueued back to back on three different streams (a caller's, the handle's own through
     rtc_render, another caller's) without any host synchronisation in between: they share the handle's counters and
