@@ -9,9 +9,9 @@ flat scene already resident in HBM and the canvas left in HBM.
 
 N == 1: one rtc_render_device launch per step.
 N  > 1: (launched by torch.distributed.run, one rank per GPU, backend nccl == RCCL)  the image is cut
-        into 64x64 tiles dealt round-robin to the ranks; every rank renders its tiles into a compact
-        buffer, ONE gather per frame brings them to rank 0 over xGMI, rank 0 un-permutes them into the
-        row-major canvas.  Frames are double-buffered: the gather of frame i runs on a side stream
+        into 64x64 tiles, dealt to the ranks by the tiles' MEASURED cost (one round-robin frame measures
+        them during setup); every rank renders its tiles into a compact buffer, ONE gather per frame brings
+        them to rank 0 over xGMI, rank 0 un-permutes them into the row-major canvas.  Frames are double-buffered: the gather of frame i runs on a side stream
         under the render of frame i+1.  Total work per step is fixed -> "scaling": "strong".
 
 Rank 0 prints ONE JSON line (see the keys at the bottom).  `roofline` describes the dominant (only)
@@ -295,6 +295,26 @@ def main():
         n_tiles = tx * ty
         first, stride, count, padded = rtc.tiles_of_rank(n_tiles, rank, world)
         bufs = [torch.zeros((padded, TILE, TILE, 3), dtype=torch.float64, device="cuda") for _ in range(2)]
+        # Scene setup, part 1: one frame with the tiles dealt round-robin MEASURES what every tile costs
+        # (rtc_get_tile_costs); the ranks exchange those few hundred numbers once (not in the timed loop) and every rank
+        # computes the same cost-balanced split (rtc_assign_tiles: longest tile first onto the least-loaded rank, equal
+        # buffer sizes).  From here on a rank renders its tile LIST.
+        cost = torch.zeros(n_tiles, dtype=torch.float64)
+        if count:
+            gpu.render_tiles_device(cam, bufs[0].data_ptr(), TILE, TILE, first, stride, count, args.depth, sptr)
+            cost[first::stride] = torch.from_numpy(gpu.tile_costs(count))
+        if world > 1:
+            c = cost if args.rehearse else cost.cuda()
+            dist.all_reduce(c)
+            cost = c.cpu()
+        rank_of, slot_of = rtc.assign_tiles(cost.numpy(), world)
+        my_tiles = np.flatnonzero(rank_of == rank).astype(np.uint32)
+        count = len(my_tiles)
+        load = np.bincount(rank_of, weights=cost.numpy(), minlength=world)
+        split_note = "%dx%d tiles dealt by measured cost (busiest rank %.2f x the mean; round-robin would be %.2f x)" % (
+            TILE, TILE, load.max() / max(load.mean(), 1e-30),
+            np.bincount(np.arange(n_tiles) % world, weights=cost.numpy(), minlength=world).max() / max(load.mean(), 1e-30))
+        d_slot = torch.from_numpy(slot_of.astype(np.int32)).cuda() if rank == 0 else None
         # rank 0 receives straight into [world][padded][T][T][3]: the gather list is that buffer's rows
         gathered = ([torch.empty((world,) + tuple(bufs[0].shape), dtype=torch.float64, device="cuda") for _ in range(2)]
                     if rank == 0 else [None, None])
@@ -309,7 +329,8 @@ def main():
         def step(i):
             b = i & 1
             stream.wait_event(gathered_ev[b])        # buffer b is free again (frame i-2 has been sent)
-            gpu.render_tiles_device(cam, bufs[b].data_ptr(), TILE, TILE, first, stride, count, args.depth, sptr)
+            if count:
+                gpu.render_tile_list_device(cam, bufs[b].data_ptr(), TILE, TILE, my_tiles, args.depth, sptr)
             rendered[b].record(stream)
             with torch.cuda.stream(comm):            # gather + un-permute of frame i under the render of frame i+1
                 comm.wait_event(rendered[b])
@@ -323,8 +344,8 @@ def main():
                 else:
                     dist.gather(bufs[b], gather_list[b], dst=0)
                 if rank == 0:                        # one un-permute kernel: tiles -> row-major canvas
-                    rtc.assemble_tiles_device(gathered[b].data_ptr(), world, padded, TILE, TILE, W, H,
-                                              canvas.data_ptr(), comm.cuda_stream)
+                    rtc.assemble_tile_list_device(gathered[b].data_ptr(), d_slot.data_ptr(), TILE, TILE, W, H,
+                                                  canvas.data_ptr(), comm.cuda_stream)
                 gathered_ev[b].record(comm)
 
         def finish():
@@ -394,7 +415,7 @@ def main():
             "data": "reference scene file tests/golden/scenes/%s (copy of the reference's scenes/), camera %dx%d" % (args.scene, W, H),
             "config": {"workload": "%s %dx%d depth %d, %d leaves, %d lights; tile-split %s" %
                                    (args.scene, W, H, args.depth, hs.desc.n_leaves, hs.desc.n_lights,
-                                    "none (1 GPU)" if world == 1 else f"{TILE}x{TILE} round-robin over {world} GPUs + 1 RCCL gather/frame"),
+                                    "none (1 GPU)" if world == 1 and not args.tile_path else f"{split_note} over {world} GPUs + 1 RCCL gather/frame"),
                        "rays_per_frame": {"primary": stats["primary"], "secondary": stats["secondary"],
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
                        "mrays_per_s_incl_shadow_traced": (rays + stats["shadow_traced"]) * args.steps / elapsed / 1e6,

@@ -59,6 +59,70 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def _worker_balanced(rank, world, port, out_path):
+    """bench.py's N > 1 setup and frame, with the oracle as the renderer: a round-robin frame yields per-tile costs (here:
+    the oracle's ray counts), ONE all_reduce spreads them, every rank computes the same cost-balanced split
+    (rtc_assign_tiles), renders its tile LIST, and rank 0 un-permutes the gathered buffers by the slot table."""
+    import importlib
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    import oracle_binding as ob
+    rtc = importlib.import_module("ray-tracer-challenge_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs = rtc.HostScene.from_file("fresnel.json")
+    cam = hs.camera(W, H)
+    osc = ob.OracleScene(hs.desc)
+    tx, ty = rtc.tile_grid(W, H, TILE_W, TILE_H)
+    n_tiles = tx * ty
+    padded = (n_tiles + world - 1) // world
+
+    def render_tile(t):
+        x0, y0 = (t % tx) * TILE_W, (t // tx) * TILE_H
+        w, h = min(TILE_W, W - x0), min(TILE_H, H - y0)
+        img, c = osc.render(cam, 5, (x0, y0, w, h), threads=1)
+        return img, h, w, c["primary"] + c["secondary"] + c["shadow"]
+
+    first, stride, count, _ = rtc.tiles_of_rank(n_tiles, rank, world)
+    cost = torch.zeros(n_tiles, dtype=torch.float64)
+    for i in range(count):
+        cost[first + i * stride] = render_tile(first + i * stride)[3]
+    dist.all_reduce(cost)                       # setup only: a few hundred numbers, once
+    rank_of, slot_of = rtc.assign_tiles(cost.numpy(), world)
+    mine = np.flatnonzero(rank_of == rank)
+    buf = torch.zeros((padded, TILE_H, TILE_W, 3), dtype=torch.float64)
+    for k, t in enumerate(mine):
+        img, h, w, _ = render_tile(int(t))
+        buf[k, :h, :w] = torch.from_numpy(img)
+    gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, gathered, dst=0)          # the ONE collective of a frame
+    if rank == 0:
+        g = torch.stack(gathered).numpy().reshape(world * padded, TILE_H, TILE_W, 3)
+        canvas = np.zeros((ty * TILE_H, tx * TILE_W, 3))
+        for t in range(n_tiles):
+            canvas[(t // tx) * TILE_H:(t // tx + 1) * TILE_H, (t % tx) * TILE_W:(t % tx + 1) * TILE_W] = g[slot_of[t]]
+        full, _ = osc.render(cam, 5, threads=1)
+        load = np.bincount(rank_of, weights=cost.numpy(), minlength=world)
+        rr = np.bincount(np.arange(n_tiles) % world, weights=cost.numpy(), minlength=world)
+        np.save(out_path, np.array([np.abs(canvas[:H, :W] - full).max(), load.max(), rr.max()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cost_balanced_split_gather_reassemble(tmp_path, world):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "delta.npy")
+    mp.spawn(_worker_balanced, args=(world, _free_port(), out), nprocs=world, join=True)
+    delta, load_max, rr_max = np.load(out)
+    assert delta == 0.0
+    assert load_max <= rr_max
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_tile_partition_gather_reassemble(tmp_path, world):
     torch = pytest.importorskip("torch")

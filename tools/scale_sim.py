@@ -8,6 +8,7 @@ The render time of the slowest share bounds the N-GPU step from below (the gathe
 partition itself decides (load balance + per-launch fixed cost).  Real multi-GPU runs are the driver's.
 """
 import argparse, importlib, json, os, sys
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
@@ -33,7 +34,7 @@ def main():
     def timed(fn):
         for _ in range(8):
             fn()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()   # (a host-side re-pack of the schedule, if the share needs one, happens here)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         for _ in range(args.reps):
@@ -49,16 +50,29 @@ def main():
     for tile in [int(x) for x in args.tiles.split(",")]:
         tx, ty = rtc.tile_grid(W, H, tile, tile)
         for world in [int(x) for x in args.worlds.split(",")]:
-            ts = []
+            ts, cost = [], np.zeros(tx * ty)
             for rank in range(world):
                 g = rtc.GpuScene(hs.desc)      # one handle per simulated rank: its own schedule feedback
                 first, stride, count, padded = rtc.tiles_of_rank(tx * ty, rank, world)
                 buf = torch.zeros((padded, tile, tile, 3), dtype=torch.float64, device="cuda")
+                g.render_tiles_device(cam, buf.data_ptr(), tile, tile, first, stride, count, args.depth, sptr)
+                cost[first::stride] = g.tile_costs(count)     # the first (measuring) frame: what every tile costs
                 ts.append(timed(lambda: g.render_tiles_device(cam, buf.data_ptr(), tile, tile, first, stride, count,
                                                               args.depth, sptr)))
                 g.close()
-            print(json.dumps({"tile": tile, "world": world, "max_ms": max(ts), "mean_ms": sum(ts) / world,
-                              "ideal_ms": t_full / world, "compute_eff": t_full / (world * max(ts))}), flush=True)
+            # the split bench.py and librtc_multi use after their first frame: tiles dealt by measured cost
+            rank_of, _ = rtc.assign_tiles(cost, world)
+            tb = []
+            for rank in range(world):
+                g = rtc.GpuScene(hs.desc)
+                mine = np.flatnonzero(rank_of == rank).astype(np.uint32)
+                buf = torch.zeros(((tx * ty + world - 1) // world, tile, tile, 3), dtype=torch.float64, device="cuda")
+                tb.append(timed(lambda: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sptr)))
+                g.close()
+            print(json.dumps({"tile": tile, "world": world, "ideal_ms": t_full / world,
+                              "round_robin": {"max_ms": max(ts), "mean_ms": sum(ts) / world, "compute_eff": t_full / (world * max(ts))},
+                              "by_measured_cost": {"max_ms": max(tb), "mean_ms": sum(tb) / world, "compute_eff": t_full / (world * max(tb))}}),
+                  flush=True)
 
 
 if __name__ == "__main__":
