@@ -23,8 +23,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 REPO_ROOT = os.path.dirname(_HERE)
-SCENE_DIR = os.path.join(REPO_ROOT, "tests", "golden", "scenes")
-DATA_DIR = os.path.join(REPO_ROOT, "tests", "golden", "data")
+# Where HostScene.from_file looks for a scene given by name, and for the OBJ / PNG files a scene names.  The harness
+# (tests, bench.py) uses the copies of the reference's scene and data files kept as fixtures under tests/golden/ (the
+# reference tree does not exist on the GPU box); another host points these at its own directories.
+SCENE_DIR = os.environ.get("RTC_SCENE_DIR", os.path.join(REPO_ROOT, "tests", "golden", "scenes"))
+DATA_DIR = os.environ.get("RTC_DATA_DIR", os.path.join(REPO_ROOT, "tests", "golden", "data"))
 
 RTC_CHILD_NODE_BIT = 0x80000000
 RTC_MAT_STRIDE = 7

@@ -426,11 +426,7 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, const BvhLeafRec& 
     }
   });
   if (!relevant) return;
-#ifdef RTC_EXP_EXACTCHAIN  // diagnostic: always run the exact reference box tests
-  if (!chain_ok(S, L.parent, ray, t_rel, true)) return;
-#else
   if (!chain_ok(S, L.parent, ray, t_rel, degenerate)) return;
-#endif
   leaf_entries(kind, cy, L.tri, lr,
                [&](double t, double u, double v) { vis.entry(leaf, shadow, meta.z, t, u, v); });
 }
@@ -566,11 +562,7 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
                                              unsigned& overflow, uint32_t* lds_stack) {
   const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
   const float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
-#ifdef RTC_EXP_BIGDELTA
-  const float delta = 5e-2f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
-#else
   const float delta = 5e-7f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
-#endif
   const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
   const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
   // origin shifted against / along the direction: (near - on) and (far - of) grow the box by delta
@@ -630,13 +622,7 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
       int entered = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-#if defined(RTC_EXP_NOBVHCULL)  // diagnostic: visit every node
-        const bool h = c4[k] != RTC_NO_LEAF;
-#elif defined(RTC_EXP_NOCULLF)  // diagnostic: box test only, no t-interval pruning
-        const bool h = (c4[k] != RTC_NO_LEAF) & (tn[k] <= tf[k]);
-#else
         const bool h = (c4[k] != RTC_NO_LEAF) & (tn[k] <= tf[k]) & (tn[k] < __builtin_inff()) & !vis.cullf(tn[k], tf[k]);
-#endif
         key[k] = h ? tn[k] : __builtin_inff();
         refs[k] = c4[k];
         entered += h ? 1 : 0;
@@ -731,9 +717,6 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
   const Float2 ac = (oc2 - R.r2) * ray.a;
   const Float2 bb = b * b;
   const Float2 disc = bb - ac;
-#ifdef RTC_EXP_NOROOTCULL  // diagnostic: keep every root
-  return 3u;
-#endif
   uint32_t kept = 0u;
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
@@ -861,11 +844,6 @@ struct ClosestVisitor {
   }
   __device__ __forceinline__ bool cullf(float tn, float tf) const {  // FP32 box interval of the candidate BVH
     const float best = static_cast<float>(t);
-#ifdef RTC_EXP_CULL_A
-    return tf < -1e-4f * (1.0f + __builtin_fabsf(tf));
-#elif defined(RTC_EXP_CULL_B)
-    return tn > best + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(best));
-#endif
     return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > best + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(best));
   }
   __device__ __forceinline__ bool done() const { return false; }
@@ -888,11 +866,6 @@ struct ShadowVisitor {
   }
   __device__ __forceinline__ bool cullf(float tn, float tf) const {
     const float lim = static_cast<float>(distance);
-#ifdef RTC_EXP_CULL_A
-    return tf < -1e-4f * (1.0f + __builtin_fabsf(tf));
-#elif defined(RTC_EXP_CULL_B)
-    return tn > lim + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(lim));
-#endif
     return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > lim + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(lim));
   }
   __device__ __forceinline__ bool done() const { return shadowed; }
@@ -1492,32 +1465,18 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         if (has_pixel) {
           double* __restrict__ o = out + 3 * out_index;  // Canvas pixel, canvas.zig:132-137
           const double acc_r = acc[0], acc_g = acc[1], acc_b = acc[2];
-#ifdef RTC_EXP_NOWRITE  // traffic experiment only: the canvas is never written
-          if (acc_r == 12345.678) {
-#elif defined(RTC_EXP_STORE)  // traffic experiment only (wrong for shared pixels)
-          if (true) {
-#else
           if (!shared) {  // the whole ray tree ran in this lane: the pixel is written exactly once
-#endif
             // 24 B at an 8-byte-aligned address: one 16-byte and one 8-byte store (gfx950 takes unaligned
             // vector accesses) instead of three separate write requests
             typedef double Double2 __attribute__((ext_vector_type(2), aligned(8)));
             Double2 rg;
             rg.x = acc_r;
             rg.y = acc_g;
-#ifdef RTC_EXP_TEMPORAL_STORE
-            *reinterpret_cast<Double2*>(o) = rg;
-            o[2] = acc_b;
-#else
             // streaming stores: a finished pixel is not read again, and the canvas (50 MB at 1080p) must not push the
             // BVH nodes and triangles of a mesh scene out of the 4 MB L2s
             __builtin_nontemporal_store(rg, reinterpret_cast<Double2*>(o));
             __builtin_nontemporal_store(acc_b, o + 2);
-#endif
           } else
-#ifdef RTC_EXP_NOWRITE
-          if (acc_r == 12345.678)
-#endif
           {
             atomicAdd(o + 0, acc_r);
             atomicAdd(o + 1, acc_g);

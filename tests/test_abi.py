@@ -98,18 +98,44 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
     ops[0] = 3
 
 
-def test_zig_binding_in_integration_md_matches_the_header():
-    """INTEGRATION.md shows the extern struct a Zig maintainer would declare; its fields must be rtc.h's, in order."""
+def test_zig_binding_matches_the_header():
+    """integration/gpu.zig (the reference-side binding, shipped as source) and the excerpt of it in INTEGRATION.md declare
+    the extern struct a Zig maintainer binds: its fields must be rtc.h's, in order; every function of rtc.h that the
+    binding uses must exist in the header with the same number of parameters; and the Flattener must fill every field."""
     import re
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(repo, "include", "rtc.h")).read()
     i = header.index("typedef struct rtc_scene_desc")
     body = re.sub(r"/\*.*?\*/", "", header[i:header.index("} rtc_scene_desc;", i)], flags=re.S)
     c_fields = re.findall(r"(?:const\s+)?(?:uint\d+_t|double|float)\s*\*?\s*(\w+)\s*;", body)
-    md = open(os.path.join(repo, "INTEGRATION.md")).read()
-    i = md.index("pub const RtcSceneDesc = extern struct {")
-    zig_fields = re.findall(r"(\w+):", md[i:md.index("};", i)])
-    assert len(c_fields) > 50 and c_fields == zig_fields
+    assert len(c_fields) > 50
+    zig = open(os.path.join(repo, "integration", "gpu.zig")).read()
+    for name, text in (("INTEGRATION.md", open(os.path.join(repo, "INTEGRATION.md")).read()), ("integration/gpu.zig", zig)):
+        i = text.index("pub const RtcSceneDesc = extern struct {")
+        zig_fields = re.findall(r"(\w+):", text[i:text.index("};", i)])
+        assert c_fields == zig_fields, name
+    # the camera and stats structs
+    for zig_name, c_name in (("RtcCamera", "rtc_camera"), ("RtcStats", "rtc_stats")):
+        i = header.index("typedef struct " + c_name)
+        cb = re.sub(r"/\*.*?\*/", "", header[i:header.index("} " + c_name + ";", i)], flags=re.S)
+        cf = [n for decl in re.findall(r"(?:uint\d+_t|double)\s+([^;]+);", cb) for n in re.findall(r"(\w+)(?:\[\d+\])?\s*(?:,|$)", decl)]
+        i = zig.index("pub const %s = extern struct {" % zig_name)
+        zf = re.findall(r"(\w+):", zig[i:zig.index("};", i)])
+        assert cf == zf, (zig_name, cf, zf)
+    # extern functions: declared in a header, same arity
+    headers = re.sub(r"/\*.*?\*/", "", header + open(os.path.join(repo, "include", "rtc_multi.h")).read(), flags=re.S)
+    externs = re.findall(r"pub extern fn (\w+)\(([^)]*)\)", zig)
+    assert len(externs) >= 10
+    for fn, params in externs:
+        m = re.search(r"\b%s\s*\(([^)]*)\)" % fn, headers)
+        assert m, fn
+        c_n = 0 if m.group(1).strip() in ("", "void") else m.group(1).count(",") + 1
+        z_n = 0 if not params.strip() else params.count(":")
+        assert c_n == z_n, (fn, c_n, z_n)
+    # the Flattener's desc() names every field of the struct
+    i = zig.index("pub fn desc(self: *const Self) RtcSceneDesc {")
+    filled = re.findall(r"\.(\w+) =", zig[i:zig.index("};", i)])
+    assert filled == c_fields
 
 
 _ONE_RUNTIME_PROBE = r"""
