@@ -28,6 +28,14 @@ with open(os.path.join(src, "configs.txt")) as f, open(os.path.join(dst, "config
     g.writelines(l for l in f if l.startswith("{"))
 if os.path.exists(os.path.join(src, "scale_sim.txt")):
     shutil.copy(os.path.join(src, "scale_sim.txt"), os.path.join(dst, "scale_sim_one_gpu.jsonl"))
+dstats = glob.glob(os.path.join(src, "d_stats", "**", "*_kernel_stats.csv"), recursive=True)
+if dstats:
+    shutil.copy(dstats[0], os.path.join(dst, "kernel_stats_dragons.csv"))
+    dpmc = summarize([os.path.join(src, d) for d in ("d_pmc_fetch", "d_pmc_write", "d_pmc_sq1", "d_pmc_tcc")])
+    with open(os.path.join(dst, "pmc_dragons.txt"), "w") as g:
+        g.write("# dragons.json 3840x2160 depth 5 (rtc_render_kernel): per-launch means, separate rocprofv3 --pmc passes (tools/profile_round.sh)\n")
+        for k, v in sorted(dpmc.items()):
+            g.write(f"{k:32s} {v:18.1f}\n")
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 traffic = {"scene": "cover.json", "width": 1920, "height": 1080, "depth": 5,
            "fetch_size_kb": round(pmc["FETCH_SIZE"], 1), "write_size_kb": round(pmc["WRITE_SIZE"], 1),
