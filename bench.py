@@ -89,6 +89,7 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
     moves the camera every frame, lib.zig:166-190): the first frame of a fresh scene handle (heuristic schedule + the
     host's share), the second (re-pack), a frame with host output (rtc_render: + D2H), and an orbit of 64 frames at
     0.01 rad per frame (enqueued back to back, as an interactive host would)."""
+    import numpy as np
     W, H = args.width, args.height
     sptr = stream.cuda_stream
     cam = hs.camera(W, H)
@@ -105,12 +106,21 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
         stream.synchronize()
         out[name + "_ms"] = (time.perf_counter() - t0) * 1e3
         out[name + "_kernel_ms"] = ev[0].elapsed_time(ev[1])
+    host_canvas = np.empty((H, W, 3), dtype=np.float64)   # the caller's Canvas.pixels: pageable host memory
+    times = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        g.render_into(cam, host_canvas, args.depth)
+        times.append((time.perf_counter() - t0) * 1e3)
+    out["host_output_first_ms"] = times[0]                 # a one-shot render: the 24 B/pixel copy into pageable memory
+    out["host_output_ms"] = sorted(times[2:])[len(times[2:]) // 2]   # the same canvas again (registered on its second use)
+    host_rgba = np.empty((H, W, 4), dtype=np.uint8)        # lib.zig's RGBA8 framebuffer, clamped on the device
     times = []
     for _ in range(5):
         t0 = time.perf_counter()
-        g.render(cam, args.depth)
+        g.render_rgba8(cam, args.depth, out=host_rgba)
         times.append((time.perf_counter() - t0) * 1e3)
-    out["host_output_ms"] = sorted(times)[len(times) // 2]
+    out["host_output_rgba8_ms"] = sorted(times)[len(times) // 2]
     frames, angle = 64, 0.01
     for rep in range(2):                                  # the second orbit goes on from where the first stopped
         torch.cuda.synchronize()

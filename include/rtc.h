@@ -241,10 +241,23 @@ void rtc_scene_destroy(rtc_scene *scene);
  * Replaces Camera.render (camera.zig:80-125) for the tile [x0,x0+w) x [y0,y0+h):
  * rgb_out[(y-y0)*w + (x-x0)][0..2] = colorAt(rayForPixel(x,y), max_depth).
  * The reference value of max_depth is 5 (camera.zig:118).  `rgb_out` is host
- * memory, [h][w][3] doubles.  Synchronous.
+ * memory, [h][w][3] doubles.  Synchronous.  (A caller that passes the same
+ * buffer again - an interactive host - gets it registered with the HIP runtime
+ * on the second call, so that the copy runs at link speed; the registration is
+ * dropped when another buffer is passed or the scene is destroyed, which must
+ * happen before the buffer is freed.)
  */
 int rtc_render(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
                uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, double *rgb_out);
+
+/*
+ * The same frame as the RGBA8 framebuffer of the reference's interactive seam (Renderer, src/lib.zig:135-164):
+ * rgba_out[((y-y0)*w + (x-x0))*4 + 0..2] = clamp(channel) of src/raytracer/color.zig:61-71 (@round of
+ * channel * 255, clamped to 0..255), [+3] = 255.  Clamped on the device: 4 bytes per pixel cross the link
+ * instead of 24.  `rgba_out` is host memory, [h][w][4] bytes.  Synchronous.
+ */
+int rtc_render_rgba8(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
+                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t *rgba_out);
 
 /*
  * Same, but `d_rgb_out` is device memory on the scene's device and the work is

@@ -79,6 +79,8 @@ pub extern fn rtc_scene_create(desc: *const RtcSceneDesc, out: *?*RtcScene) c_in
 pub extern fn rtc_scene_destroy(scene: ?*RtcScene) void;
 pub extern fn rtc_render(scene: *RtcScene, cam: *const RtcCamera, max_depth: u32,
                          x0: u32, y0: u32, w: u32, h: u32, rgb_out: [*]f64) c_int;
+pub extern fn rtc_render_rgba8(scene: *RtcScene, cam: *const RtcCamera, max_depth: u32,
+                               x0: u32, y0: u32, w: u32, h: u32, rgba_out: [*]u8) c_int; // lib.zig's framebuffer
 pub extern fn rtc_render_device(scene: *RtcScene, cam: *const RtcCamera, max_depth: u32, x0: u32, y0: u32, w: u32, h: u32,
                                 d_rgb_out: [*]f64, hip_stream: ?*anyopaque) c_int; // output stays in HBM
 pub extern fn rtc_scene_synchronize(scene: *RtcScene) c_int;

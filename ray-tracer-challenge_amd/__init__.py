@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("shadow_traced", C.c_uint64), ("overflow", C.c_uint64)]
 
 
-RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_device",
+RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
                "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
                "rtc_status_name"]
@@ -143,6 +143,7 @@ def hip_lib():
         lib.rtc_scene_destroy.argtypes = [C.c_void_p]
         lib.rtc_scene_destroy.restype = None
         lib.rtc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p]
+        lib.rtc_render_rgba8.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p]
         lib.rtc_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_render_tiles_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 5 + [C.c_void_p, C.c_void_p]
         lib.rtc_assemble_tiles_device.argtypes = [C.c_void_p] + [C.c_uint32] * 6 + [C.c_void_p, C.c_void_p]
@@ -328,6 +329,20 @@ class GpuScene:
         x0, y0, w, h = tile if tile else (0, 0, cam.hsize, cam.vsize)
         out = np.empty((h, w, 3), dtype=np.float64)
         _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, x0, y0, w, h, out.ctypes.data))
+        return out
+
+    def render_into(self, cam, out, max_depth=REFERENCE_DEPTH):
+        """Camera.render into a caller-owned [h][w][3] f64 array (an interactive host reuses its canvas)."""
+        assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.shape == (cam.vsize, cam.hsize, 3)
+        _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, 0, 0, cam.hsize, cam.vsize, out.ctypes.data))
+        return out
+
+    def render_rgba8(self, cam, max_depth=REFERENCE_DEPTH, tile=None, out=None):
+        """The RGBA8 framebuffer of lib.zig:146-153, clamped on the device; returns [h][w][4] u8 (host)."""
+        x0, y0, w, h = tile if tile else (0, 0, cam.hsize, cam.vsize)
+        if out is None:
+            out = np.empty((h, w, 4), dtype=np.uint8)
+        _check_hip(hip_lib().rtc_render_rgba8(self._s, C.byref(cam), max_depth, x0, y0, w, h, out.ctypes.data))
         return out
 
     def render_device(self, cam, d_out_ptr, max_depth=REFERENCE_DEPTH, tile=None, stream=None):

@@ -47,6 +47,7 @@ extern "C" __global__ void rtc_pack_sort_kernel(const uint32_t* __restrict__ chu
 extern "C" __global__ void rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves,
                                                 const float t_min, const DevPackState* __restrict__ state,
                                                 uint32_t* __restrict__ order_out);
+extern "C" __global__ void rtc_rgba8_kernel(const double* __restrict__ canvas, const size_t n_pixels, uint32_t* __restrict__ rgba);
 extern "C" __global__ void rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
                                                     const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
                                                     const uint32_t vsize, double* __restrict__ canvas);
@@ -1415,6 +1416,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   }
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
+  if (s->host_out_registered) (void)hipHostUnregister(s->host_out);
   for (int b = 0; b < 2; ++b)
     if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
   if (s->d_sched_info) (void)hipFree(s->d_sched_info);
@@ -1590,29 +1592,80 @@ int rtc_assemble_tile_list_device(const double* d_gathered, const uint32_t* d_sl
   return RTC_OK;
 }
 
+namespace {
+
+// The frame of a host-output render: device staging for w x h pixels.
+int ensureFrame(rtc_scene* s, size_t doubles) {
+  if (doubles <= s->frame_capacity) return RTC_OK;
+  HIP_TRY(hipEventSynchronize(s->launch_done));
+  if (s->d_frame) (void)hipFree(s->d_frame);
+  s->d_frame = nullptr;
+  s->frame_capacity = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), std::max<size_t>(doubles, 1) * sizeof(double)));
+  s->frame_capacity = doubles;
+  return RTC_OK;
+}
+
+// A lane that ran out of traversal stack, pending-ray stack or csg list space has dropped work: the image is not the
+// reference's.  Say so instead of returning it (asynchronous callers check rtc_get_stats).
+int checkOverflow(rtc_scene* s) {
+  unsigned long long dropped = 0;
+  HIP_TRY(hipMemcpy(&dropped, &(s->d_stats + s->stats_parity)->overflow, sizeof dropped, hipMemcpyDeviceToHost));
+  if (dropped) return fail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", dropped);
+  return RTC_OK;
+}
+
+}  // namespace
+
 int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                double* rgb_out) {
   g_error.clear();
   if (!s || !rgb_out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   const size_t need = 3ull * w * h;
   HIP_TRY(hipSetDevice(s->device));
-  if (need > s->frame_capacity) {
-    if (s->d_frame) (void)hipFree(s->d_frame);
-    s->d_frame = nullptr;
-    s->frame_capacity = 0;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), std::max<size_t>(need, 1) * sizeof(double)));
-    s->frame_capacity = need;
-  }
+  if (const int st = ensureFrame(s, need); st != RTC_OK) return st;
   const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
   if (st != RTC_OK) return st;
-  HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, need * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  // The caller's canvas is pageable memory: a copy into it runs at a fifth of the link's rate (5.6 ms for a 1080p frame).
+  // A caller that renders into the SAME buffer again (an interactive host: lib.zig:135-190) gets it registered with the
+  // runtime on the second use and the copy at link speed from then on; a one-shot render does not pay for pinning.
+  const size_t bytes = need * sizeof(double);
+  if (s->host_out == rgb_out && s->host_out_bytes == bytes) {
+    if (!s->host_out_registered && !s->host_out_register_failed) {
+      if (hipHostRegister(rgb_out, bytes, hipHostRegisterDefault) == hipSuccess) {
+        s->host_out_registered = true;
+      } else {
+        (void)hipGetLastError();
+        s->host_out_register_failed = true;
+      }
+    }
+  } else {
+    if (s->host_out_registered) (void)hipHostUnregister(s->host_out);
+    s->host_out = rgb_out;
+    s->host_out_bytes = bytes;
+    s->host_out_registered = false;
+    s->host_out_register_failed = false;
+  }
+  HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  // a lane that ran out of traversal stack, pending-ray stack or csg list space has dropped work: the image
-  // is not the reference's.  Say so instead of returning it (asynchronous callers check rtc_get_stats).
-  unsigned long long dropped = 0;
-  HIP_TRY(hipMemcpy(&dropped, &(s->d_stats + s->stats_parity)->overflow, sizeof dropped, hipMemcpyDeviceToHost));
-  if (dropped) return fail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", dropped);
-  return RTC_OK;
+  return checkOverflow(s);
+}
+
+int rtc_render_rgba8(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                     uint8_t* rgba_out) {
+  g_error.clear();
+  if (!s || !rgba_out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t n = static_cast<size_t>(w) * h;
+  HIP_TRY(hipSetDevice(s->device));
+  if (const int st = ensureFrame(s, 3 * n + (n + 1) / 2); st != RTC_OK) return st;  // the f64 frame, then n u32 behind it
+  const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
+  if (st != RTC_OK) return st;
+  uint32_t* d_rgba = reinterpret_cast<uint32_t*>(s->d_frame + 3 * n);
+  hipLaunchKernelGGL(rtc_rgba8_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s->stream, s->d_frame, n, d_rgba);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(rgba_out, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return checkOverflow(s);
 }
 
 int rtc_assemble_tiles_device(const double* d_gathered, uint32_t world, uint32_t padded_tiles, uint32_t tile_w,

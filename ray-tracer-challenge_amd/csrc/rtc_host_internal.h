@@ -67,6 +67,10 @@ struct rtc_scene {
   uint32_t stats_parity = 0;    // which of the two the last launch counted in
   double* d_frame = nullptr;  // staging for rtc_render (host output)
   size_t frame_capacity = 0;  // in doubles
+  // rtc_render's destination: registered with the runtime when the caller comes back with the same buffer
+  void* host_out = nullptr;
+  size_t host_out_bytes = 0;
+  bool host_out_registered = false, host_out_register_failed = false;
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;

@@ -2076,6 +2076,23 @@ rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world, c
   }
 }
 
+// The RGBA8 framebuffer of the reference's interactive seam (lib.zig:146-153): clamp() of color.zig:61-71 on every
+// channel of an [n][3] f64 canvas - @round (half away from zero) of channel * 255, clamped to 0..255 - alpha 255.
+// One thread per pixel; 8 MB instead of 50 leave the GPU for a 1080p frame.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_rgba8_kernel(const double* __restrict__ canvas, const size_t n_pixels, uint32_t* __restrict__ rgba) {
+  const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_pixels) return;
+  auto clamp = [](double channel) -> uint32_t {
+    const double t = round(channel * 255);
+    if (!(t >= 0)) return 0u;  // negative (or NaN, on which Zig's @intFromFloat would trap)
+    if (t > 255) return 255u;
+    return static_cast<uint32_t>(t);
+  };
+  const double r = canvas[3 * i], g = canvas[3 * i + 1], b = canvas[3 * i + 2];
+  rgba[i] = clamp(r) | (clamp(g) << 8) | (clamp(b) << 16) | 0xFF000000u;
+}
+
 // The same for a cost-balanced split: tile t sits in slot slot_of_tile[t] (rank * padded + k) of the gathered buffer.
 extern "C" __global__ void __launch_bounds__(256)
 rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,

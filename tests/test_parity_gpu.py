@@ -520,6 +520,28 @@ def test_launches_on_different_streams_are_ordered(rtc):
         assert [st["primary"], st["secondary"], st["shadow_calls"]] == [counters["primary"], counters["secondary"], counters["shadow"]]
 
 
+def test_host_output_into_a_reused_canvas(rtc):
+    """rtc_render into the same caller-owned buffer again and again (an interactive host): from the second call on the
+    buffer is registered with the runtime; changing buffers and sizes in between must keep every image right."""
+    hs = rtc.HostScene.from_file("fresnel.json")
+    gpu = rtc.GpuScene(hs.desc)
+    cam = hs.camera(160, 120)
+    want, _ = ob.OracleScene(hs.desc).render(cam, 5)
+    a = np.full((120, 160, 3), np.nan)
+    b = np.full((120, 160, 3), np.nan)
+    for out in (a, a, a, b, a, b, b):
+        out[:] = np.nan
+        assert gpu.render_into(cam, out, 5) is out
+        assert np.abs(out - want).max() < TOL
+    small = hs.camera(40, 30)
+    c = np.full((30, 40, 3), np.nan)
+    for _ in range(3):
+        gpu.render_into(small, c, 5)
+    assert np.abs(c - ob.OracleScene(hs.desc).render(small, 5)[0]).max() < TOL
+    gpu.close()                                           # drops the registration before the arrays go away
+    del a, b, c
+
+
 def test_errors_through_the_abi(rtc):
     hs = rtc.HostScene.from_file("fresnel.json")
     gpu = rtc.GpuScene(hs.desc)
@@ -748,6 +770,8 @@ def test_interactive_camera_loop(rtc):
         frames.append(got)
         rgba = rtc.canvas_rgba8(got)
         assert rgba.shape == (54, 96, 4) and (rgba[..., 3] == 255).all()
+        assert np.array_equal(gpu.render_rgba8(cam, 5), rgba)     # the same clamp on the device (rtc_render_rgba8)
+        assert np.array_equal(gpu.render_rgba8(cam, 5, (10, 5, 33, 20)), rgba[5:25, 10:43])
         assert np.array_equal(rgba[..., :3], np.clip(np.floor(got * 255.0 + 0.5), 0, 255).astype(np.uint8))   # color.zig:61-71 (@round: half away from 0)
         if step % 2 == 0:
             hs.rotate_camera(0.35)
