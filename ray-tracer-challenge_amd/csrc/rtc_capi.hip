@@ -25,6 +25,9 @@ extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const De
 extern "C" __global__ void rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                     const uint32_t max_depth, double* __restrict__ out,
                                                     DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                        const uint32_t max_depth, double* __restrict__ out,
+                                                        DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                  const uint32_t max_depth, double* __restrict__ out,
                                                  DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
@@ -395,7 +398,7 @@ int enqueueRender(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_
 #endif
   // No clear of the canvas: every pixel of the rectangle is either stored once or zeroed by the lane that first
   // hands part of its ray tree to a neighbour (render_body step 2a).
-  auto* const kernel = s->ext_kernel ? (lds ? rtc_render_kernel_ext : rtc_render_kernel_bigworld_ext)
+  auto* const kernel = s->ext_kernel ? (lds ? (s->simple_kernel ? rtc_render_kernel_simple_ext : rtc_render_kernel_ext) : rtc_render_kernel_bigworld_ext)
                                      : (lds ? (s->simple_kernel ? rtc_render_kernel_simple : rtc_render_kernel) : rtc_render_kernel_bigworld);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
@@ -1298,7 +1301,8 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   s->has_csg = has_csg;
   s->ext_kernel = ext_kernel;
   // spheres, planes and cubes at top level only, small enough for the LDS tables: the `simple` kernel
-  s->simple_kernel = !ext_kernel && d.n_nodes == 0 && d.n_roots <= RTC_LDS_ROOTS && d.n_materials <= RTC_LDS_MATERIALS &&
+  // (with texture maps among the patterns: the `simple_ext` form of it; a csg is a node, so never simple)
+  s->simple_kernel = d.n_nodes == 0 && d.n_roots <= RTC_LDS_ROOTS && d.n_materials <= RTC_LDS_MATERIALS &&
                      d.n_patterns <= RTC_LDS_PATTERNS && d.n_lights <= RTC_LDS_LIGHTS;
   for (uint32_t i = 0; i < d.n_roots && s->simple_kernel; ++i)
     s->simple_kernel = !(d.roots[i] & RTC_CHILD_NODE_BIT) && d.leaf_kind[d.roots[i]] <= RTC_CUBE;
@@ -1323,7 +1327,8 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &nb, ext_kernel ? rtc_render_kernel_ext : (s->simple_kernel ? rtc_render_kernel_simple : rtc_render_kernel), 256, 0));
+        &nb, s->simple_kernel ? (ext_kernel ? rtc_render_kernel_simple_ext : rtc_render_kernel_simple)
+                              : (ext_kernel ? rtc_render_kernel_ext : rtc_render_kernel), 256, 0));
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));

@@ -2050,6 +2050,14 @@ rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap m
   render_body<true, true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
+// Worlds of top-level spheres, planes and cubes whose patterns include texture maps (earth, skybox, align_check): the
+// `simple` kernel with the texture-map path compiled in - none of the group traversal, no csg.
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
+rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                             double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, true, true>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                                double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
