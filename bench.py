@@ -143,12 +143,10 @@ def kernel_name(hs):
     ops = hs.array("node_op", d.n_nodes)
     ext = bool((pats == 8).any()) or bool(len(ops) and (ops != 0).any())
     small = d.n_roots <= 128 and d.n_materials <= 64 and d.n_patterns <= 48 and d.n_lights <= 16
-    simple = small and d.n_nodes == 0 and bool((kinds <= 2).all())
-    if ext:
-        return "rtc_render_kernel_simple_ext" if simple else ("rtc_render_kernel_ext" if small else "rtc_render_kernel_bigworld_ext")
-    if simple:
-        return "rtc_render_kernel_simple"
-    return "rtc_render_kernel" if small else "rtc_render_kernel_bigworld"
+    flat = small and d.n_nodes == 0
+    simple = flat and bool((kinds <= 2).all())
+    name = "rtc_render_kernel" + ("_simple" if simple else "_flat" if flat else "" if small else "_bigworld")
+    return name + ("_ext" if ext else "")
 
 
 def algorithmic_flops(desc, hs, stats):

@@ -28,6 +28,12 @@ extern "C" __global__ void rtc_render_kernel_simple(const DevScene S, const DevC
 extern "C" __global__ void rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                         const uint32_t max_depth, double* __restrict__ out,
                                                         DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_flat(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                  const uint32_t max_depth, double* __restrict__ out,
+                                                  DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_flat_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                      const uint32_t max_depth, double* __restrict__ out,
+                                                      DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                  const uint32_t max_depth, double* __restrict__ out,
                                                  DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
@@ -149,6 +155,13 @@ DevCamera devCamera(const rtc_camera& c) {
   d.hsize = c.hsize;
   d.vsize = c.vsize;
   return d;
+}
+
+// The render kernel of a scene whose tables fit in LDS.
+auto ldsKernel(const rtc_scene* s) -> decltype(&rtc_render_kernel) {
+  if (s->simple_kernel) return s->ext_kernel ? rtc_render_kernel_simple_ext : rtc_render_kernel_simple;
+  if (s->flat_kernel) return s->ext_kernel ? rtc_render_kernel_flat_ext : rtc_render_kernel_flat;
+  return s->ext_kernel ? rtc_render_kernel_ext : rtc_render_kernel;
 }
 
 double residentWaves(const rtc_scene* s) {
@@ -291,7 +304,7 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   // A probe counted the rays of ONE pixel per chunk and timed nothing: 64 pixels x about 10 ticks (of 16 shader cycles)
   // per unit of cost, twice that where rays walk a BVH (cover: a sky chunk 1 280 ticks = 8 us, the heaviest glass chunk
   // 45 000 = 0.28 ms; measured 5 us and 0.37 ms).
-  const float per_cost = s->simple_kernel ? 10.0f : 20.0f, cost_to_time = is_probe ? 64.0f * per_cost : per_cost;
+  const float per_cost = s->flat_kernel ? 10.0f : 20.0f, cost_to_time = is_probe ? 64.0f * per_cost : per_cost;
   const uint32_t prev_packets = map.order == nullptr ? n : map.n_units;  // (device-packed: an upper bound)
   hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost, s->d_chunk_time,
                      s->d_pack_state);
@@ -398,8 +411,7 @@ int enqueueRender(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_
 #endif
   // No clear of the canvas: every pixel of the rectangle is either stored once or zeroed by the lane that first
   // hands part of its ray tree to a neighbour (render_body step 2a).
-  auto* const kernel = s->ext_kernel ? (lds ? (s->simple_kernel ? rtc_render_kernel_simple_ext : rtc_render_kernel_ext) : rtc_render_kernel_bigworld_ext)
-                                     : (lds ? (s->simple_kernel ? rtc_render_kernel_simple : rtc_render_kernel) : rtc_render_kernel_bigworld);
+  auto* const kernel = lds ? ldsKernel(s) : (s->ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
@@ -1300,12 +1312,16 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const bool has_csg = traits.has_csg, ext_kernel = traits.ext_kernel;
   s->has_csg = has_csg;
   s->ext_kernel = ext_kernel;
-  // spheres, planes and cubes at top level only, small enough for the LDS tables: the `simple` kernel
-  // (with texture maps among the patterns: the `simple_ext` form of it; a csg is a node, so never simple)
-  s->simple_kernel = d.n_nodes == 0 && d.n_roots <= RTC_LDS_ROOTS && d.n_materials <= RTC_LDS_MATERIALS &&
-                     d.n_patterns <= RTC_LDS_PATTERNS && d.n_lights <= RTC_LDS_LIGHTS;
-  for (uint32_t i = 0; i < d.n_roots && s->simple_kernel; ++i)
-    s->simple_kernel = !(d.roots[i] & RTC_CHILD_NODE_BIT) && d.leaf_kind[d.roots[i]] <= RTC_CUBE;
+  // Worlds without groups (or csg: a csg is a node) that fit the LDS tables run kernels without the group traversal:
+  // `flat` (every leaf kind), or `simple` when all leaves are spheres, planes or cubes; each with an `_ext` form when
+  // texture maps are among the patterns.
+  s->flat_kernel = d.n_nodes == 0 && d.n_roots <= RTC_LDS_ROOTS && d.n_materials <= RTC_LDS_MATERIALS &&
+                   d.n_patterns <= RTC_LDS_PATTERNS && d.n_lights <= RTC_LDS_LIGHTS;
+  s->simple_kernel = s->flat_kernel;
+  for (uint32_t i = 0; i < d.n_roots && s->flat_kernel; ++i) {
+    if (d.roots[i] & RTC_CHILD_NODE_BIT) s->flat_kernel = s->simple_kernel = false;
+    else if (d.leaf_kind[d.roots[i]] > RTC_CUBE) s->simple_kernel = false;
+  }
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   // Zeroed ON THE HANDLE'S STREAM, followed by the event every launch on another stream waits for (launch()): the
@@ -1327,8 +1343,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
     int nb = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &nb, s->simple_kernel ? (ext_kernel ? rtc_render_kernel_simple_ext : rtc_render_kernel_simple)
-                              : (ext_kernel ? rtc_render_kernel_ext : rtc_render_kernel), 256, 0));
+        &nb, ldsKernel(s), 256, 0));
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));

@@ -91,6 +91,7 @@ struct rtc_scene {
   bool has_csg = false;
   bool ext_kernel = false;         // csg nodes or texture maps: the *_ext kernels
   bool simple_kernel = false;      // only top-level spheres / planes / cubes: the `simple` kernel
+  bool flat_kernel = false;        // no groups at all (any leaf kind): the `flat` kernel
   void* d_csg_buf = nullptr;       // DevPixelMap::csg_buf, only for scenes with csg nodes
   size_t csg_buf_capacity = 0;     // bytes
   uint32_t max_trav_stack = 0;

@@ -741,10 +741,14 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 //           the 144-byte-strided root records (per-lane LDS addresses; the stride spreads the banks).
 // Rays of one wave are a mix of pixels and bounces after a few iterations, so the union of the lanes'
 // survivors is most of the world while each lane's own list is 2-4 roots long.
-template <bool CSG, bool SIMPLE, class V>
+// WORLD: 0 = anything (groups, csg: the root loop below visits the survivors in table order and walks the candidate BVH
+// of a group); 1 = `flat`: no groups at all, every leaf kind; 2 = `simple`: top-level planes, spheres and cubes only.
+// The flat and simple kernels carry none of the group traversal and run the exact tests one kind at a time.
+template <bool CSG, int WORLD, class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
                                       const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow,
                                       uint32_t* lds_stack) {
+  constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
   const RayF rf = ray_f32(ray, S.cull_cmax);
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
@@ -752,7 +756,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
     for (uint32_t i = 0; i < n; i += 4u) {
       const RootCullPair p0 = cull[(base + i) >> 1], p1 = cull[((base + i) >> 1) + 1u];
-      const unsigned long long k = roots_kept<V, !SIMPLE>(p0, rf) | (roots_kept<V, !SIMPLE>(p1, rf) << 2);
+      const unsigned long long k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
       mine |= k << i;
     }
     if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
@@ -781,22 +785,23 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         leaf_entries<SIMPLE>(KIND, cy, nullptr, lr, [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
       }
     };
-    // (Only the `simple` kernel - worlds of top-level planes, spheres and cubes - is built this way: reflection_and_
-    // refraction depth 8 2.74 -> 2.22 ms, cover 0.730 -> 0.698; in the kernels that also carry the group traversal the
-    // three extra loops cost the mesh scenes 1-2 % and their worlds have few top-level objects.)
-    if constexpr (SIMPLE) {
+    // (The kernels without group traversal are built this way: reflection_and_refraction depth 8 2.74 -> 2.22 ms,
+    // cover 0.730 -> 0.698; in the kernels that also carry the group traversal the three extra loops cost the mesh
+    // scenes 1-2 % and their worlds have few top-level objects.)
+    if constexpr (FLAT) {
       const uint32_t k1 = S.n_root_planes, k2 = k1 + S.n_root_spheres, k3 = k2 + S.n_root_cubes;
       leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(0u, k1));
       leaves_of_kind(std::integral_constant<uint32_t, 0u>{}, mine & range(k1, k2));
       leaves_of_kind(std::integral_constant<uint32_t, 2u>{}, mine & range(k2, k3));
-      continue;  // (a simple world has nothing else)
+      if constexpr (SIMPLE) continue;  // (a simple world has nothing else)
+      mine &= range(k3, S.n_roots);    // the other leaf kinds: cylinders, cones, triangles
     }
     while (mine != 0ull && !vis.done()) {
       const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mine));
       mine &= mine - 1ull;
       const RootRec& R = recs[base + bit];
       const uint32_t kf = R.kind_flags;
-      if (!(kf & RTC_ROOT_IS_GROUP)) {
+      if (FLAT || !(kf & RTC_ROOT_IS_GROUP)) {
         const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
         const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
         const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
@@ -806,7 +811,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         continue;
       }
       vis.set_root(RTC_NO_LEAF);
-      if constexpr (!SIMPLE) {
+      if constexpr (!FLAT) {
         if (CSG && (kf & RTC_ROOT_IS_CSG)) {
           if constexpr (CSG) visit_csg(S, R.index, ray, vis, overflow);
         } else {
@@ -1328,7 +1333,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // reflection / refraction children (one continues in registers, the other goes to the lane's stack).
 // Exit: the counter runs past n_chunks (`drained`) and no lane holds a ray; every wave reaches it.
 // ------------------------------------------------------------------------------------------
-template <bool LDS, bool CSG, bool SIMPLE = false>
+template <bool LDS, bool CSG, int WORLD = 0>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
@@ -1354,13 +1359,14 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // store_pending_lds); deeper levels are in the buffer in memory (DevPixelMap::ray_stack).  A lane's stack is empty
   // again after almost every pixel, so nearly every push and pop stays here: the pops no longer wait for memory and the
   // 2048 resident waves no longer cycle 59 MB of stack lines through the L2s (142 MB written per cover frame).
-  constexpr int LDS_LEVELS = SIMPLE ? 2 : (LDS ? 1 : 2);  // (what fits beside the tables at two work-groups per CU)
+  constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
+  constexpr int LDS_LEVELS = FLAT ? 2 : (LDS ? 1 : 2);  // (what fits beside the tables at two work-groups per CU)
   __shared__ Quad2 lds_pend[4][LDS_LEVELS][4][64];
   // The colour a lane has accumulated for its pixel: touched once per iteration and when the pixel is finished, live
   // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
   // six VGPRs of a kernel at the 256-register limit.
   __shared__ double lds_acc[4][64][3];
-  __shared__ uint32_t lds_trav[SIMPLE ? 1 : 4][SIMPLE ? 1 : RTC_LDS_TRAV][64];  // per lane: the top of the BVH walk's stack
+  __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : RTC_LDS_TRAV][64];  // per lane: the top of the BVH walk's stack
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -1409,7 +1415,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // roughly their shares of an iteration's time; a pixel behind glass costs several times a pixel on a wall per ray)
   uint32_t share_rays = 0u;
   double* const acc = lds_acc[threadIdx.x >> 6][threadIdx.x & 63u];
-  uint32_t* const trav_stack = SIMPLE ? nullptr : &lds_trav[threadIdx.x >> 6][0][threadIdx.x & 63u];
+  uint32_t* const trav_stack = FLAT ? nullptr : &lds_trav[threadIdx.x >> 6][0][threadIdx.x & 63u];
   acc[0] = acc[1] = acc[2] = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
@@ -1676,7 +1682,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_COUNT(0);
     {
       RTC_HIST_BEGIN();
-      trace<CSG, SIMPLE>(S, recs, cull, ray, hv, overflow, trav_stack);
+      trace<CSG, WORLD>(S, recs, cull, ray, hv, overflow, trav_stack);
       RTC_HIST_END(0);
     }
     RTC_STAMP(2);
@@ -1688,7 +1694,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     uint32_t kind, geom, mat_index;
     double M[12];
     DevCyl hcy{0.0, 0.0, 0u, 0u};
-    if (SIMPLE || hv.root != RTC_NO_LEAF) {  // (a simple world has no groups: every hit is a top-level object)
+    if (FLAT || hv.root != RTC_NO_LEAF) {  // (a world without groups: every hit is a top-level object)
       const RootRec& R = recs[hv.root];
 #pragma unroll
       for (int i = 0; i < 12; ++i) M[i] = R.inv[i];
@@ -1721,7 +1727,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       RTC_COUNT(4);
       {
         RTC_HIST_BEGIN();
-        trace<CSG, SIMPLE>(S, recs, cull, ray, bv, overflow, trav_stack);
+        trace<CSG, WORLD>(S, recs, cull, ray, bv, overflow, trav_stack);
         RTC_HIST_END(2);
       }
       RTC_STAMP(6);
@@ -1868,7 +1874,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, SIMPLE>(S, recs, cull, sray, sv, overflow, trav_stack);
+            trace<CSG, WORLD>(S, recs, cull, sray, sv, overflow, trav_stack);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
@@ -2038,7 +2044,7 @@ rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixel
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                          double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true, false, true>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, false, 2>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // The same two kernels with the csg and texture-map paths compiled in (template flag CSG), for scenes that
@@ -2055,7 +2061,22 @@ rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap m
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                              double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true, true, true>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, true, 2>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
+// Worlds without groups or csg but with other leaf kinds at top level (cylinders, cones, triangles: cylinders.json,
+// earth.json's pedestal, xyz.json): none of the group traversal either; planes, spheres and cubes one kind at a time,
+// the rest in table order.
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
+rtc_render_kernel_flat(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                       double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, false, 1>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
+rtc_render_kernel_flat_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                           double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, true, 1>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)

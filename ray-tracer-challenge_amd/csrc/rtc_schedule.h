@@ -102,7 +102,7 @@ int uploadSchedule(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
 // 2.79 / 2.78 / 2.79 / 2.91 ms.
 inline double groupFloor(const rtc_scene* s) {
   static const double forced = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 0.0;
-  return forced > 0.0 ? forced : (s->simple_kernel ? 8000.0 : 16000.0);
+  return forced > 0.0 ? forced : (s->flat_kernel ? 8000.0 : 16000.0);  // (flat: no mesh to keep in cache)
 }
 
 // The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,

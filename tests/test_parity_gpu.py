@@ -272,8 +272,11 @@ SCHEDULE_CASES = [
     ("teapot.json", 192, 108, 5),                       # rtc_render_kernel (BVH)
     ("dragons.json", 192, 108, 5),                      # rtc_render_kernel, deep reference tree
     ("groups.json", 150, 50, 5),                        # cones in divided groups
-    ("csg_demo.json", 160, 90, 5),                      # rtc_render_kernel_ext (csg)
-    ("texture_demo.json", 160, 90, 5),                  # rtc_render_kernel_ext (texture maps)
+    ("csg_demo.json", 160, 90, 5),                      # rtc_render_kernel_ext (csg, and texture-free groups)
+    ("texture_demo.json", 160, 90, 5),                  # rtc_render_kernel_flat_ext (texture maps, no groups)
+    ("cylinders.json", 160, 80, 5),                     # rtc_render_kernel_flat (cylinders at top level, no groups)
+    ("skybox_demo.json", 200, 100, 5),                  # rtc_render_kernel_simple_ext (cubes and spheres with texture maps)
+    ("earth.json", 200, 100, 5),                        # a texture-mapped sphere on a cylinder
 ]
 
 
