@@ -741,6 +741,56 @@ def test_random_scenes(rtc, seed):
     assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0
 
 
+def _random_flat_scene(seed, simple):
+    """Random world WITHOUT groups: many top-level leaves with random transforms, glass inside glass, every pattern kind.
+    simple: spheres, planes and cubes only (rtc_render_kernel_simple); else every leaf kind (rtc_render_kernel_flat)."""
+    import json
+    import random
+    rnd = random.Random(1000 + seed)
+    base = json.loads(_random_scene(40 + seed))          # materials / patterns / lights / camera of the grouped generator
+    kinds = ["sphere", "cube", "plane"] if simple else ["sphere", "cube", "plane", "cylinder", "cone", "triangle"]
+
+    def leaves(o):
+        t = o["type"]
+        if "group" in t:
+            for c in t["group"]:
+                yield from leaves(c)
+        elif "csg" in t:
+            yield from leaves(t["csg"]["left"])
+            yield from leaves(t["csg"]["right"])
+        else:
+            yield o
+    objs = []
+    for o in base["objects"]:
+        for leaf in leaves(o):
+            kind = next(iter(leaf["type"]))
+            if kind not in kinds:
+                leaf = dict(leaf, type={rnd.choice(["sphere", "cube"]): {}})
+            leaf = dict(leaf)
+            leaf["transform"] = list(leaf.get("transform", [])) + [{"translate": [rnd.uniform(-3, 3), rnd.uniform(0, 2), rnd.uniform(-3, 3)]}]
+            objs.append(leaf)
+    objs = objs[:60]
+    objs.append({"type": {"plane": {}}, "transform": [{"rotate-x": 1.5707963}, {"translate": [0, 0, 12]}],
+                 "material": {"reflective": 0.3, "pattern": {"type": {"checkers": [{"type": {"solid": [0.1, 0.1, 0.1]}}, {"type": {"solid": [0.9, 0.9, 0.9]}}]}}}})
+    base["objects"] = objs
+    return json.dumps(base)
+
+
+@pytest.mark.parametrize("seed,simple", [(s, True) for s in range(1, 9)] + [(s, False) for s in range(1, 9)])
+def test_random_scenes_without_groups(rtc, seed, simple):
+    hs = rtc.HostScene(_random_flat_scene(seed, simple))
+    assert hs.desc.n_nodes == 0
+    cam = hs.camera()
+    gpu = rtc.GpuScene(hs.desc)
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    for launch in range(2):                                 # heuristic schedule, then the device-packed one
+        got = gpu.render(cam, 5)
+        delta = np.abs(got - want)
+        assert delta.max() < TOL, (seed, simple, launch, delta.max(), np.unravel_index(np.argmax(delta), delta.shape))
+        st = gpu.stats()
+        assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0
+
+
 def test_csg_list_overflow_is_reported(rtc):
     """A csg whose list would need more than RTC_CSG_ENTRIES = 32 slots on some ray fails loudly (no truncation)."""
     import json
