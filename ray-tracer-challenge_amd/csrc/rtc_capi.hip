@@ -40,6 +40,9 @@ extern "C" __global__ void rtc_render_kernel_ext(const DevScene S, const DevCame
 extern "C" __global__ void rtc_render_kernel_bigworld_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                           const uint32_t max_depth, double* __restrict__ out,
                                                           DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_estimate_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                               uint32_t* __restrict__ chunk_cost, uint32_t* __restrict__ chunk_time,
+                                               DevPackState* __restrict__ state);
 extern "C" __global__ void rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map,
                                                  uint32_t* __restrict__ chunk_cost, uint32_t* __restrict__ chunk_time,
                                                  DevPackState* __restrict__ state);
@@ -204,26 +207,24 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
   return RTC_OK;
 }
 
-// The schedule of one launch (results never depend on it).
-//   * first launch of a pixel map: the geometric heuristic of chunkOrder() on the host - except for frames of 65 536
-//     chunks and more (4K), where that heuristic costs the host more than the frame takes (14 ms wall for the first
-//     frame of dragons.json at 4K): a PROBE launch renders one pixel of every 8x8 chunk (1/64 of the rays) and counts
-//     its rays, and the packer orders the frame's chunks by that.  Measured first frames, probe / heuristic, GPU time:
-//     cover 1080p 1.56 / 1.31 ms, reflection_and_refraction depth 8 4.88 / 4.41, teapot 1.35 / 0.70, dragons 4K
-//     4.45 / 5.10 (the probe launch itself takes 0.3 ms: one pixel's ray tree is a chain of dependent iterations);
+// The schedule of one launch (results never depend on it).  All of it is made on the device.
+//   * first launch of a pixel map: rtc_estimate_kernel guesses what every chunk will cost from the roots its pixels can
+//     see (bounding spheres, material weights) and the packer orders the frame by that.  (Round 1 did this with a
+//     three-class heuristic on the host - 14 ms of wall time for dragons at 4K -, an earlier round-2 build with a probe
+//     launch of one pixel per chunk.  Measured first frames, estimate / host heuristic / probe, GPU time: cover 1080p
+//     0.96 / 1.22 / 1.56 ms, reflection_and_refraction depth 8 3.5 / 3.6 / 4.9, teapot 0.65 / 0.68 / 1.35, dragons 4K
+//     3.2 / 5.1 / 4.3.)
 //   * a launch whose schedule was not measured on its own view MEASURES: per-pixel ray counts and the time every packet
-//     took in the wave that pulled it; it is followed on its stream by rtc_chunk_cost_kernel and rtc_pack_kernel: the
-//     next launch runs a schedule packed on the device from those measurements.  Nothing waits for the host;
+//     took in the wave that pulled it; it is followed on its stream by rtc_chunk_cost_kernel and the packer's launches:
+//     the next launch runs a schedule packed on the device from those measurements.  Nothing waits for the host;
 //   * so an orbiting camera (lib.zig:166-190) renders every frame with the schedule of the frame before, and a static
 //     view keeps the schedule of its first full frame and measures nothing more;
 //   * the first full measurement is also read back (per-chunk costs and times, the packer's verdict): if a chunk took
-//     longer than a wave's fair share (small images, one rank's share of a frame split over GPUs) the host cuts such
+//     much longer than a wave's fair share (small images, one rank's share of a frame split over GPUs) the host cuts such
 //     chunks into runs of pixels (packSchedule) and the launch that finds the read-back complete switches to that.
-#define RTC_PROBE_MIN_CHUNKS 65536u
-
 struct SchedulePlan {
-  bool measure = false;  // this launch collects costs and packet times, and the next schedule is packed from them
-  bool probe = false;    // ... and is preceded by a probe launch that packs ITS schedule
+  bool measure = false;   // this launch collects costs and packet times, and the next schedule is packed from them
+  bool estimate = false;  // ... and is preceded by rtc_estimate_kernel + the packer: ITS schedule from the roots' bounds
 };
 
 int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, size_t out_pixels,
@@ -236,7 +237,6 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->launches_with_key = 0;
     s->sched_valid = false;
     s->split_checked = false;
-    s->order_key.clear();
     if (s->readback_enqueued) HIP_TRY(hipEventSynchronize(s->measure_done));  // (its copies must not land in a later read-back's buffers)
     s->readback_enqueued = false;
   }
@@ -265,51 +265,52 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
         s->sched_valid = true;
         s->sched_cam = s->readback_cam;
         s->sched_depth = s->readback_depth;
-        s->order_key.clear();  // the heuristic cache no longer describes the buffers
       }
     } else if (ready != hipErrorNotReady) {
       HIP_TRY(ready);
     }
   }
-  static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: never measure, keep the first launch's schedule
-  static const bool no_probe = getenv("RTC_NO_PROBE") != nullptr;    // diagnostic: the host heuristic for every first frame
-  if (schedulable && !sched_off)
-    if (const int st = ensureMeasureBuffers(s, map); st != RTC_OK) return st;
-  uint32_t probe_min = RTC_PROBE_MIN_CHUNKS;
-  if (!s->sched_valid)
-    if (const char* e = getenv("RTC_PROBE_MIN_CHUNKS")) probe_min = static_cast<uint32_t>(std::max(64, atoi(e)));  // tests: probe small frames too
-  plan.probe = schedulable && !sched_off && !no_probe && !s->sched_valid && map.n_chunks >= probe_min;
-  if (plan.probe) {
-    plan.measure = true;
-    return RTC_OK;  // (launch() runs the probe and then comes back through useSchedule)
+  static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: no schedule at all (packet i is chunk i)
+  if (!schedulable || sched_off) {  // a handful of chunks, or more than an item can name: packet i is chunk i, whole
+    map.order = nullptr;
+    map.n_units_dev = nullptr;
+    map.n_units = map.n_chunks;
+    return RTC_OK;
   }
-  if (s->sched_valid) {
-    useSchedule(s, map);
-  } else {
-    if (const int st = chunkOrder(s, cam, map, stream); st != RTC_OK) return st;
-    if (map.order == nullptr) s->h_order.clear();  // unscheduled: packet i is chunk i
+  if (const int st = ensureMeasureBuffers(s, map); st != RTC_OK) return st;
+  if (!s->sched_valid) {  // (launch() runs the estimate and the packer and then comes back through useSchedule)
+    plan.estimate = plan.measure = true;
+    return RTC_OK;
   }
-  const bool view_changed = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
-  plan.measure = schedulable && !sched_off && (!s->sched_valid || view_changed);
+  useSchedule(s, map);
+  plan.measure = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
   return RTC_OK;
 }
 
 // Right after a measuring launch, on its stream: per-chunk sums of the per-pixel costs, then the next frame's schedule
 // packed into the buffer that is not in use; the buffers swap.  The first full measurement of a pixel map also goes to
 // pinned host memory behind an event (see updateSchedule).  Nothing here waits.
+enum class PackFrom { Measurement, Estimate };
+
 int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map, uint32_t max_depth, hipStream_t stream,
-                     bool is_probe) {
+                     PackFrom from) {
+  const bool unmeasured = from != PackFrom::Measurement;  // (no frame has been measured: nothing to read back)
   const uint32_t n = map.n_chunks, target = s->sched_cur ^ 1u;
   const float n_waves = static_cast<float>(residentWaves(s)), t_min = static_cast<float>(groupFloor(s));
-  // A probe counted the rays of ONE pixel per chunk and timed nothing: 64 pixels x about 10 ticks (of 16 shader cycles)
-  // per unit of cost, twice that where rays walk a BVH (cover: a sky chunk 1 280 ticks = 8 us, the heaviest glass chunk
-  // 45 000 = 0.28 ms; measured 5 us and 0.37 ms).
-  const float per_cost = s->flat_kernel ? 10.0f : 20.0f, cost_to_time = is_probe ? 64.0f * per_cost : per_cost;
+  // (what an untimed chunk's cost is worth in ticks: the estimate is in ticks already; a measured frame times every
+  // packet, so this only covers chunks whose share of a packet's time rounded to zero)
+  const float cost_to_time = from == PackFrom::Estimate ? 1.0f : (s->flat_kernel ? 10.0f : 20.0f);
   const uint32_t prev_packets = map.order == nullptr ? n : map.n_units;  // (device-packed: an upper bound)
-  hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost, s->d_chunk_time,
-                     s->d_pack_state);
-  hipLaunchKernelGGL(rtc_chunk_time_kernel, dim3((prev_packets + 255u) / 256u), dim3(256), 0, stream, map.order, map.n_units_dev,
-                     map.n_units, s->d_packet_time, s->d_chunk_cost, n, s->d_chunk_time);
+  if (from == PackFrom::Estimate) {
+    // no frame has run yet: what every chunk is likely to cost, from the roots its pixels look at (in ticks already)
+    hipLaunchKernelGGL(rtc_estimate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, s->dev, devCamera(cam), map, s->d_chunk_cost,
+                       s->d_chunk_time, s->d_pack_state);
+  } else {
+    hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost, s->d_chunk_time,
+                       s->d_pack_state);
+    hipLaunchKernelGGL(rtc_chunk_time_kernel, dim3((prev_packets + 255u) / 256u), dim3(256), 0, stream, map.order, map.n_units_dev,
+                       map.n_units, s->d_packet_time, s->d_chunk_cost, n, s->d_chunk_time);
+  }
   hipLaunchKernelGGL(rtc_pack_class_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_cost, n, cost_to_time,
                      s->d_chunk_time, s->d_pack_state);
   hipLaunchKernelGGL(rtc_pack_sort_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, t_min,
@@ -318,11 +319,11 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
                      s->d_pack_state, s->d_sched[target]);
   HIP_TRY(hipGetLastError());
   s->measure_gen++;
-  if (!is_probe) {
+  if (!unmeasured) {
     s->measured_regions = map.mode == 0u ? 1u : map.n_my_tiles;
     s->measured_chunks_per_region = map.chunks_per_region;
   }
-  if (!is_probe && !s->split_checked && !s->readback_enqueued) {  // the first full measurement of this pixel map
+  if (!unmeasured && !s->split_checked && !s->readback_enqueued) {  // the first full measurement of this pixel map
     auto pinned = [](auto*& p, size_t& capacity, size_t n) -> hipError_t {
       if (n <= capacity) return hipSuccess;
       if (p) (void)hipHostFree(p);
@@ -351,7 +352,6 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   s->sched_on_device = true;
   s->sched_cam = cam;
   s->sched_depth = max_depth;
-  s->order_key.clear();
   return RTC_OK;
 }
 
@@ -418,29 +418,6 @@ int enqueueRender(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_
   return RTC_OK;
 }
 
-// The probe launch of a first frame: pixel 27 (row 3, column 3) of every chunk, sixteen chunks to a packet, with the
-// per-pixel ray counts switched on; the packer then orders the chunks by those counts (no packet was timed: a chunk's
-// time falls back to its cost).  The probe's pixels are real pixels of the frame - the frame renders them again.
-int probeAndPack(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
-                 size_t out_pixels, hipStream_t stream) {
-  DevPixelMap map = map_in;
-  const uint32_t n_packets = (map.n_chunks + RTC_PACKET_ITEMS - 1u) / RTC_PACKET_ITEMS;
-  s->h_order.assign(static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
-  for (uint32_t c = 0; c < map.n_chunks; ++c) s->h_order[c] = scheduleItem(c, 27u, 1u);
-  s->h_split_inflation.clear();
-  if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
-  s->order_key.clear();
-  map.order = s->d_sched[s->sched_cur];
-  map.n_units_dev = nullptr;
-  map.n_units = n_packets;
-  map.cost = s->d_cost;
-  map.packet_time = nullptr;  // (the probe's packets are not what the frame's will be: the packer sees zero times)
-  HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
-  HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(n_packets) * sizeof(uint32_t), stream));
-  if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
-  return packNextSchedule(s, cam, map, max_depth, stream, true);
-}
-
 int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint32_t max_depth, double* d_out,
            size_t out_pixels, hipStream_t stream) {
   DevPixelMap map = map_in;
@@ -455,15 +432,19 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
   SchedulePlan plan;
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
-  if (plan.probe) {
-    if (const int st = probeAndPack(s, cam, map_in, max_depth, d_out, out_pixels, stream); st != RTC_OK) return st;
+  if (plan.estimate) {
+    DevPixelMap none = map_in;  // (no schedule ran before: the packer sees no packets and no times)
+    none.order = nullptr;
+    none.n_units_dev = nullptr;
+    none.n_units = 0;
+    if (const int st = packNextSchedule(s, cam, none, max_depth, stream, PackFrom::Estimate); st != RTC_OK) return st;
     useSchedule(s, map);
   }
   map.cost = plan.measure ? s->d_cost : nullptr;
   map.packet_time = plan.measure ? s->d_packet_time : nullptr;
   if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
   if (plan.measure)
-    if (const int st = packNextSchedule(s, cam, map, max_depth, stream, false); st != RTC_OK) return st;
+    if (const int st = packNextSchedule(s, cam, map, max_depth, stream, PackFrom::Measurement); st != RTC_OK) return st;
   HIP_TRY(hipEventRecord(s->launch_done, stream));
   s->last_stream = stream;
   return RTC_OK;
@@ -515,14 +496,12 @@ struct HostTables {
   std::vector<BvhNode> bvh_nodes;      // the binary SAH trees (host only)
   std::vector<Bvh4Node> bvh4_nodes;    // ... collapsed to four children per node: what the kernel walks
   bool chain_nested = false;           // every reference node box lies inside its parent's box
-  bool plane_spawns_rays = false;      // some top-level plane is reflective or transparent
   std::vector<uint32_t> bvh_leaves;
   std::vector<uint32_t> node_info;
   std::vector<uint2> node_range;
-  std::vector<Sphere> branching_spheres;
-  std::vector<Sphere> occupied_spheres;
   std::vector<RootRec> root_recs;
   std::vector<RootCull> root_cull;
+  std::vector<float> root_weight;      // per root (table order): what a chunk that looks at it costs (rtc_estimate_kernel)
   std::vector<double> xf;
   std::vector<DevPattern> pat;
   std::vector<DevCyl> cyl;
@@ -536,8 +515,6 @@ struct HostTables {
   uint32_t n_root_kind[3] = {0, 0, 0};  // planes, spheres, cubes at the head of root_recs (in that order)
   float bvh_mag = 0.0f;
   float cull_cmax = 0.0f;
-  bool branching_everywhere = false;
-  bool unbounded_nonplane = false;
 };
 
 // Everything rtc_scene_create refuses, checked on the host before anything touches the GPU.
@@ -672,23 +649,17 @@ int validateScene(const rtc_scene_desc& d, SceneTraits& traits) {
   return RTC_OK;
 }
 
-// One record and one bounding sphere per World.objects entry, and what the first-frame schedule wants to know about
-// them (where the branching materials are, what can be seen at all).
+// One record, one bounding sphere and one cost weight (for the first frame's schedule) per World.objects entry.
 void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_of, const std::vector<uint32_t>& bvh_root_of,
                      HostTables& T) {
   auto opOf = [&](uint32_t n) -> uint32_t { return d.node_op ? d.node_op[n] : RTC_CSG_NONE; };
   auto& root_recs = T.root_recs;
   auto& root_cull = T.root_cull;
   auto& cull_cmax = T.cull_cmax;
-  auto& branching_spheres = T.branching_spheres;
-  auto& occupied_spheres = T.occupied_spheres;
-  auto& branching_everywhere = T.branching_everywhere;
-  auto& unbounded_nonplane = T.unbounded_nonplane;
-  branching_everywhere = false;
-  unbounded_nonplane = false;
   root_recs.assign(d.n_roots, RootRec{});
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
   root_cull.assign((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  T.root_weight.assign((d.n_roots + 3u) & ~3u, 0.0f);
   cull_cmax = 0.0f;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     RootRec& R = root_recs[i];
@@ -777,9 +748,10 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
     sp = inflate(sp);
     {
       // does anything under this root branch the ray tree (reflective AND transparent, world.zig:101-102)?
-      bool branches = false;
+      bool branches = false, reflects = false, refracts = false;
+      uint32_t n_below = 0;
       std::vector<uint32_t> todo{ref};
-      while (!todo.empty() && !branches) {
+      while (!todo.empty()) {
         const uint32_t r = todo.back();
         todo.pop_back();
         if (r & RTC_CHILD_NODE_BIT) {
@@ -787,21 +759,23 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
           for (uint32_t k = 0; k < d.node_count[n]; ++k) todo.push_back(d.children[d.node_first[n] + k]);
         } else {
           const double* mp = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * d.leaf_material[r];
-          branches = mp[4] != 0.0 && mp[5] != 0.0;
+          branches = branches || (mp[4] != 0.0 && mp[5] != 0.0);
+          reflects = reflects || mp[4] != 0.0;
+          refracts = refracts || mp[5] != 0.0;
+          ++n_below;
         }
       }
-      if (branches) {
-        if (sp.finite()) branching_spheres.push_back(sp);
-        else branching_everywhere = true;
-      }
-      if (sp.finite()) {
-        occupied_spheres.push_back(sp);
-      } else if ((ref & RTC_CHILD_NODE_BIT) || d.leaf_kind[ref] != RTC_PLANE) {
-        unbounded_nonplane = true;
-      } else {
-        // a plane that reflects or refracts: a pixel that sees "only planes" can still cost a whole ray tree
-        const double* mp = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * d.leaf_material[ref];
-        if (mp[4] != 0.0 || mp[5] != 0.0) T.plane_spawns_rays = true;
+      // What a chunk of pixels that looks at this root costs, for the first frame's schedule (rtc_estimate_kernel): in
+      // the packer's time unit (16 shader cycles; 150 of them a microsecond), from round-1 measurements on cover and
+      // teapot - an opaque box 10 us per chunk, a mirror three times that, glass that reflects twenty-five times (the
+      // heaviest cover chunk: 0.37 ms); a mesh by the depth of its BVH.  Only the order of magnitude matters: the first
+      // frame measures, and the second runs on measurements.
+      {
+        float w = 1500.0f * (1.0f + 0.5f * std::log2(1.0f + static_cast<float>(n_below)));
+        if (branches) w *= 25.0f;
+        else if (refracts) w *= 4.0f;
+        else if (reflects) w *= 3.0f;
+        T.root_weight[i] = w;
       }
     }
     RootCull& C = root_cull[i];
@@ -844,15 +818,18 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
   std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return klass(root_recs[a]) < klass(root_recs[b]); });
   std::vector<RootRec> recs2(d.n_roots);
   std::vector<RootCull> cull2(root_cull.size(), RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  std::vector<float> weight2(T.root_weight.size(), 0.0f);
   T.n_root_kind[0] = T.n_root_kind[1] = T.n_root_kind[2] = 0;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     recs2[i] = root_recs[perm[i]];
     cull2[i] = root_cull[perm[i]];
+    weight2[i] = T.root_weight[perm[i]];
     const int k = klass(recs2[i]);
     if (k < 3) T.n_root_kind[k]++;
   }
   root_recs.swap(recs2);
   root_cull.swap(cull2);
+  T.root_weight.swap(weight2);
 }
 
 // The tables that are the caller's arrays in the kernel's element layout.
@@ -1218,8 +1195,6 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const auto& bvh_leaves = T.bvh_leaves;
   const auto& node_info = T.node_info;
   const auto& node_range = T.node_range;
-  const auto& branching_spheres = T.branching_spheres;
-  const auto& occupied_spheres = T.occupied_spheres;
   const auto& root_recs = T.root_recs;
   const auto& root_cull = T.root_cull;
   const auto& xf = T.xf;
@@ -1234,8 +1209,6 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const auto& n_live = T.n_live;
   const auto& bvh_mag = T.bvh_mag;
   const auto& cull_cmax = T.cull_cmax;
-  const auto& branching_everywhere = T.branching_everywhere;
-  const auto& unbounded_nonplane = T.unbounded_nonplane;
   HIP_TRY(hipGetDevice(&s->device));
   HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(s->roots.upload(roots));
@@ -1249,6 +1222,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     root_cull_pairs[i].r2 = {a.r2, b.r2};
   }
   HIP_TRY(s->root_cull.upload(root_cull_pairs));
+  HIP_TRY(s->root_weight.upload(T.root_weight));
   HIP_TRY(s->kids.upload(kids));
   HIP_TRY(s->leaf_meta.upload(leaf_meta));
   HIP_TRY(s->xf.upload(xf));
@@ -1332,11 +1306,6 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(hipEventRecord(s->launch_done, s->stream));
   s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
-  s->branching = branching_spheres;
-  s->branching_everywhere = branching_everywhere;
-  s->occupied = occupied_spheres;
-  s->unbounded_nonplane = unbounded_nonplane;
-  s->plane_spawns_rays = T.plane_spawns_rays;
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -1356,6 +1325,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   DevScene& D = s->dev;
   D.root_recs = s->root_recs.p;
   D.root_cull = s->root_cull.p;
+  D.root_weight = s->root_weight.p;
   D.roots = s->roots.p;
   D.leaf_meta = s->leaf_meta.p;
   D.xf = s->xf.p;

@@ -155,6 +155,7 @@ struct __attribute__((aligned(32))) CsgRec {
 struct DevScene {
   const RootRec* __restrict__ root_recs;
   const RootCullPair* __restrict__ root_cull;  // (n_roots + 3) / 4 * 2 pairs, padded with never-kept spheres
+  const float* __restrict__ root_weight;       // per root: what a chunk that looks at it costs (rtc_estimate_kernel), in packer ticks
   const uint32_t* __restrict__ roots;
   const uint4* __restrict__ leaf_meta;
   const double* __restrict__ xf;        // [n_xforms][12]

@@ -74,6 +74,7 @@ struct rtc_scene {
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;
+  DevBuf<float> root_weight;
   DevBuf<uint4> leaf_meta;
   DevBuf<double> xf, tri, trin, node_box, light;
   DevBuf<DevPattern> pat;
@@ -96,12 +97,6 @@ struct rtc_scene {
   size_t csg_buf_capacity = 0;     // bytes
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
-  // heavy-first scheduling hint (see DevPixelMap::order)
-  std::vector<Sphere> occupied;    // bounding spheres of every bounded root
-  bool unbounded_nonplane = false; // a root other than a plane without a finite bound (cannot be projected)
-  bool plane_spawns_rays = false;  // a top-level plane reflects or refracts: "sees only planes" does not mean cheap
-  std::vector<Sphere> branching;   // bounding spheres of roots whose materials branch the ray tree
-  bool branching_everywhere = false;  // such a root without a finite bound
   // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next
   // launch runs; a measuring launch is followed by rtc_pack_kernel, which packs the other buffer from what the launch
   // measured, and the buffers swap - no host in the loop.  The host only writes a buffer for the first launch of a pixel
@@ -118,7 +113,6 @@ struct rtc_scene {
   uint32_t sched_n_units = 0;             // ... packed by the host: its packet count
   rtc_camera sched_cam{};                 // the view (and depth) that schedule was measured with: another view measures again
   uint32_t sched_depth = 0;
-  std::vector<double> order_key;          // camera + map the heuristic order in h_order was built for
   uint32_t* d_chunk_time = nullptr;       // rtc_pack_kernel scratch: per-chunk times, sorted chunks
   uint32_t* d_sorted = nullptr;
   size_t pack_capacity = 0;               // chunks

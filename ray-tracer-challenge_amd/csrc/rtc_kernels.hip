@@ -2159,6 +2159,70 @@ __device__ __forceinline__ uint32_t pack_class(uint32_t t) {
   return static_cast<uint32_t>(4.0f * __builtin_log2f(1.0f + static_cast<float>(t)));  // < RTC_PACK_CLASSES for any 32-bit t
 }
 
+// The first frame of a pixel map has no measurement to be packed from.  One thread per chunk estimates what the chunk
+// will cost from what its pixels can see: the ray through the chunk's centre, widened to a cone that holds the chunk's
+// 64 pixels, against the bounding sphere of every World.objects entry (the FP32 spheres of the root loop), summing the
+// roots' weights (rtc_scene_create: an opaque box 10 us per chunk, a mirror 3 x, glass 4 x, glass that also reflects
+// 25 x, a mesh by the depth of its BVH).  Crude - it knows nothing about what a reflection goes on to hit - but it
+// puts the glass first and the sky last in one launch of a few microseconds, on the device; round 1 did this on the host
+// (14 ms of wall time for dragons at 4K).  Writes what rtc_chunk_cost_kernel + rtc_chunk_time_kernel would have left.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_estimate_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, uint32_t* __restrict__ chunk_cost,
+                    uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state) {
+  if (blockIdx.x == 0u) {
+    uint32_t* z = reinterpret_cast<uint32_t*>(state);
+    for (uint32_t i = threadIdx.x; i < sizeof(DevPackState) / sizeof(uint32_t); i += blockDim.x) z[i] = 0u;
+  }
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= map.n_chunks) return;
+  const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
+  const uint32_t ccy = cr / map.chunks_x;
+  uint32_t px0 = (cr - ccy * map.chunks_x) * 8u, py0 = ccy * 8u;
+  if (map.mode == 0u) {
+    px0 += map.x0;
+    py0 += map.y0;
+  } else {
+    const uint32_t tile = map.mode == 1u ? map.first_tile + region * map.tile_stride : map.tile_list[region];
+    const uint32_t ty = tile / map.tiles_x;
+    px0 += (tile - ty * map.tiles_x) * map.tile_w;
+    py0 += ty * map.tile_h;
+  }
+  // Camera.rayForPixel (camera.zig:64-76) through the middle of the chunk, in FP32
+  const float ps = static_cast<float>(cam.pixel_size);
+  const float wx = static_cast<float>(cam.half_width) - (static_cast<float>(px0) + 4.0f) * ps;
+  const float wy = static_cast<float>(cam.half_height) - (static_cast<float>(py0) + 4.0f) * ps;
+  float m[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) m[i] = static_cast<float>(cam.inv[i]);
+  const float ox = m[3], oy = m[7], oz = m[11];
+  float dx = m[0] * wx + m[1] * wy - m[2], dy = m[4] * wx + m[5] * wy - m[6], dz = m[8] * wx + m[9] * wy - m[10];
+  const float len = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
+  const float inv_len = len > 0.0f ? 1.0f / len : 0.0f;
+  dx *= inv_len;
+  dy *= inv_len;
+  dz *= inv_len;
+  // half the chunk's diagonal seen from the camera: the pixel vector has length >= 1 in camera space (z = -1); the view
+  // transform may scale, which `len` carries
+  const float tan_a = 5.7f * ps * (len > 0.0f ? __builtin_sqrtf(m[0] * m[0] + m[4] * m[4] + m[8] * m[8]) * inv_len : 0.0f) + 1e-6f;
+  float cost = 400.0f;  // a chunk of sky: ray generation and one trace that finds nothing
+  for (uint32_t i = 0; i < S.n_roots; ++i) {
+    const RootCullPair P = S.root_cull[i >> 1];
+    const float cx = P.cx[i & 1u], cy = P.cy[i & 1u], cz = P.cz[i & 1u], r2 = P.r2[i & 1u];
+    bool seen = true;  // no finite bound (a plane): every pixel may see it
+    if (r2 < 3.0e38f) {
+      const float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
+      const float t = ocx * dx + ocy * dy + ocz * dz;
+      const float r = __builtin_sqrtf(r2);
+      const float perp2 = (ocx * ocx + ocy * ocy + ocz * ocz) - t * t;
+      const float reach = r + fmaxf(t, 0.0f) * tan_a;
+      seen = (t + r > 0.0f) & (perp2 <= reach * reach);
+    }
+    cost += seen ? S.root_weight[i] : 0.0f;
+  }
+  chunk_cost[c] = static_cast<uint32_t>(fminf(cost, 4.0e9f));
+  chunk_time[c] = 0u;  // nothing was timed: the packer takes the cost (cost_to_time = 1)
+}
+
 // One wave per 8x8 chunk: coalesced rows of the cost array.
 extern "C" __global__ void __launch_bounds__(256)
 rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, uint32_t* __restrict__ chunk_cost,
@@ -2323,7 +2387,9 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
   if (blockIdx.x == 0u && tid == 0u) {
     info->n_units = L.n_packets;
     info->heaviest = state->heaviest;
-    info->needs_split = static_cast<double>(state->heaviest) > static_cast<double>(state->total) / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
+    // (the host's re-pack costs it 10-30 ms once, per-pixel work: only where a chunk is well above a wave's share - a rank's
+    // share of a split frame, a small image - not where the heaviest chunk of a full frame is about one share)
+    info->needs_split = static_cast<double>(state->heaviest) > 1.5 * static_cast<double>(state->total) / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
     info->pad_ = 0u;
     info->total = state->total;
   }

@@ -1,5 +1,7 @@
-// rtc_schedule.h — the order in which the persistent waves are handed pixels ("Schedule"):
-// the geometric first-frame heuristic and the packing from measured per-pixel ray counts.  Never affects results.
+// rtc_schedule.h — the host's part of the order in which the persistent waves are handed pixels (DESIGN.md section 3,
+// "Schedule"): the schedule buffers, and the packing with chunks cut into runs of pixels (packSchedule), for launches
+// where some chunk takes much longer than a wave's fair share.  Everything else - the first frame's estimate, the packing
+// of whole chunks from measured times - runs on the device (rtc_kernels.hip).  Never affects results.
 #pragma once
 #include "rtc_host_internal.h"
 #include "rtc_bounds.h"
@@ -21,7 +23,6 @@ int ensureScheduleBuffers(rtc_scene* s, size_t words) {
   }
   s->sched_capacity = 0;
   s->sched_valid = false;
-  s->order_key.clear();
   for (int b = 0; b < 2; ++b) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched[b]), words * sizeof(uint32_t)));
   if (!s->d_sched_info) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched_info), 2 * sizeof(DevSchedInfo)));
   if (!s->d_pack_state) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pack_state), sizeof(DevPackState)));
@@ -367,123 +368,6 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
   if (getenv("RTC_PROFILE_DUMP"))
     std::fprintf(stderr, "rtc schedule: %zu packets (%zu parts of %zu split chunks, %zu filler chunks), cap %.0f, total %.0f\n",
                  packets.size(), split_parts.size(), static_cast<size_t>(n_chunks) - whole.size(), whole.size() - light_end, cap, total);
-}
-
-// Heavy-first chunk order (DevPixelMap::order): chunks whose pixels may look straight at an object with a
-// branching material come first.  A heuristic on the host, cached per (camera, map); never affects results.
-int chunkOrder(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, hipStream_t stream) {
-  map.order = nullptr;
-  map.n_units_dev = nullptr;
-  map.n_units = map.n_chunks;
-  if (map.n_chunks >= RTC_ITEM_MAX_CHUNKS) return RTC_OK;  // chunk index must fit the item encoding
-  if (map.n_chunks < 64) return RTC_OK;
-  const bool rank_heavy = !s->branching.empty() && !s->branching_everywhere;
-  const bool rank_trivial = !s->occupied.empty() && !s->unbounded_nonplane;
-  if (!rank_heavy && !rank_trivial) return RTC_OK;
-  std::vector<double> key{static_cast<double>(cam.hsize), static_cast<double>(cam.vsize), cam.half_width, cam.half_height,
-                          cam.pixel_size};
-  key.insert(key.end(), cam.inv_view, cam.inv_view + 16);
-  const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
-  for (size_t i = 0; i < offsetof(DevPixelMap, n_units) / sizeof(uint32_t); ++i) key.push_back(mp[i]);
-  if (key == s->order_key && s->sched_capacity != 0 && !s->sched_on_device) {  // (the buffer in use still holds it)
-    map.order = s->d_sched[s->sched_cur];
-    map.n_units = s->sched_n_units;
-    return RTC_OK;
-  }
-  // forward view matrix (world -> camera)
-  double V[12];
-  if (!forwardOf(cam.inv_view, V)) return RTC_OK;
-  struct Box { double x0, x1, y0, y1; };  // pixel-space boxes of projected bounding spheres
-  // false: the sphere cannot be projected (camera inside / next to it): give up on that ranking
-  auto project = [&](const std::vector<Sphere>& spheres, std::vector<Box>& boxes) {
-    for (const Sphere& sp : spheres) {
-      const double X = V[0] * sp.cx + V[1] * sp.cy + V[2] * sp.cz + V[3];
-      const double Y = V[4] * sp.cx + V[5] * sp.cy + V[6] * sp.cz + V[7];
-      const double Z = V[8] * sp.cx + V[9] * sp.cy + V[10] * sp.cz + V[11];
-      const double depth = -Z;  // the camera looks down -z (camera.zig:70)
-      if (depth <= sp.r * 1.05) {
-        if (depth > -sp.r) return false;
-        continue;  // entirely behind the camera
-      }
-      // silhouette of the sphere on the image plane z = -1: per axis the interval tan(theta -+ alpha)
-      auto extent = [&](double c, double& lo, double& hi) {
-        const double theta = std::atan2(c, depth);
-        const double alpha = std::asin(std::fmin(1.0, sp.r / std::sqrt(c * c + depth * depth)));
-        if (theta + alpha >= 1.5 || theta - alpha <= -1.5) return false;
-        lo = std::tan(theta - alpha);
-        hi = std::tan(theta + alpha);
-        return true;
-      };
-      double wx0, wx1, wy0, wy1;
-      if (!extent(X, wx0, wx1) || !extent(Y, wy0, wy1)) return false;
-      // world_x = half_width - (x + 0.5) * pixel_size  (camera.zig:65-69)
-      boxes.push_back({(cam.half_width - wx1) / cam.pixel_size - 1.5, (cam.half_width - wx0) / cam.pixel_size + 0.5,
-                       (cam.half_height - wy1) / cam.pixel_size - 1.5, (cam.half_height - wy0) / cam.pixel_size + 0.5});
-    }
-    return true;
-  };
-  std::vector<Box> heavy_boxes, any_boxes;
-  const bool have_heavy = rank_heavy && project(s->branching, heavy_boxes) && !heavy_boxes.empty();
-  const bool have_any = rank_trivial && project(s->occupied, any_boxes);
-  if (!have_heavy && !have_any) return RTC_OK;
-  // Longest-job-first: [chunks looking at a branching material][chunks looking at any bounded object]
-  // [chunks that can only see unbounded planes or nothing: one or two rays per pixel].  The launch ends
-  // when the LAST unit handed out is finished, so the cheapest work goes last.
-  std::vector<uint32_t> order;
-  order.reserve(map.n_chunks);
-  std::vector<uint32_t> medium, trivial;
-  for (uint32_t c = 0; c < map.n_chunks; ++c) {
-    const uint32_t region = c / map.chunks_per_region, cr = c - region * map.chunks_per_region;
-    const uint32_t ccy = cr / map.chunks_x;
-    double px0 = (cr - ccy * map.chunks_x) * 8.0, py0 = ccy * 8.0;
-    if (map.mode == 0u) {
-      px0 += map.x0;
-      py0 += map.y0;
-    } else {
-      const uint32_t tile = map.mode == 1u ? map.first_tile + region * map.tile_stride : s->h_tile_list[region];
-      const uint32_t ty = tile / map.tiles_x;
-      px0 += static_cast<double>(tile - ty * map.tiles_x) * map.tile_w;
-      py0 += static_cast<double>(ty) * map.tile_h;
-    }
-    auto overlaps = [&](const std::vector<Box>& boxes) {
-      for (const Box& b : boxes)
-        if (px0 + 8.0 >= b.x0 && px0 <= b.x1 && py0 + 8.0 >= b.y0 && py0 <= b.y1) return true;
-      return false;
-    };
-    if (have_heavy && overlaps(heavy_boxes)) {
-      order.push_back(c);
-    } else if (!have_any || overlaps(any_boxes)) {
-      medium.push_back(c);
-    } else {
-      trivial.push_back(c);
-    }
-  }
-  if (order.size() + trivial.size() == 0 || order.size() == map.n_chunks || medium.size() == map.n_chunks) return RTC_OK;
-  if (getenv("RTC_PROFILE_DUMP"))
-    std::fprintf(stderr, "rtc schedule: %zu heavy, %zu medium, %zu trivial chunks\n", order.size(), medium.size(), trivial.size());
-  // Packets: a chunk that may branch the ray tree travels alone, the others several to a packet (neighbours in
-  // image order): a one-chunk packet of a few microseconds costs a pull of the work counter and a drain of the wave.
-  s->h_order.assign(static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS, RTC_NO_ITEM);
-  uint32_t n_packets = 0;
-  auto emit = [&](const std::vector<uint32_t>& chunks, uint32_t per_packet) {
-    for (size_t i = 0; i < chunks.size(); i += per_packet, ++n_packets)
-      for (uint32_t n = 0; n < per_packet && i + n < chunks.size(); ++n)
-        s->h_order[static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS + n] = scheduleItem(chunks[i + n], 0, 64);
-  };
-  static const uint32_t per_medium = getenv("RTC_FIRST_MEDIUM") ? std::max(1, std::min(16, atoi(getenv("RTC_FIRST_MEDIUM")))) : 1u;
-  static const uint32_t per_trivial = getenv("RTC_FIRST_TRIVIAL") ? std::max(1, std::min(16, atoi(getenv("RTC_FIRST_TRIVIAL")))) : 16u;
-  emit(order, 1);
-  emit(medium, per_medium);
-  // (chunks that see only planes are cheap only if no plane spawns rays: reflection_and_refraction's mirror floor made
-  // sixteen-chunk packets of 16 ms at the very end of its first frame)
-  emit(trivial, s->plane_spawns_rays ? 1u : per_trivial);
-  s->h_order.resize(static_cast<size_t>(n_packets) * RTC_PACKET_ITEMS);
-  const int st = uploadSchedule(s, map, stream);
-  if (st != RTC_OK) return st;
-  s->order_key = key;
-  map.order = s->d_sched[s->sched_cur];
-  map.n_units = n_packets;
-  return RTC_OK;
 }
 
 }  // namespace

@@ -306,12 +306,12 @@ def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth):
         _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
 
 
-def test_probe_launch_at_small_sizes(rtc, monkeypatch):
-    """Frames of 8192 chunks and more start with a probe launch (one pixel per chunk, its ray count orders the chunks of
-    the first frame).  Here the threshold is lowered so that every kernel variant and the tile mode run it at sizes the
-    oracle renders whole; the probe's pixels are rendered twice (probe, frame) and must not be counted twice."""
+def test_first_launches_write_every_pixel(rtc):
+    """The first frame of a pixel map runs a schedule packed from rtc_estimate_kernel's guesses (which roots a chunk's
+    pixels can see), the second one packed from the first's measurements.  Whatever the guesses, every pixel is handed
+    out exactly once: render over NaNs with every kind of kernel and in tile mode (edge tiles stick out of the image),
+    and count the primary rays."""
     torch = pytest.importorskip("torch")
-    monkeypatch.setenv("RTC_PROBE_MIN_CHUNKS", "64")
     for scene, w, h, depth in (("cover.json", 192, 108, 5), ("teapot.json", 96, 54, 5), ("csg_demo.json", 96, 54, 5),
                                ("reflection_and_refraction.json", 150, 97, 8)):
         hs = rtc.HostScene.from_file(scene)
@@ -327,7 +327,7 @@ def test_probe_launch_at_small_sizes(rtc, monkeypatch):
             assert np.isfinite(got).all(), (scene, launch)
             assert np.abs(got - want).max() < TOL, (scene, launch)
             assert [st["primary"], st["secondary"], st["shadow_calls"], st["overflow"]] == [counters["primary"], counters["secondary"], counters["shadow"], 0]
-    # tile mode (one rank's share of a frame): edge tiles stick out of the image, probe pixels outside it are skipped
+    # tile mode (one rank's share of a frame): edge tiles stick out of the image
     hs = rtc.HostScene.from_file("fresnel.json")
     cam = hs.camera(200, 140)
     full = rtc.GpuScene(hs.desc).render(cam, 5)
