@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <fstream>
 #include <sstream>
+#include <vector>
 #include "rtc.h"
 #include "rtc_host.h"
 int main(int argc, char** argv) {
@@ -18,5 +19,17 @@ int main(int argc, char** argv) {
     if (st != RTC_ERR_NO_DEVICE) ++bad;
     rtch_scene_free(h);
   }
+  // rtc_assign_tiles (host only): skewed costs, every world size; every tile once, no rank above its buffer
+  for (unsigned world = 1; world <= 9; ++world)
+    for (unsigned n : {1u, 5u, 64u, 510u}) {
+      std::vector<double> cost(n);
+      for (unsigned t = 0; t < n; ++t) cost[t] = (t * 2654435761u % 97u) + (t % 13u == 0 ? 4000.0 : 1.0);
+      std::vector<unsigned> rank_of(n), slot_of(n), seen((n + world - 1) / world * world, 0);
+      if (rtc_assign_tiles(cost.data(), n, world, rank_of.data(), slot_of.data()) != 0) ++bad;
+      for (unsigned t = 0; t < n; ++t) {
+        if (rank_of[t] >= world || slot_of[t] >= seen.size() || seen[slot_of[t]]++) ++bad;
+      }
+    }
+  std::printf("rtc_assign_tiles: %s\n", bad ? "FAIL" : "ok");
   return bad;
 }
