@@ -135,20 +135,6 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
     return out
 
 
-def kernel_name(hs):
-    """Which variant of the render kernel rtc_capi.hip's launch() picks for this scene (rocprof shows the same name)."""
-    d = hs.desc
-    kinds = hs.array("leaf_kind", d.n_leaves)
-    pats = hs.array("pat_kind", d.n_patterns)
-    ops = hs.array("node_op", d.n_nodes)
-    ext = bool((pats == 8).any()) or bool(len(ops) and (ops != 0).any())
-    small = d.n_roots <= 128 and d.n_materials <= 64 and d.n_patterns <= 48 and d.n_lights <= 16
-    flat = small and d.n_nodes == 0
-    simple = flat and bool((kinds <= 2).all())
-    name = "rtc_render_kernel" + ("_simple" if simple else "_flat" if flat else "" if small else "_bigworld")
-    return name + ("_ext" if ext else "")
-
-
 def algorithmic_flops(desc, hs, stats):
     """SURVEY §8(d) flop table, reference arithmetic: per ray, per leaf: 56 (ray->object) + test."""
     import numpy as np
@@ -439,7 +425,7 @@ def main():
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.scene, W, H, args.depth),
                 "traffic_source": "committed profile (profiles/traffic.json), not measured in this run",
-                "kernel": kernel_name(hs), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
+                "kernel": gpu.last_kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
                 "note": "HBM is NOT what binds this kernel: the compulsory traffic is the canvas (24*W*H B) plus "
                         "a few KB of scene tables that live in LDS; the binding limit is per-wave FP64 issue "
@@ -479,7 +465,7 @@ def main():
             gbs = ab / (kernel_ms * 1e-3) / 1e9
             result["roofline"] = {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "kernel": kernel_name(hs), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
+                "traffic": None, "kernel": gpu.last_kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "note": "rank 0's kernel over rank 0's tiles (1/%d of the frame); see the 1-GPU line for the counters "
                         "and DESIGN.md section 8 for what bounds the split of a 1 ms frame" % world,
             }

@@ -333,6 +333,11 @@ int rtc_scene_synchronize(rtc_scene *scene);
 /* Counters of the last render that was enqueued on this handle (synchronises). */
 int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
 
+/* Diagnostic: the name of the render kernel the last launch on this handle ran
+ * (the name rocprofv3 shows - which variant is picked depends on what the world
+ * contains and on the size of the launch); "" before the first launch.  Static storage. */
+const char *rtc_last_kernel_name(const rtc_scene *scene);
+
 /* Thread-local, static storage; "" when the last call on this thread succeeded. */
 const char *rtc_last_error(void);
 /* "NotInvertible", "OutOfMemory", ... (Zig error-name style, cf. lib.zig:226-227). */

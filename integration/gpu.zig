@@ -85,6 +85,7 @@ pub extern fn rtc_render_device(scene: *RtcScene, cam: *const RtcCamera, max_dep
                                 d_rgb_out: [*]f64, hip_stream: ?*anyopaque) c_int; // output stays in HBM
 pub extern fn rtc_scene_synchronize(scene: *RtcScene) c_int;
 pub extern fn rtc_get_stats(scene: *RtcScene, out: *RtcStats) c_int;
+pub extern fn rtc_last_kernel_name(scene: *const RtcScene) [*:0]const u8;
 pub extern fn rtc_last_error() [*:0]const u8;
 pub extern fn rtc_status_name(status: c_int) [*:0]const u8;
 

@@ -90,7 +90,7 @@ class Stats(C.Structure):
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
-               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error",
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_last_error",
                "rtc_status_name"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
@@ -154,6 +154,8 @@ def hip_lib():
         lib.rtc_assemble_tile_list_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_scene_synchronize.argtypes = [C.c_void_p]
         lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        lib.rtc_last_kernel_name.argtypes = [C.c_void_p]
+        lib.rtc_last_kernel_name.restype = C.c_char_p
         _hip = lib
     return _hip
 
@@ -373,6 +375,10 @@ class GpuScene:
         st = Stats()
         _check_hip(hip_lib().rtc_get_stats(self._s, C.byref(st)))
         return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def last_kernel_name(self):
+        """The render kernel the last launch on this handle ran (the name rocprofv3 shows)."""
+        return hip_lib().rtc_last_kernel_name(self._s).decode()
 
     def close(self):
         if self._s:

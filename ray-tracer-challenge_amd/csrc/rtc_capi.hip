@@ -25,6 +25,8 @@ extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const De
 extern "C" __global__ void rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                     const uint32_t max_depth, double* __restrict__ out,
                                                     DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_simple3(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                     uint32_t max_depth, double* out, DevStats* stats, DevStats* next_stats);
 extern "C" __global__ void rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                         const uint32_t max_depth, double* __restrict__ out,
                                                         DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
@@ -161,17 +163,43 @@ DevCamera devCamera(const rtc_camera& c) {
 }
 
 // The render kernel of a scene whose tables fit in LDS.
-auto ldsKernel(const rtc_scene* s) -> decltype(&rtc_render_kernel) {
-  if (s->simple_kernel) return s->ext_kernel ? rtc_render_kernel_simple_ext : rtc_render_kernel_simple;
-  if (s->flat_kernel) return s->ext_kernel ? rtc_render_kernel_flat_ext : rtc_render_kernel_flat;
-  return s->ext_kernel ? rtc_render_kernel_ext : rtc_render_kernel;
+// The three-waves-per-SIMD form of the simple kernel pays when every wave has several packets to run (see the kernel):
+// from about five chunks per resident wave on.
+bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
+  const char* const env = getenv("RTC_SIMPLE3_MIN_CHUNKS");  // test / experiment knob, read per launch: 0 = always
+  const long forced = env != nullptr ? atol(env) : -1;
+  const uint64_t min_chunks = forced >= 0 ? static_cast<uint64_t>(forced) : 5ull * 4u * s->n_cus * s->blocks_per_cu_simple3;
+  return s->simple3_ok && map.n_chunks >= min_chunks;
 }
 
-double residentWaves(const rtc_scene* s) {
-  const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
-                   s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
-  return 4.0 * s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+bool tablesInLds(const rtc_scene* s) {
+  return s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
+         s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
 }
+
+struct KernelChoice {
+  decltype(&rtc_render_kernel) fn;
+  const char* name;
+};
+#define RTC_KERNEL(k) KernelChoice{k, #k}
+KernelChoice ldsKernel(const rtc_scene* s, const DevPixelMap& map) {
+  if (usesSimple3(s, map)) return RTC_KERNEL(rtc_render_kernel_simple3);
+  if (s->simple_kernel) return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_simple_ext) : RTC_KERNEL(rtc_render_kernel_simple);
+  if (s->flat_kernel) return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_flat_ext) : RTC_KERNEL(rtc_render_kernel_flat);
+  return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_ext) : RTC_KERNEL(rtc_render_kernel);
+}
+KernelChoice renderKernel(const rtc_scene* s, const DevPixelMap& map) {
+  if (tablesInLds(s)) return ldsKernel(s, map);
+  return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_bigworld_ext) : RTC_KERNEL(rtc_render_kernel_bigworld);
+}
+#undef RTC_KERNEL
+
+// Work-groups of the launch's kernel that are resident at once, and the waves in them.
+uint32_t residentBlocks(const rtc_scene* s, const DevPixelMap& map) {
+  if (usesSimple3(s, map)) return s->n_cus * s->blocks_per_cu_simple3;
+  return s->n_cus * (tablesInLds(s) ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+}
+double residentWaves(const rtc_scene* s, const DevPixelMap& map) { return 4.0 * residentBlocks(s, map); }
 
 // The measured schedule in use, into a launch's pixel map.
 void useSchedule(const rtc_scene* s, DevPixelMap& map) {
@@ -255,12 +283,18 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     if (ready == hipSuccess) {
       s->readback_enqueued = false;
       // (a later measuring launch has overwritten the per-pixel costs: that read-back describes a frame that is gone)
-      if (s->pin_info->needs_split && s->readback_gen == s->measure_gen) {
+      // (the host's re-pack costs 10-30 ms once, per-pixel work: only where a chunk is well above a wave's share - a rank's
+      // share of a split frame, a small image - not where the heaviest chunk of a full frame is about one share.  The
+      // three-wave kernel has half again as many waves and smaller shares: there the cut pays from one share on -
+      // reflection_and_refraction depth 8 at 1080p 2.12 -> 1.91 ms, cover 0.676 -> 0.670)
+      const double factor = usesSimple3(s, map) ? 1.0 : 1.5;
+      const bool split = static_cast<double>(s->pin_info->heaviest) > factor * static_cast<double>(s->pin_info->total) / residentWaves(s, map);
+      if (split && s->readback_gen == s->measure_gen) {
         const std::vector<uint32_t> h_chunk_cost(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
         const std::vector<uint32_t> h_chunk_time(s->pin_chunk_time, s->pin_chunk_time + map.n_chunks);
         s->h_cost.resize(out_pixels);
         HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        packSchedule(s, map, s->h_cost, h_chunk_cost, h_chunk_time, residentWaves(s), s->readback_depth);
+        packSchedule(s, map, s->h_cost, h_chunk_cost, h_chunk_time, residentWaves(s, map), s->readback_depth);
         if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
         s->sched_valid = true;
         s->sched_cam = s->readback_cam;
@@ -296,7 +330,7 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
                      PackFrom from) {
   const bool unmeasured = from != PackFrom::Measurement;  // (no frame has been measured: nothing to read back)
   const uint32_t n = map.n_chunks, target = s->sched_cur ^ 1u;
-  const float n_waves = static_cast<float>(residentWaves(s)), t_min = static_cast<float>(groupFloor(s));
+  const float n_waves = static_cast<float>(residentWaves(s, map)), t_min = static_cast<float>(groupFloor(s));
   // (what an untimed chunk's cost is worth in ticks: the estimate is in ticks already; a measured frame times every
   // packet, so this only covers chunks whose share of a packet's time rounded to zero)
   const float cost_to_time = from == PackFrom::Estimate ? 1.0f : (s->flat_kernel ? 10.0f : 20.0f);
@@ -393,11 +427,9 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
 
 // One launch of the render kernel for `map` (schedule and measurement buffers already chosen).
 int enqueueRender(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, double* d_out, hipStream_t stream) {
-  const bool lds = s->dev.n_roots <= RTC_LDS_ROOTS && s->dev.n_materials <= RTC_LDS_MATERIALS &&
-                   s->dev.n_patterns <= RTC_LDS_PATTERNS && s->dev.n_lights <= RTC_LDS_LIGHTS;
   // Persistent launch: as many work-groups as the chip can hold at once (never more than there are
   // packets to hand out, 4 waves each); the waves pull packets until the counter runs out.
-  const uint32_t resident = s->n_cus * (lds ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+  const uint32_t resident = residentBlocks(s, map);
   const uint32_t blocks = std::max(1u, std::min(resident, (map.n_units + 3u) / 4u));
   if (const int st = ensureScratch(s, map, blocks, max_depth); st != RTC_OK) return st;
   if (map.packet_time != nullptr)
@@ -411,8 +443,9 @@ int enqueueRender(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_
 #endif
   // No clear of the canvas: every pixel of the rectangle is either stored once or zeroed by the lane that first
   // hands part of its ray tree to a neighbour (render_body step 2a).
-  auto* const kernel = lds ? ldsKernel(s) : (s->ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
+  const KernelChoice kernel = renderKernel(s, map);
+  s->last_kernel = kernel.name;
+  hipLaunchKernelGGL(kernel.fn, dim3(blocks), dim3(256), 0, stream, s->dev, devCamera(cam), map, max_depth, d_out, st_now,
                      st_next);
   HIP_TRY(hipGetLastError());
   return RTC_OK;
@@ -1296,6 +1329,8 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     if (d.roots[i] & RTC_CHILD_NODE_BIT) s->flat_kernel = s->simple_kernel = false;
     else if (d.leaf_kind[d.roots[i]] > RTC_CUBE) s->simple_kernel = false;
   }
+  s->simple3_ok = s->simple_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
+                  d.n_patterns <= RTC_LDS3_PATTERNS;
   HIP_TRY(s->light.upload(light));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
   // Zeroed ON THE HANDLE'S STREAM, followed by the event every launch on another stream waits for (launch()): the
@@ -1311,9 +1346,12 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     HIP_TRY(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
     int nb = 0;
+    DevPixelMap no_map{};  // (n_chunks 0: the kernel of a small launch)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &nb, ldsKernel(s), 256, 0));
+        &nb, ldsKernel(s, no_map).fn, 256, 0));
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel_simple3, 256, 0));
+    s->blocks_per_cu_simple3 = static_cast<uint32_t>(std::max(nb, 1));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));
     s->blocks_per_cu_big = static_cast<uint32_t>(std::max(nb, 1));
@@ -1683,6 +1721,8 @@ int rtc_scene_synchronize(rtc_scene* s) {
   HIP_TRY(hipStreamSynchronize(s->stream));
   return RTC_OK;
 }
+
+const char* rtc_last_kernel_name(const rtc_scene* s) { return s != nullptr ? s->last_kernel : ""; }
 
 int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   g_error.clear();

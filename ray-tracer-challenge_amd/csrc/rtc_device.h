@@ -76,6 +76,12 @@ struct RootRec {
 #define RTC_LDS_ROOTS 128
 #define RTC_LDS_MATERIALS 64
 #define RTC_LDS_PATTERNS 48
+// (the three-waves-per-SIMD variant of the simple kernel: 49.8 KB per work-group)
+#ifndef RTC_LDS3_ROOTS
+#define RTC_LDS3_ROOTS 96
+#define RTC_LDS3_MATERIALS 48
+#define RTC_LDS3_PATTERNS 32
+#endif
 #define RTC_LDS_LIGHTS 16
 
 struct DevPattern {      // 144 B

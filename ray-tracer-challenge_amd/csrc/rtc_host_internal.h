@@ -93,10 +93,12 @@ struct rtc_scene {
   bool ext_kernel = false;         // csg nodes or texture maps: the *_ext kernels
   bool simple_kernel = false;      // only top-level spheres / planes / cubes: the `simple` kernel
   bool flat_kernel = false;        // no groups at all (any leaf kind): the `flat` kernel
+  const char* last_kernel = "";   // name of the render kernel of the last launch (rtc_last_kernel_name)
+  bool simple3_ok = false;         // a simple world whose tables fit the three-waves-per-SIMD kernel's LDS (RTC_LDS3_*)
   void* d_csg_buf = nullptr;       // DevPixelMap::csg_buf, only for scenes with csg nodes
   size_t csg_buf_capacity = 0;     // bytes
   uint32_t max_trav_stack = 0;
-  uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1;
+  uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1, blocks_per_cu_simple3 = 1;
   // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next
   // launch runs; a measuring launch is followed by rtc_pack_kernel, which packs the other buffer from what the launch
   // measured, and the buffers swap - no host in the loop.  The host only writes a buffer for the first launch of a pixel

@@ -1333,7 +1333,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // reflection / refraction children (one continues in registers, the other goes to the lane's stack).
 // Exit: the counter runs past n_chunks (`drained`) and no lane holds a ray; every wave reaches it.
 // ------------------------------------------------------------------------------------------
-template <bool LDS, bool CSG, int WORLD = 0>
+template <bool LDS, bool CSG, int WORLD = 0, int WAVES = 2>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
@@ -1348,10 +1348,14 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // Small-world tables (World.objects records + bounding spheres, materials, patterns, lights):
   // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
   // chases pointers through memory.  Larger worlds run the same code on the tables in memory.
-  __shared__ RootRec lds_recs[LDS ? RTC_LDS_ROOTS : 1];
-  __shared__ RootCullPair lds_cull[LDS ? RTC_LDS_ROOTS / 2 : 1];
-  __shared__ DevMaterial lds_mat[LDS ? RTC_LDS_MATERIALS : 1];
-  __shared__ DevPattern lds_pat[LDS ? RTC_LDS_PATTERNS : 1];
+  // (WAVES: what the launch bounds leave room for per SIMD; a three-wave kernel has 53 KB of LDS per work-group and
+  // smaller tables, RTC_LDS3_*)
+  constexpr int N_ROOTS = WAVES == 3 ? RTC_LDS3_ROOTS : RTC_LDS_ROOTS, N_MATS = WAVES == 3 ? RTC_LDS3_MATERIALS : RTC_LDS_MATERIALS,
+                N_PATS = WAVES == 3 ? RTC_LDS3_PATTERNS : RTC_LDS_PATTERNS;
+  __shared__ RootRec lds_recs[LDS ? N_ROOTS : 1];
+  __shared__ RootCullPair lds_cull[LDS ? N_ROOTS / 2 : 1];
+  __shared__ DevMaterial lds_mat[LDS ? N_MATS : 1];
+  __shared__ DevPattern lds_pat[LDS ? N_PATS : 1];
   __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
   // per wave: which pending ray (donor lane, level of its stack) an idle lane takes over, and the canvas pixel it belongs to
   __shared__ uint4 lds_mail[4][64];
@@ -1360,7 +1364,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // again after almost every pixel, so nearly every push and pop stays here: the pops no longer wait for memory and the
   // 2048 resident waves no longer cycle 59 MB of stack lines through the L2s (142 MB written per cover frame).
   constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
-  constexpr int LDS_LEVELS = FLAT ? 2 : (LDS ? 1 : 2);  // (what fits beside the tables at two work-groups per CU)
+  constexpr int LDS_LEVELS = WAVES == 3 ? 1 : (FLAT ? 2 : (LDS ? 1 : 2));  // (what fits beside the tables at WAVES work-groups per CU)
   __shared__ Quad2 lds_pend[4][LDS_LEVELS][4][64];
   // The colour a lane has accumulated for its pixel: touched once per iteration and when the pixel is finished, live
   // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
@@ -2047,6 +2051,18 @@ rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMa
   render_body<true, false, 2>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
+// The `simple` kernel at THREE waves per SIMD (168 VGPRs; about a hundred values go to scratch memory, nearly all of them
+// outside the loops that matter).  The vector pipes of a SIMD issue in 62 % of a cover frame's cycles at two waves
+// (DESIGN.md section 5): the third wave fills part of the rest.  cover.json 1080p 0.696 -> 0.667 ms,
+// reflection_and_refraction depth 8 2.22 -> 2.02.  Only this kernel gains (every other variant spills three times as
+// much at 168 registers and loses), and only with several packets per wave: small images and one rank's share of a
+// split frame are bound by single waves' chains of dependent iterations and run the two-wave kernel (rtc_capi.hip).
+extern "C" __global__ void __launch_bounds__(256, 3)
+rtc_render_kernel_simple3(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                          double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, false, 2, 3>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
 // The same two kernels with the csg and texture-map paths compiled in (template flag CSG), for scenes that
 // have csg nodes or texture maps.  Kept apart because the out-of-line calls cost the main loop ~150 spilled
 // VGPRs at every trace site (1.07 -> 1.38 ms on cover.json when csg was part of the only kernel).
@@ -2387,9 +2403,8 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
   if (blockIdx.x == 0u && tid == 0u) {
     info->n_units = L.n_packets;
     info->heaviest = state->heaviest;
-    // (the host's re-pack costs it 10-30 ms once, per-pixel work: only where a chunk is well above a wave's share - a rank's
-    // share of a split frame, a small image - not where the heaviest chunk of a full frame is about one share)
-    info->needs_split = static_cast<double>(state->heaviest) > 1.5 * static_cast<double>(state->total) / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
+    // (whether the heaviest chunk is cut into runs is the host's call, from `heaviest` and `total`: updateSchedule)
+    info->needs_split = static_cast<double>(state->heaviest) > static_cast<double>(state->total) / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
     info->pad_ = 0u;
     info->total = state->total;
   }

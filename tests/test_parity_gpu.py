@@ -241,6 +241,7 @@ def test_full_size_cover_properties(rtc):
     gpu = rtc.GpuScene(hs.desc)
     full = gpu.render(cam, 5)
     st = gpu.stats()
+    assert gpu.last_kernel_name() == "rtc_render_kernel_simple3"   # (what bench.py times)
     assert st["primary"] == 1920 * 1080 and st["overflow"] == 0
     assert np.isfinite(full).all() and full.min() >= 0.0
     # idempotence
@@ -304,6 +305,54 @@ def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth):
     assert np.abs(want2 - want).max() > 1e-3
     for launch in range(4, 30):         # launch 16 re-measures, a later one re-packs (at the latest 8 launches on)
         _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
+
+
+SIMPLE3_CASES = [("cover.json", 640, 360, 5), ("fresnel.json", 150, 150, 5), ("reflection_and_refraction.json", 192, 108, 8),
+                 ("cubes.json", 200, 100, 5)]
+
+
+@pytest.mark.parametrize("scene,w,h,depth", SIMPLE3_CASES)
+def test_three_wave_simple_kernel_renders_the_same_image(rtc, scene, w, h, depth, monkeypatch):
+    """rtc_render_kernel_simple3 (168 VGPRs, three waves per SIMD) is what a large launch on a world of planes, spheres
+    and cubes runs - cover.json at 1080p, the bench - while the small launches of this suite run the two-wave kernel.
+    RTC_SIMPLE3_MIN_CHUNKS=0 (read per launch) makes every launch take it: the same launches as above, first frame on
+    the estimate, packed, steady state, moved camera, each against the oracle."""
+    monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "0")
+    hs = rtc.HostScene.from_file(scene)
+    gpu = rtc.GpuScene(hs.desc)
+    osc = ob.OracleScene(hs.desc)
+    cam = hs.camera(w, h)
+    want, counters = osc.render(cam, depth)
+    for launch in range(1, 4):
+        _check_launch(gpu, cam, depth, want, counters, (scene, "launch", launch))
+        assert gpu.last_kernel_name() == "rtc_render_kernel_simple3"
+    hs.rotate_camera(0.3)
+    cam2 = hs.camera(w, h)
+    want2, counters2 = osc.render(cam2, depth)
+    for launch in range(4, 12):
+        _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
+    monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "1000000000")   # ... and back on the same handle: the two-wave kernel
+    _check_launch(gpu, cam2, depth, want2, counters2, (scene, "two-wave kernel again"))
+    assert gpu.last_kernel_name() == "rtc_render_kernel_simple"
+
+
+def test_three_wave_simple_kernel_random_scenes(rtc, monkeypatch):
+    monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "0")
+    ran = 0
+    for seed in range(40):
+        hs = rtc.HostScene(_random_flat_scene(seed, simple=True, max_objects=5 + seed % 7))   # (few objects: nested patterns fill its 32-entry table)
+        cam = hs.camera()
+        gpu = rtc.GpuScene(hs.desc)
+        got = gpu.render(cam, 5)
+        fits = hs.desc.n_roots <= 96 and hs.desc.n_materials <= 48 and hs.desc.n_patterns <= 32   # RTC_LDS3_*
+        assert (gpu.last_kernel_name() == "rtc_render_kernel_simple3") == bool(fits), seed   # (larger worlds: other kernels)
+        ran += fits
+        want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+        st = gpu.stats()
+        assert np.abs(got - want).max() < TOL, seed
+        assert [st["secondary"], st["shadow_calls"], st["overflow"]] == [counters["secondary"], counters["shadow"], 0], seed
+        gpu.close()
+    assert ran >= 10
 
 
 def test_first_launches_write_every_pixel(rtc):
@@ -741,7 +790,7 @@ def test_random_scenes(rtc, seed):
     assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0
 
 
-def _random_flat_scene(seed, simple):
+def _random_flat_scene(seed, simple, max_objects=60):
     """Random world WITHOUT groups: many top-level leaves with random transforms, glass inside glass, every pattern kind.
     simple: spheres, planes and cubes only (rtc_render_kernel_simple); else every leaf kind (rtc_render_kernel_flat)."""
     import json
@@ -769,7 +818,7 @@ def _random_flat_scene(seed, simple):
             leaf = dict(leaf)
             leaf["transform"] = list(leaf.get("transform", [])) + [{"translate": [rnd.uniform(-3, 3), rnd.uniform(0, 2), rnd.uniform(-3, 3)]}]
             objs.append(leaf)
-    objs = objs[:60]
+    objs = objs[:max_objects]
     objs.append({"type": {"plane": {}}, "transform": [{"rotate-x": 1.5707963}, {"translate": [0, 0, 12]}],
                  "material": {"reflective": 0.3, "pattern": {"type": {"checkers": [{"type": {"solid": [0.1, 0.1, 0.1]}}, {"type": {"solid": [0.9, 0.9, 0.9]}}]}}}})
     base["objects"] = objs

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Spread of the steady-state frame time over scene handles (every handle measures its own first frame and packs its own
+schedule): python tools/handle_spread.py [scene] [handles]."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+name = sys.argv[1] if len(sys.argv) > 1 else "cover"
+handles = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+depth = 8 if name.startswith("reflection") else 5
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+hs = rtc.HostScene.from_file(name + ".json"); cam = hs.camera(1920, 1080)
+canvas = torch.empty((1080, 1920, 3), dtype=torch.float64, device="cuda")
+ts = []
+for _ in range(handles):
+    gpu = rtc.GpuScene(hs.desc)
+    for _ in range(12):
+        gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(12): gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
+    b.record(stream); torch.cuda.synchronize()
+    ts.append(a.elapsed_time(b) / 12)
+    gpu.close()
+ts.sort()
+print(name, " ".join(f"{t:.3f}" for t in ts), f"| mean {sum(ts) / len(ts):.3f}", flush=True)
