@@ -357,6 +357,11 @@ def main():
     # static view renders from that schedule.  Done here so that --warmup 0 still times steady-state frames.
     for i in range(2):
         step(i)
+        barrier()
+    # (where a chunk exceeds a wave's share the library cuts it into runs on a worker thread and switches when that is
+    # finished: wait for it - rtc_scene_synchronize - so that the launch below, not some timed frame, picks it up)
+    gpu.synchronize()
+    step(2)
     finish()
     barrier()
     for i in range(args.warmup):

@@ -324,6 +324,7 @@ class GpuScene:
 
     def __init__(self, desc):
         self._s = C.c_void_p()
+        self._last_out = None
         _check_hip(hip_lib().rtc_scene_create(C.byref(desc), C.byref(self._s)))
 
     def render(self, cam, max_depth=REFERENCE_DEPTH, tile=None):
@@ -331,11 +332,16 @@ class GpuScene:
         x0, y0, w, h = tile if tile else (0, 0, cam.hsize, cam.vsize)
         out = np.empty((h, w, 3), dtype=np.float64)
         _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, x0, y0, w, h, out.ctypes.data))
+        # rtc_render registers a canvas it is handed twice, and that canvas must then outlive the registration (rtc.h):
+        # the handle keeps the last array it returned alive, so a fresh np.empty can never sit at the address of a
+        # freed one that the library still holds.
+        self._last_out = out
         return out
 
     def render_into(self, cam, out, max_depth=REFERENCE_DEPTH):
         """Camera.render into a caller-owned [h][w][3] f64 array (an interactive host reuses its canvas)."""
         assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.shape == (cam.vsize, cam.hsize, 3)
+        self._last_out = out
         _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, 0, 0, cam.hsize, cam.vsize, out.ctypes.data))
         return out
 
@@ -384,6 +390,7 @@ class GpuScene:
         if self._s:
             hip_lib().rtc_scene_destroy(self._s)
             self._s = C.c_void_p()
+        self._last_out = None
 
     def __del__(self):
         try:

@@ -235,6 +235,76 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
   return RTC_OK;
 }
 
+// ---- cutting chunks into runs, off the caller's thread.  packSchedule is per-pixel work on the host (10-30 ms for a
+// 1080p frame).  The launch that learns from the read-back that a chunk is too heavy enqueues a copy of the per-pixel
+// costs to pinned memory on a stream of its own (it overlaps the frames that follow); the launch that finds the copy
+// complete hands it to a worker thread (pure CPU work, no HIP calls: a worker that copied the costs itself held the
+// runtime's locks and delayed the caller's next launch by half a millisecond); the launch that finds the worker finished
+// uploads the result and switches.  Until then the frames run the device-packed schedule.  d_cost is only written by a
+// MEASURING launch, which makes the copy stale (its generation no longer matches: it is dropped).  Freeing d_cost, a new
+// pixel map and rtc_scene_destroy wait for copy and worker.
+void waitSplitJob(rtc_scene* s) {
+  if (s->split_job && s->split_job->worker.joinable()) s->split_job->worker.join();
+}
+
+void dropSplitJob(rtc_scene* s) {
+  if (s->cost_copy_pending) (void)hipEventSynchronize(s->cost_copied);
+  s->cost_copy_pending = false;
+  waitSplitJob(s);
+  s->split_job.reset();
+}
+
+int enqueueCostCopy(rtc_scene* s, size_t out_pixels) {
+  dropSplitJob(s);
+  if (out_pixels > s->pin_cost_capacity) {  // (beyond what rtc_scene_create set aside: about a millisecond per 8 MB, once)
+    if (s->pin_cost) (void)hipHostFree(s->pin_cost);
+    s->pin_cost = nullptr;
+    s->pin_cost_capacity = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_cost), out_pixels * sizeof(uint32_t), hipHostMallocDefault));
+    s->pin_cost_capacity = out_pixels;
+  }
+  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->launch_done, 0));  // (the measuring launch and everything enqueued since)
+  HIP_TRY(hipMemcpyAsync(s->pin_cost, s->d_cost, out_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
+  HIP_TRY(hipEventRecord(s->cost_copied, s->copy_stream));
+  s->cost_copy_pending = true;
+  s->cost_copy_pixels = out_pixels;
+  return RTC_OK;
+}
+
+void startSplitJob(rtc_scene* s, const DevPixelMap& map) {
+  waitSplitJob(s);
+  s->split_job.reset(new SplitJob);
+  SplitJob& job = *s->split_job;
+  job.map = map;
+  job.key = s->cost_key;
+  job.gen = s->readback_gen;
+  job.cam = s->readback_cam;
+  job.depth = s->readback_depth;
+  job.n_waves = residentWaves(s, map);
+  job.chunk_cost.assign(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
+  job.chunk_time.assign(s->pin_chunk_time, s->pin_chunk_time + map.n_chunks);
+  job.state.store(1);
+  job.worker = std::thread([s, &job] {
+    job.cost.assign(s->pin_cost, s->pin_cost + s->cost_copy_pixels);  // (pin_cost is not written again before this job is dropped)
+    packSchedule(s, job.map, job.cost, job.chunk_cost, job.chunk_time, job.n_waves, job.depth, job.order);
+    job.state.store(2);
+  });
+}
+
+// A finished job's schedule becomes the one in use - if it still describes this pixel map and the last measured frame.
+int finishSplitJob(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
+  if (!s->split_job || s->split_job->state.load() < 2) return RTC_OK;
+  waitSplitJob(s);
+  const std::unique_ptr<SplitJob> job = std::move(s->split_job);
+  if (job->state.load() != 2 || job->key != s->cost_key || job->gen != s->measure_gen) return RTC_OK;
+  s->h_order.swap(job->order);
+  if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
+  s->sched_valid = true;
+  s->sched_cam = job->cam;
+  s->sched_depth = job->depth;
+  return RTC_OK;
+}
+
 // The schedule of one launch (results never depend on it).  All of it is made on the device.
 //   * first launch of a pixel map: rtc_estimate_kernel guesses what every chunk will cost from the roots its pixels can
 //     see (bounding spheres, material weights) and the packer orders the frame by that.  (Round 1 did this with a
@@ -267,8 +337,10 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->split_checked = false;
     if (s->readback_enqueued) HIP_TRY(hipEventSynchronize(s->measure_done));  // (its copies must not land in a later read-back's buffers)
     s->readback_enqueued = false;
+    dropSplitJob(s);  // (it packs the pixel map that is gone)
   }
   if (out_pixels > s->cost_capacity) {
+    dropSplitJob(s);  // (it reads d_cost)
     HIP_TRY(hipEventSynchronize(s->launch_done));
     if (s->d_cost) (void)hipFree(s->d_cost);
     s->d_cost = nullptr;
@@ -282,28 +354,31 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     const hipError_t ready = hipEventQuery(s->measure_done);
     if (ready == hipSuccess) {
       s->readback_enqueued = false;
+      // Cut chunks into runs where one is well above a wave's fair share (a small image, a rank's share of a split
+      // frame); the three-wave kernel has half again as many waves and smaller shares, and there the cut pays from one
+      // share on: reflection_and_refraction depth 8 at 1080p 2.12 -> 1.91 ms, cover 0.676 -> 0.670.
       // (a later measuring launch has overwritten the per-pixel costs: that read-back describes a frame that is gone)
-      // (the host's re-pack costs 10-30 ms once, per-pixel work: only where a chunk is well above a wave's share - a rank's
-      // share of a split frame, a small image - not where the heaviest chunk of a full frame is about one share.  The
-      // three-wave kernel has half again as many waves and smaller shares: there the cut pays from one share on -
-      // reflection_and_refraction depth 8 at 1080p 2.12 -> 1.91 ms, cover 0.676 -> 0.670)
       const double factor = usesSimple3(s, map) ? 1.0 : 1.5;
       const bool split = static_cast<double>(s->pin_info->heaviest) > factor * static_cast<double>(s->pin_info->total) / residentWaves(s, map);
-      if (split && s->readback_gen == s->measure_gen) {
-        const std::vector<uint32_t> h_chunk_cost(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
-        const std::vector<uint32_t> h_chunk_time(s->pin_chunk_time, s->pin_chunk_time + map.n_chunks);
-        s->h_cost.resize(out_pixels);
-        HIP_TRY(hipMemcpy(s->h_cost.data(), s->d_cost, s->h_cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        packSchedule(s, map, s->h_cost, h_chunk_cost, h_chunk_time, residentWaves(s, map), s->readback_depth);
-        if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
-        s->sched_valid = true;
-        s->sched_cam = s->readback_cam;
-        s->sched_depth = s->readback_depth;
-      }
+      if (split && s->readback_gen == s->measure_gen)
+        if (const int st = enqueueCostCopy(s, out_pixels); st != RTC_OK) return st;
     } else if (ready != hipErrorNotReady) {
       HIP_TRY(ready);
     }
   }
+  const bool split_sync = getenv("RTC_SPLIT_SYNC") != nullptr;  // tests (read per call): this very launch runs the cut schedule
+  if (schedulable && s->cost_copy_pending) {
+    const hipError_t ready = split_sync ? hipEventSynchronize(s->cost_copied) : hipEventQuery(s->cost_copied);
+    if (ready == hipSuccess) {
+      s->cost_copy_pending = false;
+      if (s->readback_gen == s->measure_gen) startSplitJob(s, map);
+      if (split_sync) waitSplitJob(s);
+    } else if (ready != hipErrorNotReady) {
+      HIP_TRY(ready);
+    }
+  }
+  if (schedulable)
+    if (const int st = finishSplitJob(s, map, stream); st != RTC_OK) return st;
   static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: no schedule at all (packet i is chunk i)
   if (!schedulable || sched_off) {  // a handful of chunks, or more than an item can name: packet i is chunk i, whole
     map.order = nullptr;
@@ -1339,6 +1414,12 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
   HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(s->launch_done, s->stream));
+  // What the off-thread cutting of chunks needs (enqueueCostCopy), made here rather than in the frame that first wants
+  // it: a stream costs 2 ms to create, pinned memory a millisecond per 8 MB.  Room for a 1080p frame's per-pixel costs.
+  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&s->cost_copied, hipEventDisableTiming));
+  s->pin_cost_capacity = 1920u * 1080u;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_cost), s->pin_cost_capacity * sizeof(uint32_t), hipHostMallocDefault));
   s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
   {
@@ -1437,6 +1518,10 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
 void rtc_scene_destroy(rtc_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  dropSplitJob(s);
+  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+  if (s->cost_copied) (void)hipEventDestroy(s->cost_copied);
+  if (s->pin_cost) (void)hipHostFree(s->pin_cost);
   if (s->launch_done) (void)hipEventSynchronize(s->launch_done);  // the last launch, whatever stream it ran on
   if (s->stream) {
     (void)hipStreamSynchronize(s->stream);
@@ -1444,7 +1529,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   }
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
-  if (s->host_out_registered) (void)hipHostUnregister(s->host_out);
+  if (s->host_out_registered && hipHostUnregister(s->host_out) != hipSuccess) (void)hipGetLastError();  // (a canvas the caller has freed: not an error of this thread's next HIP call)
   for (int b = 0; b < 2; ++b)
     if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
   if (s->d_sched_info) (void)hipFree(s->d_sched_info);
@@ -1668,7 +1753,7 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
       }
     }
   } else {
-    if (s->host_out_registered) (void)hipHostUnregister(s->host_out);
+    if (s->host_out_registered && hipHostUnregister(s->host_out) != hipSuccess) (void)hipGetLastError();
     s->host_out = rgb_out;
     s->host_out_bytes = bytes;
     s->host_out_registered = false;
@@ -1719,6 +1804,8 @@ int rtc_scene_synchronize(rtc_scene* s) {
   if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->cost_copy_pending) HIP_TRY(hipEventSynchronize(s->cost_copied));
+  waitSplitJob(s);  // (a schedule the host is still cutting: the next launch finds it finished)
   return RTC_OK;
 }
 

@@ -260,13 +260,21 @@ struct DevPackState {
   uint32_t heaviest, pad_;
 };
 
-// Zero at the start of every launch; counters get one atomic per wave.  A scene owns TWO of these and
-// alternates: launch n counts in [n & 1] and clears [(n + 1) & 1] for its successor (stream order makes
-// that safe), so no launch needs a memset of its own.
+// Zero at the start of every launch.  A scene owns TWO of these and alternates: launch n counts in [n & 1] and clears
+// [(n + 1) & 1] for its successor (stream order makes that safe), so no launch needs a memset of its own.
+// Every counter sits in a cache line of its own.  Atomics on one line are served one after the other, and a frame ends
+// with every wave adding its counts and making its last (failing) pull within a few microseconds of each other: with
+// all of it in one 48-byte block - 2048 waves x 4 counters + the pulls - the queue on that line WAS the end of the frame
+// (cover.json 1080p 0.70 ms; 0.66 with the work counter by chance in the other half of the line; 0.605 with a line per
+// counter; 0.575 with the counts summed per work-group first, a quarter of the atomics).
 struct DevStats {
-  unsigned long long primary, secondary, shadow_calls, shadow_traced, overflow;
-  unsigned int next_chunk;  // work counter of the persistent waves
-  unsigned int stolen;      // rays handed from one lane to another (diagnostic)
+  alignas(128) unsigned int next_chunk;  // work counter of the persistent waves
+  alignas(128) unsigned long long primary;
+  alignas(128) unsigned long long secondary;
+  alignas(128) unsigned long long shadow_calls;
+  alignas(128) unsigned long long shadow_traced;
+  alignas(128) unsigned long long overflow;
+  unsigned int stolen;                   // rays handed from one lane to another (diagnostic)
 #ifdef RTC_PROFILE          // diagnostic builds only (cleared by a host memset there)
   unsigned long long prof[16];  // wave cycles per section
   unsigned long long prof2[8];  // trace invocations (wave level) and active lanes: closest, shadow, behind

@@ -8,6 +8,9 @@
 #include <cstddef>
 #include <cstring>
 #include <string>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtc.h"
@@ -59,6 +62,19 @@ struct Sphere {
   bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
 };
 
+// One run of packSchedule on a worker thread (rtc_capi.hip: startSplitJob / finishSplitJob).
+struct SplitJob {
+  std::thread worker;
+  std::atomic<int> state{0};        // 1 running, 2 finished
+  DevPixelMap map{};                // what it packs: the pixel map, and its key in rtc_scene::cost_key
+  std::vector<uint32_t> key;
+  uint64_t gen = 0;                 // the measuring launch its inputs come from
+  rtc_camera cam{};
+  uint32_t depth = 0;
+  double n_waves = 0.0;
+  std::vector<uint32_t> chunk_cost, chunk_time, cost, order;
+};
+
 struct rtc_scene {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -104,7 +120,6 @@ struct rtc_scene {
   // measured, and the buffers swap - no host in the loop.  The host only writes a buffer for the first launch of a pixel
   // map (the geometric heuristic, chunkOrder) and when some chunk has to be cut into runs (packSchedule).
   std::vector<uint32_t> h_order;          // the last schedule the HOST built (heuristic or split)
-  std::vector<float> h_split_inflation;   // per chunk: modelled time of its parts / its time whole, for the schedule in h_order (empty: nothing is cut)
   uint32_t* d_sched[2] = {nullptr, nullptr};
   size_t sched_capacity = 0;              // words per buffer
   uint32_t sched_cur = 0;
@@ -132,6 +147,15 @@ struct rtc_scene {
   // The FIRST full measuring launch of a pixel map is also read back: per-chunk costs and times and the packer's verdict
   // go to pinned host memory behind an event; a later launch that finds the event complete cuts the chunks that exceed a
   // wave's fair share into runs (packSchedule) if the packer asked for it.
+  // Cutting chunks into runs is per-pixel work on the host (10-30 ms at 1080p): a worker thread does it while the frames
+  // go on with the device-packed schedule, and the launch that finds it finished switches (SplitJob, rtc_capi.hip).
+  std::unique_ptr<SplitJob> split_job;
+  hipStream_t copy_stream = nullptr;  // the copy of the per-pixel costs to pin_cost (non-blocking: it must not wait for the caller's streams)
+  hipEvent_t cost_copied = nullptr;
+  bool cost_copy_pending = false;
+  size_t cost_copy_pixels = 0;
+  uint32_t* pin_cost = nullptr;
+  size_t pin_cost_capacity = 0;
   hipEvent_t measure_done = nullptr;
   bool readback_enqueued = false;
   uint64_t readback_gen = 0;

@@ -2012,21 +2012,32 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     for (int i = 0; i < 16; ++i) stats->prof_last[wid][i] = prof_acc[i] - prof_snap[i];  // sections of the last packet
   }
 #endif
-  // one atomic per counter per wave
-  const unsigned long long s_pri = wave_sum(n_primary);
-  const unsigned long long s_sec = wave_sum(n_secondary);
-  const unsigned long long s_shc = wave_sum(n_shadow_calls);
-  const unsigned long long s_sht = wave_sum(n_shadow_traced);
-  const unsigned long long s_ovf = wave_sum(overflow);
-  if (lane == 0u) {
-    atomicAdd(&stats->primary, s_pri);
-    atomicAdd(&stats->secondary, s_sec);
-    atomicAdd(&stats->shadow_calls, s_shc);
-    atomicAdd(&stats->shadow_traced, s_sht);
-    if (s_ovf) atomicAdd(&stats->overflow, s_ovf);
+  // The counters: summed over the wave, then over the work-group in LDS, one atomic per counter per work-group (each
+  // counter in a cache line of its own, see DevStats).
+  {
+    __shared__ unsigned long long wg_sum[6];
+    if (threadIdx.x < 6u) wg_sum[threadIdx.x] = 0ull;
+    __syncthreads();  // (every wave of the group gets here: the loop above ends for all of them)
+    const unsigned long long s_pri = wave_sum(n_primary), s_sec = wave_sum(n_secondary), s_shc = wave_sum(n_shadow_calls),
+                             s_sht = wave_sum(n_shadow_traced), s_ovf = wave_sum(overflow), s_stolen = wave_sum(n_stolen);
+    if (lane == 0u) {
+      atomicAdd(&wg_sum[0], s_pri);
+      atomicAdd(&wg_sum[1], s_sec);
+      atomicAdd(&wg_sum[2], s_shc);
+      atomicAdd(&wg_sum[3], s_sht);
+      if (s_ovf) atomicAdd(&wg_sum[4], s_ovf);
+      if (s_stolen) atomicAdd(&wg_sum[5], s_stolen);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+      atomicAdd(&stats->primary, wg_sum[0]);
+      atomicAdd(&stats->secondary, wg_sum[1]);
+      atomicAdd(&stats->shadow_calls, wg_sum[2]);
+      atomicAdd(&stats->shadow_traced, wg_sum[3]);
+      if (wg_sum[4]) atomicAdd(&stats->overflow, wg_sum[4]);
+      if (wg_sum[5]) atomicAdd(&stats->stolen, static_cast<unsigned int>(wg_sum[5]));
+    }
   }
-  const unsigned long long s_stolen = wave_sum(n_stolen);
-  if (lane == 0u && s_stolen) atomicAdd(&stats->stolen, static_cast<unsigned int>(s_stolen));
 }
 
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)

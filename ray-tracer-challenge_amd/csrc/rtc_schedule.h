@@ -121,7 +121,6 @@ inline double groupFloor(const rtc_scene* s) {
   }
   const double cap = std::max(1.0, alpha * total / std::max(1.0, n_waves));
   if (static_cast<double>(heaviest) > cap) return false;
-  s->h_split_inflation.clear();
   std::vector<uint32_t> order(map.n_chunks);
   for (uint32_t i = 0; i < map.n_chunks; ++i) order[i] = i;
   // Longest first, but in classes of about equal length (a quarter octave) that keep the chunks' image order: waves
@@ -173,9 +172,9 @@ inline double groupFloor(const rtc_scene* s) {
   return true;
 }
 
-void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost,
+void packSchedule(const rtc_scene* s, const DevPixelMap& map, const std::vector<uint32_t>& cost,
                   const std::vector<uint32_t>& chunk_cost_sum, const std::vector<uint32_t>& chunk_time, double n_waves,
-                  uint32_t max_depth) {
+                  uint32_t max_depth, std::vector<uint32_t>& out) {
   static const double alpha = getenv("RTC_SPLIT_ALPHA") ? atof(getenv("RTC_SPLIT_ALPHA")) : 1.0;
   struct Item { uint32_t cost, code; };
   const uint32_t n_chunks = map.n_chunks;
@@ -237,8 +236,7 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     fair = (total + extra) / std::max(1.0, n_waves);
   }
   const double cap = std::max(1.0, alpha * fair);
-  std::vector<float>& inflation = s->h_split_inflation;
-  inflation.assign(n_chunks, 1.0f);
+  std::vector<float> inflation(n_chunks, 1.0f);  // per chunk: modelled time of its parts / its time whole
   std::vector<Item> whole;
   struct Part { uint64_t est; uint32_t code, npx; };
   std::vector<Part> split_parts;
@@ -266,7 +264,6 @@ void packSchedule(rtc_scene* s, const DevPixelMap& map, const std::vector<uint32
     }
     inflation[c] = static_cast<float>(std::max(1.0, est_sum / std::max(T, 1.0)));
   }
-  std::vector<uint32_t>& out = s->h_order;
   out.clear();
   struct Packet { uint64_t cost; uint32_t npx, n_items; uint32_t items[RTC_PACKET_ITEMS]; };
   std::vector<Packet> packets;

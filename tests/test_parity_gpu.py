@@ -291,7 +291,8 @@ def _check_launch(gpu, cam, depth, want, counters, what):
 
 
 @pytest.mark.parametrize("scene,w,h,depth", SCHEDULE_CASES)
-def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth):
+def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth, monkeypatch):
+    monkeypatch.setenv("RTC_SPLIT_SYNC", "1")   # chunks are cut into runs before launch 2 returns, not when a worker thread gets to it
     hs = rtc.HostScene.from_file(scene)
     gpu = rtc.GpuScene(hs.desc)
     osc = ob.OracleScene(hs.desc)
@@ -318,6 +319,7 @@ def test_three_wave_simple_kernel_renders_the_same_image(rtc, scene, w, h, depth
     RTC_SIMPLE3_MIN_CHUNKS=0 (read per launch) makes every launch take it: the same launches as above, first frame on
     the estimate, packed, steady state, moved camera, each against the oracle."""
     monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "0")
+    monkeypatch.setenv("RTC_SPLIT_SYNC", "1")
     hs = rtc.HostScene.from_file(scene)
     gpu = rtc.GpuScene(hs.desc)
     osc = ob.OracleScene(hs.desc)
@@ -353,6 +355,32 @@ def test_three_wave_simple_kernel_random_scenes(rtc, monkeypatch):
         assert [st["secondary"], st["shadow_calls"], st["overflow"]] == [counters["secondary"], counters["shadow"], 0], seed
         gpu.close()
     assert ran >= 10
+
+
+def test_schedule_cut_on_the_worker_thread(rtc):
+    """Chunks above a wave's share are cut into runs by a worker thread of the library while the frames go on
+    (startSplitJob / finishSplitJob, rtc_capi.hip): frames before, while and after it works must all be the oracle's, as
+    must the frames of a handle whose pixel map changes or that is destroyed while the worker is busy."""
+    hs = rtc.HostScene.from_file("fresnel.json")
+    osc = ob.OracleScene(hs.desc)
+    cam = hs.camera(150, 150)
+    want, counters = osc.render(cam, 5)
+    gpu = rtc.GpuScene(hs.desc)
+    for launch in range(1, 5):
+        _check_launch(gpu, cam, 5, want, counters, ("launch", launch))
+    gpu.synchronize()                     # (waits for the worker)
+    for launch in range(5, 8):            # the first of these switches to the cut schedule
+        _check_launch(gpu, cam, 5, want, counters, ("launch", launch))
+    cam2 = hs.camera(120, 90)             # another pixel map right behind a measuring launch: the job of the old one is dropped
+    want2, counters2 = osc.render(cam2, 5)
+    for launch in range(3):
+        g2 = rtc.GpuScene(hs.desc)
+        _check_launch(g2, cam, 5, want, counters, "first")
+        _check_launch(g2, cam, 5, want, counters, "second (starts the worker)")
+        if launch == 1:
+            _check_launch(g2, cam2, 5, want2, counters2, "new pixel map")
+            _check_launch(g2, cam2, 5, want2, counters2, "new pixel map, second")
+        g2.close()                        # ... or the handle goes away under it
 
 
 def test_first_launches_write_every_pixel(rtc):

@@ -14,7 +14,7 @@ for name, w, h, depth in (("cover.json", 1920, 1080, 5), ("reflection_and_refrac
         gpu = rtc.GpuScene(hs.desc)
         torch.cuda.synchronize()
         row = []
-        for i in range(3):
+        for i in range(12):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             a.record(stream)
@@ -23,5 +23,5 @@ for name, w, h, depth in (("cover.json", 1920, 1080, 5), ("reflection_and_refrac
             row.append((a.elapsed_time(b), (time.perf_counter() - t0) * 1e3))
         res.append(row)
         gpu.close()
-    med = [sorted(r[i] for r in res)[len(res) // 2] for i in range(3)]   # per launch: the median handle
+    med = [sorted(r[i] for r in res)[len(res) // 2] for i in range(12)]   # per launch: the median handle
     print(name, " | ".join(f"launch {i}: gpu {g:.3f} ms, wall {wl:.3f} ms" for i, (g, wl) in enumerate(med)), flush=True)

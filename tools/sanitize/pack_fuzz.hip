@@ -97,7 +97,7 @@ int main() {
       char what[128];
       std::snprintf(what, sizeof what, "rep %d mode %u chunks %u waves %.0f", rep, map.mode, map.n_chunks, n_waves);
       ++cases;
-      if (!packWholeChunks(&s, map, chunk_time, n_waves)) packSchedule(&s, map, cost, chunk_cost, chunk_time, n_waves, 1 + rng() % 8);
+      if (!packWholeChunks(&s, map, chunk_time, n_waves)) packSchedule(&s, map, cost, chunk_cost, chunk_time, n_waves, 1 + rng() % 8, s.h_order);
       if (!coversOnce(s.h_order, map.n_chunks, what)) {
         ++failures;
         continue;
