@@ -164,11 +164,11 @@ DevCamera devCamera(const rtc_camera& c) {
 
 // The render kernel of a scene whose tables fit in LDS.
 // The three-waves-per-SIMD form of the simple kernel pays when every wave has several packets to run (see the kernel):
-// from about five chunks per resident wave on.
+// from about four chunks per resident wave on (1280x720; tools/simple3_sweep.py).
 bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
   const char* const env = getenv("RTC_SIMPLE3_MIN_CHUNKS");  // test / experiment knob, read per launch: 0 = always
   const long forced = env != nullptr ? atol(env) : -1;
-  const uint64_t min_chunks = forced >= 0 ? static_cast<uint64_t>(forced) : 5ull * 4u * s->n_cus * s->blocks_per_cu_simple3;
+  const uint64_t min_chunks = forced >= 0 ? static_cast<uint64_t>(forced) : 4ull * 4u * s->n_cus * s->blocks_per_cu_simple3;
   return s->simple3_ok && map.n_chunks >= min_chunks;
 }
 

@@ -96,14 +96,15 @@ int uploadSchedule(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
 }
 
 // Cheap chunks are handed out several to a packet, up to this much measured time (s_memtime ticks / 16: 8000 is about
-// 50 us).  Scenes with meshes get twice as much: the chunks of a packet are image neighbours, and a wave that
-// walks the same BVH nodes for all of them finds them in its CU's L1 (98 % of the kernel's loads hit L1; a chunk among
-// strangers at the end of the list takes four times what it takes among neighbours).  Measured at 8000 / 16000 /
-// 24000 / 40000: teapot 0.370 / 0.362 / 0.356 / 0.361 ms, nefertiti 0.713 / 0.720 / 0.733 / 0.775 ms, dragons 4K
-// 2.79 / 2.78 / 2.79 / 2.91 ms.
+// 50 us): the chunks of a packet are image neighbours, and a wave that walks the same BVH nodes or reads the same texels
+// for all of them finds them in its CU's L1; a pull of the work counter costs the wave a drain.  Measured at
+// 6000 / 8000 / 12000 / 16000 (1080p, after the counters got cache lines of their own - before that a pull was dearer
+// and meshes ran best at 16000): teapot 0.312 / 0.308 / 0.324 / 0.339 ms, nefertiti 0.589 / 0.599 / 0.613 / 0.632,
+// cylinders 0.291 / 0.283 / 0.296 / 0.305, dragons 4K 2.43 throughout; scenes with texture maps or csg want more:
+// earth 0.308 / 0.260 / 0.205 / 0.206, texture_demo 0.338 / 0.316 / 0.302 / 0.317, csg 0.688 / 0.684 / 0.665 / 0.676.
 inline double groupFloor(const rtc_scene* s) {
   static const double forced = getenv("RTC_SCHED_TMIN") ? atof(getenv("RTC_SCHED_TMIN")) : 0.0;
-  return forced > 0.0 ? forced : (s->flat_kernel ? 8000.0 : 16000.0);  // (flat: no mesh to keep in cache)
+  return forced > 0.0 ? forced : (s->ext_kernel ? 12000.0 : 8000.0);
 }
 
 // The common case of packSchedule below, from per-chunk sums alone: no chunk costs more than a wave's fair share,

@@ -31,10 +31,11 @@ def main():
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
-    def timed(fn):
-        for _ in range(8):
+    def timed(fn, handle=None):
+        for i in range(8):
             fn()
-            torch.cuda.synchronize()   # (a host-side re-pack of the schedule, if the share needs one, happens here)
+            torch.cuda.synchronize()
+            if i == 3 and handle is not None: handle.synchronize()   # (chunks cut into runs on the library's worker thread: the next launch switches)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         for _ in range(args.reps):
@@ -45,7 +46,7 @@ def main():
 
     gpu = rtc.GpuScene(hs.desc)
     canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
-    t_full = timed(lambda: gpu.render_device(cam, canvas.data_ptr(), args.depth, None, sptr))
+    t_full = timed(lambda: gpu.render_device(cam, canvas.data_ptr(), args.depth, None, sptr), gpu)
     print(json.dumps({"scene": args.scene, "full_ms": t_full}), flush=True)
     for tile in [int(x) for x in args.tiles.split(",")]:
         tx, ty = rtc.tile_grid(W, H, tile, tile)
@@ -58,7 +59,7 @@ def main():
                 g.render_tiles_device(cam, buf.data_ptr(), tile, tile, first, stride, count, args.depth, sptr)
                 cost[first::stride] = g.tile_costs(count)     # the first (measuring) frame: what every tile costs
                 ts.append(timed(lambda: g.render_tiles_device(cam, buf.data_ptr(), tile, tile, first, stride, count,
-                                                              args.depth, sptr)))
+                                                              args.depth, sptr), g))
                 g.close()
             # the split bench.py and librtc_multi use after their first frame: tiles dealt by measured cost
             rank_of, _ = rtc.assign_tiles(cost, world)
@@ -67,7 +68,7 @@ def main():
                 g = rtc.GpuScene(hs.desc)
                 mine = np.flatnonzero(rank_of == rank).astype(np.uint32)
                 buf = torch.zeros(((tx * ty + world - 1) // world, tile, tile, 3), dtype=torch.float64, device="cuda")
-                tb.append(timed(lambda: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sptr)))
+                tb.append(timed(lambda: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sptr), g))
                 g.close()
             print(json.dumps({"tile": tile, "world": world, "ideal_ms": t_full / world,
                               "round_robin": {"max_ms": max(ts), "mean_ms": sum(ts) / world, "compute_eff": t_full / (world * max(ts))},
