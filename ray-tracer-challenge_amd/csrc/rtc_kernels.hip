@@ -1410,6 +1410,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   uint32_t chunk_rx0 = 0u, chunk_ry0 = 0u, chunk_px0 = 0u, chunk_py0 = 0u, chunk_w = 0u, chunk_h = 0u;
   size_t chunk_out0 = 0;
   bool drained = false;
+  bool first_pull = true;
 
   // per-lane pixel and ray state
   bool has_pixel = false, have_cur = false;
@@ -1571,7 +1572,17 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           }
           uint32_t c = 0u;
           RTC_STAMP(14);  // (diagnostic builds: section 14 = the round trip of the work counter)
-          if (lane == 0u) c = atomicAdd(&stats->next_chunk, 1u);
+          // A wave's FIRST packet is the one with its own number; the counter hands out the packets after those.  (At
+          // the start of a launch every wave pulls at once, and atomics on one cache line are served one after the
+          // other: the last of 3072 waves got its first packet 25 us into the frame.  fresnel 300x300 0.129 -> 0.105 ms,
+          // cover 1080p 0.579 -> 0.554, teapot 0.310 -> 0.293.  The four waves of a work-group start on four
+          // neighbouring packets.)
+          if (first_pull) {
+            first_pull = false;
+            c = blockIdx.x * 4u + (threadIdx.x >> 6);
+          } else if (lane == 0u) {
+            c = atomicAdd(&stats->next_chunk, 1u) + gridDim.x * 4u;
+          }
           c = __builtin_amdgcn_readfirstlane(c);
           RTC_STAMP(15);
           if (c >= n_units) {
