@@ -76,12 +76,12 @@ struct RootRec {
 #define RTC_LDS_ROOTS 128
 #define RTC_LDS_MATERIALS 64
 #define RTC_LDS_PATTERNS 48
-// (the three-waves-per-SIMD variant of the simple kernel: 49.8 KB per work-group)
-#ifndef RTC_LDS3_ROOTS
-#define RTC_LDS3_ROOTS 96
-#define RTC_LDS3_MATERIALS 48
-#define RTC_LDS3_PATTERNS 32
-#endif
+// (the three-waves-per-SIMD variant of the simple kernel: 52 KB per work-group with two levels of pending rays.  That
+// is the most three work-groups can have: at 53 KB the occupancy query still says three per CU, the hardware runs two
+// and the third of the persistent work-groups starts when the others are done - cover 0.55 -> 0.75 ms)
+#define RTC_LDS3_ROOTS 32
+#define RTC_LDS3_MATERIALS 16
+#define RTC_LDS3_PATTERNS 22
 #define RTC_LDS_LIGHTS 16
 
 struct DevPattern {      // 144 B

@@ -1348,8 +1348,9 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // Small-world tables (World.objects records + bounding spheres, materials, patterns, lights):
   // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
   // chases pointers through memory.  Larger worlds run the same code on the tables in memory.
-  // (WAVES: what the launch bounds leave room for per SIMD; a three-wave kernel has 53 KB of LDS per work-group and
-  // smaller tables, RTC_LDS3_*)
+  // (WAVES: what the launch bounds leave room for per SIMD; a three-wave kernel has 53 KB of LDS per work-group: smaller
+  // tables, RTC_LDS3_*, so that two levels of the pending-ray stacks still fit - one level in LDS instead of two is
+  // 145 MB more memory traffic per cover frame)
   constexpr int N_ROOTS = WAVES == 3 ? RTC_LDS3_ROOTS : RTC_LDS_ROOTS, N_MATS = WAVES == 3 ? RTC_LDS3_MATERIALS : RTC_LDS_MATERIALS,
                 N_PATS = WAVES == 3 ? RTC_LDS3_PATTERNS : RTC_LDS_PATTERNS;
   __shared__ RootRec lds_recs[LDS ? N_ROOTS : 1];
@@ -1364,7 +1365,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // again after almost every pixel, so nearly every push and pop stays here: the pops no longer wait for memory and the
   // 2048 resident waves no longer cycle 59 MB of stack lines through the L2s (142 MB written per cover frame).
   constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
-  constexpr int LDS_LEVELS = WAVES == 3 ? 1 : (FLAT ? 2 : (LDS ? 1 : 2));  // (what fits beside the tables at WAVES work-groups per CU)
+  constexpr int LDS_LEVELS = (FLAT || !LDS) ? 2 : 1;  // (what fits beside the tables at WAVES work-groups per CU)
   __shared__ Quad2 lds_pend[4][LDS_LEVELS][4][64];
   // The colour a lane has accumulated for its pixel: touched once per iteration and when the pixel is finished, live
   // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
@@ -1395,7 +1396,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     lights = lds_light;
   }
   const uint32_t lane = threadIdx.x & 63u;
+  // (bits of a ballot below this lane, by mask and popcount.  v_mbcnt_lo / v_mbcnt_hi would do it in two instructions and
+  // without the mask's two registers - and the three-wave kernel's register allocation comes out worse for it: 117
+  // instead of 102 spilled VGPRs, 648 instead of 283 MB written per cover frame, 0.571 instead of 0.553 ms.)
   const unsigned long long lanes_below = (1ull << lane) - 1ull;
+  auto bits_below = [&](unsigned long long m) -> uint32_t { return static_cast<uint32_t>(__builtin_popcountll(m & lanes_below)); };
 
   // wave-uniform cursor: the packet the wave pulled last (lane i < 16 holds its item i), the item that is
   // open, and the run of pixels of one 8x8 chunk that item names
@@ -1516,8 +1521,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       if (imask != 0ull && dmask != 0ull) {
         const uint32_t pairs = min(static_cast<uint32_t>(__builtin_popcountll(imask)),
                                    static_cast<uint32_t>(__builtin_popcountll(dmask)));
-        const uint32_t irank = static_cast<uint32_t>(__builtin_popcountll(imask & lanes_below));
-        const uint32_t drank = static_cast<uint32_t>(__builtin_popcountll(dmask & lanes_below));
+        const uint32_t irank = bits_below(imask);
+        const uint32_t drank = bits_below(dmask);
         if (donor && drank < pairs) {
           mailbox[drank] = uint4{lane, static_cast<uint32_t>(base++), static_cast<uint32_t>(out_index), static_cast<uint32_t>(out_index >> 32)};
           if (!shared) {
@@ -1634,7 +1639,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         }
       }
       const uint32_t avail = chunk_end - chunk_pos;
-      const uint32_t rank = static_cast<uint32_t>(__builtin_popcountll(wmask & lanes_below));
+      const uint32_t rank = bits_below(wmask);
       if (want && rank < avail) {
         const uint32_t k = chunk_pos + rank;  // pixel k of the 8x8 chunk
         const uint32_t rx = chunk_rx0 + (k & 7u), ry = chunk_ry0 + (k >> 3);
