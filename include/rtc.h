@@ -327,7 +327,10 @@ int rtc_assemble_tiles_device(const double *d_gathered, uint32_t world, uint32_t
                               uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
                               double *d_canvas, void *hip_stream);
 
-/* Waits for the work enqueued on the handle's own stream. */
+/* Waits for the work enqueued on the handle's own stream - and for the worker
+ * thread, if the library is still cutting the heaviest chunks of the last
+ * measured frame into runs (a schedule refinement that otherwise arrives a few
+ * frames later; results never depend on it): the next render uses it. */
 int rtc_scene_synchronize(rtc_scene *scene);
 
 /* Counters of the last render that was enqueued on this handle (synchronises). */
