@@ -983,7 +983,9 @@ void copyPlainTables(const rtc_scene_desc& d, HostTables& T) {
   mat.assign(d.n_materials, DevMaterial{});
   for (uint32_t i = 0; i < d.n_materials; ++i) {
     const double* p = d.mat_params + static_cast<size_t>(RTC_MAT_STRIDE) * i;
-    mat[i] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], d.mat_pattern[i], 0u};
+    const double shininess = p[3];
+    const bool small_int = shininess >= 2.0 && shininess <= 1048576.0 && shininess == std::floor(shininess);
+    mat[i] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], d.mat_pattern[i], small_int ? static_cast<uint32_t>(shininess) : 0u};
   }
   node_kids.assign(d.n_nodes, uint2{0, 0});
   node_box.assign(6ull * d.n_nodes, 0.0);

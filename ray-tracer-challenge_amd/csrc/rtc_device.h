@@ -42,7 +42,7 @@
 struct DevMaterial {
   double ambient, diffuse, specular, shininess, reflective, transparency, ior;
   uint32_t pattern;
-  uint32_t pad;
+  uint32_t shininess_int;  // shininess as an integer if it is one in 2 .. 2^20, else 0: zig_pow's plain squaring loop (pow_small_int)
 };
 
 struct DevCyl {

@@ -1266,6 +1266,35 @@ __device__ __forceinline__ double zig_pow(double x, double y) {
   return ldexp(a1, ae);
 }
 
+// zig_pow(x, n) for finite x > 0 and an integer 2 <= n <= 2^20: none of the special cases above applies and the
+// fractional part is zero, so what is left of std.math.pow is the squaring loop on the frexp mantissa - the same
+// operations in the same order, hence the same bits.  (Material.lighting's specular term, material.zig:69: the exponent
+// is the material's shininess, an integer in every scene file; rtc_scene_create says so per material.  About a third
+// of zig_pow's instructions on this path were tests for cases that cannot occur.)
+__device__ __forceinline__ double pow_small_int(double x, uint32_t n) {
+  double a1 = 1.0;
+  int ae = 0;
+  int xe;
+  double x1 = frexp(x, &xe);
+  for (uint32_t i = n; i != 0u; i >>= 1) {
+    if (xe < -(1 << 12) || (1 << 12) < xe) {
+      ae += xe;
+      break;
+    }
+    if (i & 1u) {
+      a1 *= x1;
+      ae += xe;
+    }
+    x1 *= x1;
+    xe <<= 1;
+    if (x1 < 0.5) {
+      x1 += x1;
+      xe -= 1;
+    }
+  }
+  return ldexp(a1, ae);
+}
+
 // One pending secondary ray of the colorAt recursion (world.zig:157-189): the colour it
 // returns is multiplied by `weight` on its way up to the pixel.
 struct Pending {
@@ -1915,7 +1944,9 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             const double rx = lvx - nx * two_dot, ry = lvy - ny * two_dot, rz = lvz - nz * two_dot;
             const double reflect_dot_eye = ((-rx) * ex + (-ry) * ey) + (-rz) * ez;
             if (reflect_dot_eye > 0.0) {
-              const double ks = mat.specular * zig_pow(reflect_dot_eye, mat.shininess);
+              const uint32_t n = mat.shininess_int;
+              const double ks = mat.specular * (n != 0u && reflect_dot_eye < kInf ? pow_small_int(reflect_dot_eye, n)
+                                                                                  : zig_pow(reflect_dot_eye, mat.shininess));
               pr = L[3] * ks;
               pg = L[4] * ks;
               pb = L[5] * ks;
