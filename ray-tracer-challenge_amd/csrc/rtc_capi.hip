@@ -6,7 +6,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstddef>
-#include <chrono>
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -235,6 +236,77 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
   return RTC_OK;
 }
 
+// What the off-thread cutting of chunks needs from the runtime - a stream for the copy of the per-pixel costs and pinned
+// memory to copy them into - is shared by all handles of a device and kept for the life of the process: a stream costs
+// 2 ms to create and pinned memory a millisecond per 8 MB, a test run creates three hundred handles, and a host that
+// re-creates its scene per frame should not pin and unpin 8 MB each time.  (The copies are rare - one per view that
+// needs its chunks cut - and every handle has its own event on the shared stream.)
+struct CopyPool {
+  struct PerDevice {
+    hipStream_t stream = nullptr;
+    std::vector<std::pair<uint32_t*, size_t>> free_buffers;  // (pointer, capacity in u32)
+  };
+  std::mutex lock;
+  std::map<int, PerDevice> devices;
+};
+CopyPool& copyPool() {
+  static CopyPool* const pool = new CopyPool;  // (never destroyed: no HIP calls from static destructors)
+  return *pool;
+}
+
+// A pinned buffer of at least `pixels` u32 for this handle (its old one goes back to the pool).
+int acquirePinnedCosts(rtc_scene* s, size_t pixels) {
+  if (pixels <= s->pin_cost_capacity) return RTC_OK;
+  CopyPool& pool = copyPool();
+  std::lock_guard<std::mutex> guard(pool.lock);
+  CopyPool::PerDevice& dev = pool.devices[s->device];
+  if (s->pin_cost) dev.free_buffers.emplace_back(s->pin_cost, s->pin_cost_capacity);
+  s->pin_cost = nullptr;
+  s->pin_cost_capacity = 0;
+  for (size_t i = 0; i < dev.free_buffers.size(); ++i) {
+    if (dev.free_buffers[i].second >= pixels) {
+      s->pin_cost = dev.free_buffers[i].first;
+      s->pin_cost_capacity = dev.free_buffers[i].second;
+      dev.free_buffers.erase(dev.free_buffers.begin() + static_cast<std::ptrdiff_t>(i));
+      return RTC_OK;
+    }
+  }
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_cost), pixels * sizeof(uint32_t), hipHostMallocDefault));
+  s->pin_cost_capacity = pixels;
+  return RTC_OK;
+}
+
+void releasePinnedCosts(rtc_scene* s) {
+  if (!s->pin_cost) return;
+  CopyPool& pool = copyPool();
+  std::lock_guard<std::mutex> guard(pool.lock);
+  pool.devices[s->device].free_buffers.emplace_back(s->pin_cost, s->pin_cost_capacity);
+  s->pin_cost = nullptr;
+  s->pin_cost_capacity = 0;
+}
+
+// The device's copy stream, created (and its copy path warmed) by the first handle that asks.
+int acquireCopyStream(rtc_scene* s) {
+  CopyPool& pool = copyPool();
+  std::lock_guard<std::mutex> guard(pool.lock);
+  CopyPool::PerDevice& dev = pool.devices[s->device];
+  if (!dev.stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&dev.stream, hipStreamNonBlocking));
+    // The first device-to-host copy of some size in a process costs 8 ms (the runtime sets up its copy engine path; a
+    // 4-byte copy does not trigger it, 256 KB does): paid here, once, not in the frame that first cuts chunks.
+    void* d_tmp = nullptr;
+    void* h_tmp = nullptr;
+    HIP_TRY(hipMalloc(&d_tmp, 1u << 20));
+    HIP_TRY(hipHostMalloc(&h_tmp, 1u << 20, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(h_tmp, d_tmp, 1u << 20, hipMemcpyDeviceToHost, dev.stream));
+    HIP_TRY(hipStreamSynchronize(dev.stream));
+    HIP_TRY(hipHostFree(h_tmp));
+    HIP_TRY(hipFree(d_tmp));
+  }
+  s->copy_stream = dev.stream;
+  return RTC_OK;
+}
+
 // ---- cutting chunks into runs, off the caller's thread.  packSchedule is per-pixel work on the host (10-30 ms for a
 // 1080p frame).  The launch that learns from the read-back that a chunk is too heavy enqueues a copy of the per-pixel
 // costs to pinned memory on a stream of its own (it overlaps the frames that follow); the launch that finds the copy
@@ -256,13 +328,7 @@ void dropSplitJob(rtc_scene* s) {
 
 int enqueueCostCopy(rtc_scene* s, size_t out_pixels) {
   dropSplitJob(s);
-  if (out_pixels > s->pin_cost_capacity) {  // (beyond what rtc_scene_create set aside: about a millisecond per 8 MB, once)
-    if (s->pin_cost) (void)hipHostFree(s->pin_cost);
-    s->pin_cost = nullptr;
-    s->pin_cost_capacity = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_cost), out_pixels * sizeof(uint32_t), hipHostMallocDefault));
-    s->pin_cost_capacity = out_pixels;
-  }
+  if (const int st = acquirePinnedCosts(s, out_pixels); st != RTC_OK) return st;  // (beyond what rtc_scene_create took: a millisecond per 8 MB)
   HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->launch_done, 0));  // (the measuring launch and everything enqueued since)
   HIP_TRY(hipMemcpyAsync(s->pin_cost, s->d_cost, out_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
   HIP_TRY(hipEventRecord(s->cost_copied, s->copy_stream));
@@ -1416,12 +1482,12 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
   HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(s->launch_done, s->stream));
-  // What the off-thread cutting of chunks needs (enqueueCostCopy), made here rather than in the frame that first wants
-  // it: a stream costs 2 ms to create, pinned memory a millisecond per 8 MB.  Room for a 1080p frame's per-pixel costs.
-  HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  // What the off-thread cutting of chunks needs (enqueueCostCopy), taken here rather than in the frame that first wants
+  // it: the device's copy stream and pinned room for a 1080p frame's per-pixel costs (CopyPool: after the first handle of
+  // a process both come from the pool).
+  if (const int st = acquireCopyStream(s); st != RTC_OK) return st;
   HIP_TRY(hipEventCreateWithFlags(&s->cost_copied, hipEventDisableTiming));
-  s->pin_cost_capacity = 1920u * 1080u;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_cost), s->pin_cost_capacity * sizeof(uint32_t), hipHostMallocDefault));
+  if (const int st = acquirePinnedCosts(s, 1920u * 1080u); st != RTC_OK) return st;
   s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
   {
@@ -1521,9 +1587,8 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   dropSplitJob(s);
-  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
   if (s->cost_copied) (void)hipEventDestroy(s->cost_copied);
-  if (s->pin_cost) (void)hipHostFree(s->pin_cost);
+  releasePinnedCosts(s);  // (copy_stream is the device's, shared)
   if (s->launch_done) (void)hipEventSynchronize(s->launch_done);  // the last launch, whatever stream it ran on
   if (s->stream) {
     (void)hipStreamSynchronize(s->stream);

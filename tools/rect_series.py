@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""GPU time of thirty consecutive frames of three sub-rectangles of cover.json (fresh handle each), launch by launch."""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+hs = rtc.HostScene.from_file("cover.json"); cam = hs.camera(1920, 1080)
+stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
+buf = torch.empty((1080, 1920, 3), dtype=torch.float64, device="cuda")
+for rect in ((560, 720, 256, 256), (560, 720, 64, 64), (0, 0, 960, 540)):
+    gpu = rtc.GpuScene(hs.desc)
+    ts = []
+    for i in range(30):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream); gpu.render_device(cam, buf.data_ptr(), 5, rect, stream.cuda_stream); b.record(stream)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+        if i == 14: gpu.synchronize()
+    print(rect, gpu.last_kernel_name(), " ".join(f"{t:.3f}" for t in ts), flush=True)
