@@ -45,23 +45,27 @@ extern "C" __global__ void rtc_render_kernel_bigworld_ext(const DevScene S, cons
                                                           DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_estimate_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                uint32_t* __restrict__ chunk_cost, uint32_t* __restrict__ chunk_time,
-                                               DevPackState* __restrict__ state);
-extern "C" __global__ void rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map,
+                                               DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state);
+extern "C" __global__ void rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, const uint32_t max_depth,
                                                  uint32_t* __restrict__ chunk_cost, uint32_t* __restrict__ chunk_time,
-                                                 DevPackState* __restrict__ state);
+                                                 DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state);
 extern "C" __global__ void rtc_chunk_time_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
                                                  const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
                                                  const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks,
-                                                 uint32_t* __restrict__ chunk_time);
+                                                 uint32_t* __restrict__ chunk_time, DevChunkShape* __restrict__ chunk_shape);
 extern "C" __global__ void rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks,
-                                                 const float cost_to_time, uint32_t* __restrict__ chunk_time,
+                                                 const float cost_to_time, const DevChunkShape* __restrict__ chunk_shape,
+                                                 uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state);
+extern "C" __global__ void rtc_pack_extra_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves,
+                                                 const float cut_above, const DevChunkShape* __restrict__ chunk_shape, const int round,
                                                  DevPackState* __restrict__ state);
 extern "C" __global__ void rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves,
-                                                const float t_min, DevPackState* __restrict__ state, uint32_t* __restrict__ sorted,
-                                                DevSchedInfo* __restrict__ info);
+                                                const float t_min, const float cut_above,
+                                                const DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state,
+                                                uint32_t* __restrict__ sorted, uint32_t* __restrict__ order_out);
 extern "C" __global__ void rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves,
-                                                const float t_min, const DevPackState* __restrict__ state,
-                                                uint32_t* __restrict__ order_out);
+                                                const float t_min, const float cut_above, const DevPackState* __restrict__ state,
+                                                uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info);
 extern "C" __global__ void rtc_rgba8_kernel(const double* __restrict__ canvas, const size_t n_pixels, uint32_t* __restrict__ rgba);
 extern "C" __global__ void rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
                                                     const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
@@ -202,17 +206,36 @@ uint32_t residentBlocks(const rtc_scene* s, const DevPixelMap& map) {
 }
 double residentWaves(const rtc_scene* s, const DevPixelMap& map) { return 4.0 * residentBlocks(s, map); }
 
+// Chunks that take more than this many fair shares of a wave are cut into runs of pixels (small images, a rank's share
+// of a split frame; a full 1080p frame's heaviest chunk is about one share).  The three-wave kernel has half again as
+// many waves and smaller shares, and there the cut pays from one share on: reflection_and_refraction depth 8 at 1080p
+// 2.12 -> 1.91 ms, cover 0.676 -> 0.670.
+double cutAbove(const rtc_scene* s, const DevPixelMap& map) {
+  static const bool off = getenv("RTC_NO_DEVICE_CUT") != nullptr;  // experiment knob
+  static const double forced = getenv("RTC_CUT_ABOVE") ? atof(getenv("RTC_CUT_ABOVE")) : 0.0;  // experiment knob
+  (void)s;
+  (void)map;
+  return off ? 0.0 : (forced > 0.0 ? forced : 1.0);
+}
+
+// Packets a device-packed schedule of this pixel map can have at most: one per chunk, and up to fifteen more for every
+// chunk that is cut - of which there are at most as many as waves (the chunks above one share cannot outnumber the shares).
+size_t maxPackets(const rtc_scene* s, const DevPixelMap& map) {
+  const size_t waves = static_cast<size_t>(residentWaves(s, map));
+  return static_cast<size_t>(map.n_chunks) + 15u * std::min<size_t>(map.n_chunks, waves);
+}
+
 // The measured schedule in use, into a launch's pixel map.
 void useSchedule(const rtc_scene* s, DevPixelMap& map) {
   map.order = s->d_sched[s->sched_cur];
   map.n_units_dev = s->sched_on_device ? &s->d_sched_info[s->sched_cur].n_units : nullptr;
-  map.n_units = s->sched_on_device ? map.n_chunks : s->sched_n_units;  // (device-packed: an upper bound, for the grid)
+  map.n_units = s->sched_on_device ? static_cast<uint32_t>(maxPackets(s, map)) : s->sched_n_units;  // (device-packed: an upper bound, for the grid)
 }
 
 // Everything a measuring launch and the packer behind it write to.
 int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
-  if (const int st = ensureScheduleBuffers(s, static_cast<size_t>(map.n_chunks) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
-  // (a host schedule with chunks cut into runs can have more packets than there are chunks: at most 16 parts each)
+  if (const int st = ensureScheduleBuffers(s, maxPackets(s, map) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
+  // (a schedule with chunks cut into runs can have more packets than there are chunks: at most 16 parts each)
   const size_t need_pt = static_cast<size_t>(map.n_chunks) * 16u;
   if (need_pt > s->packet_time_capacity) {
     HIP_TRY(hipEventSynchronize(s->launch_done));
@@ -228,9 +251,12 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
+    if (s->d_chunk_shape) (void)hipFree(s->d_chunk_shape);
+    s->d_chunk_shape = nullptr;
     s->pack_capacity = 0;
     for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost})
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), static_cast<size_t>(map.n_chunks) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_chunk_shape), static_cast<size_t>(map.n_chunks) * sizeof(DevChunkShape)));
     s->pack_capacity = map.n_chunks;
   }
   return RTC_OK;
@@ -424,8 +450,9 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
       // frame); the three-wave kernel has half again as many waves and smaller shares, and there the cut pays from one
       // share on: reflection_and_refraction depth 8 at 1080p 2.12 -> 1.91 ms, cover 0.676 -> 0.670.
       // (a later measuring launch has overwritten the per-pixel costs: that read-back describes a frame that is gone)
+      static const bool no_host_split = getenv("RTC_NO_HOST_SPLIT") != nullptr;  // experiment knob
       const double factor = usesSimple3(s, map) ? 1.0 : 1.5;
-      const bool split = static_cast<double>(s->pin_info->heaviest) > factor * static_cast<double>(s->pin_info->total) / residentWaves(s, map);
+      const bool split = !no_host_split && static_cast<double>(s->pin_info->heaviest) > factor * static_cast<double>(s->pin_info->total) / residentWaves(s, map);
       if (split && s->readback_gen == s->measure_gen)
         if (const int st = enqueueCostCopy(s, out_pixels); st != RTC_OK) return st;
     } else if (ready != hipErrorNotReady) {
@@ -479,19 +506,24 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   if (from == PackFrom::Estimate) {
     // no frame has run yet: what every chunk is likely to cost, from the roots its pixels look at (in ticks already)
     hipLaunchKernelGGL(rtc_estimate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, s->dev, devCamera(cam), map, s->d_chunk_cost,
-                       s->d_chunk_time, s->d_pack_state);
+                       s->d_chunk_time, s->d_chunk_shape, s->d_pack_state);
   } else {
-    hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, s->d_cost, map, s->d_chunk_cost, s->d_chunk_time,
-                       s->d_pack_state);
+    hipLaunchKernelGGL(rtc_chunk_cost_kernel, dim3((n + 3u) / 4u), dim3(256), 0, stream, s->d_cost, map, max_depth, s->d_chunk_cost,
+                       s->d_chunk_time, s->d_chunk_shape, s->d_pack_state);
     hipLaunchKernelGGL(rtc_chunk_time_kernel, dim3((prev_packets + 255u) / 256u), dim3(256), 0, stream, map.order, map.n_units_dev,
-                       map.n_units, s->d_packet_time, s->d_chunk_cost, n, s->d_chunk_time);
+                       map.n_units, s->d_packet_time, s->d_chunk_cost, n, s->d_chunk_time, s->d_chunk_shape);
   }
   hipLaunchKernelGGL(rtc_pack_class_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_cost, n, cost_to_time,
-                     s->d_chunk_time, s->d_pack_state);
+                     s->d_chunk_shape, s->d_chunk_time, s->d_pack_state);
+  const float cut_above = static_cast<float>(cutAbove(s, map));
+  if (cut_above > 0.0f && from == PackFrom::Measurement)  // (RTC_PACK_ROUNDS of them; an estimate has no per-pixel spread to go by)
+    for (int round = 0; round < 3; ++round)
+      hipLaunchKernelGGL(rtc_pack_extra_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, cut_above,
+                         s->d_chunk_shape, round, s->d_pack_state);
   hipLaunchKernelGGL(rtc_pack_sort_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, t_min,
-                     s->d_pack_state, s->d_sorted, s->d_sched_info + target);
+                     cut_above, s->d_chunk_shape, s->d_pack_state, s->d_sorted, s->d_sched[target]);
   hipLaunchKernelGGL(rtc_pack_emit_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_sorted, n, n_waves, t_min,
-                     s->d_pack_state, s->d_sched[target]);
+                     cut_above, s->d_pack_state, s->d_sched[target], s->d_sched_info + target);
   HIP_TRY(hipGetLastError());
   s->measure_gen++;
   if (!unmeasured) {
@@ -1603,6 +1635,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_pack_state) (void)hipFree(s->d_pack_state);
   if (s->d_tile_list) (void)hipFree(s->d_tile_list);
   if (s->d_chunk_time) (void)hipFree(s->d_chunk_time);
+  if (s->d_chunk_shape) (void)hipFree(s->d_chunk_shape);
   if (s->d_sorted) (void)hipFree(s->d_sorted);
   if (s->pin_info) (void)hipHostFree(s->pin_info);
   if (s->d_cost) (void)hipFree(s->d_cost);

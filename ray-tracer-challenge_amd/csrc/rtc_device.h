@@ -242,6 +242,15 @@ struct DevPixelMap {
   uint32_t pull_min_idle;  // a wave pulls its next packet only when at least this many lanes are idle (or none has a ray)
 };
 
+// Per chunk, what cutting it into runs of pixels needs to know about how its rays are spread (rtc_chunk_cost_kernel, from
+// the per-pixel costs of a measured frame; the packer's emit step reads it for the few chunks it cuts).
+struct DevChunkShape {
+  float rays;     // rays its pixels' trees had, about (cost / 5: closest-hit and containers traces count 2, shadow rays 1); 0: not measured
+  float depth;    // the deepest tree among them, in levels (<= max_depth + 1, <= its rays)
+  uint32_t parts; // packets of the measured frame's schedule that held pixels of this chunk (rtc_chunk_time_kernel counts them)
+  uint8_t q[16];  // q[j]: one past the pixel (row-major in the 8x8) at which the running sum of rays passes j/16 of the total; q[0] = 0
+};
+
 // What rtc_pack_kernel leaves beside a schedule it packed.
 struct DevSchedInfo {
   uint32_t n_units;      // packets in the schedule
@@ -257,7 +266,9 @@ struct DevPackState {
   uint32_t cnt[RTC_PACK_CLASSES];     // chunks per class
   uint32_t cursor[RTC_PACK_CLASSES];  // chunks of the class already placed by the sort
   unsigned long long total;           // sum of the chunk times
-  uint32_t heaviest, pad_;
+  uint32_t heaviest;
+  uint32_t parts_cursor;              // packets handed out to the runs of cut chunks (the front of the schedule)
+  unsigned long long extra[4];        // time the cuts add (every run pays the depth of its deepest tree again): [i] as found in round i
 };
 
 // Zero at the start of every launch.  A scene owns TWO of these and alternates: launch n counts in [n & 1] and clears

@@ -132,6 +132,7 @@ struct rtc_scene {
   uint32_t sched_depth = 0;
   uint32_t* d_chunk_time = nullptr;       // rtc_pack_kernel scratch: per-chunk times, sorted chunks
   uint32_t* d_sorted = nullptr;
+  DevChunkShape* d_chunk_shape = nullptr; // per chunk: how its rays are spread over its pixels (for the chunks the packer cuts)
   size_t pack_capacity = 0;               // chunks
   // ---- measurements: per-pixel ray counts and per-packet times of a measuring launch
   uint32_t* d_cost = nullptr;

@@ -2242,7 +2242,7 @@ __device__ __forceinline__ uint32_t pack_class(uint32_t t) {
 // (14 ms of wall time for dragons at 4K).  Writes what rtc_chunk_cost_kernel + rtc_chunk_time_kernel would have left.
 extern "C" __global__ void __launch_bounds__(256)
 rtc_estimate_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map, uint32_t* __restrict__ chunk_cost,
-                    uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state) {
+                    uint32_t* __restrict__ chunk_time, DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state) {
   if (blockIdx.x == 0u) {
     uint32_t* z = reinterpret_cast<uint32_t*>(state);
     for (uint32_t i = threadIdx.x; i < sizeof(DevPackState) / sizeof(uint32_t); i += blockDim.x) z[i] = 0u;
@@ -2295,12 +2295,15 @@ rtc_estimate_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map
   }
   chunk_cost[c] = static_cast<uint32_t>(fminf(cost, 4.0e9f));
   chunk_time[c] = 0u;  // nothing was timed: the packer takes the cost (cost_to_time = 1)
+  chunk_shape[c].rays = 0.0f;  // (not measured: a chunk that is cut is cut into equal runs)
+  chunk_shape[c].parts = 0u;
 }
 
 // One wave per 8x8 chunk: coalesced rows of the cost array.
 extern "C" __global__ void __launch_bounds__(256)
-rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, uint32_t* __restrict__ chunk_cost,
-                      uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state) {
+rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, const uint32_t max_depth,
+                      uint32_t* __restrict__ chunk_cost, uint32_t* __restrict__ chunk_time,
+                      DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state) {
   if (blockIdx.x == 0u) {
     uint32_t* z = reinterpret_cast<uint32_t*>(state);
     for (uint32_t i = threadIdx.x; i < sizeof(DevPackState) / sizeof(uint32_t); i += blockDim.x) z[i] = 0u;
@@ -2312,11 +2315,34 @@ rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, 
   const uint32_t rx = (cr - ccy * map.chunks_x) * 8u + (k & 7u), ry = ccy * 8u + (k >> 3);
   const uint32_t w = map.mode == 0u ? map.w : map.tile_w, h = map.mode == 0u ? map.h : map.tile_h;
   const size_t out0 = map.mode == 0u ? 0 : static_cast<size_t>(region) * map.tile_h * map.tile_w;
-  uint32_t sum = (rx < w && ry < h) ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
+  const bool inside = rx < w && ry < h;
+  const uint32_t mine = inside ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
+  uint32_t sum = mine;
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  // How the chunk's rays are spread over its pixels (packSchedule's model, rtc_schedule.h: a pixel's tree has about
+  // cost / 5 rays and min(rays, max_depth + 1) levels): the total, the deepest tree, and the sixteenths of the running sum.
+  const float rays = inside ? fmaxf(1.0f, static_cast<float>(mine) * 0.2f) : 0.0f;
+  float run = rays;  // inclusive prefix sum over the wave's lanes = the chunk's pixels in row-major order
+  for (int off = 1; off < 64; off <<= 1) {
+    const float below = __shfl_up(run, off, 64);
+    if (k >= static_cast<uint32_t>(off)) run += below;
+  }
+  const float total = __shfl(run, 63, 64);
+  float deepest = fminf(rays, static_cast<float>(max_depth) + 1.0f);
+  for (int off = 32; off > 0; off >>= 1) deepest = fmaxf(deepest, __shfl_xor(deepest, off, 64));
+  uint32_t bound = 0u;  // lane j < 16: q[j]
+  for (uint32_t j = 1u; j < 16u; ++j) {
+    const unsigned long long passed = __ballot(run >= total * (static_cast<float>(j) * (1.0f / 16.0f)));
+    const uint32_t at = passed != 0ull ? static_cast<uint32_t>(__builtin_ctzll(passed)) : 63u;
+    if (k == j) bound = at + 1u;  // (the pixel that passes the mark still belongs to the run before it)
+  }
+  if (k < 16u) chunk_shape[c].q[k] = static_cast<uint8_t>(bound);
   if (k == 0u) {
     chunk_cost[c] = sum;
     chunk_time[c] = 0u;
+    chunk_shape[c].rays = total;
+    chunk_shape[c].depth = deepest;
+    chunk_shape[c].parts = 0u;
   }
 }
 
@@ -2324,7 +2350,8 @@ rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, 
 extern "C" __global__ void __launch_bounds__(256)
 rtc_chunk_time_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* __restrict__ prev_n_units_dev,
                       const uint32_t prev_n_units_host, const uint32_t* __restrict__ packet_time,
-                      const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, uint32_t* __restrict__ chunk_time) {
+                      const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, uint32_t* __restrict__ chunk_time,
+                      DevChunkShape* __restrict__ chunk_shape) {
   const uint32_t prev_n = prev_order == nullptr ? n_chunks : (prev_n_units_dev != nullptr ? *prev_n_units_dev : prev_n_units_host);
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= prev_n) return;
@@ -2352,16 +2379,20 @@ rtc_chunk_time_kernel(const uint32_t* __restrict__ prev_order, const uint32_t* _
     }
   }
   if (!(sum > 0.0f)) return;
-  // (atomics: a chunk that was cut into runs is timed in several packets)
+  // (atomics: a chunk that was cut into runs is timed in several packets - and counted, see rtc_pack_class_kernel)
 #pragma unroll
   for (uint32_t i = 0; i < RTC_PACKET_ITEMS; ++i)
-    if (ch[i] != RTC_NO_ITEM) atomicAdd(&chunk_time[ch[i]], static_cast<uint32_t>(static_cast<float>(pt) * w[i] / sum));
+    if (ch[i] != RTC_NO_ITEM) {
+      atomicAdd(&chunk_time[ch[i]], static_cast<uint32_t>(static_cast<float>(pt) * w[i] / sum));
+      atomicAdd(&chunk_shape[ch[i]].parts, 1u);
+    }
 }
 
 // One thread per chunk.
 extern "C" __global__ void __launch_bounds__(1024)
 rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_chunks, const float cost_to_time,
-                      uint32_t* __restrict__ chunk_time, DevPackState* __restrict__ state) {
+                      const DevChunkShape* __restrict__ chunk_shape, uint32_t* __restrict__ chunk_time,
+                      DevPackState* __restrict__ state) {
   __shared__ uint32_t cnt[RTC_PACK_CLASSES];
   __shared__ unsigned long long sh_total;
   __shared__ uint32_t sh_heaviest;
@@ -2378,7 +2409,15 @@ rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_
   if (c < n_chunks) {
     const uint32_t t = chunk_time[c];
     // a chunk that was not timed (a probe launch times nothing): its cost at the caller's estimate of ticks per unit
-    const float v = t != 0u ? static_cast<float>(t) : static_cast<float>(chunk_cost[c]) * cost_to_time;
+    float v = t != 0u ? static_cast<float>(t) : static_cast<float>(chunk_cost[c]) * cost_to_time;
+    // A chunk that ran in r parts was timed r times, and every part paid for the depth of its deepest tree: the parts
+    // took (r L + S) iterations together, the chunk whole would take L + S (the model of rtc_pack_emit_kernel).  What is
+    // packed is the time of the WHOLE chunk - otherwise a cut chunk looks heavier than it is and is cut further.
+    const DevChunkShape shape = chunk_shape[c];
+    if (t != 0u && shape.parts > 1u && shape.rays > 0.0f) {
+      const float S = shape.rays * (1.0f / 64.0f);
+      v *= (shape.depth + S) / (static_cast<float>(shape.parts) * shape.depth + S);
+    }
     const uint32_t tv = v < 4.0e9f ? static_cast<uint32_t>(v) : 4000000000u;
     chunk_time[c] = tv;
     total = tv;
@@ -2401,24 +2440,75 @@ rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_
   }
 }
 
+// Into how many runs a chunk of a cut class goes: packSchedule's model (rtc_schedule.h).  A wave renders one ray per lane
+// per iteration and the rays of a pixel's tree depend on each other level by level: pixels [a, b) take about L + S
+// iterations, L the deepest tree among them, S their rays / 64.  Every part pays L again, so the chunk is cut until a
+// part fits a wave's share or its S falls under L / 2 - a chunk that is all depth (a mirror chain, a few glass pixels on
+// a silhouette) stays whole.  At most sixteen: the runs end on sixteenths of the chunk's rays (DevChunkShape::q).
+// Without a measurement of the spread (the first frame of a pixel map): by the time alone, equal runs.
+__device__ __forceinline__ uint32_t cut_runs(const DevChunkShape& shape, const float T, const float fair) {
+  float want = T / fmaxf(fair, 1.0f);
+  if (shape.rays > 0.0f) {
+    const float S = shape.rays * (1.0f / 64.0f), depth = shape.depth;
+    const float per_iteration = T / fmaxf(depth + S, 1e-9f);
+    const float room = fmaxf(fair / fmaxf(per_iteration, 1e-9f) - depth, fmaxf(0.5f * depth, 0.5f));
+    want = S / room;
+  }
+  return static_cast<uint32_t>(fminf(fmaxf(__builtin_ceilf(want), 1.0f), 16.0f));
+}
+
+// A wave's fair share of the frame, the time the cuts add included (RTC_PACK_ROUNDS rounds of rtc_pack_extra_kernel:
+// a cut adds work, which raises the share, which takes back some cuts - packSchedule iterates the same way).
+#define RTC_PACK_ROUNDS 3
+__device__ __forceinline__ float fair_share(const DevPackState* __restrict__ state, const float n_waves, const int round) {
+  const unsigned long long extra = round > 0 ? state->extra[round - 1] : 0ull;
+  return static_cast<float>(state->total + extra) / fmaxf(1.0f, n_waves);
+}
+
+// One thread per chunk: what cutting it (with the share of round - 1) adds to the frame.
+extern "C" __global__ void __launch_bounds__(1024)
+rtc_pack_extra_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves, const float cut_above,
+                      const DevChunkShape* __restrict__ chunk_shape, const int round, DevPackState* __restrict__ state) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  float add = 0.0f;
+  if (c < n_chunks && cut_above > 0.0f) {
+    const float fair = fair_share(state, n_waves, round), T = static_cast<float>(chunk_time[c]);
+    const DevChunkShape shape = chunk_shape[c];
+    if (T > cut_above * fair && shape.rays > 0.0f) {
+      const uint32_t r = cut_runs(shape, T, fair);
+      const float S = shape.rays * (1.0f / 64.0f);
+      add = static_cast<float>(r - 1u) * shape.depth * T / fmaxf(shape.depth + S, 1e-9f);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) add += __shfl_down(add, off, 64);
+  if ((threadIdx.x & 63u) == 0u && add > 0.0f) atomicAdd(&state->extra[round], static_cast<unsigned long long>(add));
+}
+
 // Class bases (longest class first), chunks per packet and first packet of every class, from the histogram.
 struct PackLayout {
-  uint32_t cbase[RTC_PACK_CLASSES], per_packet[RTC_PACK_CLASSES], pbase[RTC_PACK_CLASSES], n_packets;
+  uint32_t cbase[RTC_PACK_CLASSES], per_packet[RTC_PACK_CLASSES], pbase[RTC_PACK_CLASSES], parts[RTC_PACK_CLASSES], n_packets;
 };
 // Called by every thread of a work-group (at least RTC_PACK_CLASSES of them); ends with a barrier.
+// cut_above: a class whose chunks take more than this many fair shares of a wave is CUT - every chunk of it into 1, 2,
+// 4, 8 or 16 runs of consecutive pixels, one packet each (cut_runs).  Small images and one rank's share of a frame split
+// over GPUs have such chunks (a full 1080p frame's heaviest chunk is about one share), and a launch ends when its
+// longest packet does.  The runs' packets are the FIRST of the schedule (the longest there are); a cut class has no
+// packets in the part of the schedule laid out here.  0: nothing is cut.
 __device__ __forceinline__ void pack_layout(const DevPackState* __restrict__ state, const float n_waves, const float t_min,
-                                            PackLayout& L) {
+                                            const float cut_above, PackLayout& L) {
   const uint32_t k = threadIdx.x;
   if (k < RTC_PACK_CLASSES) {  // per class, in parallel: its size, chunks per packet, packets
-    const float fair = static_cast<float>(state->total) / fmaxf(1.0f, n_waves);
+    const float fair = fair_share(state, n_waves, RTC_PACK_ROUNDS);
     const float group_cap = fmaxf(fair * (1.0f / 32.0f), t_min);
     const float t_hi = __builtin_exp2f(static_cast<float>(k + 1u) * 0.25f) - 1.0f;  // upper time bound of class k
     const float per = group_cap / fmaxf(t_hi, 1.0f);
     const uint32_t kk = per >= 16.0f ? 16u : (per < 1.0f ? 1u : static_cast<uint32_t>(per));
     const uint32_t n = state->cnt[k];
+    const bool cut = cut_above > 0.0f && t_hi > cut_above * fair;
     L.per_packet[k] = kk;
+    L.parts[k] = cut ? 1u : 0u;       // a cut class: its chunks' packets are at the front of the schedule (rtc_pack_sort_kernel)
     L.cbase[k] = n;                   // (turned into the exclusive sums below)
-    L.pbase[k] = (n + kk - 1u) / kk;
+    L.pbase[k] = cut ? 0u : (n + kk - 1u) / kk;
   }
   __syncthreads();
   if (k == 0u) {  // longest class first
@@ -2439,7 +2529,8 @@ __device__ __forceinline__ void pack_layout(const DevPackState* __restrict__ sta
 // (inside a block and between blocks the order is arrival order).
 extern "C" __global__ void __launch_bounds__(1024)
 rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves, const float t_min,
-                     DevPackState* __restrict__ state, uint32_t* __restrict__ sorted, DevSchedInfo* __restrict__ info) {
+                     const float cut_above, const DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state,
+                     uint32_t* __restrict__ sorted, uint32_t* __restrict__ order_out) {
   __shared__ PackLayout L;
   __shared__ uint32_t cnt[RTC_PACK_CLASSES], start[RTC_PACK_CLASSES], cursor[RTC_PACK_CLASSES];
   const uint32_t tid = threadIdx.x;
@@ -2447,7 +2538,7 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
     cnt[tid] = 0u;
     cursor[tid] = 0u;
   }
-  pack_layout(state, n_waves, t_min, L);
+  pack_layout(state, n_waves, t_min, cut_above, L);
   const uint32_t c = blockIdx.x * blockDim.x + tid;
   uint32_t k = 0u;
   if (c < n_chunks) {
@@ -2458,29 +2549,48 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
   if (tid < RTC_PACK_CLASSES && cnt[tid] != 0u) start[tid] = atomicAdd(&state->cursor[tid], cnt[tid]);
   __syncthreads();
   if (c < n_chunks) sorted[L.cbase[k] + start[k] + atomicAdd(&cursor[k], 1u)] = c | (k << 20);  // 2^20 chunks at most; the class rides along
-  if (blockIdx.x == 0u && tid == 0u) {
-    info->n_units = L.n_packets;
-    info->heaviest = state->heaviest;
-    // (whether the heaviest chunk is cut into runs is the host's call, from `heaviest` and `total`: updateSchedule)
-    info->needs_split = static_cast<double>(state->heaviest) > static_cast<double>(state->total) / fmax(1.0, static_cast<double>(n_waves)) ? 1u : 0u;
-    info->pad_ = 0u;
-    info->total = state->total;
+  if (c < n_chunks && L.parts[k] != 0u) {  // a chunk of a cut class: its runs, one packet each, at the front of the schedule
+    const DevChunkShape shape = chunk_shape[c];
+    const float fair = fair_share(state, n_waves, RTC_PACK_ROUNDS);
+    const uint32_t r = cut_runs(shape, static_cast<float>(chunk_time[c]), fair);
+    const uint32_t at = atomicAdd(&state->parts_cursor, r);
+    // run q ends at the sixteenth of the chunk's rays (or, unmeasured, of its pixels) nearest to (q + 1) / r
+    auto mark = [&](uint32_t q) -> uint32_t {
+      const uint32_t sixteenth = (16u * q + r / 2u) / r;
+      return shape.rays > 0.0f ? shape.q[sixteenth] : sixteenth * 4u;
+    };
+    for (uint32_t q = 0; q < r; ++q) {
+      const uint32_t a = q == 0u ? 0u : mark(q);
+      const uint32_t b = q + 1u == r ? 64u : mark(q + 1u);
+      uint4* row = reinterpret_cast<uint4*>(order_out + static_cast<size_t>(at + q) * RTC_PACKET_ITEMS);
+      row[0] = uint4{b > a ? (c | (a << 20) | ((b - a - 1u) << 26)) : RTC_NO_ITEM, RTC_NO_ITEM, RTC_NO_ITEM, RTC_NO_ITEM};  // (an empty run: an empty packet)
+      row[1] = row[2] = row[3] = uint4{RTC_NO_ITEM, RTC_NO_ITEM, RTC_NO_ITEM, RTC_NO_ITEM};
+    }
   }
 }
 
 // One thread per sorted chunk; the first chunk of each packet writes the whole row of 16 items.
 extern "C" __global__ void __launch_bounds__(1024)
 rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves, const float t_min,
-                     const DevPackState* __restrict__ state, uint32_t* __restrict__ order_out) {
+                     const float cut_above, const DevPackState* __restrict__ state, uint32_t* __restrict__ order_out,
+                     DevSchedInfo* __restrict__ info) {
   __shared__ PackLayout L;
-  pack_layout(state, n_waves, t_min, L);
+  pack_layout(state, n_waves, t_min, cut_above, L);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0u) {
+    info->n_units = state->parts_cursor + L.n_packets;
+    info->heaviest = state->heaviest;
+    info->needs_split = 0u;
+    info->pad_ = 0u;
+    info->total = state->total;
+  }
   if (i >= n_chunks) return;
   const uint32_t e = sorted[i];
   const uint32_t k = e >> 20;
   const uint32_t j = i - L.cbase[k], kk = L.per_packet[k];
+  if (L.parts[k] != 0u) return;  // (a cut class: rtc_pack_sort_kernel wrote its packets)
   if (j % kk != 0u) return;
-  const uint32_t p = L.pbase[k] + j / kk;
+  const uint32_t p = state->parts_cursor + L.pbase[k] + j / kk;  // (behind the runs of the cut chunks)
   const uint32_t have = min(kk, state->cnt[k] - j);
   uint32_t items[RTC_PACKET_ITEMS];
 #pragma unroll
