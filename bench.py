@@ -352,16 +352,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Scene setup, like the upload and the BVH build above: the first launch with a pixel map measures the
-    # per-pixel ray counts and the second packs the schedule from them (rtc_capi.hip, launch()); after that a
-    # static view renders from that schedule.  Done here so that --warmup 0 still times steady-state frames.
+    # Scene setup, like the upload and the BVH build above: the first launch with a pixel map runs a schedule packed from
+    # an estimate and measures (per-pixel ray counts, per-packet times); the packer behind it makes the schedule a static
+    # view renders from after that (rtc_capi.hip, launch()).  Done here so that --warmup 0 still times steady-state frames.
     for i in range(2):
         step(i)
         barrier()
-    # (where a chunk exceeds a wave's share the library cuts it into runs on a worker thread and switches when that is
-    # finished: wait for it - rtc_scene_synchronize - so that the launch below, not some timed frame, picks it up)
-    gpu.synchronize()
-    step(2)
     finish()
     barrier()
     for i in range(args.warmup):

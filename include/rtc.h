@@ -327,10 +327,7 @@ int rtc_assemble_tiles_device(const double *d_gathered, uint32_t world, uint32_t
                               uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
                               double *d_canvas, void *hip_stream);
 
-/* Waits for the work enqueued on the handle's own stream - and for the worker
- * thread, if the library is still cutting the heaviest chunks of the last
- * measured frame into runs (a schedule refinement that otherwise arrives a few
- * frames later; results never depend on it): the next render uses it. */
+/* Waits for the work enqueued on the handle's own stream. */
 int rtc_scene_synchronize(rtc_scene *scene);
 
 /* Counters of the last render that was enqueued on this handle (synchronises). */
@@ -340,6 +337,13 @@ int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
  * (the name rocprofv3 shows - which variant is picked depends on what the world
  * contains and on the size of the launch); "" before the first launch.  Static storage. */
 const char *rtc_last_kernel_name(const rtc_scene *scene);
+
+/* Diagnostic: the schedule the NEXT launch of the handle's current pixel map would run - the order in which the
+ * persistent waves are handed pixels (results never depend on it) - as `*n_packets` rows of 16 items; an item is
+ * chunk | first_pixel << 20 | (pixels - 1) << 26 (pixels of an 8x8 chunk in row-major order), 0xFFFFFFFF = none.
+ * Synchronises.  `*n_packets` = 0 when the handle has no schedule (no launch yet, or a launch of fewer than 64 chunks).
+ * RTC_ERR_INVALID_ARGUMENT if `capacity_items` is too small (`*n_packets` says how many rows there are). */
+int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, uint32_t *n_packets);
 
 /* Thread-local, static storage; "" when the last call on this thread succeeded. */
 const char *rtc_last_error(void);

@@ -86,6 +86,7 @@ pub extern fn rtc_render_device(scene: *RtcScene, cam: *const RtcCamera, max_dep
 pub extern fn rtc_scene_synchronize(scene: *RtcScene) c_int;
 pub extern fn rtc_get_stats(scene: *RtcScene, out: *RtcStats) c_int;
 pub extern fn rtc_last_kernel_name(scene: *const RtcScene) [*:0]const u8;
+pub extern fn rtc_get_schedule(scene: *RtcScene, items: ?[*]u32, capacity_items: usize, n_packets: *u32) c_int;
 pub extern fn rtc_last_error() [*:0]const u8;
 pub extern fn rtc_status_name(status: c_int) [*:0]const u8;
 

@@ -90,7 +90,7 @@ class Stats(C.Structure):
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
-               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_last_error",
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
                "rtc_status_name"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
@@ -156,6 +156,7 @@ def hip_lib():
         lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         lib.rtc_last_kernel_name.argtypes = [C.c_void_p]
         lib.rtc_last_kernel_name.restype = C.c_char_p
+        lib.rtc_get_schedule.argtypes = [C.c_void_p, _u32p, C.c_size_t, _u32p]
         _hip = lib
     return _hip
 
@@ -385,6 +386,17 @@ class GpuScene:
     def last_kernel_name(self):
         """The render kernel the last launch on this handle ran (the name rocprofv3 shows)."""
         return hip_lib().rtc_last_kernel_name(self._s).decode()
+
+    def schedule(self):
+        """Diagnostic: the packets the next launch of the current pixel map would run, [n][16] u32 (rtc_get_schedule)."""
+        n = C.c_uint32()
+        st = hip_lib().rtc_get_schedule(self._s, None, 0, C.byref(n))
+        if n.value == 0:
+            _check_hip(st)
+            return np.zeros((0, 16), dtype=np.uint32)
+        out = np.empty((n.value, 16), dtype=np.uint32)
+        _check_hip(hip_lib().rtc_get_schedule(self._s, out.ctypes.data_as(_u32p), out.size, C.byref(n)))
+        return out[:n.value]
 
     def close(self):
         if self._s:

@@ -6,8 +6,6 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstddef>
-#include <map>
-#include <mutex>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -228,8 +226,8 @@ size_t maxPackets(const rtc_scene* s, const DevPixelMap& map) {
 // The measured schedule in use, into a launch's pixel map.
 void useSchedule(const rtc_scene* s, DevPixelMap& map) {
   map.order = s->d_sched[s->sched_cur];
-  map.n_units_dev = s->sched_on_device ? &s->d_sched_info[s->sched_cur].n_units : nullptr;
-  map.n_units = s->sched_on_device ? static_cast<uint32_t>(maxPackets(s, map)) : s->sched_n_units;  // (device-packed: an upper bound, for the grid)
+  map.n_units_dev = &s->d_sched_info[s->sched_cur].n_units;
+  map.n_units = static_cast<uint32_t>(maxPackets(s, map));  // (an upper bound, for the grid: the count is in device memory)
 }
 
 // Everything a measuring launch and the packer behind it write to.
@@ -262,141 +260,6 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
   return RTC_OK;
 }
 
-// What the off-thread cutting of chunks needs from the runtime - a stream for the copy of the per-pixel costs and pinned
-// memory to copy them into - is shared by all handles of a device and kept for the life of the process: a stream costs
-// 2 ms to create and pinned memory a millisecond per 8 MB, a test run creates three hundred handles, and a host that
-// re-creates its scene per frame should not pin and unpin 8 MB each time.  (The copies are rare - one per view that
-// needs its chunks cut - and every handle has its own event on the shared stream.)
-struct CopyPool {
-  struct PerDevice {
-    hipStream_t stream = nullptr;
-    std::vector<std::pair<uint32_t*, size_t>> free_buffers;  // (pointer, capacity in u32)
-  };
-  std::mutex lock;
-  std::map<int, PerDevice> devices;
-};
-CopyPool& copyPool() {
-  static CopyPool* const pool = new CopyPool;  // (never destroyed: no HIP calls from static destructors)
-  return *pool;
-}
-
-// A pinned buffer of at least `pixels` u32 for this handle (its old one goes back to the pool).
-int acquirePinnedCosts(rtc_scene* s, size_t pixels) {
-  if (pixels <= s->pin_cost_capacity) return RTC_OK;
-  CopyPool& pool = copyPool();
-  std::lock_guard<std::mutex> guard(pool.lock);
-  CopyPool::PerDevice& dev = pool.devices[s->device];
-  if (s->pin_cost) dev.free_buffers.emplace_back(s->pin_cost, s->pin_cost_capacity);
-  s->pin_cost = nullptr;
-  s->pin_cost_capacity = 0;
-  for (size_t i = 0; i < dev.free_buffers.size(); ++i) {
-    if (dev.free_buffers[i].second >= pixels) {
-      s->pin_cost = dev.free_buffers[i].first;
-      s->pin_cost_capacity = dev.free_buffers[i].second;
-      dev.free_buffers.erase(dev.free_buffers.begin() + static_cast<std::ptrdiff_t>(i));
-      return RTC_OK;
-    }
-  }
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_cost), pixels * sizeof(uint32_t), hipHostMallocDefault));
-  s->pin_cost_capacity = pixels;
-  return RTC_OK;
-}
-
-void releasePinnedCosts(rtc_scene* s) {
-  if (!s->pin_cost) return;
-  CopyPool& pool = copyPool();
-  std::lock_guard<std::mutex> guard(pool.lock);
-  pool.devices[s->device].free_buffers.emplace_back(s->pin_cost, s->pin_cost_capacity);
-  s->pin_cost = nullptr;
-  s->pin_cost_capacity = 0;
-}
-
-// The device's copy stream, created (and its copy path warmed) by the first handle that asks.
-int acquireCopyStream(rtc_scene* s) {
-  CopyPool& pool = copyPool();
-  std::lock_guard<std::mutex> guard(pool.lock);
-  CopyPool::PerDevice& dev = pool.devices[s->device];
-  if (!dev.stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&dev.stream, hipStreamNonBlocking));
-    // The first device-to-host copy of some size in a process costs 8 ms (the runtime sets up its copy engine path; a
-    // 4-byte copy does not trigger it, 256 KB does): paid here, once, not in the frame that first cuts chunks.
-    void* d_tmp = nullptr;
-    void* h_tmp = nullptr;
-    HIP_TRY(hipMalloc(&d_tmp, 1u << 20));
-    HIP_TRY(hipHostMalloc(&h_tmp, 1u << 20, hipHostMallocDefault));
-    HIP_TRY(hipMemcpyAsync(h_tmp, d_tmp, 1u << 20, hipMemcpyDeviceToHost, dev.stream));
-    HIP_TRY(hipStreamSynchronize(dev.stream));
-    HIP_TRY(hipHostFree(h_tmp));
-    HIP_TRY(hipFree(d_tmp));
-  }
-  s->copy_stream = dev.stream;
-  return RTC_OK;
-}
-
-// ---- cutting chunks into runs, off the caller's thread.  packSchedule is per-pixel work on the host (10-30 ms for a
-// 1080p frame).  The launch that learns from the read-back that a chunk is too heavy enqueues a copy of the per-pixel
-// costs to pinned memory on a stream of its own (it overlaps the frames that follow); the launch that finds the copy
-// complete hands it to a worker thread (pure CPU work, no HIP calls: a worker that copied the costs itself held the
-// runtime's locks and delayed the caller's next launch by half a millisecond); the launch that finds the worker finished
-// uploads the result and switches.  Until then the frames run the device-packed schedule.  d_cost is only written by a
-// MEASURING launch, which makes the copy stale (its generation no longer matches: it is dropped).  Freeing d_cost, a new
-// pixel map and rtc_scene_destroy wait for copy and worker.
-void waitSplitJob(rtc_scene* s) {
-  if (s->split_job && s->split_job->worker.joinable()) s->split_job->worker.join();
-}
-
-void dropSplitJob(rtc_scene* s) {
-  if (s->cost_copy_pending) (void)hipEventSynchronize(s->cost_copied);
-  s->cost_copy_pending = false;
-  waitSplitJob(s);
-  s->split_job.reset();
-}
-
-int enqueueCostCopy(rtc_scene* s, size_t out_pixels) {
-  dropSplitJob(s);
-  if (const int st = acquirePinnedCosts(s, out_pixels); st != RTC_OK) return st;  // (beyond what rtc_scene_create took: a millisecond per 8 MB)
-  HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->launch_done, 0));  // (the measuring launch and everything enqueued since)
-  HIP_TRY(hipMemcpyAsync(s->pin_cost, s->d_cost, out_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
-  HIP_TRY(hipEventRecord(s->cost_copied, s->copy_stream));
-  s->cost_copy_pending = true;
-  s->cost_copy_pixels = out_pixels;
-  return RTC_OK;
-}
-
-void startSplitJob(rtc_scene* s, const DevPixelMap& map) {
-  waitSplitJob(s);
-  s->split_job.reset(new SplitJob);
-  SplitJob& job = *s->split_job;
-  job.map = map;
-  job.key = s->cost_key;
-  job.gen = s->readback_gen;
-  job.cam = s->readback_cam;
-  job.depth = s->readback_depth;
-  job.n_waves = residentWaves(s, map);
-  job.chunk_cost.assign(s->pin_chunk_cost, s->pin_chunk_cost + map.n_chunks);
-  job.chunk_time.assign(s->pin_chunk_time, s->pin_chunk_time + map.n_chunks);
-  job.state.store(1);
-  job.worker = std::thread([s, &job] {
-    job.cost.assign(s->pin_cost, s->pin_cost + s->cost_copy_pixels);  // (pin_cost is not written again before this job is dropped)
-    packSchedule(s, job.map, job.cost, job.chunk_cost, job.chunk_time, job.n_waves, job.depth, job.order);
-    job.state.store(2);
-  });
-}
-
-// A finished job's schedule becomes the one in use - if it still describes this pixel map and the last measured frame.
-int finishSplitJob(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
-  if (!s->split_job || s->split_job->state.load() < 2) return RTC_OK;
-  waitSplitJob(s);
-  const std::unique_ptr<SplitJob> job = std::move(s->split_job);
-  if (job->state.load() != 2 || job->key != s->cost_key || job->gen != s->measure_gen) return RTC_OK;
-  s->h_order.swap(job->order);
-  if (const int st = uploadSchedule(s, map, stream); st != RTC_OK) return st;
-  s->sched_valid = true;
-  s->sched_cam = job->cam;
-  s->sched_depth = job->depth;
-  return RTC_OK;
-}
-
 // The schedule of one launch (results never depend on it).  All of it is made on the device.
 //   * first launch of a pixel map: rtc_estimate_kernel guesses what every chunk will cost from the roots its pixels can
 //     see (bounding spheres, material weights) and the packer orders the frame by that.  (Round 1 did this with a
@@ -409,9 +272,8 @@ int finishSplitJob(rtc_scene* s, const DevPixelMap& map, hipStream_t stream) {
 //     the next launch runs a schedule packed on the device from those measurements.  Nothing waits for the host;
 //   * so an orbiting camera (lib.zig:166-190) renders every frame with the schedule of the frame before, and a static
 //     view keeps the schedule of its first full frame and measures nothing more;
-//   * the first full measurement is also read back (per-chunk costs and times, the packer's verdict): if a chunk took
-//     much longer than a wave's fair share (small images, one rank's share of a frame split over GPUs) the host cuts such
-//     chunks into runs of pixels (packSchedule) and the launch that finds the read-back complete switches to that.
+//   * chunks that take more than a wave's fair share (small images, one rank's share of a frame split over GPUs) are cut
+//     into runs of pixels by the packer itself (cutAbove, rtc_pack_sort_kernel): a launch ends when its longest packet does.
 struct SchedulePlan {
   bool measure = false;   // this launch collects costs and packet times, and the next schedule is packed from them
   bool estimate = false;  // ... and is preceded by rtc_estimate_kernel + the packer: ITS schedule from the roots' bounds
@@ -424,54 +286,17 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
   if (mkey != s->cost_key) {
     s->cost_key = mkey;
-    s->launches_with_key = 0;
     s->sched_valid = false;
-    s->split_checked = false;
-    if (s->readback_enqueued) HIP_TRY(hipEventSynchronize(s->measure_done));  // (its copies must not land in a later read-back's buffers)
-    s->readback_enqueued = false;
-    dropSplitJob(s);  // (it packs the pixel map that is gone)
   }
   if (out_pixels > s->cost_capacity) {
-    dropSplitJob(s);  // (it reads d_cost)
     HIP_TRY(hipEventSynchronize(s->launch_done));
     if (s->d_cost) (void)hipFree(s->d_cost);
     s->d_cost = nullptr;
     s->cost_capacity = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
     s->cost_capacity = out_pixels;
-    s->readback_enqueued = false;
   }
   const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
-  if (schedulable && s->readback_enqueued) {
-    const hipError_t ready = hipEventQuery(s->measure_done);
-    if (ready == hipSuccess) {
-      s->readback_enqueued = false;
-      // Cut chunks into runs where one is well above a wave's fair share (a small image, a rank's share of a split
-      // frame); the three-wave kernel has half again as many waves and smaller shares, and there the cut pays from one
-      // share on: reflection_and_refraction depth 8 at 1080p 2.12 -> 1.91 ms, cover 0.676 -> 0.670.
-      // (a later measuring launch has overwritten the per-pixel costs: that read-back describes a frame that is gone)
-      static const bool no_host_split = getenv("RTC_NO_HOST_SPLIT") != nullptr;  // experiment knob
-      const double factor = usesSimple3(s, map) ? 1.0 : 1.5;
-      const bool split = !no_host_split && static_cast<double>(s->pin_info->heaviest) > factor * static_cast<double>(s->pin_info->total) / residentWaves(s, map);
-      if (split && s->readback_gen == s->measure_gen)
-        if (const int st = enqueueCostCopy(s, out_pixels); st != RTC_OK) return st;
-    } else if (ready != hipErrorNotReady) {
-      HIP_TRY(ready);
-    }
-  }
-  const bool split_sync = getenv("RTC_SPLIT_SYNC") != nullptr;  // tests (read per call): this very launch runs the cut schedule
-  if (schedulable && s->cost_copy_pending) {
-    const hipError_t ready = split_sync ? hipEventSynchronize(s->cost_copied) : hipEventQuery(s->cost_copied);
-    if (ready == hipSuccess) {
-      s->cost_copy_pending = false;
-      if (s->readback_gen == s->measure_gen) startSplitJob(s, map);
-      if (split_sync) waitSplitJob(s);
-    } else if (ready != hipErrorNotReady) {
-      HIP_TRY(ready);
-    }
-  }
-  if (schedulable)
-    if (const int st = finishSplitJob(s, map, stream); st != RTC_OK) return st;
   static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: no schedule at all (packet i is chunk i)
   if (!schedulable || sched_off) {  // a handful of chunks, or more than an item can name: packet i is chunk i, whole
     map.order = nullptr;
@@ -525,38 +350,12 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   hipLaunchKernelGGL(rtc_pack_emit_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_sorted, n, n_waves, t_min,
                      cut_above, s->d_pack_state, s->d_sched[target], s->d_sched_info + target);
   HIP_TRY(hipGetLastError());
-  s->measure_gen++;
   if (!unmeasured) {
     s->measured_regions = map.mode == 0u ? 1u : map.n_my_tiles;
     s->measured_chunks_per_region = map.chunks_per_region;
   }
-  if (!unmeasured && !s->split_checked && !s->readback_enqueued) {  // the first full measurement of this pixel map
-    auto pinned = [](auto*& p, size_t& capacity, size_t n) -> hipError_t {
-      if (n <= capacity) return hipSuccess;
-      if (p) (void)hipHostFree(p);
-      p = nullptr;
-      capacity = 0;
-      const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), n * sizeof(*p), hipHostMallocDefault);
-      if (e == hipSuccess) capacity = n;
-      return e;
-    };
-    HIP_TRY(pinned(s->pin_chunk_cost, s->pin_chunk_cost_capacity, map.n_chunks));
-    HIP_TRY(pinned(s->pin_chunk_time, s->pin_chunk_time_capacity, map.n_chunks));
-    if (!s->pin_info) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->pin_info), sizeof(DevSchedInfo), hipHostMallocDefault));
-    if (!s->measure_done) HIP_TRY(hipEventCreateWithFlags(&s->measure_done, hipEventDisableTiming));
-    HIP_TRY(hipMemcpyAsync(s->pin_chunk_cost, s->d_chunk_cost, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(s->pin_chunk_time, s->d_chunk_time, static_cast<size_t>(map.n_chunks) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(s->pin_info, s->d_sched_info + target, sizeof(DevSchedInfo), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(s->measure_done, stream));
-    s->readback_enqueued = true;
-    s->split_checked = true;
-    s->readback_gen = s->measure_gen;
-    s->readback_cam = cam;
-    s->readback_depth = max_depth;
-  }
   s->sched_cur = target;
   s->sched_valid = true;
-  s->sched_on_device = true;
   s->sched_cam = cam;
   s->sched_depth = max_depth;
   return RTC_OK;
@@ -1514,12 +1313,6 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
   HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(s->launch_done, s->stream));
-  // What the off-thread cutting of chunks needs (enqueueCostCopy), taken here rather than in the frame that first wants
-  // it: the device's copy stream and pinned room for a 1080p frame's per-pixel costs (CopyPool: after the first handle of
-  // a process both come from the pool).
-  if (const int st = acquireCopyStream(s); st != RTC_OK) return st;
-  HIP_TRY(hipEventCreateWithFlags(&s->cost_copied, hipEventDisableTiming));
-  if (const int st = acquirePinnedCosts(s, 1920u * 1080u); st != RTC_OK) return st;
   s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
   {
@@ -1618,9 +1411,6 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
 void rtc_scene_destroy(rtc_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
-  dropSplitJob(s);
-  if (s->cost_copied) (void)hipEventDestroy(s->cost_copied);
-  releasePinnedCosts(s);  // (copy_stream is the device's, shared)
   if (s->launch_done) (void)hipEventSynchronize(s->launch_done);  // the last launch, whatever stream it ran on
   if (s->stream) {
     (void)hipStreamSynchronize(s->stream);
@@ -1637,13 +1427,9 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->d_chunk_time) (void)hipFree(s->d_chunk_time);
   if (s->d_chunk_shape) (void)hipFree(s->d_chunk_shape);
   if (s->d_sorted) (void)hipFree(s->d_sorted);
-  if (s->pin_info) (void)hipHostFree(s->pin_info);
   if (s->d_cost) (void)hipFree(s->d_cost);
   if (s->d_chunk_cost) (void)hipFree(s->d_chunk_cost);
   if (s->d_packet_time) (void)hipFree(s->d_packet_time);
-  if (s->pin_chunk_cost) (void)hipHostFree(s->pin_chunk_cost);
-  if (s->pin_chunk_time) (void)hipHostFree(s->pin_chunk_time);
-  if (s->measure_done) (void)hipEventDestroy(s->measure_done);
   if (s->launch_done) (void)hipEventDestroy(s->launch_done);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
@@ -1904,12 +1690,28 @@ int rtc_scene_synchronize(rtc_scene* s) {
   if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  if (s->cost_copy_pending) HIP_TRY(hipEventSynchronize(s->cost_copied));
-  waitSplitJob(s);  // (a schedule the host is still cutting: the next launch finds it finished)
   return RTC_OK;
 }
 
 const char* rtc_last_kernel_name(const rtc_scene* s) { return s != nullptr ? s->last_kernel : ""; }
+
+int rtc_get_schedule(rtc_scene* s, uint32_t* items, size_t capacity_items, uint32_t* n_packets) {
+  g_error.clear();
+  if (!s || !n_packets) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  *n_packets = 0;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->launch_done));
+  if (!s->sched_valid || !s->d_sched_info) return RTC_OK;
+  DevSchedInfo info{};
+  HIP_TRY(hipMemcpy(&info, s->d_sched_info + s->sched_cur, sizeof info, hipMemcpyDeviceToHost));
+  *n_packets = info.n_units;
+  const size_t need = static_cast<size_t>(info.n_units) * RTC_PACKET_ITEMS;
+  if (need > s->sched_capacity) return fail(RTC_ERR_OVERFLOW, "the schedule has %u packets, its buffer holds %zu", info.n_units, s->sched_capacity / RTC_PACKET_ITEMS);
+  if (need > capacity_items || (need != 0 && !items))
+    return fail(RTC_ERR_INVALID_ARGUMENT, "the schedule has %u packets of %u items", info.n_units, RTC_PACKET_ITEMS);
+  HIP_TRY(hipMemcpy(items, s->d_sched[s->sched_cur], need * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RTC_OK;
+}
 
 int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   g_error.clear();

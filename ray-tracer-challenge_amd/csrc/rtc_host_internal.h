@@ -8,9 +8,7 @@
 #include <cstddef>
 #include <cstring>
 #include <string>
-#include <atomic>
 #include <memory>
-#include <thread>
 #include <vector>
 
 #include "../../include/rtc.h"
@@ -62,19 +60,6 @@ struct Sphere {
   bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
 };
 
-// One run of packSchedule on a worker thread (rtc_capi.hip: startSplitJob / finishSplitJob).
-struct SplitJob {
-  std::thread worker;
-  std::atomic<int> state{0};        // 1 running, 2 finished
-  DevPixelMap map{};                // what it packs: the pixel map, and its key in rtc_scene::cost_key
-  std::vector<uint32_t> key;
-  uint64_t gen = 0;                 // the measuring launch its inputs come from
-  rtc_camera cam{};
-  uint32_t depth = 0;
-  double n_waves = 0.0;
-  std::vector<uint32_t> chunk_cost, chunk_time, cost, order;
-};
-
 struct rtc_scene {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -116,21 +101,18 @@ struct rtc_scene {
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1, blocks_per_cu_simple3 = 1;
   // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next
-  // launch runs; a measuring launch is followed by rtc_pack_kernel, which packs the other buffer from what the launch
-  // measured, and the buffers swap - no host in the loop.  The host only writes a buffer for the first launch of a pixel
-  // map (the geometric heuristic, chunkOrder) and when some chunk has to be cut into runs (packSchedule).
-  std::vector<uint32_t> h_order;          // the last schedule the HOST built (heuristic or split)
+  // launch runs; a measuring launch is followed by the packer's launches, which pack the other buffer from what the
+  // launch measured (the first launch of a pixel map: from rtc_estimate_kernel's guesses), and the buffers swap - no host
+  // in the loop, nothing is read back.
   uint32_t* d_sched[2] = {nullptr, nullptr};
   size_t sched_capacity = 0;              // words per buffer
   uint32_t sched_cur = 0;
-  DevSchedInfo* d_sched_info = nullptr;   // [2], beside the buffers
+  DevSchedInfo* d_sched_info = nullptr;   // [2], beside the buffers: the packet count of each (DevPixelMap::n_units_dev)
   DevPackState* d_pack_state = nullptr;   // the packer's histogram and totals
-  bool sched_valid = false;               // d_sched[sched_cur] holds a MEASURED schedule for the pixel map `cost_key`
-  bool sched_on_device = false;           // ... packed by rtc_pack_kernel: its packet count is in d_sched_info[sched_cur]
-  uint32_t sched_n_units = 0;             // ... packed by the host: its packet count
+  bool sched_valid = false;               // d_sched[sched_cur] holds a schedule for the pixel map `cost_key`
   rtc_camera sched_cam{};                 // the view (and depth) that schedule was measured with: another view measures again
   uint32_t sched_depth = 0;
-  uint32_t* d_chunk_time = nullptr;       // rtc_pack_kernel scratch: per-chunk times, sorted chunks
+  uint32_t* d_chunk_time = nullptr;       // the packer's scratch: per-chunk times, sorted chunks
   uint32_t* d_sorted = nullptr;
   DevChunkShape* d_chunk_shape = nullptr; // per chunk: how its rays are spread over its pixels (for the chunks the packer cuts)
   size_t pack_capacity = 0;               // chunks
@@ -138,36 +120,10 @@ struct rtc_scene {
   uint32_t* d_cost = nullptr;
   size_t cost_capacity = 0;
   std::vector<uint32_t> cost_key;  // pixel map the costs / the schedule belong to
-  std::vector<uint32_t> h_cost;
   uint32_t* d_chunk_cost = nullptr;  // per-chunk sums of d_cost (rtc_chunk_cost_kernel)
   size_t chunk_cost_capacity = 0;
   uint32_t* d_packet_time = nullptr;  // per packet of the measured schedule: the time its wave needed (DevPixelMap::packet_time)
   size_t packet_time_capacity = 0;
-  uint64_t launches_with_key = 0;
-  uint64_t measure_gen = 0;        // measuring launches so far (a read-back belongs to one of them)
-  // The FIRST full measuring launch of a pixel map is also read back: per-chunk costs and times and the packer's verdict
-  // go to pinned host memory behind an event; a later launch that finds the event complete cuts the chunks that exceed a
-  // wave's fair share into runs (packSchedule) if the packer asked for it.
-  // Cutting chunks into runs is per-pixel work on the host (10-30 ms at 1080p): a worker thread does it while the frames
-  // go on with the device-packed schedule, and the launch that finds it finished switches (SplitJob, rtc_capi.hip).
-  std::unique_ptr<SplitJob> split_job;
-  hipStream_t copy_stream = nullptr;  // the copy of the per-pixel costs to pin_cost (non-blocking: it must not wait for the caller's streams)
-  hipEvent_t cost_copied = nullptr;
-  bool cost_copy_pending = false;
-  size_t cost_copy_pixels = 0;
-  uint32_t* pin_cost = nullptr;
-  size_t pin_cost_capacity = 0;
-  hipEvent_t measure_done = nullptr;
-  bool readback_enqueued = false;
-  uint64_t readback_gen = 0;
-  bool split_checked = false;      // that read-back has been enqueued for the pixel map in use
-  rtc_camera readback_cam{};
-  uint32_t readback_depth = 0;
-  uint32_t* pin_chunk_cost = nullptr;
-  size_t pin_chunk_cost_capacity = 0;
-  uint32_t* pin_chunk_time = nullptr;
-  size_t pin_chunk_time_capacity = 0;
-  DevSchedInfo* pin_info = nullptr;
   // mode-2 pixel maps (rtc_render_tile_list_device): the list of the last such launch, on both sides
   std::vector<uint32_t> h_tile_list;
   uint32_t* d_tile_list = nullptr;

@@ -69,6 +69,7 @@ struct rtc_multi {
   std::vector<std::vector<uint32_t>> tiles_of;
   bool balanced = false;
   uint32_t frames_since_balance = 0;
+  uint32_t redeals_in_a_row = 0;   // (a re-deal that the very next frame's measurement did not confirm is done again, three times at most)
   rtc_camera balance_cam{};
   double max_over_mean = 0.0;
 };
@@ -134,8 +135,11 @@ int sizeFor(rtc_multi* m, const rtc_camera& cam) {
   return RTC_OK;
 }
 
-// Re-deal the tiles by what the ranks measured for them in the frame just rendered.
-int rebalance(rtc_multi* m, const rtc_camera& cam) {
+// Re-deal the tiles by what the ranks measured for them in the frame just rendered.  confirm: that frame was the first
+// with the current lists (new lists are new pixel maps, so every rank measured it afresh): keep them if the fresh costs
+// say they are even, re-deal if not - one wild measurement (a wave that lost its CU for a millisecond in the middle of a
+// packet: four virtual ranks on one GPU are four queues the hardware time-slices) must not skew the split for good.
+int rebalance(rtc_multi* m, const rtc_camera& cam, bool confirm) {
   std::vector<double> cost(m->n_tiles, 0.0);
   for (uint32_t r = 0; r < m->n; ++r) {
     const std::vector<uint32_t>& mine = m->tiles_of[r];
@@ -145,18 +149,28 @@ int rebalance(rtc_multi* m, const rtc_camera& cam) {
     if (rtc_get_tile_costs(m->scene[r], c.data(), static_cast<uint32_t>(mine.size())) != RTC_OK) return RTC_OK;  // nothing measured: keep the split
     for (size_t k = 0; k < mine.size(); ++k) cost[mine[k]] = c[k];
   }
+  auto imbalance = [&]() {
+    std::vector<double> load(m->n, 0.0);
+    double total = 0.0;
+    for (uint32_t t = 0; t < m->n_tiles; ++t) {
+      load[m->rank_of[t]] += cost[t];
+      total += cost[t];
+    }
+    return total > 0.0 ? *std::max_element(load.begin(), load.end()) / (total / m->n) : 0.0;
+  };
+  if (confirm) {
+    m->max_over_mean = imbalance();
+    if (m->max_over_mean <= 1.25 || m->redeals_in_a_row >= 3u) return RTC_OK;
+    m->redeals_in_a_row++;
+  } else {
+    m->redeals_in_a_row = 0;
+  }
   M_RTC(rtc_assign_tiles(cost.data(), m->n_tiles, m->n, m->rank_of.data(), m->slot_of.data()));
   setLists(m);
   M_HIP(hipSetDevice(m->dev[0]));
   M_HIP(hipStreamSynchronize(m->stream[0]));  // (the frame that used the old table is done: rtc_multi_render is synchronous)
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-  std::vector<double> load(m->n, 0.0);
-  double total = 0.0;
-  for (uint32_t t = 0; t < m->n_tiles; ++t) {
-    load[m->rank_of[t]] += cost[t];
-    total += cost[t];
-  }
-  m->max_over_mean = total > 0.0 ? *std::max_element(load.begin(), load.end()) / (total / m->n) : 0.0;
+  m->max_over_mean = imbalance();
   m->balanced = true;
   m->frames_since_balance = 0;
   m->balance_cam = cam;
@@ -268,8 +282,9 @@ int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, do
   // is not where the split was measured (a moving camera measures every frame).
   m->frames_since_balance++;
   const bool moved = std::memcmp(cam, &m->balance_cam, sizeof *cam) != 0;
-  if (m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u)))
-    if (const int s = rebalance(m, *cam); s != RTC_OK) return s;
+  const bool confirm = m->balanced && m->frames_since_balance == 1u;
+  if (m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u) || confirm))
+    if (const int s = rebalance(m, *cam, confirm); s != RTC_OK) return s;
   return RTC_OK;
 }
 

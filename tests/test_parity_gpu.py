@@ -292,7 +292,6 @@ def _check_launch(gpu, cam, depth, want, counters, what):
 
 @pytest.mark.parametrize("scene,w,h,depth", SCHEDULE_CASES)
 def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth, monkeypatch):
-    monkeypatch.setenv("RTC_SPLIT_SYNC", "1")   # chunks are cut into runs before launch 2 returns, not when a worker thread gets to it
     hs = rtc.HostScene.from_file(scene)
     gpu = rtc.GpuScene(hs.desc)
     osc = ob.OracleScene(hs.desc)
@@ -319,7 +318,6 @@ def test_three_wave_simple_kernel_renders_the_same_image(rtc, scene, w, h, depth
     RTC_SIMPLE3_MIN_CHUNKS=0 (read per launch) makes every launch take it: the same launches as above, first frame on
     the estimate, packed, steady state, moved camera, each against the oracle."""
     monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "0")
-    monkeypatch.setenv("RTC_SPLIT_SYNC", "1")
     hs = rtc.HostScene.from_file(scene)
     gpu = rtc.GpuScene(hs.desc)
     osc = ob.OracleScene(hs.desc)
@@ -357,30 +355,59 @@ def test_three_wave_simple_kernel_random_scenes(rtc, monkeypatch):
     assert ran >= 10
 
 
-def test_schedule_cut_on_the_worker_thread(rtc):
-    """Chunks above a wave's share are cut into runs by a worker thread of the library while the frames go on
-    (startSplitJob / finishSplitJob, rtc_capi.hip): frames before, while and after it works must all be the oracle's, as
-    must the frames of a handle whose pixel map changes or that is destroyed while the worker is busy."""
-    hs = rtc.HostScene.from_file("fresnel.json")
-    osc = ob.OracleScene(hs.desc)
-    cam = hs.camera(150, 150)
-    want, counters = osc.render(cam, 5)
+def _check_schedule(sched, n_chunks, what):
+    """Every pixel of every chunk in exactly one item; returns the number of items that are runs (not whole chunks)."""
+    seen = np.zeros((n_chunks, 64), dtype=np.int32)
+    items = sched[sched != 0xFFFFFFFF]
+    chunk, start, length = items & 0xFFFFF, (items >> 20) & 63, (items >> 26) + 1
+    assert (chunk < n_chunks).all() and (start + length <= 64).all(), what
+    for c, a, n in zip(chunk.tolist(), start.tolist(), length.tolist()):
+        seen[c, a:a + n] += 1
+    assert (seen == 1).all(), (what, int((seen != 1).sum()))
+    return int((length < 64).sum())
+
+
+SCHEDULE_SHAPES = [("cover.json", 1920, 1080, None, None), ("cover.json", 300, 200, None, True), ("fresnel.json", 150, 150, None, True),
+                   ("reflection_and_refraction.json", 250, 130, None, True), ("teapot.json", 320, 180, None, True),
+                   ("cover.json", 1920, 1080, (560, 720, 256, 256), True), ("cover.json", 1920, 1080, (3, 5, 131, 77), True)]
+
+
+@pytest.mark.parametrize("scene,w,h,rect,expect_runs", SCHEDULE_SHAPES)
+def test_device_schedules_hand_out_every_pixel_once(rtc, scene, w, h, rect, expect_runs):
+    """The schedule is made on the device (rtc_kernels.hip: estimate or measurement -> classes -> sort -> packets, chunks
+    above a wave's share cut into runs of pixels): read it back (rtc_get_schedule) after the first launch (packed from the
+    estimate), the second (from the first frame's measurement) and after the camera moved (from a frame that ran CUT
+    chunks, whose times are summed over their runs), and check its structure - every pixel of every 8x8 chunk in exactly
+    one item, small launches actually cut - beside the image."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file(scene)
+    cam = hs.camera(w, h)
     gpu = rtc.GpuScene(hs.desc)
-    for launch in range(1, 5):
-        _check_launch(gpu, cam, 5, want, counters, ("launch", launch))
-    gpu.synchronize()                     # (waits for the worker)
-    for launch in range(5, 8):            # the first of these switches to the cut schedule
-        _check_launch(gpu, cam, 5, want, counters, ("launch", launch))
-    cam2 = hs.camera(120, 90)             # another pixel map right behind a measuring launch: the job of the old one is dropped
-    want2, counters2 = osc.render(cam2, 5)
-    for launch in range(3):
-        g2 = rtc.GpuScene(hs.desc)
-        _check_launch(g2, cam, 5, want, counters, "first")
-        _check_launch(g2, cam, 5, want, counters, "second (starts the worker)")
-        if launch == 1:
-            _check_launch(g2, cam2, 5, want2, counters2, "new pixel map")
-            _check_launch(g2, cam2, 5, want2, counters2, "new pixel map, second")
-        g2.close()                        # ... or the handle goes away under it
+    x0, y0, rw, rh = rect if rect else (0, 0, w, h)
+    n_chunks = ((rw + 7) // 8) * ((rh + 7) // 8)
+    want = None
+    if w * h <= 300 * 200:
+        want, _ = ob.OracleScene(hs.desc).render(cam, 5)
+    canvas = torch.empty((rh, rw, 3), dtype=torch.float64, device="cuda")
+    runs = []
+    for launch in range(4):
+        if launch == 3:
+            hs.rotate_camera(0.05)
+            cam = hs.camera(w, h)
+            want = None
+        canvas.fill_(float("nan"))
+        torch.cuda.synchronize()
+        gpu.render_device(cam, canvas.data_ptr(), 5, rect, torch.cuda.current_stream().cuda_stream)
+        st = gpu.stats()
+        got = canvas.cpu().numpy()
+        assert np.isfinite(got).all() and st["primary"] == rw * rh and st["overflow"] == 0, (scene, launch)
+        if want is not None:
+            assert np.abs(got - want[y0:y0 + rh, x0:x0 + rw]).max() < TOL, (scene, launch)
+        sched = gpu.schedule()                       # what the NEXT launch would run
+        assert len(sched) > 0
+        runs.append(_check_schedule(sched, n_chunks, (scene, rect, launch)))
+    if expect_runs:                                  # (fewer chunks than waves: most chunks exceed a wave's share)
+        assert min(runs) > 0, runs
 
 
 def test_first_launches_write_every_pixel(rtc):

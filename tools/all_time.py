@@ -20,7 +20,6 @@ for name, w, h, depth in CASES:
         gpu = rtc.GpuScene(hs.desc)
         for i in range(6):
             gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
-            if i == 3: gpu.synchronize()   # (chunks cut into runs on the library's worker thread: the next launch switches)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 15 if h < 2000 else 6

@@ -20,7 +20,6 @@ for scene, w, h, depth in CONFIGS:
     canvas = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
     for _ in range(3):
         gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
-    gpu.synchronize()   # (chunks cut into runs on the library's worker thread: the next launch switches to that schedule)
     gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
     n = 5; ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:

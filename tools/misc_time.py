@@ -16,7 +16,6 @@ for name in names:
         gpu = rtc.GpuScene(hs.desc)
         for i in range(6):
             gpu.render_device(cam, canvas.data_ptr(), 5, None, stream.cuda_stream); torch.cuda.synchronize()
-            if i == 3: gpu.synchronize()   # (chunks cut into runs on the library's worker thread: the next launch switches)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         for _ in range(8): gpu.render_device(cam, canvas.data_ptr(), 5, None, stream.cuda_stream)

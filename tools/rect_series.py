@@ -15,5 +15,4 @@ for rect in ((560, 720, 256, 256), (560, 720, 64, 64), (0, 0, 960, 540)):
         a.record(stream); gpu.render_device(cam, buf.data_ptr(), 5, rect, stream.cuda_stream); b.record(stream)
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
-        if i == 14: gpu.synchronize()
     print(rect, gpu.last_kernel_name(), " ".join(f"{t:.3f}" for t in ts), flush=True)

@@ -22,14 +22,7 @@ for SYM in $(strings -a rtc_kernels_host.o rtc_capi_host.o | grep -o "__hip_fatb
 done
 $CLANG $SAN -o create_all $REPO/tools/sanitize/create_all.cpp no_device_code.cpp rtc_kernels_host.o rtc_capi_host.o $HOST -L/opt/rocm/lib -lamdhip64 -lz -Wl,-rpath,/opt/rocm/lib
 $CLANG $SAN -o host_kat $REPO/tests/cpp/host_kat_main.cpp no_device_code.cpp rtc_kernels_host.o rtc_capi_host.o $HOST -L/opt/rocm/lib -lamdhip64 -lz -Wl,-rpath,/opt/rocm/lib
-/opt/rocm/bin/hipcc --offload-arch=gfx950 --cuda-host-only $SAN -ffp-contract=off -fPIC -c -o pack_fuzz_host.o $REPO/tools/sanitize/pack_fuzz.hip
-: > no_device_code_fuzz.cpp
-for SYM in $(strings -a rtc_kernels_host.o pack_fuzz_host.o | grep -o "__hip_fatbin_[0-9a-f]*" | sort -u); do
-  echo "extern \"C\" const char $SYM[64] __attribute__((aligned(4096))) = {0};" >> no_device_code_fuzz.cpp
-done
-$CLANG $SAN -o pack_fuzz no_device_code_fuzz.cpp pack_fuzz_host.o rtc_kernels_host.o -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 export ASAN_OPTIONS=detect_leaks=1
-./pack_fuzz
 ./host_kat | tail -1
 ./create_all $REPO/tests/golden/data $REPO/tests/golden/scenes/*.json
 echo "sanitizers: clean"

@@ -17,7 +17,6 @@ def frame_ms(hs, w, h, depth):
         gpu = rtc.GpuScene(hs.desc)
         for i in range(6):
             gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
-            if i == 3: gpu.synchronize()   # (chunks cut into runs on the library's worker thread: the next launch switches)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
         for _ in range(12): gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream)
