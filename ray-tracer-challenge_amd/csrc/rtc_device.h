@@ -253,10 +253,9 @@ struct DevChunkShape {
 
 // What rtc_pack_kernel leaves beside a schedule it packed.
 struct DevSchedInfo {
-  uint32_t n_units;      // packets in the schedule
-  uint32_t needs_split;  // some chunk took longer than a wave's fair share: the host may cut it into runs (packSchedule)
+  uint32_t n_units;      // packets in the schedule (DevPixelMap::n_units_dev points here)
   uint32_t heaviest;     // longest chunk time
-  uint32_t pad_;
+  uint32_t pad_[2];
   unsigned long long total;  // sum of the chunk times
 };
 

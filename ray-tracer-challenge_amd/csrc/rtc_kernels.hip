@@ -2216,17 +2216,21 @@ rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __
 
 // ------------------------------------------------------------------------------------------
 // The schedule of the NEXT frame, packed on the device from what THIS frame measured: no host in
-// the loop, so a moving camera (lib.zig:166-190) renders every frame with a schedule that is one frame old instead of
-// one that is 16-24 frames old.  Same policy as the host's packWholeChunks (rtc_schedule.h): whole chunks, longest
-// first in classes of a quarter octave of measured time, image order (about) kept inside a class - neighbouring chunks
-// run at the same moment: same objects, same BVH nodes -, cheap chunks several to a packet.  Five small launches on the
-// render's stream, every one a grid over chunks or packets (a single work-group doing all of it took 180 us at 1080p:
-// forty dependent round trips to memory; this takes about 20):
-//   rtc_chunk_cost_kernel  per-chunk sums of the per-pixel ray counts; clears what the next steps add into
-//   rtc_chunk_time_kernel  a packet's measured time, shared among its items by their cost (host twin: chunkTimes)
-//   rtc_pack_class_kernel  per chunk: final time (cost x `cost_to_time` if it was not timed), its class; histogram, totals
-//   rtc_pack_sort_kernel   counting sort by class, a block of 1024 consecutive chunks at a time
-//   rtc_pack_emit_kernel   packets: k chunks of one class each, k = group_cap / the class's upper time bound, 1..16
+// the loop, so a moving camera (lib.zig:166-190) renders every frame with a schedule that is one frame old.  Policy:
+// longest first in classes of a quarter octave of measured time, image order (about) kept inside a class - neighbouring
+// chunks run at the same moment: same objects, same BVH nodes -, cheap chunks several to a packet, chunks above a wave's
+// fair share cut into runs of pixels, those packets first.  Small launches on the render's stream, every one a grid over
+// chunks or packets (a single work-group doing all of it took 180 us at 1080p: forty dependent round trips to memory;
+// this takes about 25):
+//   rtc_chunk_cost_kernel  per chunk: the sum of the per-pixel ray counts and how the rays are spread (DevChunkShape);
+//                          clears what the next steps add into
+//   rtc_chunk_time_kernel  a packet's measured time, shared among its items by their cost; counts the runs of a chunk
+//   rtc_pack_class_kernel  per chunk: its time whole (cost x `cost_to_time` if it was not timed; a chunk that ran in
+//                          runs: without what the runs added), its class; histogram, totals
+//   rtc_pack_extra_kernel  (three rounds) what the cuts add to the frame, for the share a wave gets with them
+//   rtc_pack_sort_kernel   counting sort by class, a block of 1024 consecutive chunks at a time; the runs of the chunks
+//                          of cut classes, one packet each, at the front of the schedule
+//   rtc_pack_emit_kernel   the other packets: k chunks of one class each, k = group_cap / the class's upper time bound, 1..16
 // Results never depend on the schedule.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t pack_class(uint32_t t) {
@@ -2319,7 +2323,7 @@ rtc_chunk_cost_kernel(const uint32_t* __restrict__ cost, const DevPixelMap map, 
   const uint32_t mine = inside ? cost[out0 + static_cast<size_t>(ry) * w + rx] : 0u;
   uint32_t sum = mine;
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-  // How the chunk's rays are spread over its pixels (packSchedule's model, rtc_schedule.h: a pixel's tree has about
+  // How the chunk's rays are spread over its pixels (the model of cut_runs below: a pixel's tree has about
   // cost / 5 rays and min(rays, max_depth + 1) levels): the total, the deepest tree, and the sixteenths of the running sum.
   const float rays = inside ? fmaxf(1.0f, static_cast<float>(mine) * 0.2f) : 0.0f;
   float run = rays;  // inclusive prefix sum over the wave's lanes = the chunk's pixels in row-major order
@@ -2440,7 +2444,7 @@ rtc_pack_class_kernel(const uint32_t* __restrict__ chunk_cost, const uint32_t n_
   }
 }
 
-// Into how many runs a chunk of a cut class goes: packSchedule's model (rtc_schedule.h).  A wave renders one ray per lane
+// Into how many runs a chunk of a cut class goes.  A wave renders one ray per lane
 // per iteration and the rays of a pixel's tree depend on each other level by level: pixels [a, b) take about L + S
 // iterations, L the deepest tree among them, S their rays / 64.  Every part pays L again, so the chunk is cut until a
 // part fits a wave's share or its S falls under L / 2 - a chunk that is all depth (a mirror chain, a few glass pixels on
@@ -2458,7 +2462,7 @@ __device__ __forceinline__ uint32_t cut_runs(const DevChunkShape& shape, const f
 }
 
 // A wave's fair share of the frame, the time the cuts add included (RTC_PACK_ROUNDS rounds of rtc_pack_extra_kernel:
-// a cut adds work, which raises the share, which takes back some cuts - packSchedule iterates the same way).
+// a cut adds work, which raises the share, which takes back some cuts).
 #define RTC_PACK_ROUNDS 3
 __device__ __forceinline__ float fair_share(const DevPackState* __restrict__ state, const float n_waves, const int round) {
   const unsigned long long extra = round > 0 ? state->extra[round - 1] : 0ull;
@@ -2580,8 +2584,7 @@ rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunk
   if (i == 0u) {
     info->n_units = state->parts_cursor + L.n_packets;
     info->heaviest = state->heaviest;
-    info->needs_split = 0u;
-    info->pad_ = 0u;
+    info->pad_[0] = info->pad_[1] = 0u;
     info->total = state->total;
   }
   if (i >= n_chunks) return;
