@@ -2,6 +2,7 @@
 // the flat scene, upload to HBM, kernel launches.  No torch types, no CPU render path: every
 // entry point either runs the HIP kernel or fails with an rtc_status.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,12 +59,13 @@ extern "C" __global__ void rtc_pack_extra_kernel(const uint32_t* __restrict__ ch
                                                  const float cut_above, const DevChunkShape* __restrict__ chunk_shape, const int round,
                                                  DevPackState* __restrict__ state);
 extern "C" __global__ void rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves,
-                                                const float t_min, const float cut_above,
+                                                const float t_min, const float cut_above, const int rounds,
                                                 const DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state,
                                                 uint32_t* __restrict__ sorted, uint32_t* __restrict__ order_out);
 extern "C" __global__ void rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves,
-                                                const float t_min, const float cut_above, const DevPackState* __restrict__ state,
-                                                uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info);
+                                                const float t_min, const float cut_above, const int rounds,
+                                                const DevPackState* __restrict__ state, uint32_t* __restrict__ order_out,
+                                                DevSchedInfo* __restrict__ info);
 extern "C" __global__ void rtc_rgba8_kernel(const double* __restrict__ canvas, const size_t n_pixels, uint32_t* __restrict__ rgba);
 extern "C" __global__ void rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
                                                     const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
@@ -204,16 +206,17 @@ uint32_t residentBlocks(const rtc_scene* s, const DevPixelMap& map) {
 }
 double residentWaves(const rtc_scene* s, const DevPixelMap& map) { return 4.0 * residentBlocks(s, map); }
 
-// Chunks that take more than this many fair shares of a wave are cut into runs of pixels (small images, a rank's share
-// of a split frame; a full 1080p frame's heaviest chunk is about one share).  The three-wave kernel has half again as
-// many waves and smaller shares, and there the cut pays from one share on: reflection_and_refraction depth 8 at 1080p
-// 2.12 -> 1.91 ms, cover 0.676 -> 0.670.
+// Chunks that take more than this many fair shares of a wave are cut into runs of pixels (rtc_pack_sort_kernel).  A launch
+// with few chunks per wave - a small image, a rank's share of a split frame - ends when its longest packet does and is
+// cut from one share on; a large launch (a full 1080p frame's heaviest chunk is about one share) only where a chunk
+// clearly sticks out: cutting costs the runs the depth of their trees again, and with a moving camera the measurement is
+// a frame old (cover 1080p, threshold 1.0 / 1.5: static 0.551 / 0.543 ms, orbiting 0.579 / 0.560).
 double cutAbove(const rtc_scene* s, const DevPixelMap& map) {
-  static const bool off = getenv("RTC_NO_DEVICE_CUT") != nullptr;  // experiment knob
-  static const double forced = getenv("RTC_CUT_ABOVE") ? atof(getenv("RTC_CUT_ABOVE")) : 0.0;  // experiment knob
-  (void)s;
-  (void)map;
-  return off ? 0.0 : (forced > 0.0 ? forced : 1.0);
+  static const bool off = getenv("RTC_NO_DEVICE_CUT") != nullptr;                               // experiment knobs
+  static const double forced = getenv("RTC_CUT_ABOVE") ? atof(getenv("RTC_CUT_ABOVE")) : 0.0;
+  if (off) return 0.0;
+  if (forced > 0.0) return forced;
+  return static_cast<double>(map.n_chunks) >= 4.0 * residentWaves(s, map) ? 1.5 : 1.0;
 }
 
 // Packets a device-packed schedule of this pixel map can have at most: one per chunk, and up to fifteen more for every
@@ -341,14 +344,16 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   hipLaunchKernelGGL(rtc_pack_class_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_cost, n, cost_to_time,
                      s->d_chunk_shape, s->d_chunk_time, s->d_pack_state);
   const float cut_above = static_cast<float>(cutAbove(s, map));
-  if (cut_above > 0.0f && from == PackFrom::Measurement)  // (RTC_PACK_ROUNDS of them; an estimate has no per-pixel spread to go by)
-    for (int round = 0; round < 3; ++round)
-      hipLaunchKernelGGL(rtc_pack_extra_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, cut_above,
-                         s->d_chunk_shape, round, s->d_pack_state);
+  // (rounds of the share a wave gets with the cuts; an estimate has no per-pixel spread to go by)
+  static const int env_rounds = getenv("RTC_PACK_ROUNDS") ? atoi(getenv("RTC_PACK_ROUNDS")) : 3;  // experiment knob
+  const int rounds = cut_above > 0.0f && from == PackFrom::Measurement ? std::max(0, std::min(4, env_rounds)) : 0;
+  for (int round = 0; round < rounds; ++round)
+    hipLaunchKernelGGL(rtc_pack_extra_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, cut_above,
+                       s->d_chunk_shape, round, s->d_pack_state);
   hipLaunchKernelGGL(rtc_pack_sort_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, t_min,
-                     cut_above, s->d_chunk_shape, s->d_pack_state, s->d_sorted, s->d_sched[target]);
+                     cut_above, rounds, s->d_chunk_shape, s->d_pack_state, s->d_sorted, s->d_sched[target]);
   hipLaunchKernelGGL(rtc_pack_emit_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_sorted, n, n_waves, t_min,
-                     cut_above, s->d_pack_state, s->d_sched[target], s->d_sched_info + target);
+                     cut_above, rounds, s->d_pack_state, s->d_sched[target], s->d_sched_info + target);
   HIP_TRY(hipGetLastError());
   if (!unmeasured) {
     s->measured_regions = map.mode == 0u ? 1u : map.n_my_tiles;
@@ -1313,6 +1318,21 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
   HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(s->launch_done, s->stream));
+  {
+    // The first device-to-host copy of some size in a process costs 8 ms (the runtime sets up its copy path; a 4-byte
+    // copy does not trigger it, 256 KB does): paid here, once per process, not by the first rtc_render of a frame.
+    static std::atomic<bool> copy_path_warm{false};
+    if (!copy_path_warm.exchange(true)) {
+      void* d_tmp = nullptr;
+      void* h_tmp = nullptr;
+      HIP_TRY(hipMalloc(&d_tmp, 1u << 20));
+      HIP_TRY(hipHostMalloc(&h_tmp, 1u << 20, hipHostMallocDefault));
+      HIP_TRY(hipMemcpyAsync(h_tmp, d_tmp, 1u << 20, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      HIP_TRY(hipHostFree(h_tmp));
+      HIP_TRY(hipFree(d_tmp));
+    }
+  }
   s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
   {

@@ -2461,9 +2461,8 @@ __device__ __forceinline__ uint32_t cut_runs(const DevChunkShape& shape, const f
   return static_cast<uint32_t>(fminf(fmaxf(__builtin_ceilf(want), 1.0f), 16.0f));
 }
 
-// A wave's fair share of the frame, the time the cuts add included (RTC_PACK_ROUNDS rounds of rtc_pack_extra_kernel:
-// a cut adds work, which raises the share, which takes back some cuts).
-#define RTC_PACK_ROUNDS 3
+// A wave's fair share of the frame, the time the cuts add included (`round` rounds of rtc_pack_extra_kernel, at most
+// four: a cut adds work, which raises the share, which takes back some cuts).
 __device__ __forceinline__ float fair_share(const DevPackState* __restrict__ state, const float n_waves, const int round) {
   const unsigned long long extra = round > 0 ? state->extra[round - 1] : 0ull;
   return static_cast<float>(state->total + extra) / fmaxf(1.0f, n_waves);
@@ -2499,10 +2498,10 @@ struct PackLayout {
 // longest packet does.  The runs' packets are the FIRST of the schedule (the longest there are); a cut class has no
 // packets in the part of the schedule laid out here.  0: nothing is cut.
 __device__ __forceinline__ void pack_layout(const DevPackState* __restrict__ state, const float n_waves, const float t_min,
-                                            const float cut_above, PackLayout& L) {
+                                            const float cut_above, const int rounds, PackLayout& L) {
   const uint32_t k = threadIdx.x;
   if (k < RTC_PACK_CLASSES) {  // per class, in parallel: its size, chunks per packet, packets
-    const float fair = fair_share(state, n_waves, RTC_PACK_ROUNDS);
+    const float fair = fair_share(state, n_waves, rounds);
     const float group_cap = fmaxf(fair * (1.0f / 32.0f), t_min);
     const float t_hi = __builtin_exp2f(static_cast<float>(k + 1u) * 0.25f) - 1.0f;  // upper time bound of class k
     const float per = group_cap / fmaxf(t_hi, 1.0f);
@@ -2533,8 +2532,8 @@ __device__ __forceinline__ void pack_layout(const DevPackState* __restrict__ sta
 // (inside a block and between blocks the order is arrival order).
 extern "C" __global__ void __launch_bounds__(1024)
 rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_chunks, const float n_waves, const float t_min,
-                     const float cut_above, const DevChunkShape* __restrict__ chunk_shape, DevPackState* __restrict__ state,
-                     uint32_t* __restrict__ sorted, uint32_t* __restrict__ order_out) {
+                     const float cut_above, const int rounds, const DevChunkShape* __restrict__ chunk_shape,
+                     DevPackState* __restrict__ state, uint32_t* __restrict__ sorted, uint32_t* __restrict__ order_out) {
   __shared__ PackLayout L;
   __shared__ uint32_t cnt[RTC_PACK_CLASSES], start[RTC_PACK_CLASSES], cursor[RTC_PACK_CLASSES];
   const uint32_t tid = threadIdx.x;
@@ -2542,7 +2541,7 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
     cnt[tid] = 0u;
     cursor[tid] = 0u;
   }
-  pack_layout(state, n_waves, t_min, cut_above, L);
+  pack_layout(state, n_waves, t_min, cut_above, rounds, L);
   const uint32_t c = blockIdx.x * blockDim.x + tid;
   uint32_t k = 0u;
   if (c < n_chunks) {
@@ -2555,7 +2554,7 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
   if (c < n_chunks) sorted[L.cbase[k] + start[k] + atomicAdd(&cursor[k], 1u)] = c | (k << 20);  // 2^20 chunks at most; the class rides along
   if (c < n_chunks && L.parts[k] != 0u) {  // a chunk of a cut class: its runs, one packet each, at the front of the schedule
     const DevChunkShape shape = chunk_shape[c];
-    const float fair = fair_share(state, n_waves, RTC_PACK_ROUNDS);
+    const float fair = fair_share(state, n_waves, rounds);
     const uint32_t r = cut_runs(shape, static_cast<float>(chunk_time[c]), fair);
     const uint32_t at = atomicAdd(&state->parts_cursor, r);
     // run q ends at the sixteenth of the chunk's rays (or, unmeasured, of its pixels) nearest to (q + 1) / r
@@ -2576,10 +2575,10 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
 // One thread per sorted chunk; the first chunk of each packet writes the whole row of 16 items.
 extern "C" __global__ void __launch_bounds__(1024)
 rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves, const float t_min,
-                     const float cut_above, const DevPackState* __restrict__ state, uint32_t* __restrict__ order_out,
-                     DevSchedInfo* __restrict__ info) {
+                     const float cut_above, const int rounds, const DevPackState* __restrict__ state,
+                     uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info) {
   __shared__ PackLayout L;
-  pack_layout(state, n_waves, t_min, cut_above, L);
+  pack_layout(state, n_waves, t_min, cut_above, rounds, L);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0u) {
     info->n_units = state->parts_cursor + L.n_packets;
