@@ -22,5 +22,6 @@ for _ in range(handles):
     b.record(stream); torch.cuda.synchronize()
     ts.append(a.elapsed_time(b) / 12)
     gpu.close()
+print(name, "in order:", " ".join(f"{t:.3f}" for t in ts))
 ts.sort()
 print(name, " ".join(f"{t:.3f}" for t in ts), f"| mean {sum(ts) / len(ts):.3f}", flush=True)
