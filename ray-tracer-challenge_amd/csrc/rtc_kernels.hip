@@ -2554,8 +2554,11 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
   if (c < n_chunks) sorted[L.cbase[k] + start[k] + atomicAdd(&cursor[k], 1u)] = c | (k << 20);  // 2^20 chunks at most; the class rides along
   if (c < n_chunks && L.parts[k] != 0u) {  // a chunk of a cut class: its runs, one packet each, at the front of the schedule
     const DevChunkShape shape = chunk_shape[c];
-    const float fair = fair_share(state, n_waves, rounds);
-    const uint32_t r = cut_runs(shape, static_cast<float>(chunk_time[c]), fair);
+    const float fair = fair_share(state, n_waves, rounds), T = static_cast<float>(chunk_time[c]);
+    // (never more than 1 + 15 T / F runs: the chunks' times add up to at most F x the waves, so all cuts together add
+    // at most 15 packets per wave - what the schedule buffers are sized for, maxPackets() in rtc_capi.hip.  The model
+    // asks for about T / F.)
+    const uint32_t r = min(cut_runs(shape, T, fair), 1u + static_cast<uint32_t>(fminf(15.0f * T / fmaxf(fair, 1.0f), 15.0f)));
     const uint32_t at = atomicAdd(&state->parts_cursor, r);
     // run q ends at the sixteenth of the chunk's rays (or, unmeasured, of its pixels) nearest to (q + 1) / r
     auto mark = [&](uint32_t q) -> uint32_t {
