@@ -344,7 +344,9 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   hipLaunchKernelGGL(rtc_pack_class_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_cost, n, cost_to_time,
                      s->d_chunk_shape, s->d_chunk_time, s->d_pack_state);
   const float cut_above = static_cast<float>(cutAbove(s, map));
-  // (rounds of the share a wave gets with the cuts; an estimate has no per-pixel spread to go by)
+  // Rounds of the share a wave gets with the cuts (rtc_pack_extra_kernel; an estimate has no per-pixel spread to go by).
+  // An odd number: the share found in round i over-corrects that of round i - 1 (fresnel 300x300 with 0 / 1 / 2 / 3
+  // rounds: 0.149 / 0.124 / 0.130 / 0.112 ms; reflection_and_refraction depth 8 at 1080p with 1 / 3: 1.78 / 1.70).
   static const int env_rounds = getenv("RTC_PACK_ROUNDS") ? atoi(getenv("RTC_PACK_ROUNDS")) : 3;  // experiment knob
   const int rounds = cut_above > 0.0f && from == PackFrom::Measurement ? std::max(0, std::min(4, env_rounds)) : 0;
   for (int round = 0; round < rounds; ++round)
