@@ -98,6 +98,17 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
     ops[0] = 3
 
 
+def test_diagnostic_entry_points_refuse_null_handles(rtc):
+    """rtc_get_schedule / rtc_last_kernel_name (diagnostics of include/rtc.h) check their arguments before they touch the
+    device: callable on a box without one."""
+    import ctypes as C
+    lib = rtc.hip_lib()
+    n = C.c_uint32(7)
+    assert lib.rtc_get_schedule(None, None, 0, C.byref(n)) != 0 and b"null" in lib.rtc_last_error()
+    assert lib.rtc_get_schedule(None, None, 0, None) != 0
+    assert lib.rtc_last_kernel_name(None) == b""
+
+
 def test_zig_binding_matches_the_header():
     """integration/gpu.zig (the reference-side binding, shipped as source) and the excerpt of it in INTEGRATION.md declare
     the extern struct a Zig maintainer binds: its fields must be rtc.h's, in order; every function of rtc.h that the
