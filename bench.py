@@ -364,8 +364,14 @@ def main():
     # what follows (same handle, same schedule: 0.54 ms per frame after 6 frames, 0.516 after 50 and after 1500;
     # tools/first_handle_probe.py), and --warmup 5 --steps 20 is 14 ms of work in all.  Untimed, like the rest of the
     # setup; reported as config.settle_frames.
+    cold_ms = None
+    t_cold = time.perf_counter()
     for i in range(args.settle_frames):
         step(i)
+        if i + 1 == min(args.steps, args.settle_frames):   # what the same K steps take right after start-up, for the record
+            finish()
+            barrier()
+            cold_ms = (time.perf_counter() - t_cold) * 1e3 / (i + 1)
     finish()
     barrier()
     for i in range(args.warmup):
@@ -424,6 +430,7 @@ def main():
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
                        "mrays_per_s_incl_shadow_traced": (rays + stats["shadow_traced"]) * args.steps / elapsed / 1e6,
                        "settle_frames": args.settle_frames,
+                       "ms_per_step_right_after_startup": cold_ms,
                        "timed_frames": "steady state of a STATIC view: the schedule was measured on this same frame by the two "
                                        "untimed setup launches; first_frame_ms / orbit_ms below are the other cases"},
         }
