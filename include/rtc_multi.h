@@ -6,7 +6,9 @@
  * the image is cut into 64x64 tiles, every GPU renders its share into a compact buffer, ONE ncclGather per frame
  * brings the shares to GPU 0 over xGMI, one kernel un-permutes them into the row-major Canvas (canvas.zig:132-137),
  * which is copied to the caller.  The split starts round-robin; after the first frame (and, while the camera moves,
- * every 16 frames) the tiles are re-dealt by their MEASURED cost (rtc_get_tile_costs + rtc_assign_tiles of rtc.h).
+ * every 16 frames) the tiles are re-dealt by their MEASURED cost (rtc_get_tile_costs + rtc_assign_tiles of rtc.h); the
+ * frame after a re-deal measures the new shares afresh, and a split that then proves uneven (busiest rank more than a
+ * quarter above the mean) is dealt again, three times at most.
  *
  * (The multi-PROCESS form of the same path - one rank per GPU under torch.distributed, which is what bench.py's
  * N > 1 mode runs - uses the per-rank entry points of rtc.h directly and the process group's gather.)
