@@ -251,7 +251,8 @@ struct Shape {
   // shape.zig:286-310
   void setTransform(const Matrix4& m);
   // group.zig:75-78
-  void addChild(Shape child);
+  void addChild(Shape&& child);  // (a Shape is a kilobyte: taken by reference, moved once)
+  void addChild(const Shape& child) { addChild(Shape(child)); }
   // group.zig:85-115: returns {left,right}; children keeps the straddlers.
   std::pair<std::vector<Shape>, std::vector<Shape>> partitionChildren();
   // group.zig:117-135
