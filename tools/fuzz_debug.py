@@ -12,6 +12,6 @@ for seed in seeds:
         got = gpu.render(cam, depth); want, c = osc.render(cam, depth)
         d = np.abs(got - want).max(axis=2); bad = np.argwhere(d > 1e-5)
         st = gpu.stats()
-        print(f"seed {seed} depth {depth}: bad pixels {len(bad)} max {d.max():.3e} sec gpu/cpu {st['secondary']}/{c['secondary']} shadow {st['shadow_calls']}/{c['shadow']}")
+        print(f"seed {seed} depth {depth}: bad pixels {len(bad)} max {d.max():.3e} sec gpu/cpu {st['secondary']}/{c['secondary']} shadow {st['shadow_calls']}/{c['shadow']} overflow {st['overflow']}")
         for y, x in bad[:4]:
             print("   px", x, y, "gpu", got[y, x].round(6), "cpu", want[y, x].round(6))
