@@ -1756,6 +1756,8 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
                  h.prof_t1 >> 24, h.prof_t1 & 0xFFFFFFull, h.prof_busy, h.stolen);
     std::fprintf(stderr, "rtc traces (invocations, lanes): closest %llu %llu | shadow %llu %llu | behind %llu %llu\n", h.prof2[0],
                  h.prof2[1], h.prof2[2], h.prof2[3], h.prof2[4], h.prof2[5]);
+    std::fprintf(stderr, "rtc walks: %llu lanes %llu node-steps %llu leaf-steps %llu lanes-at-nodes %llu lanes-at-leaves %llu | without a leaf: %llu walks %llu node-steps\n",
+                 h.prof4[0], h.prof4[1], h.prof4[2], h.prof4[3], h.prof4[4], h.prof4[5], h.prof4[6], h.prof4[7]);
     std::fprintf(stderr, "rtc trace cycles by lanes with a ray (1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64):");
     for (int k = 0; k < 3; ++k) {
       std::fprintf(stderr, " %s", k == 0 ? "closest" : k == 1 ? "| shadow" : "| behind");

@@ -19,7 +19,6 @@
 //   light[]      6 f64    position, intensity
 #pragma once
 #include <hip/hip_runtime.h>
-#include <stddef.h>
 #include <stdint.h>
 
 #define RTC_NODE_BIT 0x80000000u
@@ -34,14 +33,6 @@
 #endif
 #ifndef RTC_LDS_TRAV
 #define RTC_LDS_TRAV 8  // entries of the BVH walk's stack kept in LDS (the rest in scratch memory)
-#endif
-// Packet traversal of a group's candidate BVH (traverse_bvh_packet): the fewest lanes worth a wave-wide walk of their
-// own, and how many sets of rays that travel together a wave looks for per group before the rest walk lane by lane.
-#ifndef RTC_PACKET_MIN
-#define RTC_PACKET_MIN 6u
-#endif
-#ifndef RTC_PACKET_ROUNDS
-#define RTC_PACKET_ROUNDS 4
 #endif
 #ifndef RTC_MAX_DEPTH
 #define RTC_MAX_DEPTH 16
@@ -120,9 +111,6 @@ struct Bvh4Node {
   uint32_t c[4];             // as BvhNode::c0
   uint32_t pad_[4];
 };
-
-static_assert(sizeof(Bvh4Node) == 128 && offsetof(Bvh4Node, hi) == 48 && offsetof(Bvh4Node, c) == 96,
-              "traverse_bvh_packet reads a node as two 16-dword scalar loads");
 
 // Everything a visit of one BVH leaf needs, in BVH order: one fetch where leaf index -> leaf_meta -> tri would be three
 // dependent ones (the walk waits on memory latency).
@@ -301,6 +289,7 @@ struct DevStats {
   unsigned long long prof[16];  // wave cycles per section
   unsigned long long prof2[8];  // trace invocations (wave level) and active lanes: closest, shadow, behind
   unsigned long long prof3[21]; // wave cycles in traces by lanes with a ray: [closest, shadow, behind][1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64]
+  unsigned long long prof4[8];  // group walks: walks of a wave, their lanes, wave steps at nodes, at leaves, lanes at nodes, at leaves (summed over the steps), walks that reach no leaf, their node steps
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime
   unsigned long long prof_log[4096][4];            // per wave: lifetime, iterations, units, first<<32|last unit
   unsigned long long prof_last[4096][16];          // per wave: prof[] of its last packet only

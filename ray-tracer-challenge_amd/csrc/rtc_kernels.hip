@@ -71,6 +71,17 @@
 #define RTC_HIST_END(kind) do { } while (0)
 #endif
 
+#ifdef RTC_PROFILE
+__shared__ DevStats* rtc_prof_stats;  // (diagnostic builds: where the walks add their counts, DevStats::prof4)
+#define RTC_WALK_ADD(slot, n)                                                                              \
+  do {                                                                                                      \
+    if (__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(__ballot(true)), 0u)) == 0u) \
+      atomicAdd(&rtc_prof_stats->prof4[slot], static_cast<unsigned long long>(n));                             \
+  } while (0)
+#else
+#define RTC_WALK_ADD(slot, n) do { } while (0)
+#endif
+
 #ifndef RTC_LB2
 #define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -593,9 +604,17 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
     return sp < RTC_LDS_TRAV ? lds_stack[sp * 64] : stack[sp - RTC_LDS_TRAV];
   };
   uint32_t next = root;  // the node to visit next stays in a register: the stack (scratch memory) is one more dependent fetch
+#ifdef RTC_PROFILE
+  unsigned long long pw_nodes = 0, pw_leaves = 0, pw_node_lanes = 0, pw_leaf_lanes = 0;
+  const unsigned long long pw_lanes = __builtin_popcountll(__ballot(true));
+#endif
   for (;;) {
     uint32_t leaf_ref = RTC_NO_LEAF;
     while ((next != RTC_NO_LEAF || sp > 0) && !vis.done()) {
+#ifdef RTC_PROFILE
+      pw_nodes += 1ull;
+      pw_node_lanes += __builtin_popcountll(__ballot(true));
+#endif
       uint32_t ref = next;
       next = RTC_NO_LEAF;
       if (ref == RTC_NO_LEAF) ref = pop();
@@ -662,6 +681,10 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
     if (leaf_ref == RTC_NO_LEAF) break;  // nothing left (or the visitor is done)
     const uint32_t first = (leaf_ref & ~RTC_NODE_BIT) >> 3, count = (leaf_ref & 7u) + 1u;
     for (uint32_t i = 0; i < count; ++i) {
+#ifdef RTC_PROFILE
+      pw_leaves += 1ull;
+      pw_leaf_lanes += __builtin_popcountll(__ballot(true));
+#endif
       const BvhLeafRec& L = S.bvh_leaf[first + i];
       if (CSG && (L.leaf & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
         if constexpr (CSG) visit_csg(S, L.leaf & ~RTC_NODE_BIT, ray, vis, overflow);
@@ -670,223 +693,16 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
       }
     }
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// The same walk by a whole wave at once: PACKET traversal for rays that travel together (the primary rays of an 8x8
-// chunk, their shadow rays to one light, the rays that carry on through a flat pane of glass).  The wave visits ONE node
-// at a time: the node - and later the leaf record, the triangle, the instance's inverse, the reference box of the chain
-// replay - is fetched once, by SCALAR loads (s_load_dwordx8/x16 through the constant address space: the walk is
-// wave-uniform, so every address is), and sits in SGPRs; every lane tests its own ray against it; a child is entered if
-// ANY lane's ray enters it (__ballot).  The stack is the wave's: 64 words of LDS, written by every lane of the packet
-// with the same value and read back at a wave-uniform address, the stack pointer in an SGPR.  (One VGPR with entry i in
-// lane i - v_writelane / v_readlane - would do without LDS, but every copy the register allocator makes of it is masked
-// by exec and loses the slots of the lanes outside the packet.)  What the per-lane walk of traverse_bvh() pays per step,
-// 64 lanes x a 128-byte node gathered through the vector memory path (8 KB per wave and step at the L1's 64 B per
-// clock), a per-lane stack in LDS and scratch, and waves in which some lanes are at leaves while others are at nodes,
-// is gone; what a packet pays instead is the UNION of its rays' walks, which for coherent rays is about the longest of
-// them - the per-lane walk's cost as well, a wave being as slow as its slowest lane.
-// Candidates only, as before: exactness is decided by the FP64 leaf tests and the replay of the reference's box chain.
-// ------------------------------------------------------------------------------------------
-#define RTC_CONST_AS __attribute__((address_space(4)))
-template <class T>
-__device__ __forceinline__ const RTC_CONST_AS T* in_const(const T* p) {
-  return (const RTC_CONST_AS T*)p;  // read-only scene tables: a load at a wave-uniform address becomes a scalar load
-}
-
-// chain_ok() for a wave-uniform first parent: the boxes come through the scalar path.
-__device__ __forceinline__ bool chain_ok_u(const DevScene& S, uint32_t first_parent, const Ray& ray, double t, bool degenerate) {
-  const double px = ray.ox + ray.dx * t, py = ray.oy + ray.dy * t, pz = ray.oz + ray.dz * t;
-  const double scale = zmax(zmax(__builtin_fabs(px), __builtin_fabs(py)), __builtin_fabs(pz)) +
-                       zmax(zmax(__builtin_fabs(ray.ox), __builtin_fabs(ray.oy)), __builtin_fabs(ray.oz));
-  const double m = 1e-9 * (1.0 + scale);
-  uint32_t n = first_parent;
-  while (n != RTC_NO_LEAF) {
-    const RTC_CONST_AS double* B = in_const(S.node_box) + 6ull * n;
-    const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4], b5 = B[5];
-    const bool inside = !degenerate & (b0 + m <= px) & (px <= b3 - m) & (b1 + m <= py) & (py <= b4 - m) &
-                        (b2 + m <= pz) & (pz <= b5 - m);
-    if (!inside) {
-      double tmin, tmax;
-      if (!slab(ray, b0, b1, b2, b3, b4, b5, tmin, tmax)) return false;
-    }
-    if (S.chain_nested) return true;  // (see chain_ok)
-    n = in_const(S.node_parent)[n];
-  }
-  return true;
-}
-
-// visit_leaf() for a wave-uniform leaf record: header, triangle and inverse arrive in SGPRs.  Called by every lane of the
-// packet; `live` lanes (those whose visitor still wants entries) run the exact test.
-template <class V>
-__device__ __forceinline__ void visit_leaf_u(const DevScene& S, const RTC_CONST_AS BvhLeafRec* L, const Ray& ray, bool degenerate,
-                                             bool live, uint32_t& cur_xf, Ray& lr, V& vis) {
-  // (field by field - the compiler merges them into one s_load_dwordx8; read through a 32-byte vector type the record,
-  // which is only 8-byte aligned, is undefined behaviour, and it showed: wrong `material` words in the containers pass)
-  const uint32_t leaf = L->leaf, kind_flags = L->kind_flags, xform = L->xform, material = L->material, geom = L->geom;
-  const uint32_t parent = L->parent;
-  if (xform != cur_xf) {  // Shape.intersect: ray.transform(_inverse_transform), shape.zig:314-318 (wave-uniform branch)
-    const RTC_CONST_AS double* X = in_const(S.xf) + 12ull * xform;
-    double m[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) m[i] = X[i];
-    lr = xform_ray(m, ray);
-    cur_xf = xform;
-  }
-  const uint32_t kind = kind_flags & 0xFFu;
-  CylParams cy{0.0, 0.0, false};
-  if (kind == 3u || kind == 6u) {
-    const RTC_CONST_AS DevCyl* c = in_const(S.cyl) + geom;
-    cy = {c->ymin, c->ymax, c->closed != 0u};
-  }
-  const uint32_t shadow = (kind_flags >> 8) & 1u;
-  if (!live) return;
-  if (kind == 4u || kind == 5u) {  // a triangle has at most one entry: evaluate it once
-    double tri[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) tri[i] = L->tri[i];
-    bool hit = false;
-    double ht = 0.0, hu = 0.0, hv = 0.0;
-    leaf_entries(kind, cy, tri, lr, [&](double t, double u, double v) {
-      hit = true;
-      ht = t;
-      hu = u;
-      hv = v;
-    });
-    if (!hit || !vis.relevant(leaf, shadow, ht)) return;
-    if (!chain_ok_u(S, parent, ray, ht, degenerate)) return;
-    vis.entry(leaf, shadow, material, ht, hu, hv);
-    return;
-  }
-  bool relevant = false;
-  double t_rel = 0.0;
-  leaf_entries(kind, cy, nullptr, lr, [&](double t, double, double) {
-    if (!relevant && vis.relevant(leaf, shadow, t)) {
-      relevant = true;
-      t_rel = t;
-    }
-  });
-  if (!relevant) return;
-  if (!chain_ok_u(S, parent, ray, t_rel, degenerate)) return;
-  leaf_entries(kind, cy, nullptr, lr, [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
-}
-
-// Called with exec = the lanes of the packet (the caller's `if`); `root` is wave-uniform.
-template <bool CSG, class V>
-__device__ __forceinline__ void traverse_bvh_packet(const DevScene& S, const uint32_t root, const Ray& ray, V& vis,
-                                                    unsigned& overflow, uint32_t* wave_stack) {
-  const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
-  const float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
-  // The slab test per axis, select-free (the box is in SGPRs and a VALU instruction reads one SGPR): with i = 1 / d and
-  // q = o * i, the two plane distances are lo * i - q and hi * i - q, the near one their min, the far one their max,
-  // and the margin e = delta * |i| (delta: what the FP32 ray and arithmetic can be off by, in space: 1e-6 of the
-  // largest coordinate involved; every rounding below is under 4e-7 of it) moves the near one down and the far one up.
-  // |d| is kept above 1e-18 so that i, q and e stay finite: no inf - inf, no NaN; a ray that parallel to a slab it
-  // starts outside of reaches it beyond any t that matters.
-  const float delta = 1e-6f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
-  auto inverse = [](float d) { return 1.0f / (__builtin_fabsf(d) < 1e-18f ? __builtin_copysignf(1e-18f, d) : d); };
-  const float ix = inverse(dx), iy = inverse(dy), iz = inverse(dz);
-  const float ex = delta * __builtin_fabsf(ix), ey = delta * __builtin_fabsf(iy), ez = delta * __builtin_fabsf(iz);
-  const float qx = ox * ix, qy = oy * iy, qz = oz * iz;
-  const float nx = -qx - ex, ny = -qy - ey, nz = -qz - ez;  // near planes: lo * i + n
-  const float fx = ex - qx, fy = ey - qy, fz = ez - qz;     // far planes:  hi * i + f
-  const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
-  uint32_t cur_xf = 0xFFFFFFFFu;  // wave-uniform
-  Ray lr = ray;
-  uint32_t sp = 0u;
-  uint32_t next = root;
-  for (;;) {
-    if (next == RTC_NO_LEAF) {
-      if (sp == 0u) break;
-      --sp;
-      next = __builtin_amdgcn_readfirstlane(wave_stack[sp]);
-    }
-    const uint32_t ref = next;
-    next = RTC_NO_LEAF;
-    const bool live = !vis.done();
-    if (__ballot(live) == 0ull) break;  // (a shadow packet ends when every ray is shadowed)
-    if (ref & RTC_NODE_BIT) {  // a range of 1..8 leaves
-      const uint32_t first = (ref & ~RTC_NODE_BIT) >> 3, count = (ref & 7u) + 1u;
-      for (uint32_t i = 0; i < count; ++i) {
-        const RTC_CONST_AS BvhLeafRec* L = in_const(S.bvh_leaf) + (first + i);
-        const uint32_t leaf = L->leaf;
-        if (CSG && (leaf & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
-          if constexpr (CSG) {
-            if (live) visit_csg(S, leaf & ~RTC_NODE_BIT, ray, vis, overflow);
-          }
-        } else {
-          visit_leaf_u(S, L, ray, degenerate, !vis.done(), cur_xf, lr, vis);
-        }
-      }
-      continue;
-    }
-    // the whole 128-byte node in two scalar loads (child by child the walk would wait eight times per node)
-    typedef uint32_t Dwords16 __attribute__((ext_vector_type(16)));
-    const RTC_CONST_AS Dwords16* N = reinterpret_cast<const RTC_CONST_AS Dwords16*>(in_const(S.bvh) + ref);
-    const Dwords16 nlo = N[0], nhi = N[1];  // lo[3][4] hi[0][4] | hi[1][4] hi[2][4] c[4] pad
-    uint32_t key[4], refs[4];
-    uint32_t entered = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t c = nhi[8 + k];
-      key[k] = 0xFFFFFFFFu;
-      refs[k] = c;
-      if (c == RTC_NO_LEAF) continue;  // (wave-uniform)
-      // (through a function argument: __builtin_bit_cast applied to a vector ELEMENT reads element 0 of the vector)
-      auto as_float = [](uint32_t bits) { return __builtin_bit_cast(float, bits); };
-      const float lox = as_float(nlo[k]), loy = as_float(nlo[4 + k]), loz = as_float(nlo[8 + k]);
-      const float hix = as_float(nlo[12 + k]), hiy = as_float(nhi[k]), hiz = as_float(nhi[4 + k]);
-      const float tnx = fminf(__builtin_fmaf(lox, ix, nx), __builtin_fmaf(hix, ix, nx));
-      const float tny = fminf(__builtin_fmaf(loy, iy, ny), __builtin_fmaf(hiy, iy, ny));
-      const float tnz = fminf(__builtin_fmaf(loz, iz, nz), __builtin_fmaf(hiz, iz, nz));
-      const float tfx = fmaxf(__builtin_fmaf(lox, ix, fx), __builtin_fmaf(hix, ix, fx));
-      const float tfy = fmaxf(__builtin_fmaf(loy, iy, fy), __builtin_fmaf(hiy, iy, fy));
-      const float tfz = fmaxf(__builtin_fmaf(loz, iz, fz), __builtin_fmaf(hiz, iz, fz));
-      const float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);
-      // (written so that a NaN - there should be none - enters the child)
-      const bool h = live & !(tn > tf) & !(tn >= __builtin_inff()) & !vis.cullf(tn, tf);
-      const unsigned long long m = __ballot(h);
-      if (m == 0ull) continue;
-      entered++;
-      if constexpr (!V::kAnyHit) {  // order by the entry distance of the first ray that enters (bits of a float >= 0 order like it)
-        const uint32_t bits = __builtin_bit_cast(uint32_t, fmaxf(tn, 0.0f));
-        key[k] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bits), static_cast<int>(__builtin_ctzll(m))));
-      } else {
-        key[k] = 0u;
-      }
-    }
-    if (entered == 0u) continue;
-    if (sp + entered > 64u) {
-      overflow = 1u;
-      continue;
-    }
-    if constexpr (!V::kAnyHit) {  // farthest first, so that the nearest child is visited next (children not entered sort to the front)
-      auto order = [&](int a, int b) {
-        const bool swap = key[a] < key[b];
-        const uint32_t ka = swap ? key[b] : key[a], kb = swap ? key[a] : key[b];
-        const uint32_t ra = swap ? refs[b] : refs[a], rb = swap ? refs[a] : refs[b];
-        key[a] = ka;
-        key[b] = kb;
-        refs[a] = ra;
-        refs[b] = rb;
-      };
-      order(0, 1);
-      order(2, 3);
-      order(0, 2);
-      order(1, 3);
-      order(1, 2);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (key[k] != 0xFFFFFFFFu) {
-        if (next != RTC_NO_LEAF) {
-          wave_stack[sp] = next;
-          ++sp;
-        }
-        next = refs[k];
-      }
-    }
-  }
+#ifdef RTC_PROFILE  // walks of the wave, their lanes, wave steps at nodes / at leaves, lanes at nodes / at leaves (summed over the steps)
+  RTC_WALK_ADD(0, 1);
+  RTC_WALK_ADD(1, pw_lanes);
+  RTC_WALK_ADD(2, pw_nodes);
+  RTC_WALK_ADD(3, pw_leaves);
+  RTC_WALK_ADD(4, pw_node_lanes);
+  RTC_WALK_ADD(5, pw_leaf_lanes);
+  if (pw_leaves == 0ull) RTC_WALK_ADD(6, 1);         // walks that reach no leaf at all ...
+  if (pw_leaves == 0ull) RTC_WALK_ADD(7, pw_nodes);  // ... and the node steps they took
+#endif
 }
 
 // Conservative bounding-sphere rejection for one World.objects entry, in FP32.
@@ -964,7 +780,7 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 template <bool CSG, int WORLD, class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
                                       const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow,
-                                      uint32_t* lds_stack, uint32_t* wave_stack) {
+                                      uint32_t* lds_stack) {
   constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
   const RayF rf = ray_f32(ray, S.cull_cmax);
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
@@ -1012,51 +828,6 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       leaves_of_kind(std::integral_constant<uint32_t, 2u>{}, mine & range(k2, k3));
       if constexpr (SIMPLE) continue;  // (a simple world has nothing else)
       mine &= range(k3, S.n_roots);    // the other leaf kinds: cylinders, cones, triangles
-    }
-    if constexpr (!FLAT) {
-      // Groups first, root by root, by the whole wave: the lanes that want a group and whose rays travel together walk
-      // its candidate BVH as a packet (traverse_bvh_packet).  "Together": within about 14 degrees of the first such
-      // lane's direction, origins no further apart than a quarter of the group's bounding radius; up to RTC_PACKET_ROUNDS
-      // such sets per group, each led by the first lane not yet served.  A set of fewer than RTC_PACKET_MIN lanes is not
-      // worth a walk of its own: those lanes keep the group's bit and walk it lane by lane in the loop below, next to
-      // whatever else they - and the other stragglers, in other groups - have left.
-      const uint32_t g0 = S.n_root_planes + S.n_root_spheres + S.n_root_cubes;  // (groups sit behind the sorted kinds)
-      const uint32_t r_lo = max(g0, base), r_hi = min(S.n_roots, base + 64u);
-      for (uint32_t r = r_lo; r < r_hi; ++r) {
-        const unsigned long long bit = 1ull << (r - base);
-        bool want = (mine & bit) != 0ull && !vis.done();
-        unsigned long long todo = __ballot(want);
-        if (todo == 0ull) continue;
-        const uint32_t kf = __builtin_amdgcn_readfirstlane(recs[r].kind_flags);
-        if ((kf & (RTC_ROOT_IS_GROUP | RTC_ROOT_IS_CSG)) != RTC_ROOT_IS_GROUP) continue;
-        const uint32_t bvh_root = __builtin_amdgcn_readfirstlane(recs[r].geom);
-        const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(uint32_t, static_cast<float>(cull[r >> 1].r2[r & 1u]))));
-#pragma unroll 1
-        for (int round = 0; round < RTC_PACKET_ROUNDS && todo != 0ull; ++round) {
-          const int leader = __builtin_ctzll(todo);
-          auto of_leader = [&](float v) {
-            return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), leader));
-          };
-          const float lox = of_leader(rf.ox), loy = of_leader(rf.oy), loz = of_leader(rf.oz);
-          const float ldx = of_leader(rf.dx), ldy = of_leader(rf.dy), ldz = of_leader(rf.dz);
-          const float sx = rf.ox - lox, sy = rf.oy - loy, sz = rf.oz - loz;
-          const float dot = rf.dx * ldx + rf.dy * ldy + rf.dz * ldz;
-          const float l2 = ldx * ldx + ldy * ldy + ldz * ldz;
-          const bool coherent = want & (dot > 0.0f) & (dot * dot >= 0.94f * rf.a * l2) &
-                                (sx * sx + sy * sy + sz * sz <= 0.0625f * r2);
-          const unsigned long long set = __ballot(coherent);
-          if (static_cast<uint32_t>(__builtin_popcountll(set)) >= RTC_PACKET_MIN) {
-            if (coherent) {
-              vis.set_root(RTC_NO_LEAF);
-              traverse_bvh_packet<CSG>(S, bvh_root, ray, vis, overflow, wave_stack);
-              mine &= ~bit;
-            }
-          }
-          want = want & !coherent;
-          todo &= ~set;
-          if (set == 0ull) break;  // (a leader whose own ray is not a number)
-        }
-      }
     }
     while (mine != 0ull && !vis.done()) {
       const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mine));
@@ -1635,6 +1406,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   }
 #else
   (void)next_stats;
+  if (threadIdx.x == 0u) rtc_prof_stats = stats;
+  __syncthreads();
 #endif
   // Small-world tables (World.objects records + bounding spheres, materials, patterns, lights):
   // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
@@ -1663,7 +1436,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // six VGPRs of a kernel at the 256-register limit.
   __shared__ double lds_acc[4][64][3];
   __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : RTC_LDS_TRAV][64];  // per lane: the top of the BVH walk's stack
-  __shared__ uint32_t lds_wave_stack[FLAT ? 1 : 4][FLAT ? 1 : 64];             // per wave: the stack of a packet walk
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -1718,7 +1490,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   uint32_t share_rays = 0u;
   double* const acc = lds_acc[threadIdx.x >> 6][threadIdx.x & 63u];
   uint32_t* const trav_stack = FLAT ? nullptr : &lds_trav[threadIdx.x >> 6][0][threadIdx.x & 63u];
-  uint32_t* const wave_stack = FLAT ? nullptr : &lds_wave_stack[threadIdx.x >> 6][0];
   acc[0] = acc[1] = acc[2] = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;
@@ -1995,7 +1766,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_COUNT(0);
     {
       RTC_HIST_BEGIN();
-      trace<CSG, WORLD>(S, recs, cull, ray, hv, overflow, trav_stack, wave_stack);
+      trace<CSG, WORLD>(S, recs, cull, ray, hv, overflow, trav_stack);
       RTC_HIST_END(0);
     }
     RTC_STAMP(2);
@@ -2040,7 +1811,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       RTC_COUNT(4);
       {
         RTC_HIST_BEGIN();
-        trace<CSG, WORLD>(S, recs, cull, ray, bv, overflow, trav_stack, wave_stack);
+        trace<CSG, WORLD>(S, recs, cull, ray, bv, overflow, trav_stack);
         RTC_HIST_END(2);
       }
       RTC_STAMP(6);
@@ -2187,7 +1958,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, WORLD>(S, recs, cull, sray, sv, overflow, trav_stack, wave_stack);
+            trace<CSG, WORLD>(S, recs, cull, sray, sv, overflow, trav_stack);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
