@@ -54,13 +54,14 @@
 #ifndef RTC_H
 #define RTC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 2u
+#define RTC_ABI_VERSION 3u
 
 /* ---- status codes; names mirror the reference's Zig error names where one exists ---- */
 typedef enum rtc_status {
@@ -241,14 +242,23 @@ void rtc_scene_destroy(rtc_scene *scene);
  * Replaces Camera.render (camera.zig:80-125) for the tile [x0,x0+w) x [y0,y0+h):
  * rgb_out[(y-y0)*w + (x-x0)][0..2] = colorAt(rayForPixel(x,y), max_depth).
  * The reference value of max_depth is 5 (camera.zig:118).  `rgb_out` is host
- * memory, [h][w][3] doubles.  Synchronous.  (A caller that passes the same
- * buffer again - an interactive host - gets it registered with the HIP runtime
- * on the second call, so that the copy runs at link speed; the registration is
- * dropped when another buffer is passed or the scene is destroyed, which must
- * happen before the buffer is freed.)
+ * memory, [h][w][3] doubles.  Synchronous, and without side effects on the
+ * caller's memory: the frame is copied into `rgb_out`, nothing is remembered
+ * about the pointer.  (Into pageable memory that copy runs at a fifth of the
+ * link's rate; see rtc_canvas_register.)
  */
 int rtc_render(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
                uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, double *rgb_out);
+
+/*
+ * Optional, for a host that renders frame after frame into ONE canvas (the interactive seam, lib.zig:135-190): pins
+ * the caller's buffer for the HIP runtime (hipHostRegister), so that rtc_render's / rtc_multi_render's copy into it
+ * runs at link speed (1080p: 1.5 ms per call instead of 3.8-5.6).  Explicit on purpose: the registration belongs to the
+ * MEMORY, not to a scene handle, and the caller - who knows when the canvas is freed - drops it with
+ * rtc_canvas_unregister BEFORE freeing or reallocating the buffer.  Both are process-wide and need no scene.
+ */
+int rtc_canvas_register(void *canvas, size_t bytes);
+int rtc_canvas_unregister(void *canvas);
 
 /*
  * The same frame as the RGBA8 framebuffer of the reference's interactive seam (Renderer, src/lib.zig:135-164):
@@ -258,6 +268,10 @@ int rtc_render(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
  */
 int rtc_render_rgba8(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint8_t *rgba_out);
+
+/* The clamp alone, device to device: d_rgba[i] = R | G << 8 | B << 16 | 255 << 24 of pixel i of an [n_pixels][3] f64
+ * canvas on the current device; asynchronous on `hip_stream` (not NULL).  Needs no scene. */
+int rtc_rgba8_device(const double *d_canvas, size_t n_pixels, uint32_t *d_rgba, void *hip_stream);
 
 /*
  * Same, but `d_rgb_out` is device memory on the scene's device and the work is
@@ -344,6 +358,17 @@ const char *rtc_last_kernel_name(const rtc_scene *scene);
  * Synchronises.  `*n_packets` = 0 when the handle has no schedule (no launch yet, or a launch of fewer than 64 chunks).
  * RTC_ERR_INVALID_ARGUMENT if `capacity_items` is too small (`*n_packets` says how many rows there are). */
 int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, uint32_t *n_packets);
+
+/*
+ * Tuning and test options, process-wide; none changes a rendered value.  Read when a scene is created (bvh_*,
+ * blocks_per_cu) or a launch is enqueued (the rest).  Names: "simple3_min_chunks" (chunks from which a world of
+ * top-level spheres / planes / cubes runs the three-waves-per-SIMD kernel; 0 always, < 0 the library's choice),
+ * "sched_off" (!= 0: no schedule, packet i is chunk i), "cut_above" (shares of a wave above which a chunk is cut into
+ * runs of pixels; < 0 never, 0 the library's choice), "pack_rounds", "pull_min_idle", "blocks_per_cu", "sched_tmin",
+ * "bvh_leaf", "bvh_one_axis", "bvh_check".  RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
+ * (The library reads no environment variables.)
+ */
+int rtc_set_option(const char *name, double value);
 
 /* Thread-local, static storage; "" when the last call on this thread succeeded. */
 const char *rtc_last_error(void);

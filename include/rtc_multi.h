@@ -5,7 +5,7 @@
  * host that wants the 8 GPUs of a node behind that one call binds this: the flat scene is replicated on every GPU,
  * the image is cut into 64x64 tiles, every GPU renders its share into a compact buffer, ONE ncclGather per frame
  * brings the shares to GPU 0 over xGMI, one kernel un-permutes them into the row-major Canvas (canvas.zig:132-137),
- * which is copied to the caller.  The split starts round-robin; after the first frame (and, while the camera moves,
+ * which is copied to the caller (or clamped to RGBA8 first, or left on GPU 0: the three render entry points).  The split starts round-robin; after the first frame (and, while the camera moves,
  * every 16 frames) the tiles are re-dealt by their MEASURED cost (rtc_get_tile_costs + rtc_assign_tiles of rtc.h); the
  * frame after a re-deal measures the new shares afresh, and a split that then proves uneven (busiest rank more than a
  * quarter above the mean) is dealt again, three times at most.
@@ -40,6 +40,26 @@ void rtc_multi_destroy(rtc_multi *m);
  * failures too.
  */
 int rtc_multi_render(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, double *rgb_out);
+
+/*
+ * The same frame as the RGBA8 framebuffer of the reference's interactive seam (Renderer, src/lib.zig:135-164; clamp of
+ * color.zig:61-71, alpha 255): rgba_out[(y * hsize + x) * 4 + 0..3], host memory.  Clamped on GPU 0: 4 bytes per pixel
+ * cross the link instead of 24.  Synchronous.
+ */
+int rtc_multi_render_rgba8(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, uint8_t *rgba_out);
+
+/*
+ * The frame left on GPU 0, nothing copied and nothing waited for: *d_canvas is device memory on device 0,
+ * [vsize][hsize][3] doubles, complete once the work enqueued on rtc_multi_stream() has run (rtc_multi_synchronize, or
+ * the caller's own work enqueued on that stream).  Two canvases alternate: a frame's canvas stays valid until the
+ * render after the next one.  The bookkeeping a frame owes (overflow check, re-deal of the tiles) is done by the next
+ * call on the handle; its status is that call's status.
+ */
+int rtc_multi_render_device(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, const double **d_canvas);
+int rtc_multi_synchronize(rtc_multi *m);
+void *rtc_multi_stream(rtc_multi *m); /* the hipStream_t (device 0) behind which a frame's canvas is complete */
+
+/* (For host output at link speed register the canvas once: rtc_canvas_register of rtc.h.) */
 
 /* Ray counters of the last frame, summed over the GPUs. */
 int rtc_multi_get_stats(rtc_multi *m, rtc_stats *out);

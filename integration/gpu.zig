@@ -33,7 +33,7 @@ const Camera = @import("camera.zig").Camera;
 
 // ------------------------------------------------------------------------------------------------ include/rtc.h
 
-pub const RTC_ABI_VERSION: u32 = 2;
+pub const RTC_ABI_VERSION: u32 = 3;
 pub const RTC_CHILD_NODE_BIT: u32 = 0x80000000;
 pub const RTC_MAT_STRIDE = 7;
 
@@ -83,6 +83,10 @@ pub extern fn rtc_render_rgba8(scene: *RtcScene, cam: *const RtcCamera, max_dept
                                x0: u32, y0: u32, w: u32, h: u32, rgba_out: [*]u8) c_int; // lib.zig's framebuffer
 pub extern fn rtc_render_device(scene: *RtcScene, cam: *const RtcCamera, max_depth: u32, x0: u32, y0: u32, w: u32, h: u32,
                                 d_rgb_out: [*]f64, hip_stream: ?*anyopaque) c_int; // output stays in HBM
+pub extern fn rtc_canvas_register(canvas: *anyopaque, bytes: usize) c_int; // pin a canvas that is rendered into again and again ...
+pub extern fn rtc_canvas_unregister(canvas: *anyopaque) c_int; // ... and drop the pin BEFORE the canvas is freed
+pub extern fn rtc_rgba8_device(d_canvas: [*]const f64, n_pixels: usize, d_rgba: [*]u32, hip_stream: ?*anyopaque) c_int;
+pub extern fn rtc_set_option(name: [*:0]const u8, value: f64) c_int; // tuning / test options; the library reads no environment
 pub extern fn rtc_scene_synchronize(scene: *RtcScene) c_int;
 pub extern fn rtc_get_stats(scene: *RtcScene, out: *RtcStats) c_int;
 pub extern fn rtc_last_kernel_name(scene: *const RtcScene) [*:0]const u8;
@@ -95,6 +99,10 @@ pub const RtcMulti = opaque {};
 pub extern fn rtc_multi_create(desc: *const RtcSceneDesc, n_gpus: u32, flags: u32, out: *?*RtcMulti) c_int;
 pub extern fn rtc_multi_destroy(m: ?*RtcMulti) void;
 pub extern fn rtc_multi_render(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, rgb_out: [*]f64) c_int;
+pub extern fn rtc_multi_render_rgba8(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, rgba_out: [*]u8) c_int; // lib.zig's framebuffer
+pub extern fn rtc_multi_render_device(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, d_canvas: *?[*]const f64) c_int; // stays on GPU 0
+pub extern fn rtc_multi_synchronize(m: *RtcMulti) c_int;
+pub extern fn rtc_multi_stream(m: *RtcMulti) ?*anyopaque;
 pub extern fn rtc_multi_last_error() [*:0]const u8;
 
 pub const GpuError = error{ GpuSceneRejected, GpuRenderFailed };

@@ -91,12 +91,12 @@ class Stats(C.Structure):
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
                "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
-               "rtc_status_name"]
+               "rtc_status_name", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
-MULTI_SYMBOLS = ["rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_multi_get_stats", "rtc_multi_balance",
-                 "rtc_multi_last_error"]
+MULTI_SYMBOLS = ["rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_multi_render_rgba8", "rtc_multi_render_device",
+                 "rtc_multi_synchronize", "rtc_multi_stream", "rtc_multi_get_stats", "rtc_multi_balance", "rtc_multi_last_error"]
 RTC_MULTI_VIRTUAL = 1
 
 _hip = None
@@ -157,6 +157,10 @@ def hip_lib():
         lib.rtc_last_kernel_name.argtypes = [C.c_void_p]
         lib.rtc_last_kernel_name.restype = C.c_char_p
         lib.rtc_get_schedule.argtypes = [C.c_void_p, _u32p, C.c_size_t, _u32p]
+        lib.rtc_canvas_register.argtypes = [C.c_void_p, C.c_size_t]
+        lib.rtc_canvas_unregister.argtypes = [C.c_void_p]
+        lib.rtc_rgba8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.rtc_set_option.argtypes = [C.c_char_p, C.c_double]
         _hip = lib
     return _hip
 
@@ -203,6 +207,11 @@ def multi_lib():
         lib.rtc_multi_destroy.argtypes = [C.c_void_p]
         lib.rtc_multi_destroy.restype = None
         lib.rtc_multi_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
+        lib.rtc_multi_render_rgba8.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
+        lib.rtc_multi_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.rtc_multi_synchronize.argtypes = [C.c_void_p]
+        lib.rtc_multi_stream.argtypes = [C.c_void_p]
+        lib.rtc_multi_stream.restype = C.c_void_p
         lib.rtc_multi_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         lib.rtc_multi_balance.argtypes = [C.c_void_p, _u32p, _dp]
         _multi = lib
@@ -222,10 +231,31 @@ class MultiGpu:
         if status != 0:
             raise RtcError(hip_lib().rtc_status_name(status).decode(), multi_lib().rtc_multi_last_error().decode())
 
-    def render(self, cam, max_depth=REFERENCE_DEPTH):
-        out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
+    def render(self, cam, max_depth=REFERENCE_DEPTH, out=None):
+        if out is None:
+            out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
         self._check(multi_lib().rtc_multi_render(self._m, C.byref(cam), max_depth, out.ctypes.data))
         return out
+
+    def render_rgba8(self, cam, max_depth=REFERENCE_DEPTH, out=None):
+        """The RGBA8 framebuffer of lib.zig:146-153, clamped on GPU 0; [vsize][hsize][4] u8 (host)."""
+        if out is None:
+            out = np.empty((cam.vsize, cam.hsize, 4), dtype=np.uint8)
+        self._check(multi_lib().rtc_multi_render_rgba8(self._m, C.byref(cam), max_depth, out.ctypes.data))
+        return out
+
+    def render_device(self, cam, max_depth=REFERENCE_DEPTH):
+        """Enqueues the frame and returns the device pointer (GPU 0) of its [vsize][hsize][3] f64 canvas; nothing is
+        copied or waited for (synchronize(), or work enqueued on stream(), orders behind it)."""
+        ptr = C.c_void_p()
+        self._check(multi_lib().rtc_multi_render_device(self._m, C.byref(cam), max_depth, C.byref(ptr)))
+        return ptr.value
+
+    def synchronize(self):
+        self._check(multi_lib().rtc_multi_synchronize(self._m))
+
+    def stream(self):
+        return multi_lib().rtc_multi_stream(self._m)
 
     def stats(self):
         st = Stats()
@@ -325,7 +355,6 @@ class GpuScene:
 
     def __init__(self, desc):
         self._s = C.c_void_p()
-        self._last_out = None
         _check_hip(hip_lib().rtc_scene_create(C.byref(desc), C.byref(self._s)))
 
     def render(self, cam, max_depth=REFERENCE_DEPTH, tile=None):
@@ -333,16 +362,12 @@ class GpuScene:
         x0, y0, w, h = tile if tile else (0, 0, cam.hsize, cam.vsize)
         out = np.empty((h, w, 3), dtype=np.float64)
         _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, x0, y0, w, h, out.ctypes.data))
-        # rtc_render registers a canvas it is handed twice, and that canvas must then outlive the registration (rtc.h):
-        # the handle keeps the last array it returned alive, so a fresh np.empty can never sit at the address of a
-        # freed one that the library still holds.
-        self._last_out = out
         return out
 
     def render_into(self, cam, out, max_depth=REFERENCE_DEPTH):
-        """Camera.render into a caller-owned [h][w][3] f64 array (an interactive host reuses its canvas)."""
+        """Camera.render into a caller-owned [h][w][3] f64 array (an interactive host reuses its canvas, and pins it
+        once with canvas_register so that the copy runs at link speed)."""
         assert out.dtype == np.float64 and out.flags["C_CONTIGUOUS"] and out.shape == (cam.vsize, cam.hsize, 3)
-        self._last_out = out
         _check_hip(hip_lib().rtc_render(self._s, C.byref(cam), max_depth, 0, 0, cam.hsize, cam.vsize, out.ctypes.data))
         return out
 
@@ -402,13 +427,27 @@ class GpuScene:
         if self._s:
             hip_lib().rtc_scene_destroy(self._s)
             self._s = C.c_void_p()
-        self._last_out = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+def canvas_register(array):
+    """rtc_canvas_register: pins a caller-owned numpy canvas for the HIP runtime (copies into it then run at link
+    speed).  The caller keeps the array alive and calls canvas_unregister before dropping it."""
+    _check_hip(hip_lib().rtc_canvas_register(array.ctypes.data, array.nbytes))
+
+
+def canvas_unregister(array):
+    _check_hip(hip_lib().rtc_canvas_unregister(array.ctypes.data))
+
+
+def set_option(name, value):
+    """rtc_set_option: a process-wide tuning / test option of the library (include/rtc.h lists them)."""
+    _check_hip(hip_lib().rtc_set_option(name.encode(), float(value)))
 
 
 def canvas_ppm(rgb):

@@ -279,7 +279,7 @@ struct BvhBuilder {
     // Up to two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
     // tests together), the four-wide nodes and the final schedule, measured at 1 / 2 / 3 leaves per node:
     // dragons 4K 2.78 / 2.72 / 2.73 ms, nefertiti 0.728 / 0.713 / 0.719 ms, teapot 0.382 / 0.357 / 0.368 ms.
-    static const size_t max_leaf = getenv("RTC_BVH_LEAF") ? std::min<size_t>(8, std::max<size_t>(1, atoi(getenv("RTC_BVH_LEAF")))) : 2;
+    const size_t max_leaf = static_cast<size_t>(std::min(8.0, std::max(1.0, rtcOptions().bvh_leaf)));
     if (count <= max_leaf) {
       const uint32_t at = static_cast<uint32_t>(leaves.size());
       for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
@@ -306,7 +306,7 @@ struct BvhBuilder {
       int b = static_cast<int>((p.c[ax] - clo[ax]) / extent * kBins);
       return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
     };
-    static const bool one_axis = getenv("RTC_BVH_ONE_AXIS") != nullptr;  // experiment knob: longest axis only
+    const bool one_axis = rtcOptions().bvh_one_axis != 0.0;  // (tuning option: longest axis only)
     for (int ax = 0; ax < 3; ++ax) {
       if (one_axis && ax != axis) continue;
       const double extent = chi[ax] - clo[ax];

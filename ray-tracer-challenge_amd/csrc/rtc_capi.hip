@@ -2,7 +2,6 @@
 // the flat scene, upload to HBM, kernel launches.  No torch types, no CPU render path: every
 // entry point either runs the HIP kernel or fails with an rtc_status.
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -76,7 +75,6 @@ extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gather
 
 #include "rtc_host_internal.h"
 #include "rtc_bounds.h"
-#include "rtc_schedule.h"
 
 namespace {
 
@@ -167,13 +165,42 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
+// Both schedule buffers hold at least `words` words (16 per packet; maxPackets() of them).  Growing drops what the
+// buffers held.
+int ensureScheduleBuffers(rtc_scene* s, size_t words) {
+  if (words <= s->sched_capacity) return RTC_OK;
+  HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be reading a buffer)
+  for (int b = 0; b < 2; ++b) {
+    if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
+    s->d_sched[b] = nullptr;
+  }
+  s->sched_capacity = 0;
+  s->sched_valid = false;
+  for (int b = 0; b < 2; ++b) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched[b]), words * sizeof(uint32_t)));
+  if (!s->d_sched_info) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_sched_info), 2 * sizeof(DevSchedInfo)));
+  if (!s->d_pack_state) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_pack_state), sizeof(DevPackState)));
+  s->sched_capacity = words;
+  return RTC_OK;
+}
+
+// Cheap chunks are handed out several to a packet, up to this much measured time (s_memtime ticks / 16: 8000 is about
+// 50 us): the chunks of a packet are image neighbours, and a wave that walks the same BVH nodes or reads the same texels
+// for all of them finds them in its CU's L1; a pull of the work counter costs the wave a drain.  Measured at
+// 6000 / 8000 / 12000 / 16000 (1080p, after the counters got cache lines of their own - before that a pull was dearer
+// and meshes ran best at 16000): teapot 0.312 / 0.308 / 0.324 / 0.339 ms, nefertiti 0.589 / 0.599 / 0.613 / 0.632,
+// cylinders 0.291 / 0.283 / 0.296 / 0.305, dragons 4K 2.43 throughout; scenes with texture maps or csg want more:
+// earth 0.308 / 0.260 / 0.205 / 0.206, texture_demo 0.338 / 0.316 / 0.302 / 0.317, csg 0.688 / 0.684 / 0.665 / 0.676.
+double groupFloor(const rtc_scene* s) {
+  const double forced = rtcOptions().sched_tmin;
+  return forced > 0.0 ? forced : (s->ext_kernel ? 12000.0 : 8000.0);
+}
+
 // The render kernel of a scene whose tables fit in LDS.
 // The three-waves-per-SIMD form of the simple kernel pays when every wave has several packets to run (see the kernel):
 // from about four chunks per resident wave on (1280x720; tools/simple3_sweep.py).
 bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
-  const char* const env = getenv("RTC_SIMPLE3_MIN_CHUNKS");  // test / experiment knob, read per launch: 0 = always
-  const long forced = env != nullptr ? atol(env) : -1;
-  const uint64_t min_chunks = forced >= 0 ? static_cast<uint64_t>(forced) : 4ull * 4u * s->n_cus * s->blocks_per_cu_simple3;
+  const double forced = rtcOptions().simple3_min_chunks;  // (tests reach the kernel at small sizes with 0: always)
+  const uint64_t min_chunks = forced >= 0.0 ? static_cast<uint64_t>(forced) : 4ull * 4u * s->n_cus * s->blocks_per_cu_simple3;
   return s->simple3_ok && map.n_chunks >= min_chunks;
 }
 
@@ -212,9 +239,8 @@ double residentWaves(const rtc_scene* s, const DevPixelMap& map) { return 4.0 * 
 // clearly sticks out: cutting costs the runs the depth of their trees again, and with a moving camera the measurement is
 // a frame old (cover 1080p, threshold 1.0 / 1.5: static 0.551 / 0.543 ms, orbiting 0.579 / 0.560).
 double cutAbove(const rtc_scene* s, const DevPixelMap& map) {
-  static const bool off = getenv("RTC_NO_DEVICE_CUT") != nullptr;                               // experiment knobs
-  static const double forced = getenv("RTC_CUT_ABOVE") ? atof(getenv("RTC_CUT_ABOVE")) : 0.0;
-  if (off) return 0.0;
+  const double forced = rtcOptions().cut_above;
+  if (forced < 0.0) return 0.0;
   if (forced > 0.0) return forced;
   return static_cast<double>(map.n_chunks) >= 4.0 * residentWaves(s, map) ? 1.5 : 1.0;
 }
@@ -297,10 +323,13 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     s->d_cost = nullptr;
     s->cost_capacity = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
+    // (pixels of edge tiles outside the image are never written by a launch, and rtc_chunk_cost_kernel sums whole tiles:
+    // they must read as zero, once is enough)
+    HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
     s->cost_capacity = out_pixels;
   }
   const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
-  static const bool sched_off = getenv("RTC_SCHED_OFF") != nullptr;  // diagnostic: no schedule at all (packet i is chunk i)
+  const bool sched_off = rtcOptions().sched_off != 0.0;  // (diagnostic: no schedule at all, packet i is chunk i)
   if (!schedulable || sched_off) {  // a handful of chunks, or more than an item can name: packet i is chunk i, whole
     map.order = nullptr;
     map.n_units_dev = nullptr;
@@ -347,7 +376,7 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   // Rounds of the share a wave gets with the cuts (rtc_pack_extra_kernel; an estimate has no per-pixel spread to go by).
   // An odd number: the share found in round i over-corrects that of round i - 1 (fresnel 300x300 with 0 / 1 / 2 / 3
   // rounds: 0.149 / 0.124 / 0.130 / 0.112 ms; reflection_and_refraction depth 8 at 1080p with 1 / 3: 1.78 / 1.70).
-  static const int env_rounds = getenv("RTC_PACK_ROUNDS") ? atoi(getenv("RTC_PACK_ROUNDS")) : 3;  // experiment knob
+  const int env_rounds = static_cast<int>(rtcOptions().pack_rounds);
   const int rounds = cut_above > 0.0f && from == PackFrom::Measurement ? std::max(0, std::min(4, env_rounds)) : 0;
   for (int round = 0; round < rounds; ++round)
     hipLaunchKernelGGL(rtc_pack_extra_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, cut_above,
@@ -386,7 +415,7 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   // 3.29 / 3.24 / 3.16 / 3.05 / 2.84 ms, dragons 4K 8.33 / 7.99 / 7.59 / 7.18 / 6.60 ms: a wave that finishes its
   // packet before it starts the next keeps neighbouring pixels (the same objects, materials, BVH paths) together;
   // the lanes that run out early are fed by the work sharing of step 2a, not by pixels of another chunk.
-  static const uint32_t pull_min = getenv("RTC_PULL_MIN_IDLE") ? static_cast<uint32_t>(atoi(getenv("RTC_PULL_MIN_IDLE"))) : 64u;
+  const uint32_t pull_min = static_cast<uint32_t>(std::max(1.0, rtcOptions().pull_min_idle));
   map.pull_min_idle = std::max(1u, std::min(64u, pull_min));
   s->dev.csg_buf = nullptr;
   if (s->has_csg) {
@@ -1114,7 +1143,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
       return fail(RTC_ERR_OVERFLOW, "root %u: walking its candidate BVH can take %u stack entries, the kernel's traversal stack holds %d", i,
                   stack_need + 1, RTC_TRAV_STACK);
   }
-  if (getenv("RTC_BVH_CHECK")) {
+  if (rtcOptions().bvh_check != 0.0) {
     // diagnostic: every leaf once, every stored child box contains the world boxes below it
     std::vector<Aabb> world(n_live);
     for (uint32_t c = 0; c < d.n_leaves; ++c)
@@ -1320,21 +1349,6 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
   HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(s->launch_done, s->stream));
-  {
-    // The first device-to-host copy of some size in a process costs 8 ms (the runtime sets up its copy path; a 4-byte
-    // copy does not trigger it, 256 KB does): paid here, once per process, not by the first rtc_render of a frame.
-    static std::atomic<bool> copy_path_warm{false};
-    if (!copy_path_warm.exchange(true)) {
-      void* d_tmp = nullptr;
-      void* h_tmp = nullptr;
-      HIP_TRY(hipMalloc(&d_tmp, 1u << 20));
-      HIP_TRY(hipHostMalloc(&h_tmp, 1u << 20, hipHostMallocDefault));
-      HIP_TRY(hipMemcpyAsync(h_tmp, d_tmp, 1u << 20, hipMemcpyDeviceToHost, s->stream));
-      HIP_TRY(hipStreamSynchronize(s->stream));
-      HIP_TRY(hipHostFree(h_tmp));
-      HIP_TRY(hipFree(d_tmp));
-    }
-  }
   s->last_stream = s->stream;
   s->max_trav_stack = traits.max_stack;
   {
@@ -1351,10 +1365,8 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));
     s->blocks_per_cu_big = static_cast<uint32_t>(std::max(nb, 1));
-    if (const char* e = getenv("RTC_BLOCKS_PER_CU")) {  // experiment knob
-      const int v = atoi(e);
-      if (v >= 1) s->blocks_per_cu_lds = std::min<uint32_t>(s->blocks_per_cu_lds, v), s->blocks_per_cu_big = std::min<uint32_t>(s->blocks_per_cu_big, v);
-    }
+    if (const int v = static_cast<int>(rtcOptions().blocks_per_cu); v >= 1)  // (tuning option)
+      s->blocks_per_cu_lds = std::min<uint32_t>(s->blocks_per_cu_lds, v), s->blocks_per_cu_big = std::min<uint32_t>(s->blocks_per_cu_big, v);
   }
   DevScene& D = s->dev;
   D.root_recs = s->root_recs.p;
@@ -1440,7 +1452,6 @@ void rtc_scene_destroy(rtc_scene* s) {
   }
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
-  if (s->host_out_registered && hipHostUnregister(s->host_out) != hipSuccess) (void)hipGetLastError();  // (a canvas the caller has freed: not an error of this thread's next HIP call)
   for (int b = 0; b < 2; ++b)
     if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
   if (s->d_sched_info) (void)hipFree(s->d_sched_info);
@@ -1638,6 +1649,39 @@ int checkOverflow(rtc_scene* s) {
 
 }  // namespace
 
+int rtc_canvas_register(void* canvas, size_t bytes) {
+  g_error.clear();
+  if (!canvas || bytes == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "null canvas or no bytes");
+  HIP_TRY(hipHostRegister(canvas, bytes, hipHostRegisterPortable));
+  return RTC_OK;
+}
+
+int rtc_canvas_unregister(void* canvas) {
+  g_error.clear();
+  if (!canvas) return fail(RTC_ERR_INVALID_ARGUMENT, "null canvas");
+  HIP_TRY(hipHostUnregister(canvas));
+  return RTC_OK;
+}
+
+int rtc_set_option(const char* name, double value) {
+  g_error.clear();
+  if (!name) return fail(RTC_ERR_INVALID_ARGUMENT, "null option name");
+  RtcOptions& o = rtcOptions();
+  const struct {
+    const char* name;
+    double* slot;
+  } table[] = {{"simple3_min_chunks", &o.simple3_min_chunks}, {"sched_off", &o.sched_off}, {"cut_above", &o.cut_above},
+               {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
+               {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
+               {"bvh_check", &o.bvh_check}};
+  for (const auto& e : table)
+    if (std::strcmp(e.name, name) == 0) {
+      *e.slot = value;
+      return RTC_OK;
+    }
+  return fail(RTC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+}
+
 int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                double* rgb_out) {
   g_error.clear();
@@ -1647,29 +1691,22 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
   if (const int st = ensureFrame(s, need); st != RTC_OK) return st;
   const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
   if (st != RTC_OK) return st;
-  // The caller's canvas is pageable memory: a copy into it runs at a fifth of the link's rate (5.6 ms for a 1080p frame).
-  // A caller that renders into the SAME buffer again (an interactive host: lib.zig:135-190) gets it registered with the
-  // runtime on the second use and the copy at link speed from then on; a one-shot render does not pay for pinning.
+  // (into pageable memory the copy runs at a fifth of the link's rate - 5.6 ms for a 1080p frame; a host that renders
+  // frame after frame registers its canvas once: rtc_canvas_register)
   const size_t bytes = need * sizeof(double);
-  if (s->host_out == rgb_out && s->host_out_bytes == bytes) {
-    if (!s->host_out_registered && !s->host_out_register_failed) {
-      if (hipHostRegister(rgb_out, bytes, hipHostRegisterDefault) == hipSuccess) {
-        s->host_out_registered = true;
-      } else {
-        (void)hipGetLastError();
-        s->host_out_register_failed = true;
-      }
-    }
-  } else {
-    if (s->host_out_registered && hipHostUnregister(s->host_out) != hipSuccess) (void)hipGetLastError();
-    s->host_out = rgb_out;
-    s->host_out_bytes = bytes;
-    s->host_out_registered = false;
-    s->host_out_register_failed = false;
-  }
   HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return checkOverflow(s);
+}
+
+int rtc_rgba8_device(const double* d_canvas, size_t n_pixels, uint32_t* d_rgba, void* hip_stream) {
+  g_error.clear();
+  if (!d_canvas || !d_rgba || !hip_stream) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_pixels == 0 || n_pixels > (static_cast<size_t>(1) << 40)) return fail(RTC_ERR_INVALID_ARGUMENT, "%zu pixels", n_pixels);
+  hipLaunchKernelGGL(rtc_rgba8_kernel, dim3(static_cast<uint32_t>((n_pixels + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(hip_stream), d_canvas, n_pixels, d_rgba);
+  HIP_TRY(hipGetLastError());
+  return RTC_OK;
 }
 
 int rtc_render_rgba8(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
@@ -1682,8 +1719,7 @@ int rtc_render_rgba8(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, ui
   const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
   if (st != RTC_OK) return st;
   uint32_t* d_rgba = reinterpret_cast<uint32_t*>(s->d_frame + 3 * n);
-  hipLaunchKernelGGL(rtc_rgba8_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, s->stream, s->d_frame, n, d_rgba);
-  HIP_TRY(hipGetLastError());
+  if (const int st2 = rtc_rgba8_device(s->d_frame, n, d_rgba, s->stream); st2 != RTC_OK) return st2;
   HIP_TRY(hipMemcpyAsync(rgba_out, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return checkOverflow(s);

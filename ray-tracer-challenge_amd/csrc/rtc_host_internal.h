@@ -32,10 +32,30 @@ int fail(int status, const char* fmt, ...) {
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) {                                                                   \
+      (void)hipGetLastError(); /* reported here: not the next call's hipGetLastError() */     \
       return fail(e_ == hipErrorOutOfMemory ? RTC_ERR_OUT_OF_MEMORY : RTC_ERR_NO_DEVICE,      \
                   "%s -> %s", #expr, hipGetErrorString(e_));                                  \
     }                                                                                         \
   } while (0)
+
+// Tuning and test options (rtc_set_option, include/rtc.h): process-wide, read when a scene is created or a launch is
+// enqueued; none changes a result.  0 / negative = the library's own choice.
+struct RtcOptions {
+  double simple3_min_chunks = -1.0;  // chunks from which a simple world runs the three-wave kernel (0: always)
+  double sched_off = 0.0;            // != 0: no schedule at all (packet i is chunk i)
+  double cut_above = 0.0;            // shares of a wave above which a chunk is cut into runs (< 0: never)
+  double pack_rounds = 3.0;          // rounds of rtc_pack_extra_kernel
+  double pull_min_idle = 64.0;       // idle lanes before a wave pulls its next packet
+  double blocks_per_cu = 0.0;        // cap on resident work-groups per CU
+  double sched_tmin = 0.0;           // time up to which cheap chunks share a packet
+  double bvh_leaf = 2.0;             // leaves per candidate-BVH leaf
+  double bvh_one_axis = 0.0;         // != 0: SAH on the longest axis only
+  double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
+};
+inline RtcOptions& rtcOptions() {
+  static RtcOptions options;
+  return options;
+}
 
 template <typename T>
 struct DevBuf {
@@ -68,10 +88,6 @@ struct rtc_scene {
   uint32_t stats_parity = 0;    // which of the two the last launch counted in
   double* d_frame = nullptr;  // staging for rtc_render (host output)
   size_t frame_capacity = 0;  // in doubles
-  // rtc_render's destination: registered with the runtime when the caller comes back with the same buffer
-  void* host_out = nullptr;
-  size_t host_out_bytes = 0;
-  bool host_out_registered = false, host_out_register_failed = false;
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;

@@ -63,8 +63,12 @@ struct rtc_multi {
   uint32_t hsize = 0, vsize = 0, n_tiles = 0, padded = 0;
   std::vector<double*> d_buf;  // [n] a rank's compact tiles [padded][64][64][3], on its device
   double* d_gathered = nullptr;  // device 0: [n][padded][64][64][3]
-  double* d_canvas = nullptr;    // device 0
+  double* d_canvas[2] = {nullptr, nullptr};  // device 0: the frame being produced and the one handed out before it
+  uint32_t cur = 0;                          // which of the two the next frame is assembled into
+  uint32_t* d_rgba = nullptr;    // device 0: the RGBA8 form of a frame (rtc_multi_render_rgba8), allocated on first use
   uint32_t* d_slot = nullptr;    // device 0: rtc_assign_tiles' slot_of_tile
+  bool pending = false;          // a frame has been enqueued and its bookkeeping (overflow check, re-deal) is still due
+  rtc_camera pending_cam{};
   std::vector<uint32_t> rank_of, slot_of;
   std::vector<std::vector<uint32_t>> tiles_of;
   bool balanced = false;
@@ -92,21 +96,20 @@ void freeFrameBuffers(rtc_multi* m) {
   m->d_buf.clear();
   if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
   if (m->d_gathered) (void)hipFree(m->d_gathered);
-  if (m->d_canvas) (void)hipFree(m->d_canvas);
+  for (double*& c : m->d_canvas) {
+    if (c) (void)hipFree(c);
+    c = nullptr;
+  }
+  if (m->d_rgba) (void)hipFree(m->d_rgba);
   if (m->d_slot) (void)hipFree(m->d_slot);
-  m->d_gathered = m->d_canvas = nullptr;
+  m->d_gathered = nullptr;
+  m->d_rgba = nullptr;
   m->d_slot = nullptr;
 }
 
-int sizeFor(rtc_multi* m, const rtc_camera& cam) {
-  if (cam.hsize == m->hsize && cam.vsize == m->vsize && !m->d_buf.empty()) return RTC_OK;
-  for (uint32_t r = 0; r < m->n; ++r) {
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_HIP(hipStreamSynchronize(m->stream[r]));
-  }
-  freeFrameBuffers(m);
-  m->hsize = cam.hsize;
-  m->vsize = cam.vsize;
+// Buffers and the first (round-robin) deal for one image size.  All or nothing: a failure half way leaves the handle
+// without frame buffers and without a size, so that the next call starts over instead of rendering into what is missing.
+int sizeForUnguarded(rtc_multi* m, const rtc_camera& cam) {
   const uint32_t tx = (cam.hsize + kTile - 1) / kTile, ty = (cam.vsize + kTile - 1) / kTile;
   m->n_tiles = tx * ty;
   m->padded = (m->n_tiles + m->n - 1) / m->n;
@@ -118,7 +121,8 @@ int sizeFor(rtc_multi* m, const rtc_camera& cam) {
   }
   M_HIP(hipSetDevice(m->dev[0]));
   M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_gathered), slabDoubles(m) * m->n * sizeof(double)));
-  M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_canvas), static_cast<size_t>(cam.hsize) * cam.vsize * 3u * sizeof(double)));
+  for (double*& c : m->d_canvas)
+    M_HIP(hipMalloc(reinterpret_cast<void**>(&c), static_cast<size_t>(cam.hsize) * cam.vsize * 3u * sizeof(double)));
   M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_slot), m->n_tiles * sizeof(uint32_t)));
   // the first frame: tiles dealt round-robin (nothing has been measured yet)
   m->rank_of.resize(m->n_tiles);
@@ -129,9 +133,39 @@ int sizeFor(rtc_multi* m, const rtc_camera& cam) {
   }
   setLists(m);
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+  return RTC_OK;
+}
+
+int sizeFor(rtc_multi* m, const rtc_camera& cam) {
+  if (cam.hsize == m->hsize && cam.vsize == m->vsize && !m->d_buf.empty()) return RTC_OK;
+  // (a frame of 2^32 pixels and more does not fit the 32-bit tile arithmetic - and no GPU)
+  if (static_cast<uint64_t>(cam.hsize) * cam.vsize >= (1ull << 31))
+    return mfail(RTC_ERR_INVALID_ARGUMENT, "image %ux%u is beyond what the tile split indexes", cam.hsize, cam.vsize);
+  for (uint32_t r = 0; r < m->n; ++r) {
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_HIP(hipStreamSynchronize(m->stream[r]));
+  }
+  freeFrameBuffers(m);
+  m->hsize = m->vsize = 0;
   m->balanced = false;
   m->frames_since_balance = 0;
+  m->redeals_in_a_row = 0;
   m->max_over_mean = 0.0;
+  m->cur = 0;
+  m->rank_of.clear();
+  m->slot_of.clear();
+  m->tiles_of.assign(m->n, {});
+  const int st = sizeForUnguarded(m, cam);
+  if (st != RTC_OK) {
+    (void)hipGetLastError();
+    freeFrameBuffers(m);
+    m->rank_of.clear();
+    m->slot_of.clear();
+    m->tiles_of.assign(m->n, {});
+    return st;
+  }
+  m->hsize = cam.hsize;
+  m->vsize = cam.vsize;
   return RTC_OK;
 }
 
@@ -167,8 +201,10 @@ int rebalance(rtc_multi* m, const rtc_camera& cam, bool confirm) {
   }
   M_RTC(rtc_assign_tiles(cost.data(), m->n_tiles, m->n, m->rank_of.data(), m->slot_of.data()));
   setLists(m);
-  M_HIP(hipSetDevice(m->dev[0]));
-  M_HIP(hipStreamSynchronize(m->stream[0]));  // (the frame that used the old table is done: rtc_multi_render is synchronous)
+  for (uint32_t r = m->n; r-- > 0u;) {  // (every rank's stream: the frame that used the old table is done everywhere; device 0 last)
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_HIP(hipStreamSynchronize(m->stream[r]));
+  }
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
   m->max_over_mean = imbalance();
   m->balanced = true;
@@ -240,19 +276,49 @@ void rtc_multi_destroy(rtc_multi* m) {
   delete m;
 }
 
-int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double* rgb_out) {
-  g_multi_error.clear();
-  if (!m || !cam || !rgb_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+}  // extern "C"
+
+namespace {
+
+// What a frame owes once it is done: every stream drained, the overflow check, the re-deal of the tiles by measured cost
+// (after the first frame of an image size, and every 16 frames while the camera is not where the split was measured - a
+// moving camera measures every frame; the frame after a re-deal confirms it).  Idempotent.
+int finishFrame(rtc_multi* m) {
+  if (!m->pending) return RTC_OK;
+  m->pending = false;
+  for (uint32_t r = m->n; r-- > 0u;) {
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_HIP(hipStreamSynchronize(m->stream[r]));
+  }
+  rtc_stats st;
+  if (const int s = rtc_multi_get_stats(m, &st); s != RTC_OK) return s;
+  if (st.overflow) return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", (unsigned long long)st.overflow);
+  m->frames_since_balance++;
+  const rtc_camera& cam = m->pending_cam;
+  const bool moved = std::memcmp(&cam, &m->balance_cam, sizeof cam) != 0;
+  const bool confirm = m->balanced && m->frames_since_balance == 1u;
+  if (m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u) || confirm))
+    if (const int s = rebalance(m, cam, confirm); s != RTC_OK) return s;
+  return RTC_OK;
+}
+
+// One frame, enqueued: every rank renders its tiles into its compact buffer, ONE gather brings them to rank 0 (each
+// rank's send is ordered behind its render on its stream), one kernel un-permutes them into the row-major canvas
+// d_canvas[cur] on device 0, stream[0].  Nothing here waits for the GPUs (the frame before has been finished: the
+// buffers are free).
+int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double** d_canvas) {
+  if (!m || !cam) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   if (cam->hsize == 0 || cam->vsize == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
+  if (const int st = finishFrame(m); st != RTC_OK) return st;
   if (const int st = sizeFor(m, *cam); st != RTC_OK) return st;
-  // every rank renders its tiles into its compact buffer ...
   for (uint32_t r = 0; r < m->n; ++r) {
     if (m->tiles_of[r].empty()) continue;
     M_HIP(hipSetDevice(m->dev[r]));
     M_RTC(rtc_render_tile_list_device(m->scene[r], cam, max_depth, kTile, kTile, m->tiles_of[r].data(),
                                       static_cast<uint32_t>(m->tiles_of[r].size()), m->d_buf[r], m->stream[r]));
   }
-  // ... ONE gather brings them to rank 0 (each rank's send is ordered behind its render on its stream) ...
+  m->pending = true;  // (from here on the streams hold work of this frame)
+  m->pending_cam = *cam;
   const size_t slab = slabDoubles(m);
   if (!m->virt) {
     M_NCCL(ncclGroupStart());
@@ -269,24 +335,56 @@ int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, do
       if (r != 0) M_HIP(hipStreamWaitEvent(m->stream[0], m->shared[r], 0));
     }
   }
-  // ... and one kernel un-permutes them into the row-major canvas
   M_HIP(hipSetDevice(m->dev[0]));
-  M_RTC(rtc_assemble_tile_list_device(m->d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, m->d_canvas, m->stream[0]));
-  M_HIP(hipMemcpyAsync(rgb_out, m->d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
-                       hipMemcpyDeviceToHost, m->stream[0]));
-  M_HIP(hipStreamSynchronize(m->stream[0]));
-  rtc_stats st;
-  if (const int s = rtc_multi_get_stats(m, &st); s != RTC_OK) return s;
-  if (st.overflow) return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", (unsigned long long)st.overflow);
-  // Re-deal the tiles by measured cost: after the first frame of an image size, and every 16 frames while the camera
-  // is not where the split was measured (a moving camera measures every frame).
-  m->frames_since_balance++;
-  const bool moved = std::memcmp(cam, &m->balance_cam, sizeof *cam) != 0;
-  const bool confirm = m->balanced && m->frames_since_balance == 1u;
-  if (m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u) || confirm))
-    if (const int s = rebalance(m, *cam, confirm); s != RTC_OK) return s;
+  double* const canvas = m->d_canvas[m->cur];
+  m->cur ^= 1u;
+  M_RTC(rtc_assemble_tile_list_device(m->d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, canvas, m->stream[0]));
+  *d_canvas = canvas;
   return RTC_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double* rgb_out) {
+  g_multi_error.clear();
+  if (!rgb_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  double* d_canvas = nullptr;
+  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas); st != RTC_OK) return st;
+  M_HIP(hipMemcpyAsync(rgb_out, d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
+                       hipMemcpyDeviceToHost, m->stream[0]));
+  return finishFrame(m);
+}
+
+int rtc_multi_render_rgba8(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, uint8_t* rgba_out) {
+  g_multi_error.clear();
+  if (!rgba_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  double* d_canvas = nullptr;
+  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas); st != RTC_OK) return st;
+  const size_t n = static_cast<size_t>(cam->hsize) * cam->vsize;
+  if (!m->d_rgba) M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_rgba), n * sizeof(uint32_t)));  // (freed with the frame buffers of this size)
+  M_RTC(rtc_rgba8_device(d_canvas, n, m->d_rgba, m->stream[0]));
+  M_HIP(hipMemcpyAsync(rgba_out, m->d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream[0]));
+  return finishFrame(m);
+}
+
+int rtc_multi_render_device(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, const double** d_canvas_out) {
+  g_multi_error.clear();
+  if (!d_canvas_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  double* d_canvas = nullptr;
+  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas); st != RTC_OK) return st;
+  *d_canvas_out = d_canvas;
+  return RTC_OK;
+}
+
+int rtc_multi_synchronize(rtc_multi* m) {
+  g_multi_error.clear();
+  if (!m) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  return finishFrame(m);
+}
+
+void* rtc_multi_stream(rtc_multi* m) { return m ? static_cast<void*>(m->stream[0]) : nullptr; }
 
 int rtc_multi_get_stats(rtc_multi* m, rtc_stats* out) {
   if (!m || !out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");

@@ -28,6 +28,18 @@ def pytest_collection_modifyitems(config, items):
                 item.add_marker(pytest.mark.timeout(240, method="thread"))
 
 
+@pytest.fixture(autouse=True)
+def _watchdog():
+    """A test that sits in native code must be NAMED in the log before the box's silence limit (seven minutes) ends the
+    run.  pytest-timeout's thread method needs the GIL to dump the stacks, and round 2's silent stop was a main thread
+    that never gave it up: faulthandler's watchdog is a C thread that needs no GIL - after five
+    minutes in one test it writes every thread's Python stack to stderr and exits the process."""
+    import faulthandler
+    faulthandler.dump_traceback_later(300, exit=True)
+    yield
+    faulthandler.cancel_dump_traceback_later()
+
+
 def _built():
     need = ["ray-tracer-challenge_amd/lib/librtc_hip.so", "ray-tracer-challenge_amd/lib/librtc_host.so",
             "ray-tracer-challenge_amd/lib/rtc_host_kat", "oracle/build/liboracle.so", "oracle/build/oracle_kat"]

@@ -38,6 +38,29 @@ def test_multi_symbols_are_exported(rtc):
         assert getattr(lib, n) is not None
 
 
+def test_headers_are_valid_c():
+    """include/*.h is a C ABI: every header compiles as strict C99 on its own (a Zig @cImport or a C host sees this)."""
+    import subprocess
+    for name in ("rtc.h", "rtc_host.h", "rtc_multi.h"):
+        r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
+                            os.path.join(REPO, "include", name)], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr)
+
+
+def test_library_reads_no_environment(rtc):
+    """Tuning and test knobs go through rtc_set_option; the product library does not read the environment (the
+    RTC_PROFILE diagnostics build does, behind its #ifdef)."""
+    src = os.path.join(REPO, "ray-tracer-challenge_amd", "csrc")
+    for name in os.listdir(src):
+        text = open(os.path.join(src, name)).read()
+        text = re.sub(r"#ifdef RTC_PROFILE.*?#endif", "", text, flags=re.S)
+        assert "getenv" not in text, name
+    lib = rtc.hip_lib()
+    assert lib.rtc_set_option(b"simple3_min_chunks", -1.0) == 0
+    assert lib.rtc_set_option(b"no_such_option", 1.0) == 1
+    assert b"no_such_option" in lib.rtc_last_error()
+
+
 def test_status_names(rtc):
     lib = rtc.hip_lib()
     assert lib.rtc_status_name(0) == b"Ok"
@@ -65,7 +88,7 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
     d.abi_version = 99
     assert lib.rtc_scene_create(C.byref(d), C.byref(out)) == 1
     assert b"InvalidArgument" in lib.rtc_last_error()
-    d.abi_version = 2   # RTC_ABI_VERSION (node_op was added in 2)
+    d.abi_version = 3   # RTC_ABI_VERSION (2: node_op; 3: rtc_canvas_register / rtc_set_option / rtc_rgba8_device, rtc_render keeps no pointer)
     # a non-affine inverse (last row != (0,0,0,1))
     xf = hs.array("xf_inv", d.n_xforms, 16)
     saved = xf[0, 12]
@@ -141,7 +164,7 @@ def test_zig_binding_matches_the_header():
         m = re.search(r"\b%s\s*\(([^)]*)\)" % fn, headers)
         assert m, fn
         c_n = 0 if m.group(1).strip() in ("", "void") else m.group(1).count(",") + 1
-        z_n = 0 if not params.strip() else params.count(":")
+        z_n = len(re.findall(r"\b[A-Za-z_]\w*\s*:", params))   # (`name: type` pairs; the colon of a `[*:0]` sentinel has no name before it)
         assert c_n == z_n, (fn, c_n, z_n)
     # the Flattener's desc() names every field of the struct
     i = zig.index("pub fn desc(self: *const Self) RtcSceneDesc {")

@@ -291,7 +291,7 @@ def _check_launch(gpu, cam, depth, want, counters, what):
 
 
 @pytest.mark.parametrize("scene,w,h,depth", SCHEDULE_CASES)
-def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth, monkeypatch):
+def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth):
     hs = rtc.HostScene.from_file(scene)
     gpu = rtc.GpuScene(hs.desc)
     osc = ob.OracleScene(hs.desc)
@@ -307,17 +307,24 @@ def test_every_schedule_renders_the_same_image(rtc, scene, w, h, depth, monkeypa
         _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
 
 
+@pytest.fixture
+def simple3_always(rtc):
+    """rtc_set_option("simple3_min_chunks", 0) for one test; the library's own choice (-1) afterwards."""
+    rtc.set_option("simple3_min_chunks", 0)
+    yield
+    rtc.set_option("simple3_min_chunks", -1)
+
+
 SIMPLE3_CASES = [("cover.json", 640, 360, 5), ("fresnel.json", 150, 150, 5), ("reflection_and_refraction.json", 192, 108, 8),
                  ("cubes.json", 200, 100, 5)]
 
 
 @pytest.mark.parametrize("scene,w,h,depth", SIMPLE3_CASES)
-def test_three_wave_simple_kernel_renders_the_same_image(rtc, scene, w, h, depth, monkeypatch):
+def test_three_wave_simple_kernel_renders_the_same_image(rtc, scene, w, h, depth, simple3_always):
     """rtc_render_kernel_simple3 (168 VGPRs, three waves per SIMD) is what a large launch on a world of planes, spheres
     and cubes runs - cover.json at 1080p, the bench - while the small launches of this suite run the two-wave kernel.
-    RTC_SIMPLE3_MIN_CHUNKS=0 (read per launch) makes every launch take it: the same launches as above, first frame on
-    the estimate, packed, steady state, moved camera, each against the oracle."""
-    monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "0")
+    The option simple3_min_chunks = 0 (read per launch) makes every launch take it: the same launches as above, first
+    frame on the estimate, packed, steady state, moved camera, each against the oracle."""
     hs = rtc.HostScene.from_file(scene)
     gpu = rtc.GpuScene(hs.desc)
     osc = ob.OracleScene(hs.desc)
@@ -331,13 +338,12 @@ def test_three_wave_simple_kernel_renders_the_same_image(rtc, scene, w, h, depth
     want2, counters2 = osc.render(cam2, depth)
     for launch in range(4, 12):
         _check_launch(gpu, cam2, depth, want2, counters2, (scene, "moved camera, launch", launch))
-    monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "1000000000")   # ... and back on the same handle: the two-wave kernel
+    rtc.set_option("simple3_min_chunks", 1e9)   # ... and back on the same handle: the two-wave kernel
     _check_launch(gpu, cam2, depth, want2, counters2, (scene, "two-wave kernel again"))
     assert gpu.last_kernel_name() == "rtc_render_kernel_simple"
 
 
-def test_three_wave_simple_kernel_random_scenes(rtc, monkeypatch):
-    monkeypatch.setenv("RTC_SIMPLE3_MIN_CHUNKS", "0")
+def test_three_wave_simple_kernel_random_scenes(rtc, simple3_always):
     ran = 0
     for seed in range(40):
         hs = rtc.HostScene(_random_flat_scene(seed, simple=True, max_objects=3 + seed % 5))   # (few objects: nested patterns fill its 24-entry table)
@@ -597,7 +603,26 @@ def test_single_process_multi_gpu_render(rtc):
             if frame == 1:
                 hs.rotate_camera(0.4)
         other = hs.camera(130, 70)                           # another image size on the same object
-        assert np.abs(multi.render(other, 5) - osc.render(other, 5)[0]).max() < TOL
+        want_other = osc.render(other, 5)[0]
+        assert np.abs(multi.render(other, 5) - want_other).max() < TOL
+        # the RGBA8 framebuffer of the interactive seam (lib.zig:146-153), clamped on GPU 0 ...
+        assert np.array_equal(multi.render_rgba8(other, 5), rtc.canvas_rgba8(multi.render(other, 5)))
+        # ... and the frame left on the device: nothing copied, two canvases alternate
+        ptrs = []
+        for _ in range(3):
+            ptrs.append(multi.render_device(other, 5))
+            multi.synchronize()
+            got = np.empty_like(want_other)
+            import ctypes   # (hipMemcpy of the ONE runtime already in the process: the global symbol scope, not another dlopen)
+            assert ctypes.CDLL(None).hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptrs[-1]), ctypes.c_size_t(got.nbytes), 2) == 0
+            assert np.abs(got - want_other).max() < TOL
+        assert ptrs[0] != ptrs[1] and ptrs[0] == ptrs[2]
+        # an image no GPU can hold: refused (or out of memory), and the handle renders on afterwards
+        huge = hs.camera(130, 70)
+        huge.hsize, huge.vsize = 60000, 60000
+        with pytest.raises(rtc.RtcError):
+            multi.render_device(huge, 5)
+        assert np.abs(multi.render(other, 5) - want_other).max() < TOL
         multi.close()
 
 
@@ -628,25 +653,62 @@ def test_launches_on_different_streams_are_ordered(rtc):
 
 
 def test_host_output_into_a_reused_canvas(rtc):
-    """rtc_render into the same caller-owned buffer again and again (an interactive host): from the second call on the
-    buffer is registered with the runtime; changing buffers and sizes in between must keep every image right."""
+    """rtc_render into the same caller-owned buffer again and again (an interactive host), pageable and registered
+    (rtc_canvas_register: explicit, tied to the memory, not to the handle); changing buffers and sizes in between must
+    keep every image right, and so must a canvas that is freed and re-allocated at the same address between frames."""
     hs = rtc.HostScene.from_file("fresnel.json")
     gpu = rtc.GpuScene(hs.desc)
     cam = hs.camera(160, 120)
     want, _ = ob.OracleScene(hs.desc).render(cam, 5)
     a = np.full((120, 160, 3), np.nan)
     b = np.full((120, 160, 3), np.nan)
+    rtc.canvas_register(a)
     for out in (a, a, a, b, a, b, b):
         out[:] = np.nan
         assert gpu.render_into(cam, out, 5) is out
         assert np.abs(out - want).max() < TOL
+    rtc.canvas_unregister(a)
+    with pytest.raises(rtc.RtcError):
+        rtc.canvas_unregister(a)                          # not registered any more: an error, not a crash
+    a[:] = np.nan
+    gpu.render_into(cam, a, 5)                            # the same memory, pageable again
+    assert np.abs(a - want).max() < TOL
     small = hs.camera(40, 30)
-    c = np.full((30, 40, 3), np.nan)
-    for _ in range(3):
+    for _ in range(3):                                    # a host that frees and re-allocates its canvas every frame
+        c = np.full((30, 40, 3), np.nan)
         gpu.render_into(small, c, 5)
-    assert np.abs(c - ob.OracleScene(hs.desc).render(small, 5)[0]).max() < TOL
-    gpu.close()                                           # drops the registration before the arrays go away
-    del a, b, c
+        assert np.abs(c - ob.OracleScene(hs.desc).render(small, 5)[0]).max() < TOL
+        del c
+    gpu.close()
+
+
+def test_tile_mode_costs_when_the_image_is_not_a_multiple_of_the_tile(rtc):
+    """Edge tiles reach past the image: their outside pixels are never rendered, and the per-pixel cost buffer the
+    schedule and rtc_get_tile_costs are computed from must read zero there (it is cleared when it is allocated) - a
+    tile's cost is then what its inside pixels took, and no packet of the schedule is made of outside chunks alone."""
+    hs = rtc.HostScene.from_file("cover.json")
+    torch = pytest.importorskip("torch")
+    cam = hs.camera(200, 150)                              # 64x64 tiles: 4 x 3, the last column 8 wide, the last row 22 high
+    tw = th = 64
+    tx, ty = rtc.tile_grid(cam.hsize, cam.vsize, tw, th)
+    want, _ = ob.OracleScene(hs.desc).render(cam, 5)
+    costs = []
+    for attempt in range(2):                               # two fresh handles: the same costs, not what the allocator left behind
+        gpu = rtc.GpuScene(hs.desc)
+        buf = torch.full((tx * ty, th, tw, 3), float("nan"), dtype=torch.float64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        gpu.render_tiles_device(cam, buf.data_ptr(), tw, th, 0, 1, tx * ty, 5, stream)
+        torch.cuda.synchronize()
+        c = gpu.tile_costs(tx * ty)
+        img = rtc.assemble_tiles(torch.nan_to_num(buf, nan=0.0).cpu().numpy()[None], cam.hsize, cam.vsize, tw, th, 1)
+        assert np.abs(img - want).max() < TOL
+        assert np.isfinite(c).all() and (c >= 0).all()
+        costs.append(c)
+        gpu.close()
+    full, edge = costs[0].reshape(ty, tx)[0, 0], costs[0].reshape(ty, tx)[0, tx - 1]
+    assert edge < 0.6 * full, (edge, full)                 # an 8-pixel-wide strip of sky costs less than a full tile of it
+    ratio = costs[0] / np.maximum(costs[1], 1e-9)
+    assert (ratio > 0.3).all() and (ratio < 3.0).all(), ratio   # (measured times: noisy, but not garbage)
 
 
 def test_errors_through_the_abi(rtc):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The no-group random scenes of tests/test_parity_gpu.py (_random_flat_scene) over many seeds: GPU vs oracle,
 two launches each (estimate-scheduled, device-packed).  tools/fuzz_flat.py [first] [count] [max_objects]
-(RTC_SIMPLE3_MIN_CHUNKS=0 with max_objects 7 puts the simple scenes on the three-wave kernel)"""
+(rtc.set_option('simple3_min_chunks', 0) with max_objects 7 puts the simple scenes on the three-wave kernel)"""
 import importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))

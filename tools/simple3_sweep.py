@@ -30,8 +30,8 @@ for name in sys.argv[1:] or ["cover", "reflection_and_refraction", "fresnel", "c
     hs = rtc.HostScene.from_file(name + ".json")
     depth = 8 if name.startswith("reflection") else 5
     for w, h in SIZES:
-        os.environ["RTC_SIMPLE3_MIN_CHUNKS"] = "1000000000"
+        rtc.set_option("simple3_min_chunks", 1e9)
         t2 = frame_ms(hs, w, h, depth)
-        os.environ["RTC_SIMPLE3_MIN_CHUNKS"] = "0"
+        rtc.set_option("simple3_min_chunks", 0)
         t3 = frame_ms(hs, w, h, depth)
         print(f"{name[:10]:10s} {w}x{h} chunks {((w + 7) // 8) * ((h + 7) // 8):6d}  two waves {t2:.3f}  three waves {t3:.3f}  ratio {t3 / t2:.3f}", flush=True)
