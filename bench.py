@@ -50,38 +50,61 @@ def scene_bytes_touched(desc, stats):
     return 128 * desc.n_leaves * rays if desc.n_nodes == 0 else None
 
 
+def _profiled(scene, width, height, depth):
+    """The committed PMC passes of this workload, if there are any (profiles/traffic.json, written by
+    tools/collect_profiles.py: one entry per profiled workload)."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+    except OSError:
+        return None
+    for w in t.get("workloads", [t]):
+        if [w.get("scene"), w.get("width"), w.get("height"), w.get("depth")] == [scene, width, height, depth]:
+            return w
+    return None
+
+
 def measured_traffic(scene, width, height, depth):
     """HBM bytes per launch from the PMC passes of the latest committed profile (FETCH_SIZE x2 as the
     MI355X guide prescribes for gfx950, WRITE_SIZE exact), if that profile is of this workload."""
-    path = os.path.join(REPO, "profiles", "traffic.json")
-    try:
-        t = json.load(open(path))
-    except OSError:
-        return None
-    if [t.get("scene"), t.get("width"), t.get("height"), t.get("depth")] != [scene, width, height, depth]:
-        return None
-    return 2 * 1024 * t["fetch_size_kb"] + 1024 * t["write_size_kb"]
+    t = _profiled(scene, width, height, depth)
+    return None if t is None else 2 * 1024 * t["fetch_size_kb"] + 1024 * t["write_size_kb"]
 
 
 def executed_flops(scene, width, height, depth):
     """FP64 flops the kernel EXECUTES per launch, from the committed SQ PMC pass of this workload (profiles/traffic.json,
     "pmc"): wave-level instruction counts x 64 lanes x the mean fraction of active lanes, an FMA counted as 2."""
-    try:
-        t = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-    except OSError:
-        return None
-    c = t.get("pmc") or {}
-    if [t.get("scene"), t.get("width"), t.get("height"), t.get("depth")] != [scene, width, height, depth]:
-        return None
+    t = _profiled(scene, width, height, depth)
+    c = (t or {}).get("pmc") or {}
     need = ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
             "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"]
     if any(k not in c for k in need):
         return None
     lanes = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
     wave_instr = c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + 2 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
-    return {"flops": wave_instr * 64.0 * lanes, "lanes_active": lanes, "valu_instructions": c["SQ_INSTS_VALU"],
-            "fp64_instructions": c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"],
-            "source": t.get("source")}
+    out = {"flops": wave_instr * 64.0 * lanes, "lanes_active": lanes, "valu_instructions": c["SQ_INSTS_VALU"],
+           "fp64_instructions": c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_TRANS_F64"],
+           "source": t.get("source")}
+    if "SQ_BUSY_CYCLES" in c and "SQ_WAVE_CYCLES" in c and "SQ_WAIT_ANY" in c:
+        # a SIMD's vector pipe issuing, with the profile's OWN clock: SQ_BUSY_CYCLES counts per shader engine (32 of them)
+        cycles = c["SQ_BUSY_CYCLES"] / 32.0
+        out["valu_pipe_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cycles
+        out["wave_cycles_waiting"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+        out["clock_source"] = "SQ_BUSY_CYCLES / 32 shader engines (the profiled launch's own cycles, no assumed clock)"
+    return out
+
+
+def reference_traversal_bytes(width, height, counters, rows_sampled, rows_total):
+    """24 W H + sum over rays [56 bbox tests + 72 triangle tests + 72 smooth-triangle hits + 128 transforms
+    applied], from the ORACLE's counters of the reference's own traversal (the F7 tree, every isShadowed ray a full
+    intersect) on the sampled rows, scaled to the frame.  Implementation-independent; mostly cache-level re-use."""
+    if not counters or "bbox_tests" not in counters:
+        return None
+    scale = rows_total / float(max(rows_sampled, 1))
+    per_sample = (56 * counters["bbox_tests"] + 72 * counters["tri_tests"] + 72 * counters["smooth_hits"] + 128 * counters["xforms"])
+    return {"bytes": 24 * width * height + per_sample * scale,
+            "bbox_tests": counters["bbox_tests"] * scale, "tri_tests": counters["tri_tests"] * scale,
+            "smooth_hits": counters["smooth_hits"] * scale, "xforms": counters["xforms"] * scale,
+            "source": "oracle counters of %d of %d rows, scaled" % (rows_sampled, rows_total)}
 
 
 def one_shot_and_moving_view(rtc, torch, hs, args, stream):
@@ -214,6 +237,7 @@ def cpu_baseline(rtc, hs, cam, depth, target_seconds=12.0):
     one = scaling["1"]["mrays_per_s"]
     return {
         "value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample_counters": dict(c), "sample_rows": rows,
         "sample": f"every {step}th row ({rows} of {cam.vsize} rows) of the same frame, median of {len(times)} "
                   f"passes of {dt:.2f} s, {cores} threads, one job per row (camera.zig:88-97)",
         "ms_per_frame_extrapolated": dt * 1e3 * cam.vsize / rows,
@@ -289,6 +313,7 @@ def main():
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
+    timing = [False]   # (set for the K timed steps)
     if world == 1 and not args.tile_path:
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
 
@@ -332,6 +357,7 @@ def main():
         gathered_ev = [torch.cuda.Event() for _ in range(2)]
         gathered_ev[0].record(comm)
         gathered_ev[1].record(comm)
+        comm_ev = []   # (timed steps only: HIP events on the side stream around the gather + un-permute of a frame)
 
         def step(i):
             b = i & 1
@@ -341,6 +367,9 @@ def main():
             rendered[b].record(stream)
             with torch.cuda.stream(comm):            # gather + un-permute of frame i under the render of frame i+1
                 comm.wait_event(rendered[b])
+                if timing[0]:
+                    comm_ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                    comm_ev[-1][0].record(comm)
                 if args.rehearse:                    # gloo has no device gather: through host memory
                     comm.synchronize()
                     host = [torch.empty(bufs[b].shape, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
@@ -353,6 +382,8 @@ def main():
                 if rank == 0:                        # one un-permute kernel: tiles -> row-major canvas
                     rtc.assemble_tile_list_device(gathered[b].data_ptr(), d_slot.data_ptr(), TILE, TILE, W, H,
                                                   canvas.data_ptr(), comm.cuda_stream)
+                if timing[0]:
+                    comm_ev[-1][1].record(comm)
                 gathered_ev[b].record(comm)
 
         def finish():
@@ -389,6 +420,7 @@ def main():
     finish()
     barrier()
     kernel_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    timing[0] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         kernel_ev[i][0].record(stream)
@@ -397,6 +429,7 @@ def main():
     finish()
     barrier()
     elapsed = time.perf_counter() - t0
+    timing[0] = False
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -409,6 +442,12 @@ def main():
         dist.all_reduce(v)
         stats = dict(zip(["primary", "secondary", "shadow_calls", "shadow_traced"], [int(x) for x in v.tolist()]))
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_ev]))   # HIP events on the launch stream
+    per_rank = None
+    if dist is not None:   # what every rank's share took, so that a scaling curve can be read: who was the slowest, and why
+        mine = {"rank": rank, "render_ms": kernel_ms, "tiles": int(count),
+                "gather_unpermute_ms": float(np.mean([a.elapsed_time(b) for a, b in comm_ev])) if comm_ev else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if args.check and rank == 0:
         ref = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
@@ -461,6 +500,17 @@ def main():
                         "register spills cycling through L2 into the Infinity Cache (DESIGN.md section 5), not canvas "
                         "bytes.",
             }
+            ex_only = executed_flops(args.scene, W, H, args.depth) if fl is None else None
+            if ex_only is not None:   # a scene with groups: no per-ray flop table applies; the executed figure alone
+                etf = ex_only["flops"] / (kernel_ms * 1e-3) / 1e12
+                result["roofline_valu"] = {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                                           "executed_flops": ex_only["flops"], "executed_tflops": etf,
+                                           "executed_frac": etf / FP64_VECTOR_PEAK_TF, "lanes_active": ex_only["lanes_active"],
+                                           "valu_instructions": ex_only["valu_instructions"],
+                                           "fp64_instructions": ex_only["fp64_instructions"], "source": ex_only["source"]}
+                for k in ("valu_pipe_busy", "wave_cycles_waiting", "clock_source"):
+                    if k in ex_only:
+                        result["roofline_valu"][k] = ex_only[k]
             if fl is not None:
                 tf = fl / (kernel_ms * 1e-3) / 1e12
                 result["roofline_valu"] = {
@@ -481,15 +531,33 @@ def main():
                                          "utilisation, `frac` above prices the reference's brute-force flop count"
                                          % (ex["lanes_active"], ex["fp64_instructions"], ex["valu_instructions"], ex["source"]),
                     })
+                    for k in ("valu_pipe_busy", "wave_cycles_waiting", "clock_source"):
+                        if k in ex:
+                            result["roofline_valu"][k] = ex[k]
             if not args.no_extras:
                 result["config"].update(one_shot_and_moving_view(rtc, torch, hs, args, stream))
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)
                 result["config"]["gpu_vs_cpu_frame_time"] = result["cpu_baseline"]["ms_per_frame_extrapolated"] / ms_per_step
+                ref = reference_traversal_bytes(W, H, result["cpu_baseline"].pop("sample_counters"),
+                                                result["cpu_baseline"]["sample_rows"], H)
+                if ref is not None:
+                    result["roofline"]["algorithmic_bytes_reference_traversal"] = ref["bytes"]
+                    result["roofline"]["reference_traversal"] = dict(ref, gbs=ref["bytes"] / (kernel_ms * 1e-3) / 1e9)
         else:
             # rank 0's share of the frame: its tiles' canvas bytes over its own kernel time (HIP events on its stream)
             ab = 24 * count * TILE * TILE
             gbs = ab / (kernel_ms * 1e-3) / 1e9
+            renders = [r["render_ms"] for r in per_rank]
+            result["ranks"] = {
+                "render_ms": renders, "render_ms_max": max(renders), "render_ms_mean": float(np.mean(renders)),
+                "tiles": [r["tiles"] for r in per_rank],
+                "gather_unpermute_ms_rank0": per_rank[0]["gather_unpermute_ms"],
+                "note": "HIP events per rank: render_ms = a rank's render launch on its stream (incl. waiting for its "
+                        "double buffer), gather_unpermute_ms = rank 0's side stream from `frame rendered` to `canvas "
+                        "assembled` (the gather waits for the slowest rank); ms_per_step is max over ranks of the wall "
+                        "time of K pipelined frames",
+            }
             result["roofline"] = {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": None, "kernel": gpu.last_kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,

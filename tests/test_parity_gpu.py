@@ -1017,6 +1017,9 @@ def test_bench_multi_rank_path_rehearsal():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and "roofline" in line
     assert line["config"]["rays_per_frame"]["primary"] == 480 * 270
+    ranks = line["ranks"]                         # what a scaling curve is read from: every rank's share
+    assert len(ranks["render_ms"]) == 2 and min(ranks["render_ms"]) > 0 and sum(ranks["tiles"]) == 8 * 5
+    assert ranks["render_ms_max"] >= ranks["render_ms_mean"] and ranks["gather_unpermute_ms_rank0"] > 0
 
 
 def _json_scene(objects, lights, w=24, h=16):
