@@ -33,15 +33,19 @@
  *     Two handles on two streams overlap freely.
  *
  * Limits (a scene beyond them is refused or reported, never rendered differently):
- *   - a gradient / radial-gradient / blend pattern nested inside another one:
- *     rtc_scene_create returns RTC_ERR_UNSUPPORTED;
+ *   - more than 8 gradient / radial-gradient / blend patterns nested inside one
+ *     another: rtc_scene_create returns RTC_ERR_UNSUPPORTED;
  *   - pattern select-chains (stripes / checkers / rings / perturb / texture map)
  *     deeper than 64: RTC_ERR_UNSUPPORTED at create;
- *   - more than 32 csg nodes under one csg: RTC_ERR_UNSUPPORTED at create; more
- *     than RTC_CSG_ENTRIES (32) intersections of one ray with one csg unit, or a
- *     group tree deeper than the traversal stack: the render counts the lane in
- *     rtc_stats::overflow, rtc_render returns RTC_ERR_OVERFLOW, and callers of the
- *     asynchronous entry points must check rtc_get_stats;
+ *   - more than 32 csg nodes under one csg: RTC_ERR_UNSUPPORTED at create;
+ *   - a lane's list of the intersections of one ray with one csg unit (the list
+ *     Csg.filterIntersections works on, csg.zig:51-95) starts with 32 slots: when a
+ *     frame needs more, rtc_render / rtc_render_rgba8 double them and render again
+ *     (up to 1024; the handle keeps the longer lists), while the asynchronous
+ *     entry points count the lanes that ran out in rtc_stats::overflow - callers
+ *     check rtc_get_stats (one synchronous render of the view sizes the lists);
+ *     beyond 1024 entries, or a group tree deeper than the traversal stack:
+ *     RTC_ERR_OVERFLOW, never a truncated image;
  *   - two leaves with the same Shape.id: RTC_ERR_UNSUPPORTED (identity in the
  *     containers walk is the leaf);
  *   - reproducibility: geometry and every branch are bit-identical from run to

@@ -419,7 +419,7 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   map.pull_min_idle = std::max(1u, std::min(64u, pull_min));
   s->dev.csg_buf = nullptr;
   if (s->has_csg) {
-    const size_t need_csg = static_cast<size_t>(blocks) * 4u * RTC_CSG_ENTRIES * 64u * sizeof(CsgRec);
+    const size_t need_csg = static_cast<size_t>(blocks) * 4u * s->dev.csg_entries * 64u * sizeof(CsgRec);
     if (need_csg > s->csg_buf_capacity) {
       HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
       if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
@@ -523,7 +523,8 @@ struct RootCull {  // host form of one bounding sphere; uploaded two to a RootCu
 // What validateScene learns about a scene on the way.
 struct SceneTraits {
   bool has_csg = false;     // some node is a csg operation
-  bool ext_kernel = false;  // csg or texture maps: the `_ext` kernels
+  bool ext_kernel = false;  // csg, texture maps or nested mixing patterns: the `_ext` kernels
+  bool nested_patterns = false;  // a gradient / blend below a gradient / blend
   uint32_t max_stack = 0;   // traversal stack the deepest group tree needs
 };
 
@@ -591,17 +592,20 @@ int validateScene(const rtc_scene_desc& d, SceneTraits& traits) {
       if (d.img_width[im] == 0 || d.img_height[im] == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "image %u is empty", im);
     }
   }
+  // Mixing patterns (gradient, radial gradient, blend) nested in one another run the *_ext kernels (pattern_tree);
+  // the walk's stack holds RTC_PATTERN_STACK of them on one path.
+  traits.nested_patterns = false;
   for (uint32_t i = 0; i < d.n_patterns; ++i) {
     const uint8_t k = d.pat_kind[i];
     if (k == RTC_PAT_GRADIENT || k == RTC_PAT_RADIAL_GRADIENT || k == RTC_PAT_BLEND) {
-      if (!selectChainOnly(d, d.pat_a[i]) || !selectChainOnly(d, d.pat_b[i]))
-        return fail(RTC_ERR_UNSUPPORTED, "pattern %u: a gradient/blend nested inside a gradient/blend", i);
+      if (!selectChainOnly(d, d.pat_a[i]) || !selectChainOnly(d, d.pat_b[i])) traits.nested_patterns = true;
     }
   }
   {
     // Depth of the deepest chain of patterns below each pattern (itself included): the device follows a chain for at
     // most 64 steps (pattern_chain), so a deeper one - or a cycle - is refused here rather than cut short there.
     std::vector<uint32_t> depth(d.n_patterns, 0u);  // 0: not visited, 0xFFFFFFFF: on the current path
+    std::vector<uint32_t> mixing(d.n_patterns, 0u);  // gradients / blends on the deepest path below (itself included)
     std::vector<std::pair<uint32_t, uint32_t>> stack;  // (pattern, next child)
     auto kidsOf = [&](uint32_t i, uint32_t out[32]) -> uint32_t {
       switch (d.pat_kind[i]) {
@@ -637,10 +641,17 @@ int validateScene(const rtc_scene_desc& d, SceneTraits& traits) {
           }
           continue;
         }
-        uint32_t deepest = 0u;
-        for (uint32_t k = 0; k < nk; ++k) deepest = std::max(deepest, depth[kids[k]]);
+        uint32_t deepest = 0u, mixes = 0u;
+        for (uint32_t k = 0; k < nk; ++k) {
+          deepest = std::max(deepest, depth[kids[k]]);
+          mixes = std::max(mixes, mixing[kids[k]]);
+        }
         depth[i] = deepest + 1u;
+        const uint8_t kind = d.pat_kind[i];
+        mixing[i] = mixes + ((kind == RTC_PAT_GRADIENT || kind == RTC_PAT_RADIAL_GRADIENT || kind == RTC_PAT_BLEND) ? 1u : 0u);
         if (depth[i] > 64u) return fail(RTC_ERR_UNSUPPORTED, "pattern %u: a chain of more than 64 nested patterns", i);
+        if (mixing[i] > RTC_PATTERN_STACK)
+          return fail(RTC_ERR_UNSUPPORTED, "pattern %u: more than %d gradient / blend patterns nested in one another", i, RTC_PATTERN_STACK);
         stack.pop_back();
       }
     }
@@ -671,6 +682,7 @@ int validateScene(const rtc_scene_desc& d, SceneTraits& traits) {
   bool& ext_kernel = traits.ext_kernel;
   ext_kernel = has_csg;
   for (uint32_t i = 0; i < d.n_patterns; ++i) ext_kernel |= d.pat_kind[i] == RTC_PAT_TEXTURE_MAP;
+  ext_kernel |= traits.nested_patterns;
   std::vector<uint8_t> leaf_seen(d.n_leaves, 0), node_seen(d.n_nodes, 0);
   uint32_t& max_stack = traits.max_stack;
   max_stack = 0;
@@ -1392,6 +1404,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   D.node_range = s->node_range.p;
   D.bvh_mag = bvh_mag;
   D.chain_nested = T.chain_nested ? 1u : 0u;
+  D.csg_entries = RTC_CSG_ENTRIES;
   D.node_box = s->node_box.p;
   D.node_kids = s->node_kids.p;
   D.kids = s->kids.p;
@@ -1647,6 +1660,17 @@ int checkOverflow(rtc_scene* s) {
   return RTC_OK;
 }
 
+// Csg.filterIntersections works on a list of any length (csg.zig:51-95); a lane's list here has DevScene::csg_entries
+// slots in HBM.  The synchronous entry points render again with twice the slots when a frame of a scene with csg nodes
+// reports an overflow (the traversal and pending-ray stacks are sized or refused at create, so the list is what was
+// short), up to RTC_CSG_ENTRIES_MAX; the handle keeps the larger list.  Returns true if another attempt is worth it.
+bool growCsgLists(rtc_scene* s) {
+  if (!s->has_csg || s->dev.csg_entries >= RTC_CSG_ENTRIES_MAX) return false;
+  s->dev.csg_entries *= 2u;
+  g_error.clear();
+  return true;
+}
+
 }  // namespace
 
 int rtc_canvas_register(void* canvas, size_t bytes) {
@@ -1689,14 +1713,17 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
   const size_t need = 3ull * w * h;
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = ensureFrame(s, need); st != RTC_OK) return st;
-  const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
-  if (st != RTC_OK) return st;
-  // (into pageable memory the copy runs at a fifth of the link's rate - 5.6 ms for a 1080p frame; a host that renders
-  // frame after frame registers its canvas once: rtc_canvas_register)
-  const size_t bytes = need * sizeof(double);
-  HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return checkOverflow(s);
+  for (;;) {
+    const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
+    if (st != RTC_OK) return st;
+    // (into pageable memory the copy runs at a fifth of the link's rate - 5.6 ms for a 1080p frame; a host that renders
+    // frame after frame registers its canvas once: rtc_canvas_register)
+    const size_t bytes = need * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int ov = checkOverflow(s);
+    if (ov != RTC_ERR_OVERFLOW || !growCsgLists(s)) return ov;
+  }
 }
 
 int rtc_rgba8_device(const double* d_canvas, size_t n_pixels, uint32_t* d_rgba, void* hip_stream) {
@@ -1716,13 +1743,16 @@ int rtc_render_rgba8(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, ui
   const size_t n = static_cast<size_t>(w) * h;
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = ensureFrame(s, 3 * n + (n + 1) / 2); st != RTC_OK) return st;  // the f64 frame, then n u32 behind it
-  const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
-  if (st != RTC_OK) return st;
-  uint32_t* d_rgba = reinterpret_cast<uint32_t*>(s->d_frame + 3 * n);
-  if (const int st2 = rtc_rgba8_device(s->d_frame, n, d_rgba, s->stream); st2 != RTC_OK) return st2;
-  HIP_TRY(hipMemcpyAsync(rgba_out, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
-  return checkOverflow(s);
+  for (;;) {
+    const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
+    if (st != RTC_OK) return st;
+    uint32_t* d_rgba = reinterpret_cast<uint32_t*>(s->d_frame + 3 * n);
+    if (const int st2 = rtc_rgba8_device(s->d_frame, n, d_rgba, s->stream); st2 != RTC_OK) return st2;
+    HIP_TRY(hipMemcpyAsync(rgba_out, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const int ov = checkOverflow(s);
+    if (ov != RTC_ERR_OVERFLOW || !growCsgLists(s)) return ov;
+  }
 }
 
 int rtc_assemble_tiles_device(const double* d_gathered, uint32_t world, uint32_t padded_tiles, uint32_t tile_w,

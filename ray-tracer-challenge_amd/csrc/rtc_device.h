@@ -156,7 +156,9 @@ struct __attribute__((aligned(32))) CsgRec {
   uint32_t leaf;
   uint32_t flags;  // bit 0: survives every csg filter above it; bit 1: already handed to the visitor
 };
-#define RTC_CSG_ENTRIES 32u
+#define RTC_CSG_ENTRIES 32u       // entries of a lane's list a handle starts with (DevScene::csg_entries) ...
+#define RTC_CSG_ENTRIES_MAX 1024u // ... and how far the synchronous entry points grow it when a render reports an overflow
+#define RTC_PATTERN_STACK 8       // gradient / blend patterns nested inside one another: frames of pattern_tree's stack
 
 struct DevScene {
   const RootRec* __restrict__ root_recs;
@@ -184,6 +186,7 @@ struct DevScene {
   const DevImage* __restrict__ img;
   const float* __restrict__ img_rgb;  // [pixels][3]
   CsgRec* csg_buf;  // per-launch scratch of the csg units' intersection lists; null unless the scene has csg nodes
+  uint32_t csg_entries;  // entries per lane in csg_buf
   const double* __restrict__ node_box;  // [n_nodes][6]
   const uint2* __restrict__ node_kids;  // {first, count}
   const uint32_t* __restrict__ kids;

@@ -462,7 +462,7 @@ __device__ __forceinline__ bool csg_rule(uint32_t op, bool lhit, bool inl, bool 
 }
 
 __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, const Ray& ray, unsigned& overflow) {
-  CsgRec* const buf = S.csg_buf + (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * RTC_CSG_ENTRIES * 64u +
+  CsgRec* const buf = S.csg_buf + (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * S.csg_entries * 64u +
                       (threadIdx.x & 63u);
   const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
   const uint2 range = S.node_range[unit];
@@ -488,7 +488,7 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
         boxes = chain_ok(S, S.leaf_parent[leaf], ray, t, degenerate);
       }
       if (!boxes) return;
-      if (n >= RTC_CSG_ENTRIES) {
+      if (n >= S.csg_entries) {
         overflow = 1u;
         return;
       }
@@ -545,7 +545,7 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
 template <class V>
 __device__ __forceinline__ void visit_csg(const DevScene& S, uint32_t unit, const Ray& ray, V& vis, unsigned& overflow) {
   const uint32_t n = csg_collect(S, unit, ray, overflow);
-  CsgRec* const buf = S.csg_buf + (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * RTC_CSG_ENTRIES * 64u +
+  CsgRec* const buf = S.csg_buf + (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * S.csg_entries * 64u +
                       (threadIdx.x & 63u);
   for (uint32_t i = 0; i < n; ++i) {
     const CsgRec a = buf[static_cast<size_t>(i) * 64u];
@@ -1195,8 +1195,68 @@ __device__ __forceinline__ bool pattern_chain(const DevScene& S, const DevPatter
   return true;
 }
 
-// Pattern.patternAt for the whole table.  Mixing patterns (gradient.zig, blend.zig) may sit
-// anywhere in a select-chain but their own children must be select-chains (validated at create).
+// Mixing patterns NESTED in one another (a blend of gradients, a gradient of a blend ...: gradient.zig:19-33 and
+// blend.zig:16-27 take arbitrary `*const Pattern` children).  The reference recurses; here the tree of mixing patterns
+// below `idx` is walked top-down with an explicit stack, each branch carrying its weight: a blend passes half of its
+// weight to either child ((a + b) * 0.5: exact), a gradient 1 - f and f of it (a + (b - a) f), and the solid /
+// test-pattern colours at the ends of the select-chains are summed by weight.  The sum differs from the reference's
+// nested expression in the last bits (colours need 1e-5; no branch depends on them).  Out of line, *_ext kernels only:
+// rtc_scene_create sends a scene with nested mixing patterns there and refuses more than RTC_PATTERN_STACK levels.
+template <bool EXT>
+__device__ __forceinline__ bool pattern_chain(const DevScene& S, const DevPattern* __restrict__ pat, uint32_t& idx,
+                                              double& ox, double& oy, double& oz, Rgb& out);
+__device__ __noinline__ Rgb pattern_tree(const DevScene& S, const DevPattern* pat, uint32_t idx, double ox, double oy, double oz) {
+  struct Frame {
+    double w, x, y, z;
+    uint32_t idx;
+  };
+  Frame stack[RTC_PATTERN_STACK];
+  int n = 0;
+  Rgb acc{0.0, 0.0, 0.0};
+  double w = 1.0;
+  for (int guard = 0; guard < 4096; ++guard) {
+    Rgb c;
+    if (pattern_chain<true>(S, pat, idx, ox, oy, oz, c)) {  // a select-chain that ends in a colour
+      acc.r += w * c.r;
+      acc.g += w * c.g;
+      acc.b += w * c.b;
+      if (n == 0) break;
+      --n;
+      idx = stack[n].idx;
+      w = stack[n].w;
+      ox = stack[n].x;
+      oy = stack[n].y;
+      oz = stack[n].z;
+      continue;
+    }
+    const DevPattern& P = pat[idx];  // a mixing pattern, looked up at the (possibly perturbed) object point
+    double wb = w * 0.5;             // blend.zig:21-24
+    if (P.kind != 6u) {
+      const double px = row_pt(P.inv + 0, ox, oy, oz), pz = row_pt(P.inv + 8, ox, oy, oz);
+      double fpart = px - __builtin_floor(px);  // gradient.zig:27-32
+      if (P.kind != 3u) {                       // radial gradient, gradient.zig:49-55
+        const double mag = __builtin_sqrt(px * px + pz * pz);
+        fpart = mag - __builtin_floor(mag);
+      }
+      wb = w * fpart;
+    }
+    if (n < RTC_PATTERN_STACK) {  // (deeper nestings are refused at create)
+      stack[n].w = wb;
+      stack[n].x = ox;
+      stack[n].y = oy;
+      stack[n].z = oz;
+      stack[n].idx = P.b;
+      ++n;
+    }
+    w = w - wb;
+    idx = P.a;
+  }
+  return acc;
+}
+
+// Pattern.patternAt for the whole table.  Mixing patterns (gradient.zig, blend.zig) may sit anywhere in a select-chain;
+// when their own children are select-chains - every scene of the reference - the mix is the reference's expression,
+// evaluated here; a mixing pattern below a mixing pattern goes to pattern_tree (the *_ext kernels).
 template <bool EXT>
 __device__ __forceinline__ Rgb pattern_at(const DevScene& S, const DevPattern* __restrict__ pat, uint32_t idx, double ox,
                                           double oy, double oz) {
@@ -1211,8 +1271,11 @@ __device__ __forceinline__ Rgb pattern_at(const DevScene& S, const DevPattern* _
   Rgb ca{0, 0, 0}, cb{0, 0, 0};
   {  // both children start from the mixing pattern's own object point (a perturb below moves its copy only)
     double ax = ox, ay = oy, az = oz, bx = ox, by = oy, bz = oz;
-    pattern_chain<EXT>(S, pat, ia, ax, ay, az, ca);
-    pattern_chain<EXT>(S, pat, ib, bx, by, bz, cb);
+    const bool a_ends = pattern_chain<EXT>(S, pat, ia, ax, ay, az, ca);
+    const bool b_ends = pattern_chain<EXT>(S, pat, ib, bx, by, bz, cb);
+    if constexpr (EXT) {
+      if (!(a_ends && b_ends)) return pattern_tree(S, pat, idx, ox, oy, oz);  // nested mixing patterns
+    }
   }
   if (kind == 6) {  // blend.zig:21-24
     return {(ca.r + cb.r) * 0.5, (ca.g + cb.g) * 0.5, (ca.b + cb.b) * 0.5};

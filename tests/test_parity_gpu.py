@@ -957,20 +957,72 @@ def test_random_scenes_without_groups(rtc, seed, simple):
         assert st["secondary"] == counters["secondary"] and st["shadow_calls"] == counters["shadow"] and st["overflow"] == 0
 
 
-def test_csg_list_overflow_is_reported(rtc):
-    """A csg whose list would need more than RTC_CSG_ENTRIES = 32 slots on some ray fails loudly (no truncation)."""
+def test_csg_lists_longer_than_the_first_allocation(rtc):
+    """Csg.filterIntersections works on a list of any length (csg.zig:51-95).  A lane's list starts with 32 slots; a ray
+    through 20 nested spheres and a cube needs 42.  The synchronous entry points grow the lists and render again - the
+    image is the oracle's -; an asynchronous render on a fresh handle reports the overflow in its counters."""
     import json
+    torch = pytest.importorskip("torch")
     spheres = [{"type": {"sphere": {}}, "transform": [{"scale": [0.2 + 0.05 * i] * 3}]} for i in range(20)]
     scene = {"camera": {"width": 32, "height": 32, "field-of-view": 0.6, "from": [0, 0, -6], "to": [0, 0, 0], "up": [0, 1, 0]},
              "lights": [{"point-light": {"position": [-5, 5, -5], "intensity": [1, 1, 1]}}],
              "objects": [{"type": {"csg": {"operation": "union", "left": {"type": {"group": spheres}},
                                            "right": {"type": {"cube": {}}}}}}]}
     hs = rtc.HostScene(json.dumps(scene))
+    cam = hs.camera()
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
     gpu = rtc.GpuScene(hs.desc)
+    buf = torch.zeros((32, 32, 3), dtype=torch.float64, device="cuda")
+    gpu.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert gpu.stats()["overflow"] > 0                      # 32 slots were not enough, and the launch says so
+    got = gpu.render(cam, 5)                                # grows the lists, renders again
+    st = gpu.stats()
+    assert np.abs(got - want).max() < TOL
+    assert [st["overflow"], st["secondary"], st["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]]
+    gpu.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)   # the handle keeps them
+    torch.cuda.synchronize()
+    assert gpu.stats()["overflow"] == 0 and np.abs(buf.cpu().numpy() - want).max() < TOL
+    assert np.array_equal(gpu.render_rgba8(cam, 5), rtc.canvas_rgba8(got))
+
+
+def test_mixing_patterns_nested_in_one_another(rtc):
+    """gradient.zig:19-33 and blend.zig:16-27 take arbitrary patterns as children: a blend of gradients, a gradient whose
+    ends are a blend and a radial gradient over perturbed stripes, three levels deep - walked on the device with an
+    explicit stack (pattern_tree, the *_ext kernels); nine levels are refused, loudly."""
+    import json
+    solid = lambda r, g, b: {"type": {"solid": [r, g, b]}}
+    grad = lambda a, b, t=None: {"type": {"gradient": [a, b]}, **({"transform": t} if t else {})}
+    blend = lambda a, b: {"type": {"blend": [a, b]}}
+    radial = lambda a, b: {"type": {"radial-gradient": [a, b]}, "transform": [{"scale": [0.4, 0.4, 0.4]}]}
+    stripes = {"type": {"stripes": [solid(0.9, 0.1, 0.1), solid(0.1, 0.1, 0.9)]}, "transform": [{"scale": [0.2, 0.2, 0.2]}, {"rotate-y": 0.7}]}
+    perturbed = {"type": {"perturb": stripes}}
+    floor = blend(grad(solid(1, 0, 0), solid(0, 1, 0), [{"rotate-y": 1.2}]), grad(solid(0, 0, 1), stripes))
+    ball = grad(blend(solid(1, 1, 0), radial(solid(0, 1, 1), perturbed)), radial(grad(solid(1, 0, 1), solid(0.2, 0.2, 0.2)), solid(1, 1, 1)),
+                [{"scale": [0.5, 0.5, 0.5]}])
+    scene = {"camera": {"width": 96, "height": 64, "field-of-view": 1.0, "from": [0, 2.2, -5], "to": [0, 0.6, 0], "up": [0, 1, 0]},
+             "lights": [{"point-light": {"position": [-4, 6, -6], "intensity": [1, 1, 1]}}],
+             "objects": [{"type": {"plane": {}}, "material": {"pattern": floor, "specular": 0, "reflective": 0.2}},
+                         {"type": {"sphere": {}}, "transform": [{"translate": [0, 1, 0]}], "material": {"pattern": ball, "diffuse": 0.8}},
+                         {"type": {"cube": {}}, "transform": [{"scale": [0.5, 0.5, 0.5]}, {"translate": [2, 0.5, 0.5]}],
+                          "material": {"pattern": blend(floor, ball), "transparency": 0.3, "refractive-index": 1.2}}]}
+    hs = rtc.HostScene(json.dumps(scene))
+    cam = hs.camera()
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(cam, 5)
+    assert gpu.last_kernel_name().endswith("_ext")
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    st = gpu.stats()
+    assert np.abs(got - want).max() < TOL
+    assert [st["overflow"], st["secondary"], st["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]]
+    assert len(np.unique(np.round(want.reshape(-1, 3), 3), axis=0)) > 200        # (the patterns do show)
+    deep = solid(1, 1, 1)
+    for level in range(9):
+        deep = blend(deep, solid(0, 0, 0)) if level % 2 else grad(deep, solid(0, 0, 0))
+    scene["objects"] = [{"type": {"plane": {}}, "material": {"pattern": deep}}]
     with pytest.raises(rtc.RtcError) as e:
-        gpu.render(hs.camera(), 5)
-    assert e.value.name == "StackOverflow"
-    assert gpu.stats()["overflow"] > 0
+        rtc.GpuScene(rtc.HostScene(json.dumps(scene)).desc)
+    assert e.value.name == "Unsupported"
 
 
 def test_interactive_camera_loop(rtc):
