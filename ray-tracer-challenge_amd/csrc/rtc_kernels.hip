@@ -576,6 +576,12 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
   const float delta = 5e-7f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
   const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
   const bool px = dx >= 0.0f, py = dy >= 0.0f, pz = dz >= 0.0f;
+  // Which of a node's two planes per axis the ray meets first is the ray's business, not the node's: the lane fetches
+  // "near x" and "far x" ... from the byte offsets its direction signs pick (lo[axis] at 16 * axis, hi[axis] at 48 + 16 *
+  // axis) - six 32-bit adds per node instead of twenty-four selects on the fetched boxes.
+  const uint32_t off_nx = px ? 0u : 48u, off_fx = px ? 48u : 0u;
+  const uint32_t off_ny = py ? 16u : 64u, off_fy = py ? 64u : 16u;
+  const uint32_t off_nz = pz ? 32u : 80u, off_fz = pz ? 80u : 32u;
   // origin shifted against / along the direction: (near - on) and (far - of) grow the box by delta
   const float onx = px ? ox + delta : ox - delta, ofx = px ? ox - delta : ox + delta;
   const float ony = py ? oy + delta : oy - delta, ofy = py ? oy - delta : oy + delta;
@@ -589,11 +595,15 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
   // on dragons.json).
   // The first RTC_LDS_TRAV entries of the stack live in LDS ([entry][lane]: conflict-free), the rest in scratch: a pop
   // sits between two dependent fetches, and LDS answers sooner than the vector memory path.
+  // (The LDS part goes through an LDS-typed pointer: with two generic pointers the compiler merged a pop's two loads
+  // into one FLAT load from a selected address, which waits for both the LDS and the vector-memory counters.)
+  typedef __attribute__((address_space(3))) uint32_t LdsWord;
+  LdsWord* const lds_top = (LdsWord*)lds_stack;
   uint32_t stack[RTC_TRAV_STACK - RTC_LDS_TRAV];
   int sp = 0;
   auto push = [&](uint32_t v) {
     if (sp < RTC_LDS_TRAV) {
-      lds_stack[sp * 64] = v;
+      lds_top[sp * 64] = v;
     } else {
       stack[sp - RTC_LDS_TRAV] = v;
     }
@@ -601,7 +611,13 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
   };
   auto pop = [&]() {
     --sp;
-    return sp < RTC_LDS_TRAV ? lds_stack[sp * 64] : stack[sp - RTC_LDS_TRAV];
+    uint32_t v;
+    if (sp < RTC_LDS_TRAV) {
+      v = lds_top[sp * 64];
+    } else {
+      v = stack[sp - RTC_LDS_TRAV];
+    }
+    return v;
   };
   uint32_t next = root;  // the node to visit next stays in a register: the stack (scratch memory) is one more dependent fetch
 #ifdef RTC_PROFILE
@@ -624,14 +640,15 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
       }
       // One 128-byte node: four child boxes, component by component.
       typedef float Float4 __attribute__((ext_vector_type(4)));
-      const Bvh4Node& N = S.bvh[ref];
-      const Float4 lox = *reinterpret_cast<const Float4*>(N.lo[0]), loy = *reinterpret_cast<const Float4*>(N.lo[1]);
-      const Float4 loz = *reinterpret_cast<const Float4*>(N.lo[2]), hix = *reinterpret_cast<const Float4*>(N.hi[0]);
-      const Float4 hiy = *reinterpret_cast<const Float4*>(N.hi[1]), hiz = *reinterpret_cast<const Float4*>(N.hi[2]);
-      const uint4 kids = *reinterpret_cast<const uint4*>(N.c);
-      const Float4 tnx = ((px ? lox : hix) - onx) * ix, tfx = ((px ? hix : lox) - ofx) * ix;
-      const Float4 tny = ((py ? loy : hiy) - ony) * iy, tfy = ((py ? hiy : loy) - ofy) * iy;
-      const Float4 tnz = ((pz ? loz : hiz) - onz) * iz, tfz = ((pz ? hiz : loz) - ofz) * iz;
+      const char* const table = reinterpret_cast<const char*>(S.bvh);  // (wave-uniform base + a 32-bit offset per lane)
+      const uint32_t at = ref * static_cast<uint32_t>(sizeof(Bvh4Node));
+      auto plane = [&](uint32_t off) { return *reinterpret_cast<const Float4*>(table + (at + off)); };
+      const Float4 nearx = plane(off_nx), neary = plane(off_ny), nearz = plane(off_nz);
+      const Float4 farx = plane(off_fx), fary = plane(off_fy), farz = plane(off_fz);
+      const uint4 kids = *reinterpret_cast<const uint4*>(table + (at + 96u));
+      const Float4 tnx = (nearx - onx) * ix, tfx = (farx - ofx) * ix;
+      const Float4 tny = (neary - ony) * iy, tfy = (fary - ofy) * iy;
+      const Float4 tnz = (nearz - onz) * iz, tfz = (farz - ofz) * iz;
       // max / min drop the NaN of 0 * inf (ray inside a slab, parallel to it)
       const Float4 tn = __builtin_elementwise_max(__builtin_elementwise_max(tnx, tny), tnz);
       const Float4 tf = __builtin_elementwise_min(__builtin_elementwise_min(tfx, tfy), tfz);
@@ -639,9 +656,10 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
       float key[4];
       uint32_t refs[4];
       int entered = 0;
+      const float far_limit = vis.far_limit();  // (once per node, not per child)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool h = (c4[k] != RTC_NO_LEAF) & (tn[k] <= tf[k]) & (tn[k] < __builtin_inff()) & !vis.cullf(tn[k], tf[k]);
+        const bool h = (c4[k] != RTC_NO_LEAF) & (tn[k] <= tf[k]) & (tn[k] < __builtin_inff()) & !vis.cull_limits(tn[k], tf[k], far_limit);
         key[k] = h ? tn[k] : __builtin_inff();
         refs[k] = c4[k];
         entered += h ? 1 : 0;
@@ -884,6 +902,11 @@ struct ClosestVisitor {
     const float best = static_cast<float>(t);
     return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > best + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(best));
   }
+  // cullf() with the part that does not depend on the box taken out of the per-child code (traverse_bvh computes the
+  // limit once per node): tn > best + 1e-4 (1 + |tn| + |best|) is, for best >= 0, tn > (best (1 + 1e-4) + 1e-4) / (1 - 1e-4)
+  // - the limit below, rounded up - and tf < -1e-4 (1 + |tf|) is tf < -1e-4 / (1 - 1e-4).
+  __device__ __forceinline__ float far_limit() const { return (static_cast<float>(t) * 1.0001f + 1.0001e-4f) * 1.0002f; }
+  __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
   __device__ __forceinline__ bool done() const { return false; }
 };
 
@@ -906,6 +929,8 @@ struct ShadowVisitor {
     const float lim = static_cast<float>(distance);
     return tf < -1e-4f * (1.0f + __builtin_fabsf(tf)) || tn > lim + 1e-4f * (1.0f + __builtin_fabsf(tn) + __builtin_fabsf(lim));
   }
+  __device__ __forceinline__ float far_limit() const { return (static_cast<float>(distance) * 1.0001f + 1.0001e-4f) * 1.0002f; }
+  __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
   __device__ __forceinline__ bool done() const { return shadowed; }
 };
 
@@ -975,6 +1000,8 @@ struct BehindVisitor {
     return et < 0.0 || (l == hit_leaf && et == hit_t);
   }
   __device__ __forceinline__ bool cullf(float tn, float) const { return tn > 1e-4f * (1.0f + __builtin_fabsf(tn)); }
+  __device__ __forceinline__ float far_limit() const { return 0.0f; }
+  __device__ __forceinline__ bool cull_limits(float tn, float, float) const { return tn > 1.0002e-4f; }  // tn > 1e-4 / (1 - 1e-4)
   __device__ __forceinline__ bool done() const { return false; }
 };
 
