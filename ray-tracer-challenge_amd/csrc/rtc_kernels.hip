@@ -1866,12 +1866,14 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     // the hit Shape: its record sits in the (LDS) root table when it is a top-level object,
     // otherwise it is a leaf inside a group and comes from the leaf tables in memory
     uint32_t kind, geom, mat_index;
-    double M[12];
+    // The hit shape's inverse is READ WHERE IT IS USED (three times: the local point, the normal, the pattern point) from
+    // where it lives - the root record in LDS, or the transform table - instead of sitting in 24 VGPRs from the hit to
+    // the pattern lookup: the kernels are at their register limits, and what does not fit is spilled to scratch memory.
+    const double* M;
     DevCyl hcy{0.0, 0.0, 0u, 0u};
     if (FLAT || hv.root != RTC_NO_LEAF) {  // (a world without groups: every hit is a top-level object)
       const RootRec& R = recs[hv.root];
-#pragma unroll
-      for (int i = 0; i < 12; ++i) M[i] = R.inv[i];
+      M = R.inv;
       kind = R.kind_flags & 0xFFu;
       geom = R.geom;
       mat_index = R.material;
@@ -1879,9 +1881,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       hcy.ymax = R.ymax;
     } else {
       const uint4 meta = S.leaf_meta[hv.leaf];
-      const double* __restrict__ X = S.xf + 12ull * meta.y;
-#pragma unroll
-      for (int i = 0; i < 12; ++i) M[i] = X[i];
+      M = S.xf + 12ull * meta.y;
       kind = meta.x & 0xFFu;
       geom = meta.w;
       mat_index = meta.z;
