@@ -1872,14 +1872,23 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     // the hit Shape: its record sits in the (LDS) root table when it is a top-level object,
     // otherwise it is a leaf inside a group and comes from the leaf tables in memory
     uint32_t kind, geom, mat_index;
-    // The hit shape's inverse is READ WHERE IT IS USED (three times: the local point, the normal, the pattern point) from
-    // where it lives - the root record in LDS, or the transform table - instead of sitting in 24 VGPRs from the hit to
-    // the pattern lookup: the kernels are at their register limits, and what does not fit is spilled to scratch memory.
-    const double* M;
+    // The hit shape's inverse.  The kernels that walk BVHs are at their register limit with values in scratch memory:
+    // there the matrix is READ WHERE IT IS USED (three times: the local point, the normal, the pattern point) from where
+    // it lives - the root record in LDS or the transform table - instead of sitting in 24 VGPRs from the hit to the
+    // pattern lookup (rtc_render_kernel 95 -> 54 spilled VGPRs, dragons 4K 2.33 -> 2.30 ms).  The kernels without the
+    // group traversal keep their copy: the three-wave kernel spills as much either way and writes 390 instead of 281 MB
+    // per cover frame without it.
+    double M_copy[FLAT ? 12 : 1];
+    const double* M = M_copy;
     DevCyl hcy{0.0, 0.0, 0u, 0u};
     if (FLAT || hv.root != RTC_NO_LEAF) {  // (a world without groups: every hit is a top-level object)
       const RootRec& R = recs[hv.root];
-      M = R.inv;
+      if constexpr (FLAT) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) M_copy[i] = R.inv[i];
+      } else {
+        M = R.inv;
+      }
       kind = R.kind_flags & 0xFFu;
       geom = R.geom;
       mat_index = R.material;

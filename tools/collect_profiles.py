@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Copies the summaries of one tools/profile_round.sh run (gpurun_out/profiles_<tag>/) into profiles/<round>/ and
-refreshes profiles/traffic.json (what bench.py reports as roofline.traffic).
+refreshes profiles/traffic.json (what bench.py reports as roofline.traffic / roofline_valu.executed_*), one entry per
+profiled workload.  Run again after tools/profile_round_bench.sh to pick the bench lines up.
 
-    python tools/collect_profiles.py gpurun_out/profiles_r01d r01
+    python tools/collect_profiles.py gpurun_out/profiles_r03 r03
 """
 import glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -12,37 +13,49 @@ src, rnd = sys.argv[1], sys.argv[2]
 repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(repo, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True)[0]
-shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
-trace = glob.glob(os.path.join(src, "stats", "**", "*_kernel_trace.csv"), recursive=True)[0]
-with open(trace) as f, open(os.path.join(dst, "kernel_trace_head.csv"), "w") as g:
-    rows = f.readlines()
-    g.writelines([rows[0]] + [r for r in rows[1:] if "rtc_render_kernel" in r][:3])
-pmc = summarize([os.path.join(src, d) for d in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_tcc")])
-with open(os.path.join(dst, "pmc_summary.txt"), "w") as g:
-    g.write("# per-launch means over the dispatches of rtc_render_kernel; separate rocprofv3 --pmc passes (tools/profile_round.sh)\n")
-    for k, v in sorted(pmc.items()):
-        g.write(f"{k:32s} {v:18.1f}\n")
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, "bench_n1.json"))
-with open(os.path.join(src, "configs.txt")) as f, open(os.path.join(dst, "configs_all.jsonl"), "w") as g:
-    g.writelines(l for l in f if l.startswith("{"))
+WORKLOADS = [("", "cover", {"scene": "cover.json", "width": 1920, "height": 1080, "depth": 5}),
+             ("d_", "dragons", {"scene": "dragons.json", "width": 3840, "height": 2160, "depth": 5}),
+             ("t_", "teapot", {"scene": "teapot.json", "width": 1920, "height": 1080, "depth": 5})]
+PASSES = ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2", "pmc_sq3", "pmc_tcc")
+entries = []
+for prefix, name, key in WORKLOADS:
+    stats = glob.glob(os.path.join(src, prefix + "stats", "**", "*_kernel_stats.csv"), recursive=True)
+    if not stats:
+        continue
+    shutil.copy(stats[0], os.path.join(dst, f"kernel_stats_{name}.csv"))
+    trace = glob.glob(os.path.join(src, prefix + "stats", "**", "*_kernel_trace.csv"), recursive=True)[0]
+    with open(trace) as f, open(os.path.join(dst, f"kernel_trace_head_{name}.csv"), "w") as g:
+        rows = f.readlines()
+        g.writelines([rows[0]] + [r for r in rows[1:] if "rtc_render_kernel" in r][:3])
+    pmc = summarize([os.path.join(src, prefix + d) for d in PASSES])
+    with open(os.path.join(dst, f"pmc_{name}.txt"), "w") as g:
+        g.write(f"# {key['scene']} {key['width']}x{key['height']} depth {key['depth']}: per-launch means over the dispatches of the render kernel; separate rocprofv3 --pmc passes (tools/profile_round.sh)\n")
+        for k, v in sorted(pmc.items()):
+            g.write(f"{k:32s} {v:18.1f}\n")
+        valu = pmc.get("SQ_INSTS_VALU", 0.0)
+        if valu and "SQ_BUSY_CYCLES" in pmc:
+            cycles = pmc["SQ_BUSY_CYCLES"] / 32.0
+            g.write(f"# lanes active per VALU instruction      {pmc['SQ_THREAD_CYCLES_VALU'] / 64.0 / pmc['SQ_ACTIVE_INST_VALU']:.3f}\n")
+            g.write(f"# wave cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES) {pmc['SQ_WAIT_ANY'] / pmc['SQ_WAVE_CYCLES']:.3f}\n")
+            g.write(f"# vector pipe issuing (SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs)) {pmc['SQ_ACTIVE_INST_VALU'] * 4.0 / 1024.0 / cycles:.3f}\n")
+            classes = ["ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "INT64", "CVT"]
+            known = sum(pmc.get("SQ_INSTS_VALU_" + c, 0.0) for c in classes)
+            g.write(f"# VALU instructions in no arithmetic class (moves, selects, compares, bit ops, div_scale / div_fixup ...) {(valu - known) / 1e6:.1f} M of {valu / 1e6:.1f} M\n")
+            g.write(f"# HBM traffic FETCH_SIZE x 2 + WRITE_SIZE = {(2 * pmc['FETCH_SIZE'] + pmc['WRITE_SIZE']) * 1024 / 1e6:.1f} MB; canvas {24 * key['width'] * key['height'] / 1e6:.1f} MB\n")
+    entries.append(dict(key, fetch_size_kb=round(pmc["FETCH_SIZE"], 1), write_size_kb=round(pmc["WRITE_SIZE"], 1),
+                        pmc={k: round(v, 1) for k, v in sorted(pmc.items())},
+                        source=f"profiles/{rnd}/pmc_{name}.txt (rocprofv3 --pmc, separate passes, per-launch mean)"))
+    ks = open(os.path.join(dst, f"kernel_stats_{name}.csv")).read().splitlines()
+    row = [r for r in ks if "rtc_render_kernel" in r][0].replace('"', "").split(",")
+    print(name, "kernel", row[0], "avg ns", row[3], "calls", row[1], "| VALU", round(pmc.get("SQ_INSTS_VALU", 0) / 1e6, 1), "M",
+          "FETCH", round(pmc["FETCH_SIZE"] / 1024, 1), "MiB WRITE", round(pmc["WRITE_SIZE"] / 1024, 1), "MiB")
+json.dump({"workloads": entries}, open(os.path.join(repo, "profiles", "traffic.json"), "w"), indent=1)
+for name in ("bench.json", "bench_dragons.json", "bench_teapot.json", "bench_rr.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, "bench_n1.json" if name == "bench.json" else name))
+if os.path.exists(os.path.join(src, "configs.txt")):
+    with open(os.path.join(src, "configs.txt")) as f, open(os.path.join(dst, "configs_all.jsonl"), "w") as g:
+        g.writelines(l for l in f if l.startswith("{"))
 if os.path.exists(os.path.join(src, "scale_sim.txt")):
     shutil.copy(os.path.join(src, "scale_sim.txt"), os.path.join(dst, "scale_sim_one_gpu.jsonl"))
-dstats = glob.glob(os.path.join(src, "d_stats", "**", "*_kernel_stats.csv"), recursive=True)
-if dstats:
-    shutil.copy(dstats[0], os.path.join(dst, "kernel_stats_dragons.csv"))
-    dpmc = summarize([os.path.join(src, d) for d in ("d_pmc_fetch", "d_pmc_write", "d_pmc_sq1", "d_pmc_tcc")])
-    with open(os.path.join(dst, "pmc_dragons.txt"), "w") as g:
-        g.write("# dragons.json 3840x2160 depth 5 (rtc_render_kernel): per-launch means, separate rocprofv3 --pmc passes (tools/profile_round.sh)\n")
-        for k, v in sorted(dpmc.items()):
-            g.write(f"{k:32s} {v:18.1f}\n")
-bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-traffic = {"scene": "cover.json", "width": 1920, "height": 1080, "depth": 5,
-           "fetch_size_kb": round(pmc["FETCH_SIZE"], 1), "write_size_kb": round(pmc["WRITE_SIZE"], 1),
-           "pmc": {k: round(v, 1) for k, v in sorted(pmc.items())},
-           "source": f"profiles/{rnd}/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, per-launch mean)"}
-json.dump(traffic, open(os.path.join(repo, "profiles", "traffic.json"), "w"), indent=1)
-ks = open(os.path.join(dst, "kernel_stats.csv")).read().splitlines()
-row = [r for r in ks if "rtc_render_kernel" in r][0].replace('"', "").split(",")
-print("kernel avg ns", row[3], "calls", row[1], "| bench kernel_ms", bench["roofline"]["kernel_ms"], "ms_per_step", bench["ms_per_step"])
-print({k: pmc[k] for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY") if k in pmc})
