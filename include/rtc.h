@@ -37,7 +37,7 @@
  *     another: rtc_scene_create returns RTC_ERR_UNSUPPORTED;
  *   - pattern select-chains (stripes / checkers / rings / perturb / texture map)
  *     deeper than 64: RTC_ERR_UNSUPPORTED at create;
- *   - more than 32 csg nodes under one csg: RTC_ERR_UNSUPPORTED at create;
+ *   - more than 64 csg nodes under one csg: RTC_ERR_UNSUPPORTED at create;
  *   - a lane's list of the intersections of one ray with one csg unit (the list
  *     Csg.filterIntersections works on, csg.zig:51-95) starts with 32 slots: when a
  *     frame needs more, rtc_render / rtc_render_rgba8 double them and render again

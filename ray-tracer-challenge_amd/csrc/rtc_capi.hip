@@ -1051,7 +1051,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
             info |= 1u << 17;
           }
           const uint32_t slot = unit_slots[unit]++;
-          if (slot >= 32) return fail(RTC_ERR_UNSUPPORTED, "csg node %u: more than 32 csg nodes under one csg", n);
+          if (slot >= 64) return fail(RTC_ERR_UNSUPPORTED, "csg node %u: more than 64 csg nodes under one csg", n);
           info |= slot << 8;
         }
         info |= side << 16;

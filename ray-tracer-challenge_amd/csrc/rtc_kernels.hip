@@ -514,7 +514,7 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
       ++n;
     });
   }
-  uint32_t inl = 0u, inr = 0u;  // one bit per csg node of the unit (node_info slot)
+  unsigned long long inl = 0ull, inr = 0ull;  // one bit per csg node of the unit (node_info slot, < 64)
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t leaf = buf[static_cast<size_t>(i) * 64u].leaf;
     uint32_t side = (S.leaf_meta[leaf].x >> 10) & 1u;
@@ -524,7 +524,7 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
       const uint32_t info = S.node_info[cur];
       const uint32_t op = info & 3u;
       if (op != 0u) {
-        const uint32_t bit = 1u << ((info >> 8) & 31u);
+        const unsigned long long bit = 1ull << ((info >> 8) & 63u);
         const bool lhit = side == 0u;
         const bool allowed = csg_rule(op, lhit, (inl & bit) != 0u, (inr & bit) != 0u);
         if (lhit) {

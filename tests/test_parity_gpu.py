@@ -989,6 +989,37 @@ def test_csg_lists_longer_than_the_first_allocation(rtc):
     assert np.array_equal(gpu.render_rgba8(cam, 5), rtc.canvas_rgba8(got))
 
 
+def test_csg_of_forty_nested_operations(rtc):
+    """A csg whose left operand is a csg ... forty deep (union / difference / intersection in turn, spheres and cubes
+    marching along x): one unit of forty csg nodes - the (inl, inr) toggles of every node are one bit each of a 64-bit
+    mask - and lists of up to 80 entries; sixty-five nodes are refused."""
+    import json
+
+    def chain(n):
+        node = {"type": {"sphere": {}}, "transform": [{"scale": [0.5, 0.5, 0.5]}]}
+        for i in range(n):
+            leaf = {"type": {"cube" if i % 2 else "sphere": {}},
+                    "transform": [{"scale": [0.35, 0.35 + 0.01 * i, 0.35]}, {"translate": [0.12 * (i + 1), 0.02 * (i % 5), 0]}]}
+            node = {"type": {"csg": {"operation": ["union", "difference", "intersection", "union"][i % 4] if i % 7 else "union",
+                                     "left": node, "right": leaf}}}
+        return node
+    scene = {"camera": {"width": 64, "height": 40, "field-of-view": 0.9, "from": [2.5, 1.5, -7], "to": [2.5, 0, 0], "up": [0, 1, 0]},
+             "lights": [{"point-light": {"position": [-5, 6, -8], "intensity": [1, 1, 1]}}],
+             "objects": [chain(40), {"type": {"plane": {}}, "transform": [{"translate": [0, -1, 0]}]}]}
+    hs = rtc.HostScene(json.dumps(scene))
+    cam = hs.camera()
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(cam, 5)
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    st = gpu.stats()
+    assert np.abs(got - want).max() < TOL
+    assert [st["overflow"], st["shadow_calls"]] == [0, counters["shadow"]]
+    scene["objects"] = [chain(65)]
+    with pytest.raises(rtc.RtcError) as e:
+        rtc.GpuScene(rtc.HostScene(json.dumps(scene)).desc)
+    assert e.value.name in ("Unsupported", "StackOverflow")   # (the tree's depth is checked first: refused either way)
+
+
 def test_mixing_patterns_nested_in_one_another(rtc):
     """gradient.zig:19-33 and blend.zig:16-27 take arbitrary patterns as children: a blend of gradients, a gradient whose
     ends are a blend and a radial gradient over perturbed stripes, three levels deep - walked on the device with an
