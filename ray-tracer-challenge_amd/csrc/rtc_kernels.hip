@@ -801,17 +801,21 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 // WORLD: 0 = anything (groups, csg: the root loop below visits the survivors in table order and walks the candidate BVH
 // of a group); 1 = `flat`: no groups at all, every leaf kind; 2 = `simple`: top-level planes, spheres and cubes only.
 // The flat and simple kernels carry none of the group traversal and run the exact tests one kind at a time.
+// member / stride: a cooperative trace (render_body, COOP; worlds without groups only).  The `stride` lanes of an aligned
+// group hold the same ray; lane `member` of the group takes every stride-th batch of four roots through both phases, and
+// the group's visitors are merged at the end: what one lane does in five batches and three exact tests in a row, eight
+// lanes do in one of each - the instruction stream of a wave with few rays left is what bounds it.  (0, 1): one lane, all.
 template <bool CSG, int WORLD, class V>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
                                       const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow,
-                                      uint32_t* lds_stack) {
+                                      uint32_t* lds_stack, const uint32_t member = 0u, const uint32_t stride = 1u) {
   constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
   const RayF rf = ray_f32(ray, S.cull_cmax);
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
     unsigned long long mine = 0ull;
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
-    for (uint32_t i = 0; i < n; i += 4u) {
+    for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
       const RootCullPair p0 = cull[(base + i) >> 1], p1 = cull[((base + i) >> 1) + 1u];
       const unsigned long long k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
       mine |= k << i;
@@ -877,6 +881,25 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       }
     }  // while (mine)
   }
+  if constexpr (FLAT) {
+    if (stride > 1u) vis.merge_group();  // (a cooperative trace: every lane of the group leaves with the group's result)
+  }
+}
+
+// Butterfly over an aligned group of eight lanes with DPP moves (one VALU instruction per dword and step, no LDS crossbar):
+// step 0 swaps neighbours (quad_perm [1,0,3,2]), step 1 pairs (quad_perm [2,3,0,1]), step 2 mirrors the half row
+// (lane i <-> 7 - i: after the first two steps the four lanes of a quad agree, so any lane of the other quad will do).
+template <int STEP>
+__device__ __forceinline__ uint32_t group8_other(uint32_t x) {
+  constexpr int ctrl = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : 0x141);
+  return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), ctrl, 0xF, 0xF, false));
+}
+template <int STEP>
+__device__ __forceinline__ double group8_other(double x) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+  const unsigned long long o = static_cast<unsigned long long>(group8_other<STEP>(static_cast<uint32_t>(b))) |
+                               (static_cast<unsigned long long>(group8_other<STEP>(static_cast<uint32_t>(b >> 32))) << 32);
+  return __builtin_bit_cast(double, o);
 }
 
 // hit(): first entry with t >= 0 of the stably sorted list (shape.zig:71-80) ==
@@ -914,6 +937,26 @@ struct ClosestVisitor {
   __device__ __forceinline__ float far_limit() const { return (static_cast<float>(t) * 1.0001f + 1.0001e-4f) * 1.0002f; }
   __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
   __device__ __forceinline__ bool done() const { return false; }
+  // Cooperative trace (render_body, COOP): the eight lanes of an aligned group hold the SAME ray and have each tested a
+  // share of World.objects; the lexicographic min of their results - the reduction is symmetric, so after three butterfly
+  // steps every lane of the group holds it.
+  template <int STEP>
+  __device__ __forceinline__ void merge_step() {
+    const double ot = group8_other<STEP>(t), ou = group8_other<STEP>(u), ov = group8_other<STEP>(v);
+    const uint32_t ol = group8_other<STEP>(leaf), oroot = group8_other<STEP>(root);
+    if (ot < t || (ot == t && ol < leaf)) {
+      t = ot;
+      leaf = ol;
+      root = oroot;
+      u = ou;
+      v = ov;
+    }
+  }
+  __device__ __forceinline__ void merge_group() {
+    merge_step<0>();
+    merge_step<1>();
+    merge_step<2>();
+  }
 };
 
 // isShadowed (world.zig:126-154): any entry with 0 <= t < distance on a casts_shadow leaf.
@@ -938,6 +981,10 @@ struct ShadowVisitor {
   __device__ __forceinline__ float far_limit() const { return (static_cast<float>(distance) * 1.0001f + 1.0001e-4f) * 1.0002f; }
   __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
   __device__ __forceinline__ bool done() const { return shadowed; }
+  __device__ __forceinline__ void merge_group() {  // any lane of the aligned group of eight
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    shadowed = ((__ballot(shadowed) >> (lane & ~7u)) & 0xFFull) != 0ull;
+  }
 };
 
 // The containers walk of PreComputations.new (world.zig:229-255), as a reduction.
@@ -1009,6 +1056,36 @@ struct BehindVisitor {
   __device__ __forceinline__ float far_limit() const { return 0.0f; }
   __device__ __forceinline__ bool cull_limits(float tn, float, float) const { return tn > 1.0002e-4f; }  // tn > 1e-4 / (1 - 1e-4)
   __device__ __forceinline__ bool done() const { return false; }
+  // (every root was tested by ONE lane of the group, so the entries of a leaf did arrive together; what is merged are the
+  // lanes' flushed results: the latest open leaf, the latest one other than the hit leaf, the hit leaf's own state)
+  __device__ __forceinline__ void merge_group() {
+    flush();
+    auto later = [](double at, uint32_t al, double bt, uint32_t bl) {  // is (bt, bl) the later open leaf?
+      return bl != RTC_NO_LEAF && (al == RTC_NO_LEAF || bt > at || (bt == at && bl > al));
+    };
+    auto step = [&](auto tag) {
+      constexpr int STEP = decltype(tag)::value;
+      const double ot = group8_other<STEP>(best_t), oet = group8_other<STEP>(best_excl_t);
+      const uint32_t ol = group8_other<STEP>(best_leaf), om = group8_other<STEP>(best_mat);
+      const uint32_t oel = group8_other<STEP>(best_excl_leaf), oem = group8_other<STEP>(best_excl_mat);
+      const uint32_t oopen = group8_other<STEP>(hit_open ? 1u : 0u), odups = group8_other<STEP>(hit_dups);
+      if (later(best_t, best_leaf, ot, ol)) {
+        best_t = ot;
+        best_leaf = ol;
+        best_mat = om;
+      }
+      if (later(best_excl_t, best_excl_leaf, oet, oel)) {
+        best_excl_t = oet;
+        best_excl_leaf = oel;
+        best_excl_mat = oem;
+      }
+      hit_open = hit_open || oopen != 0u;
+      hit_dups += odups;
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+  }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1491,7 +1568,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // reflection / refraction children (one continues in registers, the other goes to the lane's stack).
 // Exit: the counter runs past n_chunks (`drained`) and no lane holds a ray; every wave reaches it.
 // ------------------------------------------------------------------------------------------
-template <bool LDS, bool CSG, int WORLD = 0, int WAVES = 2>
+template <bool LDS, bool CSG, int WORLD = 0, int WAVES = 2, bool COOP = false>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
@@ -1847,9 +1924,58 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       n_primary++;
     }
     if (!__any(have_cur)) break;
-    if (!have_cur) continue;
+    // ---- 3. (COOP kernels) a wave with at most eight rays left lends each of them eight lanes.  The wave's instruction
+    // stream is what bounds it then - one wave issues an instruction every four cycles at best, and an iteration is 5 000
+    // of them whether one lane has a ray or all 64 -, so the k-th ray goes to the aligned group of lanes 8k .. 8k + 7:
+    // all eight run the iteration on the same ray and take identical branches, but inside trace() each takes its share of
+    // World.objects and the group's visitors are merged.  What the iteration yields - the colour it adds to the pixel, the
+    // children it spawns, its counts - travels back to the lane that owns the pixel (step 4), which is the only one with
+    // side effects.  A glass pixel's chain of dependent iterations, the floor under every small launch and every rank's
+    // share of a split frame, gets shorter; full waves never come here.
+    struct Yield {  // (only the COOP kernels use it)
+      double contrib[3] = {0.0, 0.0, 0.0};
+      Pending kid_now, kid_later;  // the child that continues at once (the reflection when there are two), the one that waits
+      uint32_t n_kids = 0u, share = 0u, secondary = 0u, shadow_calls = 0u, shadow_traced = 0u, overflow = 0u;
+    } yield;
+    bool coop = false, work = have_cur;
+    uint32_t member = 0u, stride = 1u, yield_from = 0u;
+    const bool owner = have_cur;
+    if constexpr (COOP) {
+      const unsigned long long live = __ballot(have_cur);
+      const uint32_t n_live = static_cast<uint32_t>(__builtin_popcountll(live));
+      coop = n_live <= 8u;  // (wave-uniform; at least one)
+      if (coop) {
+        uint32_t src = 0u;  // the lane whose ray this lane's group works on: the (lane / 8)-th lane with a ray
+        unsigned long long m = live;
+        for (uint32_t k = 0; k < n_live; ++k) {
+          const uint32_t b = static_cast<uint32_t>(__builtin_ctzll(m));
+          m &= m - 1ull;
+          if ((lane >> 3) == k) src = b;
+        }
+        yield_from = 8u * bits_below(live);  // (for an owner: the first lane of the group that works on its ray)
+        Pending w;
+        w.ray = {__shfl(cur.ray.ox, src), __shfl(cur.ray.oy, src), __shfl(cur.ray.oz, src),
+                 __shfl(cur.ray.dx, src), __shfl(cur.ray.dy, src), __shfl(cur.ray.dz, src)};
+        w.weight = __shfl(cur.weight, src);
+        w.remaining = __shfl(cur.remaining, src);
+        cur = w;
+        work = (lane >> 3) < n_live;
+        member = lane & 7u;
+        stride = 8u;
+      }
+    }
+    if constexpr (!COOP) {
+      if (!have_cur) continue;
+    }
     have_cur = false;  // `cur` is consumed; a spawned child may refill it below
-    share_rays += 2u;
+    // (the counts an iteration makes: the lane's own, or - cooperative kernels - the iteration's yield)
+    unsigned& it_share = COOP ? yield.share : share_rays;
+    unsigned& it_secondary = COOP ? yield.secondary : n_secondary;
+    unsigned& it_shadow_calls = COOP ? yield.shadow_calls : n_shadow_calls;
+    unsigned& it_shadow_traced = COOP ? yield.shadow_traced : n_shadow_traced;
+    unsigned& it_overflow = COOP ? yield.overflow : overflow;
+    if (work) do {  // (`continue` below ends the iteration's work, not the loop's turn: step 4 follows)
+    it_share += 2u;
     cur.remaining = min(cur.remaining, max_depth);  // termination never depends on a value read back from memory
     const Ray ray = cur.ray;
 
@@ -1862,7 +1988,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_COUNT(0);
     {
       RTC_HIST_BEGIN();
-      trace<CSG, WORLD>(S, recs, cull, ray, hv, overflow, trav_stack);
+      trace<CSG, WORLD>(S, recs, cull, ray, hv, it_overflow, trav_stack, member, stride);
       RTC_HIST_END(0);
     }
     RTC_STAMP(2);
@@ -1909,14 +2035,14 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     double n1 = 1.0, n2 = 1.0;
     if (cur.remaining != 0u && !(mats[mat_index].transparency == 0.0)) {
       RTC_STAMP(5);
-      share_rays += 2u;
+      it_share += 2u;
       BehindVisitor bv;
       bv.hit_leaf = hv.leaf;
       bv.hit_t = t;
       RTC_COUNT(4);
       {
         RTC_HIST_BEGIN();
-        trace<CSG, WORLD>(S, recs, cull, ray, bv, overflow, trav_stack);
+        trace<CSG, WORLD>(S, recs, cull, ray, bv, it_overflow, trav_stack, member, stride);
         RTC_HIST_END(2);
       }
       RTC_STAMP(6);
@@ -2039,7 +2165,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       const bool shadow_matters = !(mat.diffuse == 0.0 && mat.specular == 0.0);
       for (uint32_t li = 0; li < S.n_lights; ++li) {
         const double* __restrict__ L = lights + 6ull * li;
-        n_shadow_calls++;
+        it_shadow_calls++;
         // isShadowed (world.zig:127-131) and lighting's point_to_light (material.zig:51) share this
         const double vx = L[0] - ovx, vy = L[1] - ovy, vz = L[2] - ovz;
         const double distance = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);
@@ -2054,8 +2180,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
         bool shadowed = false;
         if (shadow_matters && light_dot_normal >= 0.0) {
-          n_shadow_traced++;
-          share_rays++;
+          it_shadow_traced++;
+          it_share++;
           ShadowVisitor sv;
           sv.distance = distance;
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
@@ -2063,7 +2189,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, WORLD>(S, recs, cull, sray, sv, overflow, trav_stack);
+            trace<CSG, WORLD>(S, recs, cull, sray, sv, it_overflow, trav_stack, member, stride);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
@@ -2101,9 +2227,15 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sb = sb + lb_;
       }
     }
-    acc[0] += cur.weight * sr;
-    acc[1] += cur.weight * sg;
-    acc[2] += cur.weight * sb;
+    if constexpr (COOP) {
+      yield.contrib[0] = cur.weight * sr;
+      yield.contrib[1] = cur.weight * sg;
+      yield.contrib[2] = cur.weight * sb;
+    } else {
+      acc[0] += cur.weight * sr;
+      acc[1] += cur.weight * sg;
+      acc[2] += cur.weight * sb;
+    }
 
     RTC_STAMP(6);
     // ---- reflectedColor / refractedColor / schlick (world.zig:98-107, 157-189, 272-289)
@@ -2152,7 +2284,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       const double two_dot = 2.0 * ((ray.dx * nx + ray.dy * ny) + ray.dz * nz);  // direction.reflect(normal)
       child.ray = {ovx, ovy, ovz, ray.dx - nx * two_dot, ray.dy - ny * two_dot, ray.dz - nz * two_dot};
       child.weight = cur.weight * w_reflect;
-      n_secondary++;
+      it_secondary++;
     }
     if (do_refract) {
       const double cos_t = __builtin_sqrt(1.0 - sin2_t);
@@ -2162,20 +2294,79 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       p.ray = {unx, uny, unz, nx * k - ex * n_ratio, ny * k - ey * n_ratio, nz * k - ez * n_ratio};
       p.weight = cur.weight * w_refract;
       p.remaining = cur.remaining - 1u;
-      n_secondary++;
+      it_secondary++;
       if (do_reflect) {  // both children: the reflection continues in registers, the refraction waits
-        if (sp < stack_cap) {
-          push_level(sp++, p);
+        if constexpr (COOP) {
+          yield.kid_later = p;
+          yield.n_kids = 1u;
         } else {
-          overflow = 1u;
+          if (sp < stack_cap) {
+            push_level(sp++, p);
+          } else {
+            overflow = 1u;
+          }
         }
       } else {
         child = p;
       }
     }
     if (do_reflect || do_refract) {
-      cur = child;
-      have_cur = true;
+      if constexpr (COOP) {
+        yield.kid_now = child;
+        yield.n_kids += 1u;
+      } else {
+        cur = child;
+        have_cur = true;
+      }
+    }
+    } while (0);
+    // ---- 4. (COOP kernels) what the iteration yielded, applied by the lane that owns the pixel: its own yield, or - after
+    // a cooperative iteration - that of the first lane of the group that worked on its ray
+    if constexpr (COOP) {
+      if (coop) {
+        const int from = static_cast<int>(yield_from);
+        Yield y;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) y.contrib[i] = __shfl(yield.contrib[i], from);
+        auto fetch = [&](const Pending& k) {
+          Pending r;
+          r.ray = {__shfl(k.ray.ox, from), __shfl(k.ray.oy, from), __shfl(k.ray.oz, from),
+                   __shfl(k.ray.dx, from), __shfl(k.ray.dy, from), __shfl(k.ray.dz, from)};
+          r.weight = __shfl(k.weight, from);
+          r.remaining = __shfl(k.remaining, from);
+          return r;
+        };
+        y.kid_now = fetch(yield.kid_now);
+        y.kid_later = fetch(yield.kid_later);
+        y.n_kids = __shfl(yield.n_kids, from);
+        y.share = __shfl(yield.share, from);
+        y.secondary = __shfl(yield.secondary, from);
+        y.shadow_calls = __shfl(yield.shadow_calls, from);
+        y.shadow_traced = __shfl(yield.shadow_traced, from);
+        y.overflow = __shfl(yield.overflow, from);
+        yield = y;
+      }
+      if (owner) {
+        acc[0] += yield.contrib[0];
+        acc[1] += yield.contrib[1];
+        acc[2] += yield.contrib[2];
+        share_rays += yield.share;
+        n_secondary += yield.secondary;
+        n_shadow_calls += yield.shadow_calls;
+        n_shadow_traced += yield.shadow_traced;
+        overflow |= yield.overflow;
+        if (yield.n_kids == 2u) {  // the reflection continues in registers, the refraction waits
+          if (sp < stack_cap) {
+            push_level(sp++, yield.kid_later);
+          } else {
+            overflow = 1u;
+          }
+        }
+        if (yield.n_kids != 0u) {
+          cur = yield.kid_now;
+          have_cur = true;
+        }
+      }
     }
   }
 
@@ -2246,7 +2437,7 @@ rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixel
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                          double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true, false, 2>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, false, 2, 2, true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // The `simple` kernel at THREE waves per SIMD (168 VGPRs; about a hundred values go to scratch memory, nearly all of them
