@@ -882,7 +882,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     }  // while (mine)
   }
   if constexpr (FLAT) {
-    if (stride > 1u) vis.merge_group();  // (a cooperative trace: every lane of the group leaves with the group's result)
+    if (stride > 1u) vis.merge_group(stride);  // (a cooperative trace: every lane of the group leaves with the group's result)
   }
 }
 
@@ -952,10 +952,10 @@ struct ClosestVisitor {
       v = ov;
     }
   }
-  __device__ __forceinline__ void merge_group() {
+  __device__ __forceinline__ void merge_group(uint32_t group) {  // group: 8 or 4 lanes (wave-uniform)
     merge_step<0>();
     merge_step<1>();
-    merge_step<2>();
+    if (group > 4u) merge_step<2>();
   }
 };
 
@@ -981,9 +981,9 @@ struct ShadowVisitor {
   __device__ __forceinline__ float far_limit() const { return (static_cast<float>(distance) * 1.0001f + 1.0001e-4f) * 1.0002f; }
   __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
   __device__ __forceinline__ bool done() const { return shadowed; }
-  __device__ __forceinline__ void merge_group() {  // any lane of the aligned group of eight
+  __device__ __forceinline__ void merge_group(uint32_t group) {  // any lane of the aligned group of eight (or four)
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    shadowed = ((__ballot(shadowed) >> (lane & ~7u)) & 0xFFull) != 0ull;
+    shadowed = ((__ballot(shadowed) >> (lane & ~(group - 1u))) & ((1ull << group) - 1ull)) != 0ull;
   }
 };
 
@@ -1058,7 +1058,7 @@ struct BehindVisitor {
   __device__ __forceinline__ bool done() const { return false; }
   // (every root was tested by ONE lane of the group, so the entries of a leaf did arrive together; what is merged are the
   // lanes' flushed results: the latest open leaf, the latest one other than the hit leaf, the hit leaf's own state)
-  __device__ __forceinline__ void merge_group() {
+  __device__ __forceinline__ void merge_group(uint32_t group) {
     flush();
     auto later = [](double at, uint32_t al, double bt, uint32_t bl) {  // is (bt, bl) the later open leaf?
       return bl != RTC_NO_LEAF && (al == RTC_NO_LEAF || bt > at || (bt == at && bl > al));
@@ -1084,7 +1084,7 @@ struct BehindVisitor {
     };
     step(std::integral_constant<int, 0>{});
     step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
+    if (group > 4u) step(std::integral_constant<int, 2>{});
   }
 };
 
@@ -2163,7 +2163,13 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
       // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
       const bool shadow_matters = !(mat.diffuse == 0.0 && mat.specular == 0.0);
-      for (uint32_t li = 0; li < S.n_lights; ++li) {
+      // (a cooperative iteration deals the lights to the two halves of the ray's group: lanes 0-3 take lights 0, 2, ...,
+      // lanes 4-7 lights 1, 3, ..., each half tracing its shadow rays four lanes wide; the halves' sums are added below -
+      // for two lights that is the reference's sum to the bit, for more its last bit may differ)
+      const uint32_t li_first = (COOP && coop) ? (member >> 2) : 0u, li_step = (COOP && coop) ? 2u : 1u;
+      const uint32_t s_member = (COOP && coop) ? (member & 3u) : member, s_stride = (COOP && coop) ? 4u : stride;
+      const unsigned calls_before = it_shadow_calls, traced_before = it_shadow_traced, share_before = it_share;
+      for (uint32_t li = li_first; li < S.n_lights; li += li_step) {
         const double* __restrict__ L = lights + 6ull * li;
         it_shadow_calls++;
         // isShadowed (world.zig:127-131) and lighting's point_to_light (material.zig:51) share this
@@ -2189,7 +2195,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, WORLD>(S, recs, cull, sray, sv, it_overflow, trav_stack, member, stride);
+            trace<CSG, WORLD>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
@@ -2225,6 +2231,16 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sr = sr + lr_;
         sg = sg + lg_;
         sb = sb + lb_;
+      }
+      if constexpr (COOP) {
+        if (coop) {  // the other half's lights (lane i <-> 7 - i pairs the halves), and what it counted
+          sr = sr + group8_other<2>(sr);
+          sg = sg + group8_other<2>(sg);
+          sb = sb + group8_other<2>(sb);
+          it_shadow_calls += group8_other<2>(it_shadow_calls - calls_before);
+          it_shadow_traced += group8_other<2>(it_shadow_traced - traced_before);
+          it_share += group8_other<2>(it_share - share_before);
+        }
       }
     }
     if constexpr (COOP) {
