@@ -330,10 +330,11 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   }
   const bool schedulable = map.n_chunks >= 64 && map.n_chunks < RTC_ITEM_MAX_CHUNKS;
   const bool sched_off = rtcOptions().sched_off != 0.0;  // (diagnostic: no schedule at all, packet i is chunk i)
-  if (!schedulable || sched_off) {  // a handful of chunks, or more than an item can name: packet i is chunk i, whole
+  if (!schedulable || sched_off) {  // a handful of chunks, or more than an item can name: no schedule
     map.order = nullptr;
     map.n_units_dev = nullptr;
-    map.n_units = map.n_chunks;
+    map.row_packets = (map.n_chunks < 64 && !sched_off) ? 1u : 0u;  // a handful: packet i is row i % 8 of chunk i / 8; else chunk i, whole
+    map.n_units = map.row_packets ? map.n_chunks * 8u : map.n_chunks;
     return RTC_OK;
   }
   if (const int st = ensureMeasureBuffers(s, map); st != RTC_OK) return st;

@@ -243,6 +243,7 @@ struct DevPixelMap {
   PendingRec* __restrict__ ray_stack;
   uint32_t ray_stack_levels;
   uint32_t pull_min_idle;  // a wave pulls its next packet only when at least this many lanes are idle (or none has a ray)
+  uint32_t row_packets;    // without a schedule (`order` null): != 0: packet c is ROW c % 8 of chunk c / 8 (n_units = 8 n_chunks), else chunk c whole
 };
 
 // Per chunk, what cutting it into runs of pixels needs to know about how its rays are spread (rtc_chunk_cost_kernel, from

@@ -1842,7 +1842,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           pk_t0 = __builtin_amdgcn_s_memtime();
           if (map.order != nullptr) {
             items = lane < RTC_PACKET_ITEMS ? map.order[static_cast<size_t>(c) * RTC_PACKET_ITEMS + lane] : RTC_NO_ITEM;
-          } else {  // unscheduled: packet c is chunk c, whole
+          } else {  // unscheduled: packet c is chunk c, whole - or, in a launch of a handful of chunks, one row of a chunk
             items = lane == 0u ? c : RTC_NO_ITEM;
           }
           item_next = 0u;
@@ -1850,9 +1850,13 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         }
         item_next++;
         // an item: pixels [start, start + len) of chunk c, in the chunk's row-major 8x8 numbering
-        const uint32_t c = map.order != nullptr ? (unit & 0xFFFFFu) : unit;
-        chunk_pos = map.order != nullptr ? ((unit >> 20) & 63u) : 0u;
-        chunk_end = map.order != nullptr ? chunk_pos + (unit >> 26) + 1u : 64u;
+        // (a launch too small to be scheduled - fewer chunks than a schedule is made for - hands out ROWS of chunks: eight
+        // packets per chunk on eight waves, each of which then works cooperatively where the kernel can (render_body, COOP);
+        // whole, a chunk of glass pixels is 0.34 ms in ONE wave while two thousand others have nothing to do)
+        const bool rows = map.order == nullptr && map.row_packets != 0u;
+        const uint32_t c = map.order != nullptr ? (unit & 0xFFFFFu) : (rows ? unit >> 3 : unit);
+        chunk_pos = map.order != nullptr ? ((unit >> 20) & 63u) : (rows ? (unit & 7u) * 8u : 0u);
+        chunk_end = map.order != nullptr ? chunk_pos + (unit >> 26) + 1u : (rows ? chunk_pos + 8u : 64u);
         // wave-uniform placement of the chunk, once per fetch (scalar unit)
         const uint32_t region = c / map.chunks_per_region;
         const uint32_t cr = c - region * map.chunks_per_region;
