@@ -21,9 +21,13 @@ def main():
     ap.add_argument("--tiles", default="16,32,64")
     ap.add_argument("--worlds", default="2,4,8")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--option", action="append", default=[], help="name=value for rtc_set_option (tuning experiments)")
     args = ap.parse_args()
     import torch
     rtc = importlib.import_module("ray-tracer-challenge_amd")
+    for o in args.option:
+        name, value = o.split("=")
+        rtc.set_option(name, float(value))
     hs = rtc.HostScene.from_file(args.scene)
     cam = hs.camera(args.width, args.height)
     W, H = cam.hsize, cam.vsize
