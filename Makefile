@@ -15,7 +15,8 @@ CXX     ?= g++
 PKG     := ray-tracer-challenge_amd
 LIB     := $(PKG)/lib
 
-HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -Wall -Wno-unused-result
+# (EXTRA: -D switches of diagnostic / experimental builds, e.g. make hip EXTRA=-DRTC_PROFILE)
+HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -ffp-contract=off -fPIC -Wall -Wno-unused-result $(EXTRA)
 CXXFLAGS := -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -Wextra
 
 HOST_SRC := $(PKG)/host/rtc_scene.cpp $(PKG)/host/rtc_loader.cpp $(PKG)/host/rtc_flatten.cpp \
