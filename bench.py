@@ -11,8 +11,14 @@ N == 1: one rtc_render_device launch per step.
 N  > 1: (launched by torch.distributed.run, one rank per GPU, backend nccl == RCCL)  the image is cut
         into 64x64 tiles, dealt to the ranks by the tiles' MEASURED cost (one round-robin frame measures
         them during setup); every rank renders its tiles into a compact buffer, ONE gather per frame brings
-        them to rank 0 over xGMI, rank 0 un-permutes them into the row-major canvas.  Frames are double-buffered: the gather of frame i runs on a side stream
-        under the render of frame i+1.  Total work per step is fixed -> "scaling": "strong".
+        them to rank 0 over xGMI, rank 0 un-permutes them into the row-major canvas.  The gather of frame i runs on a
+        side stream under the render of frame i+1, and a rank keeps THREE frames in flight (--inflight: three scene
+        handles, streams and tile buffers, frames dealt round-robin): an eighth of a 0.5 ms frame is a handful of
+        dependent iterations per wave, too short to fill a GPU by itself - the next frame's work-groups start on the
+        CUs the last one has left (one-GPU rehearsal, tools/scale_sim.py --inflight: the slowest 8-way share of
+        dragons 4K 0.70 -> 0.32 ms per frame, teapot 0.17 -> 0.06, cover 0.19 -> 0.12).  Total work per step is
+        fixed -> "scaling": "strong".  config.frames_in_flight says what a line was measured with; the one-GPU
+        headline is 1 (one frame after the other), its figure with 2 and 3 is in frames_in_flight_ms_per_frame.
 
 Rank 0 prints ONE JSON line (see the keys at the bottom).  `roofline` describes the dominant (only)
 kernel, rtc_render_kernel; `cpu_baseline` times the CPU oracle (a C++ restatement of the reference's
@@ -164,6 +170,36 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
         stream.synchronize()
         out["orbit_ms" if rep == 1 else "orbit_first_pass_ms"] = (time.perf_counter() - t0) * 1e3 / frames
     hs.rotate_camera(-2 * frames * angle)
+    # Throughput with several frames IN FLIGHT: independent frames (an orbit's, an animation's) on separate scene handles
+    # and streams, so that the work-groups of frame i + 1 start on the CUs frame i's last waves have left.  Not the headline
+    # (`value` is one frame after the other on one handle); what an N-way share of a frame gains from it is in
+    # tools/scale_sim.py --inflight.
+    g.close()
+    out["frames_in_flight_ms_per_frame"] = {}
+    for m in (1, 2, 3):
+        streams = [torch.cuda.Stream() for _ in range(m)]
+        gs = [rtc.GpuScene(hs.desc) for _ in range(m)]
+        cv = [torch.empty((H, W, 3), dtype=torch.float64, device="cuda") for _ in range(m)]
+        for i in range(24 * m):
+            gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
+        torch.cuda.synchronize()
+        best, k = None, 30
+        for rep in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            for st in streams:
+                st.wait_event(a)
+            for i in range(k):
+                gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
+            for st in streams:
+                stream.wait_stream(st)
+            b.record(stream)
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b) / k
+            best = t if best is None else min(best, t)
+        out["frames_in_flight_ms_per_frame"][str(m)] = best
+        for x in gs:
+            x.close()
     out["orbit"] = "%d frames, %.2f rad per frame, one handle, frames enqueued back to back; wall time / frames" % (frames, angle)
     return out
 
@@ -267,6 +303,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the first-frame / host-output / orbit timings")
     ap.add_argument("--tile-path", action="store_true",
                     help="run the multi-GPU code path (tiles + gather + un-permute) even with one rank")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames in flight per rank (that many scene handles, each with a stream and an output buffer of its "
+                         "own, frames dealt round-robin); 0 = 1 on one GPU (the headline: one frame after the other), 3 when "
+                         "the frame is split over ranks (a share is too short to fill a GPU by itself, DESIGN.md section 8)")
     ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks on ONE GPU over gloo (tiles staged through host memory): exercises the N > 1 code "
@@ -313,20 +353,29 @@ def main():
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
+    # Frames in flight: handle k renders frames k, k + M, ... on stream k into buffer k; the work-groups of a frame start on
+    # the CUs the frame before has left.  Handle 0 / stream 0 are the ones above.
+    M = args.inflight if args.inflight > 0 else (1 if world == 1 and not args.tile_path else 3)
+    gpus = [gpu] + [rtc.GpuScene(hs.desc) for _ in range(M - 1)]
+    rstreams = [stream] + [torch.cuda.Stream() for _ in range(M - 1)]
+
     timing = [False]   # (set for the K timed steps)
     if world == 1 and not args.tile_path:
-        canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+        canvases = [torch.empty((H, W, 3), dtype=torch.float64, device="cuda") for _ in range(M)]
+        canvas = canvases[0]
 
         def step(i):
-            gpu.render_device(cam, canvas.data_ptr(), args.depth, None, sptr)
+            gpus[i % M].render_device(cam, canvases[i % M].data_ptr(), args.depth, None, rstreams[i % M].cuda_stream)
 
         def finish():
-            pass
+            for st in rstreams[1:]:
+                stream.wait_stream(st)
     else:
         tx, ty = rtc.tile_grid(W, H, TILE, TILE)
         n_tiles = tx * ty
         first, stride, count, padded = rtc.tiles_of_rank(n_tiles, rank, world)
-        bufs = [torch.zeros((padded, TILE, TILE, 3), dtype=torch.float64, device="cuda") for _ in range(2)]
+        SLOTS = max(2, M)   # output buffers (one handle: two, so that frame i + 1 renders while frame i is gathered)
+        bufs = [torch.zeros((padded, TILE, TILE, 3), dtype=torch.float64, device="cuda") for _ in range(SLOTS)]
         # Scene setup, part 1: one frame with the tiles dealt round-robin MEASURES what every tile costs
         # (rtc_get_tile_costs); the ranks exchange those few hundred numbers once (not in the timed loop) and every rank
         # computes the same cost-balanced split (rtc_assign_tiles: longest tile first onto the least-loaded rank, equal
@@ -348,23 +397,24 @@ def main():
             np.bincount(np.arange(n_tiles) % world, weights=cost.numpy(), minlength=world).max() / max(load.mean(), 1e-30))
         d_slot = torch.from_numpy(slot_of.astype(np.int32)).cuda() if rank == 0 else None
         # rank 0 receives straight into [world][padded][T][T][3]: the gather list is that buffer's rows
-        gathered = ([torch.empty((world,) + tuple(bufs[0].shape), dtype=torch.float64, device="cuda") for _ in range(2)]
-                    if rank == 0 else [None, None])
-        gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None, None]
+        gathered = ([torch.empty((world,) + tuple(bufs[0].shape), dtype=torch.float64, device="cuda") for _ in range(SLOTS)]
+                    if rank == 0 else [None] * SLOTS)
+        gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None] * SLOTS
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda") if rank == 0 else None
         comm = torch.cuda.Stream()
-        rendered = [torch.cuda.Event() for _ in range(2)]
-        gathered_ev = [torch.cuda.Event() for _ in range(2)]
-        gathered_ev[0].record(comm)
-        gathered_ev[1].record(comm)
+        rendered = [torch.cuda.Event() for _ in range(SLOTS)]
+        gathered_ev = [torch.cuda.Event() for _ in range(SLOTS)]
+        for e in gathered_ev:
+            e.record(comm)
         comm_ev = []   # (timed steps only: HIP events on the side stream around the gather + un-permute of a frame)
 
         def step(i):
-            b = i & 1
-            stream.wait_event(gathered_ev[b])        # buffer b is free again (frame i-2 has been sent)
+            b = i % SLOTS
+            rs = rstreams[i % M]
+            rs.wait_event(gathered_ev[b])            # buffer b is free again (the frame that last used it has been sent)
             if count:
-                gpu.render_tile_list_device(cam, bufs[b].data_ptr(), TILE, TILE, my_tiles, args.depth, sptr)
-            rendered[b].record(stream)
+                gpus[i % M].render_tile_list_device(cam, bufs[b].data_ptr(), TILE, TILE, my_tiles, args.depth, rs.cuda_stream)
+            rendered[b].record(rs)
             with torch.cuda.stream(comm):            # gather + un-permute of frame i under the render of frame i+1
                 comm.wait_event(rendered[b])
                 if timing[0]:
@@ -387,6 +437,8 @@ def main():
                 gathered_ev[b].record(comm)
 
         def finish():
+            for st in rstreams[1:]:
+                stream.wait_stream(st)
             stream.wait_stream(comm)
 
     def barrier():
@@ -398,7 +450,7 @@ def main():
     # Scene setup, like the upload and the BVH build above: the first launch with a pixel map runs a schedule packed from
     # an estimate and measures (per-pixel ray counts, per-packet times); the packer behind it makes the schedule a static
     # view renders from after that (rtc_capi.hip, launch()).  Done here so that --warmup 0 still times steady-state frames.
-    for i in range(2):
+    for i in range(2 * M):   # (every handle's two)
         step(i)
         barrier()
     # ... and the device out of its idle state: the first 20-30 ms of GPU work after start-up run about 5 % slower than
@@ -423,9 +475,9 @@ def main():
     timing[0] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        kernel_ev[i][0].record(stream)
+        kernel_ev[i][0].record(rstreams[i % M])
         step(i)
-        kernel_ev[i][1].record(stream)
+        kernel_ev[i][1].record(rstreams[i % M])
     finish()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -478,6 +530,7 @@ def main():
                        "rays_per_frame": {"primary": stats["primary"], "secondary": stats["secondary"],
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
                        "mrays_per_s_incl_shadow_traced": (rays + stats["shadow_traced"]) * args.steps / elapsed / 1e6,
+                       "frames_in_flight": M,
                        "settle_frames": args.settle_frames,
                        "ms_per_step_right_after_startup": cold_ms,
                        "timed_frames": "steady state of a STATIC view: the schedule was measured on this same frame by the two "
@@ -554,7 +607,8 @@ def main():
                 "tiles": [r["tiles"] for r in per_rank],
                 "gather_unpermute_ms_rank0": per_rank[0]["gather_unpermute_ms"],
                 "note": "HIP events per rank: render_ms = a rank's render launch on its stream (incl. waiting for its "
-                        "double buffer), gather_unpermute_ms = rank 0's side stream from `frame rendered` to `canvas "
+                        "output buffer; with frames in flight the kernels of up to M frames share the GPU, so this is "
+                        "longer than ms_per_step), gather_unpermute_ms = rank 0's side stream from `frame rendered` to `canvas "
                         "assembled` (the gather waits for the slowest rank); ms_per_step is max over ranks of the wall "
                         "time of K pipelined frames",
             }

@@ -1102,10 +1102,27 @@ def test_bench_multi_rank_path_rehearsal():
     assert len(lines) == 1, out.stdout            # ONE JSON line on stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0 and "roofline" in line
+    assert line["config"]["frames_in_flight"] == 3   # (a split frame's default: three handles, streams and tile buffers per rank)
     assert line["config"]["rays_per_frame"]["primary"] == 480 * 270
     ranks = line["ranks"]                         # what a scaling curve is read from: every rank's share
     assert len(ranks["render_ms"]) == 2 and min(ranks["render_ms"]) > 0 and sum(ranks["tiles"]) == 8 * 5
     assert ranks["render_ms_max"] >= ranks["render_ms_mean"] and ranks["gather_unpermute_ms_rank0"] > 0
+
+
+def test_bench_frames_in_flight():
+    """bench.py --inflight 2 on one GPU: two handles, streams and canvases, frames dealt round-robin; the last frame is
+    checked against a plain render."""
+    import json
+    import subprocess
+    import sys
+    repo = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    cmd = [sys.executable, _os.path.join(repo, "bench.py"), "--steps", "5", "--warmup", "1", "--settle-frames", "4", "--width", "320",
+           "--height", "180", "--inflight", "2", "--no-cpu-baseline", "--no-extras", "--check"]
+    out = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "check ok" in out.stderr
+    line = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    assert line["config"]["frames_in_flight"] == 2 and line["n_gpus"] == 1 and line["value"] > 0
 
 
 def _json_scene(objects, lights, w=24, h=16):

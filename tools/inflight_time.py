@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Throughput with several frames in flight: M scene handles of one scene, each on its own stream with its own canvas,
+frames dealt round-robin; ms per frame = time of K frames / K.  python tools/inflight_time.py [scene w h depth] (GPU box)"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+CASES = [("cover.json", 1920, 1080, 5, None), ("fresnel.json", 300, 300, 5, None), ("cover.json", 1920, 1080, 5, (560, 720, 256, 256)),
+         ("teapot.json", 1920, 1080, 5, None), ("dragons.json", 3840, 2160, 5, None), ("reflection_and_refraction.json", 1920, 1080, 8, None)]
+if len(sys.argv) > 4: CASES = [(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), None)]
+K = 60
+for name, w, h, depth, rect in CASES:
+    hs = rtc.HostScene.from_file(name); cam = hs.camera(w, h)
+    out = []
+    for m in (1, 2, 3, 4):
+        streams = [torch.cuda.Stream() for _ in range(m)]
+        gpus = [rtc.GpuScene(hs.desc) for _ in range(m)]
+        canv = [torch.empty((h, w, 3), dtype=torch.float64, device="cuda") for _ in range(m)]
+        for i in range(50 * m):  # (every handle's schedule settles)
+            gpus[i % m].render_device(cam, canv[i % m].data_ptr(), depth, rect, streams[i % m].cuda_stream)
+        torch.cuda.synchronize()
+        best = 1e9
+        for rep in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(torch.cuda.current_stream())
+            for s in streams: s.wait_event(a)
+            for i in range(K):
+                gpus[i % m].render_device(cam, canv[i % m].data_ptr(), depth, rect, streams[i % m].cuda_stream)
+            for s in streams: torch.cuda.current_stream().wait_stream(s)
+            b.record(torch.cuda.current_stream()); torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b) / K)
+        same = all(torch.equal(canv[0], c) for c in canv[1:])
+        out.append(f"{m} in flight {best:.4f}" + ("" if same else " (canvases differ!)"))
+        for g in gpus: g.close()
+    print(name, f"{w}x{h}", rect or "", " | ".join(out), flush=True)

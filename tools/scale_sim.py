@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--tiles", default="16,32,64")
     ap.add_argument("--worlds", default="2,4,8")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="frames in flight per rank: that many handles of the share on streams of their own, frames dealt round-robin; ms = time of the frames / their number")
     ap.add_argument("--option", action="append", default=[], help="name=value for rtc_set_option (tuning experiments)")
     args = ap.parse_args()
     import torch
@@ -47,10 +49,40 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / args.reps
 
-    gpu = rtc.GpuScene(hs.desc)
-    canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
-    t_full = timed(lambda: gpu.render_device(cam, canvas.data_ptr(), args.depth, None, sptr), gpu)
-    print(json.dumps({"scene": args.scene, "full_ms": t_full}), flush=True)
+    M = max(1, args.inflight)
+    streams = [stream] + [torch.cuda.Stream() for _ in range(M - 1)]
+
+    def timed_in_flight(make):
+        """make(k) -> (handle, fn(stream_ptr)) for the k-th of M frames in flight."""
+        if M == 1:
+            h, fn = make(0)
+            t = timed(lambda: fn(sptr), h)
+            h.close()
+            return t
+        hf = [make(k) for k in range(M)]
+        for i in range(8 * M):
+            hf[i % M][1](streams[i % M].cuda_stream)
+            torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for st in streams[1:]:
+            st.wait_event(a)
+        for i in range(args.reps * M):
+            hf[i % M][1](streams[i % M].cuda_stream)
+        for st in streams[1:]:
+            stream.wait_stream(st)
+        b.record(stream)
+        torch.cuda.synchronize()
+        for h, _ in hf:
+            h.close()
+        return a.elapsed_time(b) / (args.reps * M)
+
+    def full_frame(k):
+        g = rtc.GpuScene(hs.desc)
+        canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+        return g, lambda sp: g.render_device(cam, canvas.data_ptr(), args.depth, None, sp)
+    t_full = timed_in_flight(full_frame)
+    print(json.dumps({"scene": args.scene, "full_ms": t_full, "frames_in_flight": M}), flush=True)
     for tile in [int(x) for x in args.tiles.split(",")]:
         tx, ty = rtc.tile_grid(W, H, tile, tile)
         for world in [int(x) for x in args.worlds.split(",")]:
@@ -68,11 +100,13 @@ def main():
             rank_of, _ = rtc.assign_tiles(cost, world)
             tb = []
             for rank in range(world):
-                g = rtc.GpuScene(hs.desc)
                 mine = np.flatnonzero(rank_of == rank).astype(np.uint32)
-                buf = torch.zeros(((tx * ty + world - 1) // world, tile, tile, 3), dtype=torch.float64, device="cuda")
-                tb.append(timed(lambda: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sptr), g))
-                g.close()
+
+                def share(k, mine=mine):
+                    g = rtc.GpuScene(hs.desc)
+                    buf = torch.zeros(((tx * ty + world - 1) // world, tile, tile, 3), dtype=torch.float64, device="cuda")
+                    return g, lambda sp: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sp)
+                tb.append(timed_in_flight(share))
             print(json.dumps({"tile": tile, "world": world, "ideal_ms": t_full / world,
                               "round_robin": {"max_ms": max(ts), "mean_ms": sum(ts) / world, "compute_eff": t_full / (world * max(ts))},
                               "by_measured_cost": {"max_ms": max(tb), "mean_ms": sum(tb) / world, "compute_eff": t_full / (world * max(tb))}}),

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+for m in 1 2 3; do
+  for a in "" "--scene teapot.json" "--scene dragons.json --width 3840 --height 2160"; do
+    python3 tools/scale_sim.py $a --tiles 64 --worlds 4,8 --reps 20 --inflight $m
+  done
+done
