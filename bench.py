@@ -170,15 +170,16 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
         stream.synchronize()
         out["orbit_ms" if rep == 1 else "orbit_first_pass_ms"] = (time.perf_counter() - t0) * 1e3 / frames
     hs.rotate_camera(-2 * frames * angle)
-    # Throughput with several frames IN FLIGHT: independent frames (an orbit's, an animation's) on separate scene handles
-    # and streams, so that the work-groups of frame i + 1 start on the CUs frame i's last waves have left.  Not the headline
+    # Throughput with several frames IN FLIGHT: independent frames (an orbit's, an animation's) on a scene handle and its
+    # clones (rtc_scene_clone), each on a stream of its own, so that the work-groups of frame i + 1 start on the CUs frame i's last waves have left.  Not the headline
     # (`value` is one frame after the other on one handle); what an N-way share of a frame gains from it is in
     # tools/scale_sim.py --inflight.
     g.close()
     out["frames_in_flight_ms_per_frame"] = {}
     for m in (1, 2, 3):
         streams = [torch.cuda.Stream() for _ in range(m)]
-        gs = [rtc.GpuScene(hs.desc) for _ in range(m)]
+        gs = [rtc.GpuScene(hs.desc)]
+        gs += [gs[0].clone() for _ in range(m - 1)]
         cv = [torch.empty((H, W, 3), dtype=torch.float64, device="cuda") for _ in range(m)]
         for i in range(24 * m):
             gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
@@ -356,7 +357,7 @@ def main():
     # Frames in flight: handle k renders frames k, k + M, ... on stream k into buffer k; the work-groups of a frame start on
     # the CUs the frame before has left.  Handle 0 / stream 0 are the ones above.
     M = args.inflight if args.inflight > 0 else (1 if world == 1 and not args.tile_path else 3)
-    gpus = [gpu] + [rtc.GpuScene(hs.desc) for _ in range(M - 1)]
+    gpus = [gpu] + [gpu.clone() for _ in range(M - 1)]   # (rtc_scene_clone: the same device copy of the scene)
     rstreams = [stream] + [torch.cuda.Stream() for _ in range(M - 1)]
 
     timing = [False]   # (set for the K timed steps)

@@ -243,6 +243,16 @@ int rtc_scene_create(const rtc_scene_desc *desc, rtc_scene **out);
 void rtc_scene_destroy(rtc_scene *scene);
 
 /*
+ * A second handle on the SAME scene: shares the source's device copy of the scene (no upload, no BVH build; freed
+ * with the last handle that uses it) and has a stream, launch counters, schedule and measurements of its own.  A
+ * handle runs one frame at a time; independent frames - an orbit's, an animation's, a rank's share of a split frame,
+ * which is too short to fill a GPU by itself - go to a handle and its clones in turn, each on a stream of its own,
+ * and the work-groups of a frame start on the CUs the frame before has left (bench.py --inflight, rtc_multi.h's
+ * RTC_MULTI_FRAMES).  Same device as the source (made current here); either may be destroyed first.
+ */
+int rtc_scene_clone(const rtc_scene *source, rtc_scene **out);
+
+/*
  * Replaces Camera.render (camera.zig:80-125) for the tile [x0,x0+w) x [y0,y0+h):
  * rgb_out[(y-y0)*w + (x-x0)][0..2] = colorAt(rayForPixel(x,y), max_depth).
  * The reference value of max_depth is 5 (camera.zig:118).  `rgb_out` is host

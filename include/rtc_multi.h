@@ -24,11 +24,20 @@
 extern "C" {
 #endif
 
-typedef struct rtc_multi rtc_multi; /* opaque: n scene handles, n streams, n RCCL communicators */
+typedef struct rtc_multi rtc_multi; /* opaque: per frame slot n scene handles and streams; n RCCL communicators */
 
 /* All ranks on device 0, plain device copies instead of RCCL: lets a one-GPU box run the whole split / gather /
  * un-permute / re-balance logic (tests).  Without it n_gpus must not exceed the visible devices. */
 #define RTC_MULTI_VIRTUAL 1u
+
+/* Frames in flight, 1 .. 8 (flags |= RTC_MULTI_FRAMES(k); none = 1): k frame slots, each with a scene handle per GPU
+ * (the scene itself and k - 1 rtc_scene_clone's of it: one device copy per GPU), streams and tile buffers of its own;
+ * rtc_multi_render_device hands the frames to the slots in turn and waits only for the frame that last used the slot.
+ * An N-th of a millisecond frame is a handful of dependent iterations per wave - too short to fill a GPU by itself;
+ * with three slots the work-groups of a frame start on the CUs the frame before has left (one-GPU rehearsal of the
+ * slowest 8-way share, tools/scale_sim.py --inflight 3: dragons 4K 0.70 -> 0.32 ms per frame, teapot 0.17 -> 0.06,
+ * cover 0.19 -> 0.12).  The synchronous entry points run one frame at a time whatever k is. */
+#define RTC_MULTI_FRAMES(k) (((uint32_t)(k) & 15u) << 8)
 
 /* Replicates the scene on devices 0 .. n_gpus-1 of this process and creates the communicators (ncclCommInitAll). */
 int rtc_multi_create(const rtc_scene_desc *desc, uint32_t n_gpus, uint32_t flags, rtc_multi **out);
@@ -49,15 +58,17 @@ int rtc_multi_render(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, do
 int rtc_multi_render_rgba8(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, uint8_t *rgba_out);
 
 /*
- * The frame left on GPU 0, nothing copied and nothing waited for: *d_canvas is device memory on device 0,
- * [vsize][hsize][3] doubles, complete once the work enqueued on rtc_multi_stream() has run (rtc_multi_synchronize, or
- * the caller's own work enqueued on that stream).  Two canvases alternate: a frame's canvas stays valid until the
- * render after the next one.  The bookkeeping a frame owes (overflow check, re-deal of the tiles) is done by the next
- * call on the handle; its status is that call's status.
+ * The frame left on GPU 0, nothing copied and nothing waited for (but the frame that last ran on the same slot):
+ * *d_canvas is device memory on device 0, [vsize][hsize][3] doubles, complete once the work enqueued on
+ * rtc_multi_stream() - asked for right after this call: every slot assembles on a stream of its own - has run
+ * (rtc_multi_synchronize, or the caller's own work enqueued on that stream).  max(2, k) canvases take turns: a frame's
+ * canvas stays valid while the next max(2, k) - 1 frames are enqueued.  The bookkeeping a frame owes (overflow check,
+ * re-deal of the tiles: a re-deal finishes every frame in flight first) is done by the next call that uses its slot, or
+ * by rtc_multi_synchronize; its status is that call's status.
  */
 int rtc_multi_render_device(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, const double **d_canvas);
-int rtc_multi_synchronize(rtc_multi *m);
-void *rtc_multi_stream(rtc_multi *m); /* the hipStream_t (device 0) behind which a frame's canvas is complete */
+int rtc_multi_synchronize(rtc_multi *m); /* every frame in flight */
+void *rtc_multi_stream(rtc_multi *m); /* the hipStream_t (device 0) behind which the LAST enqueued frame's canvas is complete */
 
 /* (For host output at link speed register the canvas once: rtc_canvas_register of rtc.h.) */
 

@@ -76,6 +76,7 @@ pub const RtcStats = extern struct { primary: u64, secondary: u64, shadow_calls:
 pub const RtcScene = opaque {};
 
 pub extern fn rtc_scene_create(desc: *const RtcSceneDesc, out: *?*RtcScene) c_int;
+pub extern fn rtc_scene_clone(source: ?*const RtcScene, out: *?*RtcScene) c_int;
 pub extern fn rtc_scene_destroy(scene: ?*RtcScene) void;
 pub extern fn rtc_render(scene: *RtcScene, cam: *const RtcCamera, max_depth: u32,
                          x0: u32, y0: u32, w: u32, h: u32, rgb_out: [*]f64) c_int;

@@ -88,7 +88,7 @@ class Stats(C.Structure):
                 ("shadow_traced", C.c_uint64), ("overflow", C.c_uint64)]
 
 
-RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
+RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
                "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
                "rtc_status_name", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
@@ -140,6 +140,7 @@ def hip_lib():
         lib.rtc_status_name.restype = C.c_char_p
         lib.rtc_status_name.argtypes = [C.c_int]
         lib.rtc_scene_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]
+        lib.rtc_scene_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         lib.rtc_scene_destroy.argtypes = [C.c_void_p]
         lib.rtc_scene_destroy.restype = None
         lib.rtc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32] + [C.c_uint32] * 4 + [C.c_void_p]
@@ -221,10 +222,12 @@ def multi_lib():
 class MultiGpu:
     """rtc_multi: one process, n GPUs, one gather per frame (include/rtc_multi.h)."""
 
-    def __init__(self, desc, n_gpus, virtual=False):
+    def __init__(self, desc, n_gpus, virtual=False, frames=1):
+        """frames: frame slots (RTC_MULTI_FRAMES): render_device hands the frames to them in turn."""
         self.n = n_gpus
         self._m = C.c_void_p()
-        self._check(multi_lib().rtc_multi_create(C.byref(desc), n_gpus, RTC_MULTI_VIRTUAL if virtual else 0, C.byref(self._m)))
+        flags = (RTC_MULTI_VIRTUAL if virtual else 0) | ((frames & 15) << 8)
+        self._check(multi_lib().rtc_multi_create(C.byref(desc), n_gpus, flags, C.byref(self._m)))
 
     @staticmethod
     def _check(status):
@@ -353,9 +356,17 @@ def make_camera(hsize, vsize, fov, frm, to, up):
 class GpuScene:
     """rtc_scene: the flat scene resident in HBM; many renders per upload."""
 
-    def __init__(self, desc):
+    def __init__(self, desc, _clone_of=None):
         self._s = C.c_void_p()
-        _check_hip(hip_lib().rtc_scene_create(C.byref(desc), C.byref(self._s)))
+        if _clone_of is not None:
+            _check_hip(hip_lib().rtc_scene_clone(_clone_of._s, C.byref(self._s)))
+        else:
+            _check_hip(hip_lib().rtc_scene_create(C.byref(desc), C.byref(self._s)))
+
+    def clone(self):
+        """rtc_scene_clone: a handle of its own (stream, schedule, counters) on the same device copy of the scene - one
+        per frame in flight."""
+        return GpuScene(None, _clone_of=self)
 
     def render(self, cam, max_depth=REFERENCE_DEPTH, tile=None):
         """Camera.render for the whole image or tile=(x0,y0,w,h); returns [h][w][3] f64 (host)."""

@@ -1241,6 +1241,21 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
 }
 
 // Copies the tables into HBM and fills in the scene handle.
+// What a handle owns by itself (a clone has its own): its stream, the launch counters, the event launches on other
+// streams order themselves by.  Schedules, cost buffers, ray stacks follow on first use.
+int initLaunchState(rtc_scene* s) {
+  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
+  // Zeroed ON THE HANDLE'S STREAM, followed by the event every launch on another stream waits for (launch()): the
+  // first launch, whatever stream it comes on, finds the work counter at zero.  (A hipMemset here runs on the legacy
+  // stream, which a hipStreamNonBlocking stream does not wait for.)
+  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
+  HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(s->launch_done, s->stream));
+  s->last_stream = s->stream;
+  return RTC_OK;
+}
+
 int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostTables& T, rtc_scene* s) {
   const auto& leaf_meta = T.leaf_meta;
   const auto& roots = T.roots;
@@ -1266,9 +1281,9 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const auto& bvh_mag = T.bvh_mag;
   const auto& cull_cmax = T.cull_cmax;
   HIP_TRY(hipGetDevice(&s->device));
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  HIP_TRY(s->roots.upload(roots));
-  HIP_TRY(s->root_recs.upload(root_recs));
+  s->tab = std::make_shared<SceneTables>();
+  HIP_TRY(s->tab->roots.upload(roots));
+  HIP_TRY(s->tab->root_recs.upload(root_recs));
   std::vector<RootCullPair> root_cull_pairs(root_cull.size() / 2u);
   for (size_t i = 0; i < root_cull_pairs.size(); ++i) {
     const RootCull &a = root_cull[2 * i], &b = root_cull[2 * i + 1];
@@ -1277,19 +1292,19 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     root_cull_pairs[i].cz = {a.cz, b.cz};
     root_cull_pairs[i].r2 = {a.r2, b.r2};
   }
-  HIP_TRY(s->root_cull.upload(root_cull_pairs));
-  HIP_TRY(s->root_weight.upload(T.root_weight));
-  HIP_TRY(s->kids.upload(kids));
-  HIP_TRY(s->leaf_meta.upload(leaf_meta));
-  HIP_TRY(s->xf.upload(xf));
-  HIP_TRY(s->cyl.upload(cyl));
-  HIP_TRY(s->tri.upload(tri));
-  HIP_TRY(s->trin.upload(trin));
-  HIP_TRY(s->mat.upload(mat));
-  HIP_TRY(s->pat.upload(pat));
-  HIP_TRY(s->node_box.upload(node_box));
-  HIP_TRY(s->node_kids.upload(node_kids));
-  HIP_TRY(s->bvh.upload(bvh4_nodes));
+  HIP_TRY(s->tab->root_cull.upload(root_cull_pairs));
+  HIP_TRY(s->tab->root_weight.upload(T.root_weight));
+  HIP_TRY(s->tab->kids.upload(kids));
+  HIP_TRY(s->tab->leaf_meta.upload(leaf_meta));
+  HIP_TRY(s->tab->xf.upload(xf));
+  HIP_TRY(s->tab->cyl.upload(cyl));
+  HIP_TRY(s->tab->tri.upload(tri));
+  HIP_TRY(s->tab->trin.upload(trin));
+  HIP_TRY(s->tab->mat.upload(mat));
+  HIP_TRY(s->tab->pat.upload(pat));
+  HIP_TRY(s->tab->node_box.upload(node_box));
+  HIP_TRY(s->tab->node_kids.upload(node_kids));
+  HIP_TRY(s->tab->bvh.upload(bvh4_nodes));
   std::vector<BvhLeafRec> leaf_recs(bvh_leaves.size());
   for (size_t i = 0; i < leaf_recs.size(); ++i) {
     BvhLeafRec& L = leaf_recs[i];
@@ -1305,9 +1320,9 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     const uint32_t kind = m.x & 0xFFu;
     if (kind == RTC_TRIANGLE || kind == RTC_SMOOTH_TRIANGLE) std::memcpy(L.tri, &tri[9ull * m.w], sizeof L.tri);
   }
-  HIP_TRY(s->bvh_leaf.upload(leaf_recs));
-  HIP_TRY(s->leaf_parent.upload(leaf_parent));
-  HIP_TRY(s->node_parent.upload(node_parent));
+  HIP_TRY(s->tab->bvh_leaf.upload(leaf_recs));
+  HIP_TRY(s->tab->leaf_parent.upload(leaf_parent));
+  HIP_TRY(s->tab->node_parent.upload(node_parent));
   {
     std::vector<DevTexMap> tex(d.n_texmaps);
     for (uint32_t i = 0; i < d.n_texmaps; ++i) {
@@ -1332,13 +1347,13 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
       total_px = std::max<size_t>(total_px, d.img_offset[i] + static_cast<size_t>(d.img_width[i]) * d.img_height[i]);
     }
     std::vector<float> rgb(d.img_rgb, d.img_rgb + 3 * total_px);
-    HIP_TRY(s->tex.upload(tex));
-    HIP_TRY(s->uv.upload(uv));
-    HIP_TRY(s->img.upload(img));
-    HIP_TRY(s->img_rgb.upload(rgb));
+    HIP_TRY(s->tab->tex.upload(tex));
+    HIP_TRY(s->tab->uv.upload(uv));
+    HIP_TRY(s->tab->img.upload(img));
+    HIP_TRY(s->tab->img_rgb.upload(rgb));
   }
-  HIP_TRY(s->node_info.upload(node_info));
-  HIP_TRY(s->node_range.upload(node_range));
+  HIP_TRY(s->tab->node_info.upload(node_info));
+  HIP_TRY(s->tab->node_range.upload(node_range));
   const bool has_csg = traits.has_csg, ext_kernel = traits.ext_kernel;
   s->has_csg = has_csg;
   s->ext_kernel = ext_kernel;
@@ -1354,15 +1369,8 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   }
   s->simple3_ok = s->simple_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
                   d.n_patterns <= RTC_LDS3_PATTERNS;
-  HIP_TRY(s->light.upload(light));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
-  // Zeroed ON THE HANDLE'S STREAM, followed by the event every launch on another stream waits for (launch()): the
-  // first launch, whatever stream it comes on, finds the work counter at zero.  (A hipMemset here runs on the legacy
-  // stream, which a hipStreamNonBlocking stream does not wait for.)
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
-  HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(s->launch_done, s->stream));
-  s->last_stream = s->stream;
+  HIP_TRY(s->tab->light.upload(light));
+  if (const int st = initLaunchState(s); st != RTC_OK) return st;
   s->max_trav_stack = traits.max_stack;
   {
     hipDeviceProp_t prop;
@@ -1382,34 +1390,34 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
       s->blocks_per_cu_lds = std::min<uint32_t>(s->blocks_per_cu_lds, v), s->blocks_per_cu_big = std::min<uint32_t>(s->blocks_per_cu_big, v);
   }
   DevScene& D = s->dev;
-  D.root_recs = s->root_recs.p;
-  D.root_cull = s->root_cull.p;
-  D.root_weight = s->root_weight.p;
-  D.roots = s->roots.p;
-  D.leaf_meta = s->leaf_meta.p;
-  D.xf = s->xf.p;
-  D.cyl = s->cyl.p;
-  D.tri = s->tri.p;
-  D.trin = s->trin.p;
-  D.mat = s->mat.p;
-  D.pat = s->pat.p;
-  D.bvh = s->bvh.p;
-  D.bvh_leaf = s->bvh_leaf.p;
-  D.leaf_parent = s->leaf_parent.p;
-  D.node_parent = s->node_parent.p;
-  D.node_info = s->node_info.p;
-  D.tex = s->tex.p;
-  D.uv = s->uv.p;
-  D.img = s->img.p;
-  D.img_rgb = s->img_rgb.p;
-  D.node_range = s->node_range.p;
+  D.root_recs = s->tab->root_recs.p;
+  D.root_cull = s->tab->root_cull.p;
+  D.root_weight = s->tab->root_weight.p;
+  D.roots = s->tab->roots.p;
+  D.leaf_meta = s->tab->leaf_meta.p;
+  D.xf = s->tab->xf.p;
+  D.cyl = s->tab->cyl.p;
+  D.tri = s->tab->tri.p;
+  D.trin = s->tab->trin.p;
+  D.mat = s->tab->mat.p;
+  D.pat = s->tab->pat.p;
+  D.bvh = s->tab->bvh.p;
+  D.bvh_leaf = s->tab->bvh_leaf.p;
+  D.leaf_parent = s->tab->leaf_parent.p;
+  D.node_parent = s->tab->node_parent.p;
+  D.node_info = s->tab->node_info.p;
+  D.tex = s->tab->tex.p;
+  D.uv = s->tab->uv.p;
+  D.img = s->tab->img.p;
+  D.img_rgb = s->tab->img_rgb.p;
+  D.node_range = s->tab->node_range.p;
   D.bvh_mag = bvh_mag;
   D.chain_nested = T.chain_nested ? 1u : 0u;
   D.csg_entries = RTC_CSG_ENTRIES;
-  D.node_box = s->node_box.p;
-  D.node_kids = s->node_kids.p;
-  D.kids = s->kids.p;
-  D.light = s->light.p;
+  D.node_box = s->tab->node_box.p;
+  D.node_kids = s->tab->node_kids.p;
+  D.kids = s->tab->kids.p;
+  D.light = s->tab->light.p;
   D.n_roots = d.n_roots;
   D.n_leaves = n_live;
   D.n_nodes = d.n_nodes;
@@ -1451,6 +1459,40 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     }
   } guard{s};
   if (const int st = uploadTables(d, traits, tables, s); st != RTC_OK) return st;
+  guard.s = nullptr;
+  *out = s;
+  return RTC_OK;
+}
+
+int rtc_scene_clone(const rtc_scene* src, rtc_scene** out) {
+  g_error.clear();
+  if (!src || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  auto s = new (std::nothrow) rtc_scene();
+  if (!s) return fail(RTC_ERR_OUT_OF_MEMORY, "host allocation");
+  struct Guard {
+    rtc_scene* s;
+    ~Guard() {
+      if (s) rtc_scene_destroy(s);
+    }
+  } guard{s};
+  // the scene and what was derived from it; nothing of the source's launches (schedule, measurements, buffers)
+  s->device = src->device;
+  s->tab = src->tab;
+  s->dev = src->dev;
+  s->dev.csg_buf = nullptr;
+  s->has_csg = src->has_csg;
+  s->ext_kernel = src->ext_kernel;
+  s->simple_kernel = src->simple_kernel;
+  s->flat_kernel = src->flat_kernel;
+  s->simple3_ok = src->simple3_ok;
+  s->max_trav_stack = src->max_trav_stack;
+  s->n_cus = src->n_cus;
+  s->blocks_per_cu_lds = src->blocks_per_cu_lds;
+  s->blocks_per_cu_big = src->blocks_per_cu_big;
+  s->blocks_per_cu_simple3 = src->blocks_per_cu_simple3;
+  HIP_TRY(hipSetDevice(s->device));
+  if (const int st = initLaunchState(s); st != RTC_OK) return st;
   guard.s = nullptr;
   *out = s;
   return RTC_OK;

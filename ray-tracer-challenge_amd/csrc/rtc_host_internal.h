@@ -80,14 +80,9 @@ struct Sphere {
   bool finite() const { return std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz); }
 };
 
-struct rtc_scene {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  DevScene dev{};
-  DevStats* d_stats = nullptr;  // two, used alternately (see DevStats)
-  uint32_t stats_parity = 0;    // which of the two the last launch counted in
-  double* d_frame = nullptr;  // staging for rtc_render (host output)
-  size_t frame_capacity = 0;  // in doubles
+// The scene's tables in device memory: written by rtc_scene_create, read-only from then on, so a handle and its clones
+// (rtc_scene_clone: one handle per frame in flight) share one copy; freed with the last of them.
+struct SceneTables {
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;
@@ -106,6 +101,17 @@ struct rtc_scene {
   DevBuf<DevUv> uv;
   DevBuf<DevImage> img;
   DevBuf<float> img_rgb;
+};
+
+struct rtc_scene {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevScene dev{};
+  DevStats* d_stats = nullptr;  // two, used alternately (see DevStats)
+  uint32_t stats_parity = 0;    // which of the two the last launch counted in
+  double* d_frame = nullptr;  // staging for rtc_render (host output)
+  size_t frame_capacity = 0;  // in doubles
+  std::shared_ptr<SceneTables> tab;  // the scene in device memory (`dev` points into it): shared with the handle's clones
   bool has_csg = false;
   bool ext_kernel = false;         // csg nodes or texture maps: the *_ext kernels
   bool simple_kernel = false;      // only top-level spheres / planes / cubes: the `simple` kernel

@@ -48,27 +48,41 @@ int mfail(int status, const char* fmt, ...) {
   } while (0)
 
 constexpr uint32_t kTile = 64;
+constexpr uint32_t kMaxFrames = 8;
+
+// One frame in flight: per rank a scene handle (slot 0: the scene itself; the others: its clones - same device copy of
+// the scene, own schedule and counters), the stream it renders on, its compact tile buffer; on device 0 the gathered
+// shares.  A slot runs one frame at a time; the slots take the frames in turn.
+struct Slot {
+  std::vector<rtc_scene*> scene;
+  std::vector<hipStream_t> stream;
+  std::vector<hipEvent_t> rendered;  // rank r's share is in its buffer (virtual ranks: has been copied to device 0)
+  std::vector<hipEvent_t> sent;      // RCCL: rank r's part of the gather is done, its buffer may be rendered into again
+  std::vector<double*> d_buf;        // [n] a rank's compact tiles [padded][64][64][3], on its device
+  double* d_gathered = nullptr;      // device 0: [n][padded][64][64][3]
+  hipEvent_t gathered = nullptr;     // RCCL: the gather has arrived on device 0
+  bool pending = false;              // a frame has been enqueued and its bookkeeping (overflow check, re-deal) is still due
+  rtc_camera cam{};
+};
 
 }  // namespace
 
 struct rtc_multi {
   uint32_t n = 0;
+  uint32_t frames = 1;  // slots
   bool virt = false;
   std::vector<int> dev;
-  std::vector<rtc_scene*> scene;
-  std::vector<hipStream_t> stream;
-  std::vector<hipEvent_t> shared;  // virtual mode: rank r's share has been copied into the gathered buffer
+  std::vector<Slot> slot;
+  uint32_t next_slot = 0, last_slot = 0;
   std::vector<ncclComm_t> comm;
+  std::vector<hipStream_t> cstream;  // RCCL: one stream per rank that carries its gathers, frame after frame
   // sized for one image size
   uint32_t hsize = 0, vsize = 0, n_tiles = 0, padded = 0;
-  std::vector<double*> d_buf;  // [n] a rank's compact tiles [padded][64][64][3], on its device
-  double* d_gathered = nullptr;  // device 0: [n][padded][64][64][3]
-  double* d_canvas[2] = {nullptr, nullptr};  // device 0: the frame being produced and the one handed out before it
-  uint32_t cur = 0;                          // which of the two the next frame is assembled into
-  uint32_t* d_rgba = nullptr;    // device 0: the RGBA8 form of a frame (rtc_multi_render_rgba8), allocated on first use
-  uint32_t* d_slot = nullptr;    // device 0: rtc_assign_tiles' slot_of_tile
-  bool pending = false;          // a frame has been enqueued and its bookkeeping (overflow check, re-deal) is still due
-  rtc_camera pending_cam{};
+  bool sized = false;
+  std::vector<double*> d_canvas;  // device 0: a ring of max(2, frames) canvases; a frame's stays valid while the next ones are produced
+  uint32_t cur = 0;               // which of them the next frame is assembled into
+  uint32_t* d_rgba = nullptr;     // device 0: the RGBA8 form of a frame (rtc_multi_render_rgba8), allocated on first use
+  uint32_t* d_slot = nullptr;     // device 0: rtc_assign_tiles' slot_of_tile
   std::vector<uint32_t> rank_of, slot_of;
   std::vector<std::vector<uint32_t>> tiles_of;
   bool balanced = false;
@@ -88,23 +102,37 @@ void setLists(rtc_multi* m) {
 }
 
 void freeFrameBuffers(rtc_multi* m) {
-  for (uint32_t r = 0; r < m->d_buf.size(); ++r)
-    if (m->d_buf[r]) {
-      (void)hipSetDevice(m->dev[r]);
-      (void)hipFree(m->d_buf[r]);
-    }
-  m->d_buf.clear();
-  if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
-  if (m->d_gathered) (void)hipFree(m->d_gathered);
-  for (double*& c : m->d_canvas) {
-    if (c) (void)hipFree(c);
-    c = nullptr;
+  for (Slot& S : m->slot) {
+    for (uint32_t r = 0; r < S.d_buf.size(); ++r)
+      if (S.d_buf[r]) {
+        (void)hipSetDevice(m->dev[r]);
+        (void)hipFree(S.d_buf[r]);
+      }
+    S.d_buf.clear();
+    if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+    if (S.d_gathered) (void)hipFree(S.d_gathered);
+    S.d_gathered = nullptr;
   }
+  if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+  for (double* c : m->d_canvas)
+    if (c) (void)hipFree(c);
+  m->d_canvas.clear();
   if (m->d_rgba) (void)hipFree(m->d_rgba);
   if (m->d_slot) (void)hipFree(m->d_slot);
-  m->d_gathered = nullptr;
   m->d_rgba = nullptr;
   m->d_slot = nullptr;
+  m->sized = false;
+}
+
+// Everything slot f's streams hold has run (RCCL: and every rank's part of its gather).
+int drainSlot(rtc_multi* m, uint32_t f) {
+  Slot& S = m->slot[f];
+  for (uint32_t r = m->n; r-- > 0u;) {  // (device 0 last)
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_HIP(hipStreamSynchronize(S.stream[r]));
+    if (!m->virt) M_HIP(hipEventSynchronize(S.sent[r]));
+  }
+  return RTC_OK;
 }
 
 // Buffers and the first (round-robin) deal for one image size.  All or nothing: a failure half way leaves the handle
@@ -113,14 +141,18 @@ int sizeForUnguarded(rtc_multi* m, const rtc_camera& cam) {
   const uint32_t tx = (cam.hsize + kTile - 1) / kTile, ty = (cam.vsize + kTile - 1) / kTile;
   m->n_tiles = tx * ty;
   m->padded = (m->n_tiles + m->n - 1) / m->n;
-  m->d_buf.assign(m->n, nullptr);
-  for (uint32_t r = 0; r < m->n; ++r) {
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_buf[r]), slabDoubles(m) * sizeof(double)));
-    M_HIP(hipMemset(m->d_buf[r], 0, slabDoubles(m) * sizeof(double)));  // slots and edge pixels nobody renders stay 0
+  for (Slot& S : m->slot) {
+    S.d_buf.assign(m->n, nullptr);
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipSetDevice(m->dev[r]));
+      M_HIP(hipMalloc(reinterpret_cast<void**>(&S.d_buf[r]), slabDoubles(m) * sizeof(double)));
+      M_HIP(hipMemset(S.d_buf[r], 0, slabDoubles(m) * sizeof(double)));  // slots and edge pixels nobody renders stay 0
+    }
+    M_HIP(hipSetDevice(m->dev[0]));
+    M_HIP(hipMalloc(reinterpret_cast<void**>(&S.d_gathered), slabDoubles(m) * m->n * sizeof(double)));
   }
   M_HIP(hipSetDevice(m->dev[0]));
-  M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_gathered), slabDoubles(m) * m->n * sizeof(double)));
+  m->d_canvas.assign(std::max(2u, m->frames), nullptr);
   for (double*& c : m->d_canvas)
     M_HIP(hipMalloc(reinterpret_cast<void**>(&c), static_cast<size_t>(cam.hsize) * cam.vsize * 3u * sizeof(double)));
   M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_slot), m->n_tiles * sizeof(uint32_t)));
@@ -136,15 +168,23 @@ int sizeForUnguarded(rtc_multi* m, const rtc_camera& cam) {
   return RTC_OK;
 }
 
+int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal);
+
+int finishAll(rtc_multi* m, bool may_redeal) {
+  int status = RTC_OK;
+  for (uint32_t k = 0; k < m->frames; ++k) {  // oldest first
+    const int st = finishSlot(m, (m->next_slot + k) % m->frames, may_redeal);
+    if (st != RTC_OK && status == RTC_OK) status = st;
+  }
+  return status;
+}
+
 int sizeFor(rtc_multi* m, const rtc_camera& cam) {
-  if (cam.hsize == m->hsize && cam.vsize == m->vsize && !m->d_buf.empty()) return RTC_OK;
+  if (cam.hsize == m->hsize && cam.vsize == m->vsize && m->sized) return RTC_OK;
   // (a frame of 2^32 pixels and more does not fit the 32-bit tile arithmetic - and no GPU)
   if (static_cast<uint64_t>(cam.hsize) * cam.vsize >= (1ull << 31))
     return mfail(RTC_ERR_INVALID_ARGUMENT, "image %ux%u is beyond what the tile split indexes", cam.hsize, cam.vsize);
-  for (uint32_t r = 0; r < m->n; ++r) {
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_HIP(hipStreamSynchronize(m->stream[r]));
-  }
+  if (const int st = finishAll(m, false); st != RTC_OK) return st;  // (frames of the old size still in flight)
   freeFrameBuffers(m);
   m->hsize = m->vsize = 0;
   m->balanced = false;
@@ -166,21 +206,23 @@ int sizeFor(rtc_multi* m, const rtc_camera& cam) {
   }
   m->hsize = cam.hsize;
   m->vsize = cam.vsize;
+  m->sized = true;
   return RTC_OK;
 }
 
-// Re-deal the tiles by what the ranks measured for them in the frame just rendered.  confirm: that frame was the first
-// with the current lists (new lists are new pixel maps, so every rank measured it afresh): keep them if the fresh costs
-// say they are even, re-deal if not - one wild measurement (a wave that lost its CU for a millisecond in the middle of a
-// packet: four virtual ranks on one GPU are four queues the hardware time-slices) must not skew the split for good.
-int rebalance(rtc_multi* m, const rtc_camera& cam, bool confirm) {
+// Re-deal the tiles by what the ranks measured for them in the frame slot f just rendered.  confirm: that frame was the
+// first with the current lists (new lists are new pixel maps, so every handle measures them afresh): keep them if the
+// fresh costs say they are even, re-deal if not - one wild measurement (a wave that lost its CU for a millisecond in the
+// middle of a packet: four virtual ranks on one GPU are four queues the hardware time-slices) must not skew the split
+// for good.  The lists and the slot table are shared by the frames in flight: the others are finished first.
+int rebalance(rtc_multi* m, uint32_t f, const rtc_camera& cam, bool confirm) {
   std::vector<double> cost(m->n_tiles, 0.0);
   for (uint32_t r = 0; r < m->n; ++r) {
     const std::vector<uint32_t>& mine = m->tiles_of[r];
     if (mine.empty()) continue;
     std::vector<double> c(mine.size());
     M_HIP(hipSetDevice(m->dev[r]));
-    if (rtc_get_tile_costs(m->scene[r], c.data(), static_cast<uint32_t>(mine.size())) != RTC_OK) return RTC_OK;  // nothing measured: keep the split
+    if (rtc_get_tile_costs(m->slot[f].scene[r], c.data(), static_cast<uint32_t>(mine.size())) != RTC_OK) return RTC_OK;  // nothing measured: keep the split
     for (size_t k = 0; k < mine.size(); ++k) cost[mine[k]] = c[k];
   }
   auto imbalance = [&]() {
@@ -199,17 +241,109 @@ int rebalance(rtc_multi* m, const rtc_camera& cam, bool confirm) {
   } else {
     m->redeals_in_a_row = 0;
   }
+  if (const int st = finishAll(m, false); st != RTC_OK) return st;  // (every frame that uses the old table is done, everywhere)
   M_RTC(rtc_assign_tiles(cost.data(), m->n_tiles, m->n, m->rank_of.data(), m->slot_of.data()));
   setLists(m);
-  for (uint32_t r = m->n; r-- > 0u;) {  // (every rank's stream: the frame that used the old table is done everywhere; device 0 last)
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_HIP(hipStreamSynchronize(m->stream[r]));
-  }
+  M_HIP(hipSetDevice(m->dev[0]));
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
   m->max_over_mean = imbalance();
   m->balanced = true;
   m->frames_since_balance = 0;
   m->balance_cam = cam;
+  return RTC_OK;
+}
+
+int slotStats(rtc_multi* m, uint32_t f, rtc_stats* out) {
+  std::memset(out, 0, sizeof *out);
+  for (uint32_t r = 0; r < m->n; ++r) {
+    if (m->tiles_of.size() > r && m->tiles_of[r].empty()) continue;
+    rtc_stats s;
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_RTC(rtc_get_stats(m->slot[f].scene[r], &s));
+    out->primary += s.primary;
+    out->secondary += s.secondary;
+    out->shadow_calls += s.shadow_calls;
+    out->shadow_traced += s.shadow_traced;
+    out->overflow += s.overflow;
+  }
+  return RTC_OK;
+}
+
+// What a frame owes once it is done: its streams drained, the overflow check, the re-deal of the tiles by measured cost
+// (after the first frame of an image size, and every 16 frames while the camera is not where the split was measured - a
+// moving camera measures every frame; the frame after a re-deal confirms it).  Idempotent.
+int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal) {
+  Slot& S = m->slot[f];
+  if (!S.pending) return RTC_OK;
+  S.pending = false;
+  if (const int st = drainSlot(m, f); st != RTC_OK) return st;
+  rtc_stats st;
+  if (const int s = slotStats(m, f, &st); s != RTC_OK) return s;
+  if (st.overflow) return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", (unsigned long long)st.overflow);
+  m->frames_since_balance++;
+  const rtc_camera cam = S.cam;
+  const bool moved = std::memcmp(&cam, &m->balance_cam, sizeof cam) != 0;
+  const bool confirm = m->balanced && m->frames_since_balance == 1u;
+  if (may_redeal && m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u) || confirm))
+    if (const int s = rebalance(m, f, cam, confirm); s != RTC_OK) return s;
+  return RTC_OK;
+}
+
+// One frame, enqueued on the next slot: every rank renders its tiles into its compact buffer, ONE gather brings them to
+// rank 0 (each rank's send is ordered behind its render), one kernel un-permutes them into the next canvas of the ring
+// on device 0, on the slot's stream of rank 0.  Only the frame that last ran on this slot is waited for: with several
+// slots the frames before this one are still rendering.
+int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double** d_canvas, uint32_t* slot_out) {
+  if (!m || !cam) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (cam->hsize == 0 || cam->vsize == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
+  const uint32_t f = m->next_slot;
+  if (const int st = finishSlot(m, f, true); st != RTC_OK) return st;
+  if (const int st = sizeFor(m, *cam); st != RTC_OK) return st;
+  Slot& S = m->slot[f];
+  for (uint32_t r = 0; r < m->n; ++r) {
+    if (m->tiles_of[r].empty()) continue;
+    M_HIP(hipSetDevice(m->dev[r]));
+    M_RTC(rtc_render_tile_list_device(S.scene[r], cam, max_depth, kTile, kTile, m->tiles_of[r].data(),
+                                      static_cast<uint32_t>(m->tiles_of[r].size()), S.d_buf[r], S.stream[r]));
+  }
+  S.pending = true;  // (from here on the streams hold work of this frame)
+  S.cam = *cam;
+  m->last_slot = f;
+  m->next_slot = (f + 1u) % m->frames;
+  const size_t slab = slabDoubles(m);
+  if (!m->virt) {
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipSetDevice(m->dev[r]));
+      M_HIP(hipEventRecord(S.rendered[r], S.stream[r]));
+      M_HIP(hipStreamWaitEvent(m->cstream[r], S.rendered[r], 0));
+    }
+    M_NCCL(ncclGroupStart());
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipSetDevice(m->dev[r]));
+      M_NCCL(ncclGather(S.d_buf[r], S.d_gathered, slab, ncclDouble, 0, m->comm[r], m->cstream[r]));
+    }
+    M_NCCL(ncclGroupEnd());
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipSetDevice(m->dev[r]));
+      M_HIP(hipEventRecord(S.sent[r], m->cstream[r]));
+    }
+    M_HIP(hipSetDevice(m->dev[0]));
+    M_HIP(hipEventRecord(S.gathered, m->cstream[0]));
+    M_HIP(hipStreamWaitEvent(S.stream[0], S.gathered, 0));
+  } else {
+    M_HIP(hipSetDevice(m->dev[0]));
+    for (uint32_t r = 0; r < m->n; ++r) {
+      M_HIP(hipMemcpyAsync(S.d_gathered + slab * r, S.d_buf[r], slab * sizeof(double), hipMemcpyDeviceToDevice, S.stream[r]));
+      M_HIP(hipEventRecord(S.rendered[r], S.stream[r]));
+      if (r != 0) M_HIP(hipStreamWaitEvent(S.stream[0], S.rendered[r], 0));
+    }
+  }
+  M_HIP(hipSetDevice(m->dev[0]));
+  double* const canvas = m->d_canvas[m->cur];
+  m->cur = (m->cur + 1u) % static_cast<uint32_t>(m->d_canvas.size());
+  M_RTC(rtc_assemble_tile_list_device(S.d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, canvas, S.stream[0]));
+  *d_canvas = canvas;
+  *slot_out = f;
   return RTC_OK;
 }
 
@@ -226,6 +360,8 @@ int rtc_multi_create(const rtc_scene_desc* desc, uint32_t n_gpus, uint32_t flags
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) return mfail(RTC_ERR_NO_DEVICE, "no HIP device is visible");
   const bool virt = (flags & RTC_MULTI_VIRTUAL) != 0u;
+  const uint32_t frames = std::max(1u, (flags >> 8) & 15u);
+  if (frames > kMaxFrames) return mfail(RTC_ERR_INVALID_ARGUMENT, "%u frames in flight asked for, at most %u", frames, kMaxFrames);
   if (!virt && n_gpus > static_cast<uint32_t>(n_dev))
     return mfail(RTC_ERR_INVALID_ARGUMENT, "%u GPUs asked for, %d visible", n_gpus, n_dev);
   rtc_multi* m = new (std::nothrow) rtc_multi();
@@ -237,20 +373,41 @@ int rtc_multi_create(const rtc_scene_desc* desc, uint32_t n_gpus, uint32_t flags
     }
   } guard{m};
   m->n = n_gpus;
+  m->frames = frames;
   m->virt = virt;
   m->dev.resize(n_gpus);
-  m->scene.assign(n_gpus, nullptr);
-  m->stream.assign(n_gpus, nullptr);
-  m->shared.assign(n_gpus, nullptr);
   for (uint32_t r = 0; r < n_gpus; ++r) m->dev[r] = virt ? 0 : static_cast<int>(r);
+  m->slot.resize(frames);
+  for (Slot& S : m->slot) {
+    S.scene.assign(n_gpus, nullptr);
+    S.stream.assign(n_gpus, nullptr);
+    S.rendered.assign(n_gpus, nullptr);
+    S.sent.assign(n_gpus, nullptr);
+  }
+  m->tiles_of.assign(n_gpus, {});
   for (uint32_t r = 0; r < n_gpus; ++r) {
     M_HIP(hipSetDevice(m->dev[r]));
-    M_RTC(rtc_scene_create(desc, &m->scene[r]));  // the scene (<= 30 MB) is replicated
-    M_HIP(hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking));
-    M_HIP(hipEventCreateWithFlags(&m->shared[r], hipEventDisableTiming));
+    for (uint32_t f = 0; f < frames; ++f) {
+      Slot& S = m->slot[f];
+      if (f == 0) {
+        M_RTC(rtc_scene_create(desc, &S.scene[r]));  // the scene (<= 30 MB) is replicated per GPU ...
+      } else {
+        M_RTC(rtc_scene_clone(m->slot[0].scene[r], &S.scene[r]));  // ... and shared by the frames in flight on it
+      }
+      M_HIP(hipStreamCreateWithFlags(&S.stream[r], hipStreamNonBlocking));
+      M_HIP(hipEventCreateWithFlags(&S.rendered[r], hipEventDisableTiming));
+      M_HIP(hipEventCreateWithFlags(&S.sent[r], hipEventDisableTiming));
+      M_HIP(hipEventRecord(S.sent[r], S.stream[r]));  // (never waited for before its first gather otherwise)
+      if (r == 0) M_HIP(hipEventCreateWithFlags(&S.gathered, hipEventDisableTiming));
+    }
   }
   if (!virt) {
     m->comm.assign(n_gpus, nullptr);
+    m->cstream.assign(n_gpus, nullptr);
+    for (uint32_t r = 0; r < n_gpus; ++r) {
+      M_HIP(hipSetDevice(m->dev[r]));
+      M_HIP(hipStreamCreateWithFlags(&m->cstream[r], hipStreamNonBlocking));
+    }
     M_NCCL(ncclCommInitAll(m->comm.data(), static_cast<int>(n_gpus), m->dev.data()));
   }
   guard.m = nullptr;
@@ -260,120 +417,66 @@ int rtc_multi_create(const rtc_scene_desc* desc, uint32_t n_gpus, uint32_t flags
 
 void rtc_multi_destroy(rtc_multi* m) {
   if (!m) return;
-  for (uint32_t r = 0; r < m->stream.size(); ++r) {
+  for (Slot& S : m->slot)
+    for (uint32_t r = 0; r < S.stream.size(); ++r) {
+      (void)hipSetDevice(m->dev[r]);
+      if (S.stream[r]) (void)hipStreamSynchronize(S.stream[r]);
+    }
+  for (uint32_t r = 0; r < m->cstream.size(); ++r) {
     (void)hipSetDevice(m->dev[r]);
-    if (m->stream[r]) (void)hipStreamSynchronize(m->stream[r]);
+    if (m->cstream[r]) (void)hipStreamSynchronize(m->cstream[r]);
   }
   for (ncclComm_t c : m->comm)
     if (c) (void)ncclCommDestroy(c);
   freeFrameBuffers(m);
-  for (uint32_t r = 0; r < m->scene.size(); ++r) {
+  for (uint32_t f = m->slot.size(); f-- > 0u;) {  // (clones before the scene they were made from: either order is allowed)
+    Slot& S = m->slot[f];
+    for (uint32_t r = 0; r < S.scene.size(); ++r) {
+      (void)hipSetDevice(m->dev[r]);
+      if (S.scene[r]) rtc_scene_destroy(S.scene[r]);
+      if (S.rendered[r]) (void)hipEventDestroy(S.rendered[r]);
+      if (S.sent[r]) (void)hipEventDestroy(S.sent[r]);
+      if (S.stream[r]) (void)hipStreamDestroy(S.stream[r]);
+    }
+    if (S.gathered) (void)hipEventDestroy(S.gathered);
+  }
+  for (uint32_t r = 0; r < m->cstream.size(); ++r) {
     (void)hipSetDevice(m->dev[r]);
-    if (m->scene[r]) rtc_scene_destroy(m->scene[r]);
-    if (m->shared[r]) (void)hipEventDestroy(m->shared[r]);
-    if (m->stream[r]) (void)hipStreamDestroy(m->stream[r]);
+    if (m->cstream[r]) (void)hipStreamDestroy(m->cstream[r]);
   }
   delete m;
 }
-
-}  // extern "C"
-
-namespace {
-
-// What a frame owes once it is done: every stream drained, the overflow check, the re-deal of the tiles by measured cost
-// (after the first frame of an image size, and every 16 frames while the camera is not where the split was measured - a
-// moving camera measures every frame; the frame after a re-deal confirms it).  Idempotent.
-int finishFrame(rtc_multi* m) {
-  if (!m->pending) return RTC_OK;
-  m->pending = false;
-  for (uint32_t r = m->n; r-- > 0u;) {
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_HIP(hipStreamSynchronize(m->stream[r]));
-  }
-  rtc_stats st;
-  if (const int s = rtc_multi_get_stats(m, &st); s != RTC_OK) return s;
-  if (st.overflow) return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", (unsigned long long)st.overflow);
-  m->frames_since_balance++;
-  const rtc_camera& cam = m->pending_cam;
-  const bool moved = std::memcmp(&cam, &m->balance_cam, sizeof cam) != 0;
-  const bool confirm = m->balanced && m->frames_since_balance == 1u;
-  if (m->n > 1 && (!m->balanced || (moved && m->frames_since_balance >= 16u) || confirm))
-    if (const int s = rebalance(m, cam, confirm); s != RTC_OK) return s;
-  return RTC_OK;
-}
-
-// One frame, enqueued: every rank renders its tiles into its compact buffer, ONE gather brings them to rank 0 (each
-// rank's send is ordered behind its render on its stream), one kernel un-permutes them into the row-major canvas
-// d_canvas[cur] on device 0, stream[0].  Nothing here waits for the GPUs (the frame before has been finished: the
-// buffers are free).
-int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double** d_canvas) {
-  if (!m || !cam) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  if (cam->hsize == 0 || cam->vsize == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
-  if (const int st = finishFrame(m); st != RTC_OK) return st;
-  if (const int st = sizeFor(m, *cam); st != RTC_OK) return st;
-  for (uint32_t r = 0; r < m->n; ++r) {
-    if (m->tiles_of[r].empty()) continue;
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_RTC(rtc_render_tile_list_device(m->scene[r], cam, max_depth, kTile, kTile, m->tiles_of[r].data(),
-                                      static_cast<uint32_t>(m->tiles_of[r].size()), m->d_buf[r], m->stream[r]));
-  }
-  m->pending = true;  // (from here on the streams hold work of this frame)
-  m->pending_cam = *cam;
-  const size_t slab = slabDoubles(m);
-  if (!m->virt) {
-    M_NCCL(ncclGroupStart());
-    for (uint32_t r = 0; r < m->n; ++r) {
-      M_HIP(hipSetDevice(m->dev[r]));
-      M_NCCL(ncclGather(m->d_buf[r], m->d_gathered, slab, ncclDouble, 0, m->comm[r], m->stream[r]));
-    }
-    M_NCCL(ncclGroupEnd());
-  } else {
-    M_HIP(hipSetDevice(m->dev[0]));
-    for (uint32_t r = 0; r < m->n; ++r) {
-      M_HIP(hipMemcpyAsync(m->d_gathered + slab * r, m->d_buf[r], slab * sizeof(double), hipMemcpyDeviceToDevice, m->stream[r]));
-      M_HIP(hipEventRecord(m->shared[r], m->stream[r]));
-      if (r != 0) M_HIP(hipStreamWaitEvent(m->stream[0], m->shared[r], 0));
-    }
-  }
-  M_HIP(hipSetDevice(m->dev[0]));
-  double* const canvas = m->d_canvas[m->cur];
-  m->cur ^= 1u;
-  M_RTC(rtc_assemble_tile_list_device(m->d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, canvas, m->stream[0]));
-  *d_canvas = canvas;
-  return RTC_OK;
-}
-
-}  // namespace
-
-extern "C" {
 
 int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double* rgb_out) {
   g_multi_error.clear();
   if (!rgb_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   double* d_canvas = nullptr;
-  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas); st != RTC_OK) return st;
+  uint32_t f = 0;
+  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas, &f); st != RTC_OK) return st;
   M_HIP(hipMemcpyAsync(rgb_out, d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
-                       hipMemcpyDeviceToHost, m->stream[0]));
-  return finishFrame(m);
+                       hipMemcpyDeviceToHost, m->slot[f].stream[0]));
+  return finishSlot(m, f, true);
 }
 
 int rtc_multi_render_rgba8(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, uint8_t* rgba_out) {
   g_multi_error.clear();
   if (!rgba_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   double* d_canvas = nullptr;
-  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas); st != RTC_OK) return st;
+  uint32_t f = 0;
+  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas, &f); st != RTC_OK) return st;
   const size_t n = static_cast<size_t>(cam->hsize) * cam->vsize;
   if (!m->d_rgba) M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_rgba), n * sizeof(uint32_t)));  // (freed with the frame buffers of this size)
-  M_RTC(rtc_rgba8_device(d_canvas, n, m->d_rgba, m->stream[0]));
-  M_HIP(hipMemcpyAsync(rgba_out, m->d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream[0]));
-  return finishFrame(m);
+  M_RTC(rtc_rgba8_device(d_canvas, n, m->d_rgba, m->slot[f].stream[0]));
+  M_HIP(hipMemcpyAsync(rgba_out, m->d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->slot[f].stream[0]));
+  return finishSlot(m, f, true);
 }
 
 int rtc_multi_render_device(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, const double** d_canvas_out) {
   g_multi_error.clear();
   if (!d_canvas_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   double* d_canvas = nullptr;
-  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas); st != RTC_OK) return st;
+  uint32_t f = 0;
+  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas, &f); st != RTC_OK) return st;
   *d_canvas_out = d_canvas;
   return RTC_OK;
 }
@@ -381,26 +484,14 @@ int rtc_multi_render_device(rtc_multi* m, const rtc_camera* cam, uint32_t max_de
 int rtc_multi_synchronize(rtc_multi* m) {
   g_multi_error.clear();
   if (!m) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  return finishFrame(m);
+  return finishAll(m, true);
 }
 
-void* rtc_multi_stream(rtc_multi* m) { return m ? static_cast<void*>(m->stream[0]) : nullptr; }
+void* rtc_multi_stream(rtc_multi* m) { return m ? static_cast<void*>(m->slot[m->last_slot].stream[0]) : nullptr; }
 
 int rtc_multi_get_stats(rtc_multi* m, rtc_stats* out) {
   if (!m || !out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  std::memset(out, 0, sizeof *out);
-  for (uint32_t r = 0; r < m->n; ++r) {
-    if (m->tiles_of.size() > r && m->tiles_of[r].empty()) continue;
-    rtc_stats s;
-    M_HIP(hipSetDevice(m->dev[r]));
-    M_RTC(rtc_get_stats(m->scene[r], &s));
-    out->primary += s.primary;
-    out->secondary += s.secondary;
-    out->shadow_calls += s.shadow_calls;
-    out->shadow_traced += s.shadow_traced;
-    out->overflow += s.overflow;
-  }
-  return RTC_OK;
+  return slotStats(m, m->last_slot, out);
 }
 
 int rtc_multi_balance(rtc_multi* m, uint32_t* tiles_per_rank, double* max_over_mean) {

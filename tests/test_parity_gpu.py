@@ -629,6 +629,62 @@ def test_single_process_multi_gpu_render(rtc):
         multi.close()
 
 
+def test_frames_in_flight(rtc):
+    """rtc_scene_clone and RTC_MULTI_FRAMES: independent frames on a handle and its clones (one device copy of the scene,
+    a stream, schedule and counters per handle), enqueued without waiting for each other; the clone outlives the handle
+    it was made from; four virtual ranks with three frame slots render an orbit three frames at a time."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    hs = rtc.HostScene.from_file("teapot.json")          # (a mesh: the shared tables include the BVH)
+    w, h = 240, 135
+    osc = ob.OracleScene(hs.desc)
+    first = rtc.GpuScene(hs.desc)
+    handles = [first, first.clone(), first.clone()]
+    streams = [torch.cuda.Stream() for _ in handles]
+    cams, wants = [], []
+    for k in range(3):
+        cams.append(hs.camera(w, h))
+        wants.append(osc.render(cams[-1], 5)[0])
+        hs.rotate_camera(0.3)
+    for round_ in range(3):
+        outs = [torch.full((h, w, 3), float("nan"), dtype=torch.float64, device="cuda") for _ in handles]
+        torch.cuda.synchronize()
+        for k, g in enumerate(handles):                   # three frames in flight, three views
+            g.render_device(cams[(k + round_) % 3], outs[k].data_ptr(), 5, None, streams[k].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert np.abs(outs[k].cpu().numpy() - wants[(k + round_) % 3]).max() < TOL, (round_, k)
+    first.close()                                         # the clones keep the scene alive
+    for k in (1, 2):
+        assert np.abs(handles[k].render(cams[k], 5) - wants[k]).max() < TOL
+        handles[k].close()
+
+    hs = rtc.HostScene.from_file("cover.json")
+    osc = ob.OracleScene(hs.desc)
+    multi = rtc.MultiGpu(hs.desc, 4, virtual=True, frames=3)
+    seen = []
+    for batch in range(4):                                # (the re-deal by measured cost happens in between)
+        cams, ptrs = [], []
+        for k in range(3):
+            cams.append(hs.camera(400, 230))
+            ptrs.append(multi.render_device(cams[-1], 5))
+            hs.rotate_camera(0.05)
+        multi.synchronize()
+        for cam, ptr in zip(cams, ptrs):
+            want = osc.render(cam, 5)[0]
+            got = np.empty_like(want)
+            assert ctypes.CDLL(None).hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(got.nbytes), 2) == 0
+            assert np.abs(got - want).max() < TOL, batch
+        seen.append(ptrs)
+    assert len(set(seen[0])) == 3 and seen[0] == seen[1]  # three canvases take turns
+    tiles, ratio = multi.balance()
+    assert tiles.sum() == 7 * 4 and 0.99 < ratio < 1.6
+    assert np.abs(multi.render(cams[0], 5) - osc.render(cams[0], 5)[0]).max() < TOL   # the synchronous entry point on the same object
+    multi.close()
+    with pytest.raises(rtc.RtcError):
+        rtc.MultiGpu(hs.desc, 2, virtual=True, frames=9)
+
+
 def test_launches_on_different_streams_are_ordered(rtc):
     """One handle, launches enqueued back to back on three different streams (a caller's, the handle's own through
     rtc_render, another caller's) without any host synchronisation in between: they share the handle's counters and

@@ -59,7 +59,7 @@ def main():
             t = timed(lambda: fn(sptr), h)
             h.close()
             return t
-        hf = [make(k) for k in range(M)]
+        hf = [make(k) for k in range(M)]   # (separate handles here; a host uses rtc_scene_clone: same thing, one scene copy)
         for i in range(8 * M):
             hf[i % M][1](streams[i % M].cuda_stream)
             torch.cuda.synchronize()
