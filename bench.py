@@ -308,6 +308,9 @@ def main():
                     help="frames in flight per rank (that many scene handles, each with a stream and an output buffer of its "
                          "own, frames dealt round-robin); 0 = 1 on one GPU (the headline: one frame after the other), 3 when "
                          "the frame is split over ranks (a share is too short to fill a GPU by itself, DESIGN.md section 8)")
+    ap.add_argument("--output", choices=("f64", "rgba8"), default="f64",
+                    help="what a split frame is gathered as: the f64 Canvas (canvas.zig, the default), or the RGBA8 framebuffer of "
+                         "lib.zig:146-153 - every rank clamps the tiles it rendered and 4 bytes per pixel cross xGMI instead of 24")
     ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks on ONE GPU over gloo (tiles staged through host memory): exercises the N > 1 code "
@@ -402,6 +405,13 @@ def main():
                     if rank == 0 else [None] * SLOTS)
         gather_list = [[g[r] for r in range(world)] for g in gathered] if rank == 0 else [None] * SLOTS
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda") if rank == 0 else None
+        RGBA = args.output == "rgba8"
+        if RGBA:   # the clamped tiles (one 32-bit word per pixel), their gathered form and the framebuffer
+            rgba_bufs = [torch.zeros((padded, TILE, TILE), dtype=torch.int32, device="cuda") for _ in range(SLOTS)]
+            gathered_rgba = ([torch.empty((world, padded, TILE, TILE), dtype=torch.int32, device="cuda") for _ in range(SLOTS)]
+                             if rank == 0 else [None] * SLOTS)
+            gather_list_rgba = [[g[r] for r in range(world)] for g in gathered_rgba] if rank == 0 else [None] * SLOTS
+            framebuffer = torch.empty((H, W), dtype=torch.int32, device="cuda") if rank == 0 else None
         comm = torch.cuda.Stream()
         rendered = [torch.cuda.Event() for _ in range(SLOTS)]
         gathered_ev = [torch.cuda.Event() for _ in range(SLOTS)]
@@ -415,22 +425,29 @@ def main():
             rs.wait_event(gathered_ev[b])            # buffer b is free again (the frame that last used it has been sent)
             if count:
                 gpus[i % M].render_tile_list_device(cam, bufs[b].data_ptr(), TILE, TILE, my_tiles, args.depth, rs.cuda_stream)
+            if RGBA:
+                rtc.rgba8_device(bufs[b].data_ptr(), padded * TILE * TILE, rgba_bufs[b].data_ptr(), rs.cuda_stream)
             rendered[b].record(rs)
             with torch.cuda.stream(comm):            # gather + un-permute of frame i under the render of frame i+1
                 comm.wait_event(rendered[b])
                 if timing[0]:
                     comm_ev.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
                     comm_ev[-1][0].record(comm)
+                src = rgba_bufs[b] if RGBA else bufs[b]
+                dst = (gather_list_rgba if RGBA else gather_list)[b]
                 if args.rehearse:                    # gloo has no device gather: through host memory
                     comm.synchronize()
-                    host = [torch.empty(bufs[b].shape, dtype=torch.float64) for _ in range(world)] if rank == 0 else None
-                    dist.gather(bufs[b].cpu(), host, dst=0)
+                    host = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)] if rank == 0 else None
+                    dist.gather(src.cpu(), host, dst=0)
                     if rank == 0:
                         for r in range(world):
-                            gather_list[b][r].copy_(host[r])
+                            dst[r].copy_(host[r])
                 else:
-                    dist.gather(bufs[b], gather_list[b], dst=0)
-                if rank == 0:                        # one un-permute kernel: tiles -> row-major canvas
+                    dist.gather(src, dst, dst=0)
+                if rank == 0 and RGBA:               # one un-permute kernel: tiles -> row-major framebuffer
+                    rtc.assemble_tile_list_rgba8_device(gathered_rgba[b].data_ptr(), d_slot.data_ptr(), TILE, TILE, W, H,
+                                                        framebuffer.data_ptr(), comm.cuda_stream)
+                elif rank == 0:                      # ... -> row-major canvas
                     rtc.assemble_tile_list_device(gathered[b].data_ptr(), d_slot.data_ptr(), TILE, TILE, W, H,
                                                   canvas.data_ptr(), comm.cuda_stream)
                 if timing[0]:
@@ -507,10 +524,19 @@ def main():
         gpu.render_device(cam, ref.data_ptr(), args.depth, None, sptr)
         torch.cuda.synchronize()
         # shares of one pixel's ray tree are summed in arrival order: equal up to the last bits
-        worst = float((ref - canvas).abs().max().item())
-        if not worst < 1e-12:
-            raise SystemExit(f"tile path result differs from the plain render: max |delta| = {worst}")
-        print(f"check ok: assembled canvas vs plain render, max |delta| = {worst:.3g}", file=sys.stderr)
+        if dist is not None and args.output == "rgba8":
+            got = framebuffer.cpu().numpy().view(np.uint8).reshape(H, W, 4).astype(np.int64)
+            want = rtc.canvas_rgba8(ref.cpu().numpy()).astype(np.int64)
+            # (a channel within an ulp of k + 0.5 may round either way when its pixel's shares are summed in another order)
+            worst = float(np.abs(got - want).max())
+            if not worst <= 1:
+                raise SystemExit(f"tile path framebuffer differs from the plain render's: max |delta| = {worst} of 255")
+            print(f"check ok: assembled RGBA8 framebuffer vs plain render, max |delta| = {worst:.3g} of 255", file=sys.stderr)
+        else:
+            worst = float((ref - canvas).abs().max().item())
+            if not worst < 1e-12:
+                raise SystemExit(f"tile path result differs from the plain render: max |delta| = {worst}")
+            print(f"check ok: assembled canvas vs plain render, max |delta| = {worst:.3g}", file=sys.stderr)
     if rank == 0:
         rays = stats["primary"] + stats["secondary"]
         ms_per_step = elapsed * 1e3 / args.steps
@@ -532,6 +558,7 @@ def main():
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
                        "mrays_per_s_incl_shadow_traced": (rays + stats["shadow_traced"]) * args.steps / elapsed / 1e6,
                        "frames_in_flight": M,
+                       "output": "f64 canvas" if dist is None or args.output == "f64" else "RGBA8 framebuffer (clamped by the rank that rendered the tile, 4 B/pixel gathered)",
                        "settle_frames": args.settle_frames,
                        "ms_per_step_right_after_startup": cold_ms,
                        "timed_frames": "steady state of a STATIC view: the schedule was measured on this same frame by the two "

@@ -343,6 +343,13 @@ int rtc_assemble_tile_list_device(const double *d_gathered, const uint32_t *d_sl
                                   uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
                                   double *d_canvas, void *hip_stream);
 
+/* The same for shares that were clamped before they were gathered (rtc_rgba8_device on a rank's tile buffer: 4 bytes
+ * per pixel cross the links instead of 24 - an 8-GPU host of lib.zig's RGBA8 framebuffer is otherwise bound by the gather,
+ * not the render): d_gathered_rgba[world][padded][tile_h][tile_w] -> d_rgba[vsize][hsize]. */
+int rtc_assemble_tile_list_rgba8_device(const uint32_t *d_gathered_rgba, const uint32_t *d_slot_of_tile,
+                                        uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
+                                        uint32_t *d_rgba, void *hip_stream);
+
 /*
  * Rank 0 of the tile partition, after the gather: copies the ranks' compact tile
  * buffers d_gathered[world][padded_tiles][tile_h][tile_w][3] (rank r's k-th tile

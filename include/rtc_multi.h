@@ -52,8 +52,9 @@ int rtc_multi_render(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, do
 
 /*
  * The same frame as the RGBA8 framebuffer of the reference's interactive seam (Renderer, src/lib.zig:135-164; clamp of
- * color.zig:61-71, alpha 255): rgba_out[(y * hsize + x) * 4 + 0..3], host memory.  Clamped on GPU 0: 4 bytes per pixel
- * cross the link instead of 24.  Synchronous.
+ * color.zig:61-71, alpha 255): rgba_out[(y * hsize + x) * 4 + 0..3], host memory.  Every GPU clamps the tiles it rendered:
+ * 4 bytes per pixel go through the gather and over the host link instead of 24 (at 8 GPUs the gather of an f64 frame into
+ * GPU 0, 44 MB at 1080p, takes longer than a GPU's share of the render).  Synchronous.
  */
 int rtc_multi_render_rgba8(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, uint8_t *rgba_out);
 
@@ -67,6 +68,8 @@ int rtc_multi_render_rgba8(rtc_multi *m, const rtc_camera *cam, uint32_t max_dep
  * by rtc_multi_synchronize; its status is that call's status.
  */
 int rtc_multi_render_device(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, const double **d_canvas);
+/* ... and its RGBA8 form ([vsize][hsize] words R | G << 8 | B << 16 | 255 << 24), same rules, a ring of its own. */
+int rtc_multi_render_rgba8_device(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, const uint32_t **d_rgba);
 int rtc_multi_synchronize(rtc_multi *m); /* every frame in flight */
 void *rtc_multi_stream(rtc_multi *m); /* the hipStream_t (device 0) behind which the LAST enqueued frame's canvas is complete */
 

@@ -102,6 +102,7 @@ pub extern fn rtc_multi_destroy(m: ?*RtcMulti) void;
 pub extern fn rtc_multi_render(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, rgb_out: [*]f64) c_int;
 pub extern fn rtc_multi_render_rgba8(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, rgba_out: [*]u8) c_int; // lib.zig's framebuffer
 pub extern fn rtc_multi_render_device(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, d_canvas: *?[*]const f64) c_int; // stays on GPU 0
+pub extern fn rtc_multi_render_rgba8_device(m: *RtcMulti, cam: *const RtcCamera, max_depth: u32, d_rgba: *?[*]const u32) c_int; // ... as RGBA8
 pub extern fn rtc_multi_synchronize(m: *RtcMulti) c_int;
 pub extern fn rtc_multi_stream(m: *RtcMulti) ?*anyopaque;
 pub extern fn rtc_multi_last_error() [*:0]const u8;

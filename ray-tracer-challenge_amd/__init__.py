@@ -90,12 +90,12 @@ class Stats(C.Structure):
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
-               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
                "rtc_status_name", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
-MULTI_SYMBOLS = ["rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_multi_render_rgba8", "rtc_multi_render_device",
+MULTI_SYMBOLS = ["rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_multi_render_rgba8", "rtc_multi_render_device", "rtc_multi_render_rgba8_device",
                  "rtc_multi_synchronize", "rtc_multi_stream", "rtc_multi_get_stats", "rtc_multi_balance", "rtc_multi_last_error"]
 RTC_MULTI_VIRTUAL = 1
 
@@ -153,6 +153,7 @@ def hip_lib():
         lib.rtc_get_tile_costs.argtypes = [C.c_void_p, _dp, C.c_uint32]
         lib.rtc_assign_tiles.argtypes = [_dp, C.c_uint32, C.c_uint32, _u32p, _u32p]
         lib.rtc_assemble_tile_list_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
+        lib.rtc_assemble_tile_list_rgba8_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_scene_synchronize.argtypes = [C.c_void_p]
         lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         lib.rtc_last_kernel_name.argtypes = [C.c_void_p]
@@ -210,6 +211,7 @@ def multi_lib():
         lib.rtc_multi_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
         lib.rtc_multi_render_rgba8.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
         lib.rtc_multi_render_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.rtc_multi_render_rgba8_device.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.POINTER(C.c_void_p)]
         lib.rtc_multi_synchronize.argtypes = [C.c_void_p]
         lib.rtc_multi_stream.argtypes = [C.c_void_p]
         lib.rtc_multi_stream.restype = C.c_void_p
@@ -252,6 +254,12 @@ class MultiGpu:
         copied or waited for (synchronize(), or work enqueued on stream(), orders behind it)."""
         ptr = C.c_void_p()
         self._check(multi_lib().rtc_multi_render_device(self._m, C.byref(cam), max_depth, C.byref(ptr)))
+        return ptr.value
+
+    def render_rgba8_device(self, cam, max_depth=REFERENCE_DEPTH):
+        """render_device for the RGBA8 framebuffer: the ranks clamp their tiles, 4 bytes per pixel are gathered."""
+        ptr = C.c_void_p()
+        self._check(multi_lib().rtc_multi_render_rgba8_device(self._m, C.byref(cam), max_depth, C.byref(ptr)))
         return ptr.value
 
     def synchronize(self):
@@ -507,6 +515,17 @@ def assign_tiles(tile_cost, world):
 def assemble_tile_list_device(d_gathered_ptr, d_slot_of_tile_ptr, tile_w, tile_h, hsize, vsize, d_canvas_ptr, stream):
     _check_hip(hip_lib().rtc_assemble_tile_list_device(d_gathered_ptr, d_slot_of_tile_ptr, tile_w, tile_h, hsize, vsize,
                                                        d_canvas_ptr, stream))
+
+
+def assemble_tile_list_rgba8_device(d_gathered_rgba_ptr, d_slot_of_tile_ptr, tile_w, tile_h, hsize, vsize, d_rgba_ptr, stream):
+    """Shares clamped to RGBA8 before the gather (rgba8_device on a rank's tile buffer) -> the [vsize][hsize] u32 framebuffer."""
+    _check_hip(hip_lib().rtc_assemble_tile_list_rgba8_device(d_gathered_rgba_ptr, d_slot_of_tile_ptr, tile_w, tile_h, hsize, vsize,
+                                                             d_rgba_ptr, stream))
+
+
+def rgba8_device(d_canvas_ptr, n_pixels, d_rgba_ptr, stream):
+    """rtc_rgba8_device: the clamp of color.zig:61-71 alone, device to device, asynchronous on `stream`."""
+    _check_hip(hip_lib().rtc_rgba8_device(d_canvas_ptr, n_pixels, d_rgba_ptr, stream))
 
 
 def assemble_tiles_device(d_gathered_ptr, world, padded, tile_w, tile_h, hsize, vsize, d_canvas_ptr, stream):

@@ -69,6 +69,9 @@ extern "C" __global__ void rtc_rgba8_kernel(const double* __restrict__ canvas, c
 extern "C" __global__ void rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
                                                     const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
                                                     const uint32_t vsize, double* __restrict__ canvas);
+extern "C" __global__ void rtc_assemble_list_rgba8_kernel(const uint32_t* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
+                                                          const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
+                                                          const uint32_t vsize, uint32_t* __restrict__ rgba);
 extern "C" __global__ void rtc_assemble_kernel(const double* __restrict__ gathered, const uint32_t world,
                                                const uint32_t padded, const uint32_t tile_w, const uint32_t tile_h,
                                                const uint32_t hsize, const uint32_t vsize, double* __restrict__ canvas);
@@ -1676,6 +1679,20 @@ int rtc_assemble_tile_list_device(const double* d_gathered, const uint32_t* d_sl
   const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
   hipLaunchKernelGGL(rtc_assemble_list_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_gathered,
                      d_slot_of_tile, tile_w, tile_h, hsize, vsize, d_canvas);
+  HIP_TRY(hipGetLastError());
+  return RTC_OK;
+}
+
+int rtc_assemble_tile_list_rgba8_device(const uint32_t* d_gathered_rgba, const uint32_t* d_slot_of_tile, uint32_t tile_w,
+                                        uint32_t tile_h, uint32_t hsize, uint32_t vsize, uint32_t* d_rgba, void* hip_stream) {
+  g_error.clear();
+  if (!d_gathered_rgba || !d_slot_of_tile || !d_rgba || !hip_stream) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (tile_w == 0 || tile_h == 0 || hsize == 0 || vsize == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "tile %ux%u image %ux%u", tile_w, tile_h, hsize, vsize);
+  const size_t n = static_cast<size_t>(hsize) * vsize;
+  const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
+  hipLaunchKernelGGL(rtc_assemble_list_rgba8_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                     d_gathered_rgba, d_slot_of_tile, tile_w, tile_h, hsize, vsize, d_rgba);
   HIP_TRY(hipGetLastError());
   return RTC_OK;
 }

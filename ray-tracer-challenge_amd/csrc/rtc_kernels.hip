@@ -2565,6 +2565,22 @@ rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __
   }
 }
 
+// ... and for shares that were clamped to RGBA8 before they were gathered (4 bytes per pixel cross the links instead of
+// 24): one thread per pixel of the framebuffer.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_assemble_list_rgba8_kernel(const uint32_t* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
+                               const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize, const uint32_t vsize,
+                               uint32_t* __restrict__ rgba) {
+  const size_t n = static_cast<size_t>(hsize) * vsize;
+  const uint32_t tiles_x = (hsize + tile_w - 1u) / tile_w;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const uint32_t y = static_cast<uint32_t>(i / hsize), x = static_cast<uint32_t>(i - static_cast<size_t>(y) * hsize);
+    const uint32_t slot = slot_of_tile[(y / tile_h) * tiles_x + x / tile_w];
+    rgba[i] = gathered[(static_cast<size_t>(slot) * tile_h + y % tile_h) * tile_w + x % tile_w];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // The schedule of the NEXT frame, packed on the device from what THIS frame measured: no host in
 // the loop, so a moving camera (lib.zig:166-190) renders every frame with a schedule that is one frame old.  Policy:

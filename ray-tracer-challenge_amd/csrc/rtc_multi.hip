@@ -60,6 +60,8 @@ struct Slot {
   std::vector<hipEvent_t> sent;      // RCCL: rank r's part of the gather is done, its buffer may be rendered into again
   std::vector<double*> d_buf;        // [n] a rank's compact tiles [padded][64][64][3], on its device
   double* d_gathered = nullptr;      // device 0: [n][padded][64][64][3]
+  std::vector<uint32_t*> d_rgba_buf; // [n] the same tiles clamped to RGBA8, [padded][64][64] (first RGBA8 frame on)
+  uint32_t* d_gathered_rgba = nullptr;
   hipEvent_t gathered = nullptr;     // RCCL: the gather has arrived on device 0
   bool pending = false;              // a frame has been enqueued and its bookkeeping (overflow check, re-deal) is still due
   rtc_camera cam{};
@@ -81,7 +83,8 @@ struct rtc_multi {
   bool sized = false;
   std::vector<double*> d_canvas;  // device 0: a ring of max(2, frames) canvases; a frame's stays valid while the next ones are produced
   uint32_t cur = 0;               // which of them the next frame is assembled into
-  uint32_t* d_rgba = nullptr;     // device 0: the RGBA8 form of a frame (rtc_multi_render_rgba8), allocated on first use
+  std::vector<uint32_t*> d_rgba;  // device 0: the ring of RGBA8 framebuffers (the rgba8 entry points), allocated on first use
+  uint32_t cur_rgba = 0;
   uint32_t* d_slot = nullptr;     // device 0: rtc_assign_tiles' slot_of_tile
   std::vector<uint32_t> rank_of, slot_of;
   std::vector<std::vector<uint32_t>> tiles_of;
@@ -112,14 +115,24 @@ void freeFrameBuffers(rtc_multi* m) {
     if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
     if (S.d_gathered) (void)hipFree(S.d_gathered);
     S.d_gathered = nullptr;
+    for (uint32_t r = 0; r < S.d_rgba_buf.size(); ++r)
+      if (S.d_rgba_buf[r]) {
+        (void)hipSetDevice(m->dev[r]);
+        (void)hipFree(S.d_rgba_buf[r]);
+      }
+    S.d_rgba_buf.clear();
+    if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
+    if (S.d_gathered_rgba) (void)hipFree(S.d_gathered_rgba);
+    S.d_gathered_rgba = nullptr;
   }
   if (!m->dev.empty()) (void)hipSetDevice(m->dev[0]);
   for (double* c : m->d_canvas)
     if (c) (void)hipFree(c);
   m->d_canvas.clear();
-  if (m->d_rgba) (void)hipFree(m->d_rgba);
+  for (uint32_t* c : m->d_rgba)
+    if (c) (void)hipFree(c);
+  m->d_rgba.clear();
   if (m->d_slot) (void)hipFree(m->d_slot);
-  m->d_rgba = nullptr;
   m->d_slot = nullptr;
   m->sized = false;
 }
@@ -166,6 +179,49 @@ int sizeForUnguarded(rtc_multi* m, const rtc_camera& cam) {
   setLists(m);
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
   return RTC_OK;
+}
+
+// The RGBA8 side of the frame buffers (per slot and rank the clamped tiles, on device 0 the gathered ones and the ring of
+// framebuffers): made by the first RGBA8 frame of an image size, freed with the rest.  All or nothing.
+int ensureRgbaBuffers(rtc_multi* m) {
+  if (!m->d_rgba.empty()) return RTC_OK;
+  const size_t tile_pixels = static_cast<size_t>(m->padded) * kTile * kTile;
+  auto undo = [&]() {
+    (void)hipGetLastError();
+    for (Slot& S : m->slot) {
+      for (uint32_t r = 0; r < S.d_rgba_buf.size(); ++r)
+        if (S.d_rgba_buf[r]) {
+          (void)hipSetDevice(m->dev[r]);
+          (void)hipFree(S.d_rgba_buf[r]);
+        }
+      S.d_rgba_buf.clear();
+      (void)hipSetDevice(m->dev[0]);
+      if (S.d_gathered_rgba) (void)hipFree(S.d_gathered_rgba);
+      S.d_gathered_rgba = nullptr;
+    }
+    for (uint32_t* c : m->d_rgba)
+      if (c) (void)hipFree(c);
+    m->d_rgba.clear();
+  };
+  auto make = [&]() -> int {
+    for (Slot& S : m->slot) {
+      S.d_rgba_buf.assign(m->n, nullptr);
+      for (uint32_t r = 0; r < m->n; ++r) {
+        M_HIP(hipSetDevice(m->dev[r]));
+        M_HIP(hipMalloc(reinterpret_cast<void**>(&S.d_rgba_buf[r]), tile_pixels * sizeof(uint32_t)));
+      }
+      M_HIP(hipSetDevice(m->dev[0]));
+      M_HIP(hipMalloc(reinterpret_cast<void**>(&S.d_gathered_rgba), tile_pixels * m->n * sizeof(uint32_t)));
+    }
+    M_HIP(hipSetDevice(m->dev[0]));
+    m->d_rgba.assign(std::max(2u, m->frames), nullptr);
+    for (uint32_t*& c : m->d_rgba) M_HIP(hipMalloc(reinterpret_cast<void**>(&c), static_cast<size_t>(m->hsize) * m->vsize * sizeof(uint32_t)));
+    m->cur_rgba = 0;
+    return RTC_OK;
+  };
+  const int st = make();
+  if (st != RTC_OK) undo();
+  return st;
 }
 
 int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal);
@@ -293,18 +349,23 @@ int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal) {
 // rank 0 (each rank's send is ordered behind its render), one kernel un-permutes them into the next canvas of the ring
 // on device 0, on the slot's stream of rank 0.  Only the frame that last ran on this slot is waited for: with several
 // slots the frames before this one are still rendering.
-int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double** d_canvas, uint32_t* slot_out) {
+int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, bool rgba8, void** d_out, uint32_t* slot_out) {
   if (!m || !cam) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   if (cam->hsize == 0 || cam->vsize == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
   const uint32_t f = m->next_slot;
   if (const int st = finishSlot(m, f, true); st != RTC_OK) return st;
   if (const int st = sizeFor(m, *cam); st != RTC_OK) return st;
+  if (rgba8)
+    if (const int st = ensureRgbaBuffers(m); st != RTC_OK) return st;
   Slot& S = m->slot[f];
+  const size_t tile_pixels = static_cast<size_t>(m->padded) * kTile * kTile;
   for (uint32_t r = 0; r < m->n; ++r) {
     if (m->tiles_of[r].empty()) continue;
     M_HIP(hipSetDevice(m->dev[r]));
     M_RTC(rtc_render_tile_list_device(S.scene[r], cam, max_depth, kTile, kTile, m->tiles_of[r].data(),
                                       static_cast<uint32_t>(m->tiles_of[r].size()), S.d_buf[r], S.stream[r]));
+    // (an RGBA8 frame is clamped where it was rendered: 4 bytes per pixel go through the gather instead of 24)
+    if (rgba8) M_RTC(rtc_rgba8_device(S.d_buf[r], tile_pixels, S.d_rgba_buf[r], S.stream[r]));
   }
   S.pending = true;  // (from here on the streams hold work of this frame)
   S.cam = *cam;
@@ -320,7 +381,11 @@ int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double
     M_NCCL(ncclGroupStart());
     for (uint32_t r = 0; r < m->n; ++r) {
       M_HIP(hipSetDevice(m->dev[r]));
-      M_NCCL(ncclGather(S.d_buf[r], S.d_gathered, slab, ncclDouble, 0, m->comm[r], m->cstream[r]));
+      if (rgba8) {
+        M_NCCL(ncclGather(S.d_rgba_buf[r], S.d_gathered_rgba, tile_pixels, ncclUint32, 0, m->comm[r], m->cstream[r]));
+      } else {
+        M_NCCL(ncclGather(S.d_buf[r], S.d_gathered, slab, ncclDouble, 0, m->comm[r], m->cstream[r]));
+      }
     }
     M_NCCL(ncclGroupEnd());
     for (uint32_t r = 0; r < m->n; ++r) {
@@ -333,16 +398,27 @@ int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double
   } else {
     M_HIP(hipSetDevice(m->dev[0]));
     for (uint32_t r = 0; r < m->n; ++r) {
-      M_HIP(hipMemcpyAsync(S.d_gathered + slab * r, S.d_buf[r], slab * sizeof(double), hipMemcpyDeviceToDevice, S.stream[r]));
+      if (rgba8) {
+        M_HIP(hipMemcpyAsync(S.d_gathered_rgba + tile_pixels * r, S.d_rgba_buf[r], tile_pixels * sizeof(uint32_t), hipMemcpyDeviceToDevice, S.stream[r]));
+      } else {
+        M_HIP(hipMemcpyAsync(S.d_gathered + slab * r, S.d_buf[r], slab * sizeof(double), hipMemcpyDeviceToDevice, S.stream[r]));
+      }
       M_HIP(hipEventRecord(S.rendered[r], S.stream[r]));
       if (r != 0) M_HIP(hipStreamWaitEvent(S.stream[0], S.rendered[r], 0));
     }
   }
   M_HIP(hipSetDevice(m->dev[0]));
-  double* const canvas = m->d_canvas[m->cur];
-  m->cur = (m->cur + 1u) % static_cast<uint32_t>(m->d_canvas.size());
-  M_RTC(rtc_assemble_tile_list_device(S.d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, canvas, S.stream[0]));
-  *d_canvas = canvas;
+  if (rgba8) {
+    uint32_t* const fb = m->d_rgba[m->cur_rgba];
+    m->cur_rgba = (m->cur_rgba + 1u) % static_cast<uint32_t>(m->d_rgba.size());
+    M_RTC(rtc_assemble_tile_list_rgba8_device(S.d_gathered_rgba, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, fb, S.stream[0]));
+    *d_out = fb;
+  } else {
+    double* const canvas = m->d_canvas[m->cur];
+    m->cur = (m->cur + 1u) % static_cast<uint32_t>(m->d_canvas.size());
+    M_RTC(rtc_assemble_tile_list_device(S.d_gathered, m->d_slot, kTile, kTile, cam->hsize, cam->vsize, canvas, S.stream[0]));
+    *d_out = canvas;
+  }
   *slot_out = f;
   return RTC_OK;
 }
@@ -450,9 +526,9 @@ void rtc_multi_destroy(rtc_multi* m) {
 int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double* rgb_out) {
   g_multi_error.clear();
   if (!rgb_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  double* d_canvas = nullptr;
+  void* d_canvas = nullptr;
   uint32_t f = 0;
-  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas, &f); st != RTC_OK) return st;
+  if (const int st = enqueueFrame(m, cam, max_depth, false, &d_canvas, &f); st != RTC_OK) return st;
   M_HIP(hipMemcpyAsync(rgb_out, d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
                        hipMemcpyDeviceToHost, m->slot[f].stream[0]));
   return finishSlot(m, f, true);
@@ -461,23 +537,31 @@ int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, do
 int rtc_multi_render_rgba8(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, uint8_t* rgba_out) {
   g_multi_error.clear();
   if (!rgba_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  double* d_canvas = nullptr;
+  void* d_fb = nullptr;
   uint32_t f = 0;
-  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas, &f); st != RTC_OK) return st;
-  const size_t n = static_cast<size_t>(cam->hsize) * cam->vsize;
-  if (!m->d_rgba) M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_rgba), n * sizeof(uint32_t)));  // (freed with the frame buffers of this size)
-  M_RTC(rtc_rgba8_device(d_canvas, n, m->d_rgba, m->slot[f].stream[0]));
-  M_HIP(hipMemcpyAsync(rgba_out, m->d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, m->slot[f].stream[0]));
+  if (const int st = enqueueFrame(m, cam, max_depth, true, &d_fb, &f); st != RTC_OK) return st;
+  M_HIP(hipMemcpyAsync(rgba_out, d_fb, static_cast<size_t>(cam->hsize) * cam->vsize * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                       m->slot[f].stream[0]));
   return finishSlot(m, f, true);
+}
+
+int rtc_multi_render_rgba8_device(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, const uint32_t** d_rgba_out) {
+  g_multi_error.clear();
+  if (!d_rgba_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  void* d_fb = nullptr;
+  uint32_t f = 0;
+  if (const int st = enqueueFrame(m, cam, max_depth, true, &d_fb, &f); st != RTC_OK) return st;
+  *d_rgba_out = static_cast<const uint32_t*>(d_fb);
+  return RTC_OK;
 }
 
 int rtc_multi_render_device(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, const double** d_canvas_out) {
   g_multi_error.clear();
   if (!d_canvas_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  double* d_canvas = nullptr;
+  void* d_canvas = nullptr;
   uint32_t f = 0;
-  if (const int st = enqueueFrame(m, cam, max_depth, &d_canvas, &f); st != RTC_OK) return st;
-  *d_canvas_out = d_canvas;
+  if (const int st = enqueueFrame(m, cam, max_depth, false, &d_canvas, &f); st != RTC_OK) return st;
+  *d_canvas_out = static_cast<const double*>(d_canvas);
   return RTC_OK;
 }
 

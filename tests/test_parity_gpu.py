@@ -677,6 +677,18 @@ def test_frames_in_flight(rtc):
             assert np.abs(got - want).max() < TOL, batch
         seen.append(ptrs)
     assert len(set(seen[0])) == 3 and seen[0] == seen[1]  # three canvases take turns
+    fb_ptrs, cams = [], []
+    for k in range(3):                                    # the same as RGBA8 framebuffers: clamped by the rank that rendered the tile
+        cams.append(hs.camera(400, 230))
+        fb_ptrs.append(multi.render_rgba8_device(cams[-1], 5))
+        hs.rotate_camera(0.05)
+    multi.synchronize()
+    for cam, ptr in zip(cams, fb_ptrs):
+        got = np.empty((230, 400, 4), dtype=np.uint8)
+        assert ctypes.CDLL(None).hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(got.nbytes), 2) == 0
+        want = rtc.canvas_rgba8(multi.render(cam, 5))
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1 and (got != want).mean() < 1e-4   # (a channel at k + 0.5 within an ulp)
+    assert len(set(fb_ptrs)) == 3
     tiles, ratio = multi.balance()
     assert tiles.sum() == 7 * 4 and 0.99 < ratio < 1.6
     assert np.abs(multi.render(cams[0], 5) - osc.render(cams[0], 5)[0]).max() < TOL   # the synchronous entry point on the same object
@@ -1163,6 +1175,11 @@ def test_bench_multi_rank_path_rehearsal():
     ranks = line["ranks"]                         # what a scaling curve is read from: every rank's share
     assert len(ranks["render_ms"]) == 2 and min(ranks["render_ms"]) > 0 and sum(ranks["tiles"]) == 8 * 5
     assert ranks["render_ms_max"] >= ranks["render_ms_mean"] and ranks["gather_unpermute_ms_rank0"] > 0
+    # the same with the shares clamped to RGBA8 by the rank that rendered them (4 B/pixel through the gather)
+    out = subprocess.run(cmd[:-1] + ["--output", "rgba8", "--check"], cwd=repo, capture_output=True, text=True, timeout=200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "check ok: assembled RGBA8 framebuffer" in out.stderr
+    assert json.loads([l for l in out.stdout.splitlines() if l.strip()][0])["config"]["output"].startswith("RGBA8")
 
 
 def test_bench_frames_in_flight():
