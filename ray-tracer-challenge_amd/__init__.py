@@ -312,6 +312,7 @@ class HostScene:
         self._h = C.c_void_p()
         _check_host(host_lib().rtch_scene_load(scene_json, data_dir.encode(), C.byref(self._h)))
         self.desc = host_lib().rtch_scene_desc(self._h).contents
+        self.desc._owner = self   # the tables behind `desc` are this object's: HostScene(...).desc alone must keep them alive
 
     @classmethod
     def from_file(cls, name, data_dir=DATA_DIR):
