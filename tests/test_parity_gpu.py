@@ -695,6 +695,24 @@ def test_frames_in_flight(rtc):
     multi.close()
     with pytest.raises(rtc.RtcError):
         rtc.MultiGpu(hs.desc, 2, virtual=True, frames=9)
+    # one REAL rank with two slots: the RCCL form of the same (a comm stream that carries the gathers frame after frame,
+    # the events between it and the slots' render streams)
+    real = rtc.MultiGpu(hs.desc, 1, virtual=False, frames=2)
+    cams, ptrs = [], []
+    for k in range(4):
+        cams.append(hs.camera(200, 120))
+        ptrs.append(real.render_device(cams[-1], 5) if k % 2 == 0 else real.render_rgba8_device(cams[-1], 5))
+        hs.rotate_camera(0.1)
+        if k % 2 == 1:
+            real.synchronize()
+            want = osc.render(cams[-2], 5)[0]
+            got = np.empty_like(want)
+            assert ctypes.CDLL(None).hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptrs[-2]), ctypes.c_size_t(got.nbytes), 2) == 0
+            assert np.abs(got - want).max() < TOL
+            fb = np.empty((120, 200, 4), dtype=np.uint8)
+            assert ctypes.CDLL(None).hipMemcpy(ctypes.c_void_p(fb.ctypes.data), ctypes.c_void_p(ptrs[-1]), ctypes.c_size_t(fb.nbytes), 2) == 0
+            assert np.abs(fb.astype(int) - rtc.canvas_rgba8(osc.render(cams[-1], 5)[0]).astype(int)).max() <= 1
+    real.close()
 
 
 def test_launches_on_different_streams_are_ordered(rtc):
