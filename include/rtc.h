@@ -259,7 +259,12 @@ int rtc_scene_clone(const rtc_scene *source, rtc_scene **out);
  * memory, [h][w][3] doubles.  Synchronous, and without side effects on the
  * caller's memory: the frame is copied into `rgb_out`, nothing is remembered
  * about the pointer.  (Into pageable memory that copy runs at a fifth of the
- * link's rate; see rtc_canvas_register.)
+ * link's rate; see rtc_canvas_register.)  The copy of a frame takes as long as
+ * its render or longer, so a large frame (from 400 000 pixels) is rendered in
+ * two or four horizontal bands one after the other, each copied while the next
+ * renders (1080p into a registered canvas: 1.1 ms instead of 1.45; the lower
+ * bands run on clones of the handle, made on first use; rtc_get_stats sums the
+ * bands; option "host_bands" forces the count).
  */
 int rtc_render(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
                uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, double *rgb_out);
@@ -267,7 +272,7 @@ int rtc_render(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
 /*
  * Optional, for a host that renders frame after frame into ONE canvas (the interactive seam, lib.zig:135-190): pins
  * the caller's buffer for the HIP runtime (hipHostRegister), so that rtc_render's / rtc_multi_render's copy into it
- * runs at link speed (1080p: 1.5 ms per call instead of 3.8-5.6).  Explicit on purpose: the registration belongs to the
+ * runs at link speed (1080p: 1.1 ms per call instead of 3.8-5.6).  Explicit on purpose: the registration belongs to the
  * MEMORY, not to a scene handle, and the caller - who knows when the canvas is freed - drops it with
  * rtc_canvas_unregister BEFORE freeing or reallocating the buffer.  Both are process-wide and need no scene.
  */
@@ -386,7 +391,8 @@ int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, u
  * top-level spheres / planes / cubes runs the three-waves-per-SIMD kernel; 0 always, < 0 the library's choice),
  * "sched_off" (!= 0: no schedule, packet i is chunk i), "cut_above" (shares of a wave above which a chunk is cut into
  * runs of pixels; < 0 never, 0 the library's choice), "pack_rounds", "pull_min_idle", "blocks_per_cu", "sched_tmin",
- * "bvh_leaf", "bvh_one_axis", "bvh_check".  RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
+ * "bvh_leaf", "bvh_one_axis", "bvh_check", "host_bands" (bands of a host-output frame, 1 .. 4; 0 by size).
+ * RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
  * (The library reads no environment variables.)
  */
 int rtc_set_option(const char *name, double value);

@@ -492,6 +492,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     if (const int st = packNextSchedule(s, cam, map, max_depth, stream, PackFrom::Measurement); st != RTC_OK) return st;
   HIP_TRY(hipEventRecord(s->launch_done, stream));
   s->last_stream = stream;
+  s->last_bands = 1;
   return RTC_OK;
 }
 
@@ -1504,6 +1505,15 @@ int rtc_scene_clone(const rtc_scene* src, rtc_scene** out) {
 void rtc_scene_destroy(rtc_scene* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  if (s->copy_stream) {
+    (void)hipStreamSynchronize(s->copy_stream);
+    (void)hipStreamDestroy(s->copy_stream);
+  }
+  for (rtc_scene* b : s->band) rtc_scene_destroy(b);
+  s->band.clear();
+  for (hipEvent_t& e : s->band_done)
+    if (e) (void)hipEventDestroy(e);
+  (void)hipSetDevice(s->device);
   if (s->launch_done) (void)hipEventSynchronize(s->launch_done);  // the last launch, whatever stream it ran on
   if (s->stream) {
     (void)hipStreamSynchronize(s->stream);
@@ -1757,7 +1767,7 @@ int rtc_set_option(const char* name, double value) {
   } table[] = {{"simple3_min_chunks", &o.simple3_min_chunks}, {"sched_off", &o.sched_off}, {"cut_above", &o.cut_above},
                {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
-               {"bvh_check", &o.bvh_check}};
+               {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
       *e.slot = value;
@@ -1766,6 +1776,65 @@ int rtc_set_option(const char* name, double value) {
   return fail(RTC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
 }
 
+namespace {
+
+// The copy of a frame to the host takes as long as the render or longer (24 B per pixel over the link: 0.9 ms for
+// 1080p, which renders in 0.5): a large frame is rendered in horizontal bands one after the other and every band is
+// copied on a second stream while the next one renders.  cover 1080p 1.44 -> 1.09 ms per frame into a registered canvas
+// with two bands (four: 1.11, eight: 1.45), dragons 4K 5.9 -> 4.2 with four (tools/banded_output_time.py).
+uint32_t hostBands(uint32_t w, uint32_t h) {
+  const int forced = static_cast<int>(rtcOptions().host_bands);
+  const uint64_t pixels = static_cast<uint64_t>(w) * h;
+  uint32_t bands = forced >= 1 ? static_cast<uint32_t>(forced) : (pixels >= 6000000ull ? 4u : (pixels >= 400000ull ? 2u : 1u));
+  bands = std::min(bands, RTC_MAX_HOST_BANDS);
+  while (bands > 1u && h / bands < 64u) --bands;
+  return bands;
+}
+
+int ensureBands(rtc_scene* s, uint32_t bands) {
+  while (s->band.size() + 1u < bands) {
+    rtc_scene* clone = nullptr;
+    if (const int st = rtc_scene_clone(s, &clone); st != RTC_OK) return st;
+    s->band.push_back(clone);
+  }
+  if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+  for (uint32_t b = 0; b < bands; ++b)
+    if (!s->band_done[b]) HIP_TRY(hipEventCreateWithFlags(&s->band_done[b], hipEventDisableTiming));
+  return RTC_OK;
+}
+
+int renderBanded(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                 double* rgb_out, uint32_t bands) {
+  if (const int st = ensureBands(s, bands); st != RTC_OK) return st;
+  for (;;) {
+    uint32_t row[RTC_MAX_HOST_BANDS + 1];
+    for (uint32_t b = 0; b < bands; ++b) row[b] = static_cast<uint32_t>(static_cast<uint64_t>(h) * b / bands) & ~7u;  // (whole rows of chunks)
+    row[bands] = h;
+    for (uint32_t b = 0; b < bands; ++b) {  // the renders, one after the other on the handle's stream ...
+      rtc_scene* const who = b == 0 ? s : s->band[b - 1];
+      const int st = rtc_render_device(who, cam, max_depth, x0, y0 + row[b], w, row[b + 1] - row[b],
+                                       s->d_frame + 3ull * w * row[b], s->stream);
+      if (st != RTC_OK) return st;
+      HIP_TRY(hipEventRecord(s->band_done[b], s->stream));
+    }
+    for (uint32_t b = 0; b < bands; ++b) {  // ... and behind each its copy, on the other
+      HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->band_done[b], 0));
+      HIP_TRY(hipMemcpyAsync(rgb_out + 3ull * w * row[b], s->d_frame + 3ull * w * row[b],
+                             3ull * w * (row[b + 1] - row[b]) * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    s->last_bands = bands;
+    int ov = RTC_OK;
+    for (uint32_t b = 0; b < bands && ov == RTC_OK; ++b) ov = checkOverflow(b == 0 ? s : s->band[b - 1]);
+    if (ov != RTC_ERR_OVERFLOW) return ov;
+    bool grown = growCsgLists(s);
+    for (rtc_scene* o : s->band) grown = growCsgLists(o) || grown;
+    if (!grown) return ov;
+  }
+}
+
+}  // namespace
+
 int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                double* rgb_out) {
   g_error.clear();
@@ -1773,6 +1842,7 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
   const size_t need = 3ull * w * h;
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = ensureFrame(s, need); st != RTC_OK) return st;
+  if (const uint32_t bands = hostBands(w, h); bands > 1u) return renderBanded(s, cam, max_depth, x0, y0, w, h, rgb_out, bands);
   for (;;) {
     const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
     if (st != RTC_OK) return st;
@@ -1874,6 +1944,16 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   out->shadow_calls = h.shadow_calls;
   out->shadow_traced = h.shadow_traced;
   out->overflow = h.overflow;
+  for (uint32_t b = 1; b < s->last_bands; ++b) {  // (a frame rtc_render cut into bands: the other bands' counters)
+    rtc_scene* const o = s->band[b - 1];
+    HIP_TRY(hipEventSynchronize(o->launch_done));
+    HIP_TRY(hipMemcpy(&h, o->d_stats + o->stats_parity, sizeof h, hipMemcpyDeviceToHost));
+    out->primary += h.primary;
+    out->secondary += h.secondary;
+    out->shadow_calls += h.shadow_calls;
+    out->shadow_traced += h.shadow_traced;
+    out->overflow += h.overflow;
+  }
 #ifdef RTC_PROFILE
   if (getenv("RTC_PROFILE_DUMP")) {
     std::fprintf(stderr, "rtc prof:");

@@ -51,6 +51,7 @@ struct RtcOptions {
   double bvh_leaf = 2.0;             // leaves per candidate-BVH leaf
   double bvh_one_axis = 0.0;         // != 0: SAH on the longest axis only
   double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
+  double host_bands = 0.0;           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
 };
 inline RtcOptions& rtcOptions() {
   static RtcOptions options;
@@ -102,6 +103,8 @@ struct SceneTables {
   DevBuf<DevImage> img;
   DevBuf<float> img_rgb;
 };
+
+constexpr uint32_t RTC_MAX_HOST_BANDS = 4;
 
 struct rtc_scene {
   int device = 0;
@@ -156,4 +159,11 @@ struct rtc_scene {
   hipEvent_t launch_done = nullptr;   // recorded behind everything a launch enqueues; a launch on ANOTHER stream waits for it
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack
   size_t ray_stack_capacity = 0;   // bytes
+  // ---- host output of a large frame (rtc_render): rendered in horizontal bands one after the other, each copied to the
+  // caller while the next renders.  A band is a pixel map of its own: the lower bands run on clones of this handle (made on
+  // first use), which keep their band's schedule from frame to frame.
+  std::vector<rtc_scene*> band;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t band_done[RTC_MAX_HOST_BANDS] = {};
+  uint32_t last_bands = 1;         // bands of the last frame through rtc_render (1: the last launch was an ordinary one)
 };
