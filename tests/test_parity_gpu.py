@@ -1075,6 +1075,52 @@ def test_csg_lists_longer_than_the_first_allocation(rtc):
     assert np.array_equal(gpu.render_rgba8(cam, 5), rtc.canvas_rgba8(got))
 
 
+def test_host_output_in_bands(rtc):
+    """rtc_render cuts a large frame into horizontal bands (the lower ones on clones of the handle), each copied to the
+    caller while the next renders: forced to three and four bands on small images - a rectangle that starts off the chunk
+    grid, a csg scene whose lists must grow in every band - the image, the summed counters and the RGBA8 clamp are those of
+    the whole frame."""
+    import json
+    rtc.set_option("host_bands", 3)
+    try:
+        hs = rtc.HostScene.from_file("reflection_and_refraction.json")
+        cam = hs.camera(320, 250)
+        want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+        gpu = rtc.GpuScene(hs.desc)
+        for frame in range(3):
+            got = gpu.render(cam, 5)
+            st = gpu.stats()
+            assert np.abs(got - want).max() < TOL
+            assert [st["primary"], st["secondary"], st["shadow_calls"], st["overflow"]] == [320 * 250, counters["secondary"], counters["shadow"], 0]
+        x0, y0, w, h = 13, 21, 290, 215                      # (bands of a rectangle: whole chunk rows counted from ITS top)
+        assert np.abs(gpu.render(cam, 5, (x0, y0, w, h)) - want[y0:y0 + h, x0:x0 + w]).max() < TOL
+        assert gpu.stats()["primary"] == w * h
+        buf_stats = gpu.stats()
+        import torch
+        dev = torch.zeros((250, 320, 3), dtype=torch.float64, device="cuda")
+        gpu.render_device(cam, dev.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)   # an ordinary launch after a banded one
+        torch.cuda.synchronize()
+        assert gpu.stats()["primary"] == 320 * 250 and gpu.stats() != buf_stats
+        gpu.close()
+        rtc.set_option("host_bands", 4)
+        spheres = [{"type": {"sphere": {}}, "transform": [{"scale": [0.2 + 0.05 * i] * 3}]} for i in range(20)]
+        scene = {"camera": {"width": 64, "height": 288, "field-of-view": 1.4, "from": [0, 0, -6], "to": [0, 0, 0], "up": [0, 1, 0]},
+                 "lights": [{"point-light": {"position": [-5, 5, -5], "intensity": [1, 1, 1]}}],
+                 "objects": [{"type": {"csg": {"operation": "union", "left": {"type": {"group": spheres}},
+                                               "right": {"type": {"cube": {}}}}}}]}
+        hs = rtc.HostScene(json.dumps(scene))
+        cam = hs.camera()
+        want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+        gpu = rtc.GpuScene(hs.desc)
+        got = gpu.render(cam, 5)                             # (the middle bands need 42 list entries: every handle grows)
+        st = gpu.stats()
+        assert np.abs(got - want).max() < TOL
+        assert [st["overflow"], st["secondary"], st["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]]
+        gpu.close()
+    finally:
+        rtc.set_option("host_bands", 0)
+
+
 def test_csg_of_forty_nested_operations(rtc):
     """A csg whose left operand is a csg ... forty deep (union / difference / intersection in turn, spheres and cubes
     marching along x): one unit of forty csg nodes - the (inl, inr) toggles of every node are one bit each of a 64-bit
