@@ -375,7 +375,9 @@ int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
 
 /* Diagnostic: the name of the render kernel the last launch on this handle ran
  * (the name rocprofv3 shows - which variant is picked depends on what the world
- * contains and on the size of the launch); "" before the first launch.  Static storage. */
+ * contains and on the size of the launch); "" before the first launch.  Static storage.
+ * (After an rtc_render that went to the host in bands, this, rtc_get_schedule and
+ * rtc_get_tile_costs describe the frame's first band; rtc_get_stats the whole frame.) */
 const char *rtc_last_kernel_name(const rtc_scene *scene);
 
 /* Diagnostic: the schedule the NEXT launch of the handle's current pixel map would run - the order in which the
