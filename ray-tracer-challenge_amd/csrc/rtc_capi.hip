@@ -203,7 +203,11 @@ double groupFloor(const rtc_scene* s) {
 // from about four chunks per resident wave on (1280x720; tools/simple3_sweep.py).
 bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
   const double forced = rtcOptions().simple3_min_chunks;  // (tests reach the kernel at small sizes with 0: always)
-  const uint64_t min_chunks = forced >= 0.0 ? static_cast<uint64_t>(forced) : 4ull * 4u * s->n_cus * s->blocks_per_cu_simple3;
+  // (a scene with several handles - rtc_scene_clone - is rendered with frames in flight: the GPU is full of other frames'
+  // waves whatever this launch's size, and the kernel that does more per SIMD wins from one chunk per resident wave on.
+  // The slowest 8-way share of cover with three frames in flight: 0.125 -> 0.118 ms per frame, 4-way 0.177 -> 0.164)
+  const bool in_flight = s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1;
+  const uint64_t min_chunks = forced >= 0.0 ? static_cast<uint64_t>(forced) : (in_flight ? 1ull : 4ull) * 4u * s->n_cus * s->blocks_per_cu_simple3;
   return s->simple3_ok && map.n_chunks >= min_chunks;
 }
 
@@ -1286,6 +1290,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const auto& cull_cmax = T.cull_cmax;
   HIP_TRY(hipGetDevice(&s->device));
   s->tab = std::make_shared<SceneTables>();
+  s->tab->handles.fetch_add(1, std::memory_order_relaxed);
   HIP_TRY(s->tab->roots.upload(roots));
   HIP_TRY(s->tab->root_recs.upload(root_recs));
   std::vector<RootCullPair> root_cull_pairs(root_cull.size() / 2u);
@@ -1483,6 +1488,7 @@ int rtc_scene_clone(const rtc_scene* src, rtc_scene** out) {
   // the scene and what was derived from it; nothing of the source's launches (schedule, measurements, buffers)
   s->device = src->device;
   s->tab = src->tab;
+  s->tab->handles.fetch_add(1, std::memory_order_relaxed);
   s->dev = src->dev;
   s->dev.csg_buf = nullptr;
   s->has_csg = src->has_csg;
@@ -1535,6 +1541,7 @@ void rtc_scene_destroy(rtc_scene* s) {
   if (s->launch_done) (void)hipEventDestroy(s->launch_done);
   if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
   if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
+  if (s->tab && !s->is_band) s->tab->handles.fetch_sub(1, std::memory_order_relaxed);
   delete s;
 }
 
@@ -1795,6 +1802,8 @@ int ensureBands(rtc_scene* s, uint32_t bands) {
   while (s->band.size() + 1u < bands) {
     rtc_scene* clone = nullptr;
     if (const int st = rtc_scene_clone(s, &clone); st != RTC_OK) return st;
+    clone->is_band = true;  // (bands run one after the other: not frames in flight)
+    s->tab->handles.fetch_sub(1, std::memory_order_relaxed);
     s->band.push_back(clone);
   }
   if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));

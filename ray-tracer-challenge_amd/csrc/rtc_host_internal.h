@@ -2,6 +2,7 @@
 // device-buffer holder and the scene handle behind `rtc_scene*` (include/rtc.h).  Included by rtc_capi.hip only.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -84,6 +85,7 @@ struct Sphere {
 // The scene's tables in device memory: written by rtc_scene_create, read-only from then on, so a handle and its clones
 // (rtc_scene_clone: one handle per frame in flight) share one copy; freed with the last of them.
 struct SceneTables {
+  std::atomic<int> handles{0};  // handles that share this copy: more than one = frames in flight (kernel choice, rtc_capi.hip)
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;
@@ -165,5 +167,6 @@ struct rtc_scene {
   std::vector<rtc_scene*> band;
   hipStream_t copy_stream = nullptr;
   hipEvent_t band_done[RTC_MAX_HOST_BANDS] = {};
+  bool is_band = false;            // this handle is one of another's band clones (not counted in SceneTables::handles)
   uint32_t last_bands = 1;         // bands of the last frame through rtc_render (1: the last launch was an ordinary one)
 };

@@ -53,13 +53,15 @@ def main():
     streams = [stream] + [torch.cuda.Stream() for _ in range(M - 1)]
 
     def timed_in_flight(make):
-        """make(k) -> (handle, fn(stream_ptr)) for the k-th of M frames in flight."""
+        """make(base) -> (handle, fn(stream_ptr)) for one of M frames in flight: base None = a scene handle of its own,
+        else a clone of that handle (rtc_scene_clone), as a host with frames in flight would have it."""
         if M == 1:
-            h, fn = make(0)
+            h, fn = make(None)
             t = timed(lambda: fn(sptr), h)
             h.close()
             return t
-        hf = [make(k) for k in range(M)]   # (separate handles here; a host uses rtc_scene_clone: same thing, one scene copy)
+        hf = [make(None)]
+        hf += [make(hf[0][0]) for _ in range(M - 1)]
         for i in range(8 * M):
             hf[i % M][1](streams[i % M].cuda_stream)
             torch.cuda.synchronize()
@@ -77,8 +79,8 @@ def main():
             h.close()
         return a.elapsed_time(b) / (args.reps * M)
 
-    def full_frame(k):
-        g = rtc.GpuScene(hs.desc)
+    def full_frame(base):
+        g = base.clone() if base is not None else rtc.GpuScene(hs.desc)
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
         return g, lambda sp: g.render_device(cam, canvas.data_ptr(), args.depth, None, sp)
     t_full = timed_in_flight(full_frame)
@@ -102,8 +104,8 @@ def main():
             for rank in range(world):
                 mine = np.flatnonzero(rank_of == rank).astype(np.uint32)
 
-                def share(k, mine=mine):
-                    g = rtc.GpuScene(hs.desc)
+                def share(base, mine=mine):
+                    g = base.clone() if base is not None else rtc.GpuScene(hs.desc)
                     buf = torch.zeros(((tx * ty + world - 1) // world, tile, tile, 3), dtype=torch.float64, device="cuda")
                     return g, lambda sp: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sp)
                 tb.append(timed_in_flight(share))
