@@ -249,6 +249,10 @@ double cutAbove(const rtc_scene* s, const DevPixelMap& map) {
   const double forced = rtcOptions().cut_above;
   if (forced < 0.0) return 0.0;
   if (forced > 0.0) return forced;
+  // (frames in flight - a scene with several handles -: a launch need not end when its longest packet does, the next
+  // frame's waves fill in; cuts only where a chunk is two shares.  The slowest 8-way share of cover, three in flight:
+  // 0.116 -> 0.109 ms per frame, 4-way 0.164 -> 0.146)
+  if (s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) return 2.0;
   return static_cast<double>(map.n_chunks) >= 4.0 * residentWaves(s, map) ? 1.5 : 1.0;
 }
 
