@@ -16,7 +16,7 @@ N  > 1: (launched by torch.distributed.run, one rank per GPU, backend nccl == RC
         handles, streams and tile buffers, frames dealt round-robin): an eighth of a 0.5 ms frame is a handful of
         dependent iterations per wave, too short to fill a GPU by itself - the next frame's work-groups start on the
         CUs the last one has left (one-GPU rehearsal, tools/scale_sim.py --inflight: the slowest 8-way share of
-        dragons 4K 0.70 -> 0.32 ms per frame, teapot 0.17 -> 0.06, cover 0.19 -> 0.12).  Total work per step is
+        dragons 4K 0.66 -> 0.31 ms per frame, teapot 0.18 -> 0.06, cover 0.18 -> 0.11).  Total work per step is
         fixed -> "scaling": "strong".  config.frames_in_flight says what a line was measured with; the one-GPU
         headline is 1 (one frame after the other), its figure with 2 and 3 is in frames_in_flight_ms_per_frame.
 

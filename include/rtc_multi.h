@@ -35,8 +35,8 @@ typedef struct rtc_multi rtc_multi; /* opaque: per frame slot n scene handles an
  * rtc_multi_render_device hands the frames to the slots in turn and waits only for the frame that last used the slot.
  * An N-th of a millisecond frame is a handful of dependent iterations per wave - too short to fill a GPU by itself;
  * with three slots the work-groups of a frame start on the CUs the frame before has left (one-GPU rehearsal of the
- * slowest 8-way share, tools/scale_sim.py --inflight 3: dragons 4K 0.70 -> 0.32 ms per frame, teapot 0.17 -> 0.06,
- * cover 0.19 -> 0.12).  The synchronous entry points run one frame at a time whatever k is. */
+ * slowest 8-way share, tools/scale_sim.py --inflight 3: dragons 4K 0.66 -> 0.31 ms per frame, teapot 0.18 -> 0.06,
+ * cover 0.18 -> 0.11).  The synchronous entry points run one frame at a time whatever k is. */
 #define RTC_MULTI_FRAMES(k) (((uint32_t)(k) & 15u) << 8)
 
 /* Replicates the scene on devices 0 .. n_gpus-1 of this process and creates the communicators (ncclCommInitAll). */
