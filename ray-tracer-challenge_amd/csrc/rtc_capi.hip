@@ -494,7 +494,12 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     useSchedule(s, map);
   }
   map.cost = plan.measure ? s->d_cost : nullptr;
-  map.packet_time = plan.measure ? s->d_packet_time : nullptr;
+  // (a packet's time is what its wave took for it only if the wave finishes one packet before it pulls the next - the
+  // default; with the tuning option "pull_min_idle" below 64 packets overlap in a wave, their times mean nothing - a
+  // schedule packed from them came out as thousands of one-pixel packets - and the packer goes by the ray counts alone)
+  const bool timed = plan.measure && rtcOptions().pull_min_idle >= 64.0;
+  map.packet_time = timed ? s->d_packet_time : nullptr;
+  if (plan.measure && !timed) HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
   if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
   if (plan.measure)
     if (const int st = packNextSchedule(s, cam, map, max_depth, stream, PackFrom::Measurement); st != RTC_OK) return st;
