@@ -659,6 +659,20 @@ def test_frames_in_flight(rtc):
         assert np.abs(handles[k].render(cams[k], 5) - wants[k]).max() < TOL
         handles[k].close()
 
+    # a scene with several handles is taken to have frames in flight: throughput over latency in the kernel choice
+    hs = rtc.HostScene.from_file("cover.json")
+    cam = hs.camera(720, 400)                             # 4500 chunks: between one and four per resident wave
+    alone = rtc.GpuScene(hs.desc)
+    want = alone.render(cam, 5)
+    assert alone.last_kernel_name() == "rtc_render_kernel_simple"
+    twin = alone.clone()
+    for g in (alone, twin):
+        assert np.abs(g.render(cam, 5) - want).max() < REPEAT_TOL and g.last_kernel_name() == "rtc_render_kernel_simple3"
+    twin.close()
+    alone.render(cam, 5)
+    assert alone.last_kernel_name() == "rtc_render_kernel_simple"
+    alone.close()
+
     hs = rtc.HostScene.from_file("cover.json")
     osc = ob.OracleScene(hs.desc)
     multi = rtc.MultiGpu(hs.desc, 4, virtual=True, frames=3)
