@@ -21,7 +21,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# (RTC_LIB_DIR: a diagnostic build of the three libraries somewhere else - tools/variants.py; the product is lib/)
+LIB_DIR = os.environ.get("RTC_LIB_DIR", os.path.join(_HERE, "lib"))
 REPO_ROOT = os.path.dirname(_HERE)
 # Where HostScene.from_file looks for a scene given by name, and for the OBJ / PNG files a scene names.  The harness
 # (tests, bench.py) uses the copies of the reference's scene and data files kept as fixtures under tests/golden/ (the
