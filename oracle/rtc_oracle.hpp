@@ -585,6 +585,7 @@ struct Shape {
   bool closed = false;
   // triangles
   Tuple p1{}, e1{}, e2{}, normal{}, n1{}, n2{}, n3{};
+  Tuple p2{}, p3{};  // the other two corners: only Triangle.bounds() reads them (triangle.zig:72-79; rtc_oracle_scene.hpp)
   // bounding box / group
   Tuple bmin = point(INF, INF, INF), bmax = point(-INF, -INF, -INF);
   std::vector<Shape> children;  // a csg: {left, right} (csg.zig:28-29)
@@ -599,6 +600,8 @@ struct Shape {
   static Shape triangle(Tuple p1, Tuple p2, Tuple p3) {  // shape.zig:186-204
     Shape s = make(TRIANGLE);
     s.p1 = p1;
+    s.p2 = p2;
+    s.p3 = p3;
     s.e1 = sub(p2, p1);
     s.e2 = sub(p3, p1);
     s.normal = normalized(cross(s.e2, s.e1));
@@ -607,6 +610,8 @@ struct Shape {
   static Shape smoothTriangle(Tuple p1, Tuple p2, Tuple p3, Tuple n1, Tuple n2, Tuple n3) {  // shape.zig:207-227
     Shape s = make(SMOOTH_TRIANGLE);
     s.p1 = p1;
+    s.p2 = p2;
+    s.p3 = p3;
     s.e1 = sub(p2, p1);
     s.e2 = sub(p3, p1);
     s.n1 = n1; s.n2 = n2; s.n3 = n3;

@@ -2368,8 +2368,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         // share their origin), then lighting() light by light in the reference's order.  A cooperative iteration splits
         // World.objects over the ray's eight lanes for all lights at once; every lane then adds the same terms in the
         // same order, so a pixel's colour does not depend on whether an iteration ran cooperatively.
-        constexpr int NL = RTC_SHADOW_BATCH;
-        for (uint32_t l0 = 0; l0 < S.n_lights; l0 += NL) {
+        auto batch = [&](auto nl_tag, const uint32_t l0) {
+          constexpr int NL = decltype(nl_tag)::value;
           double ldir[NL][3], ldist[NL], ldn[NL];
           uint32_t want = 0u;
 #pragma unroll
@@ -2402,7 +2402,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           for (int k = 0; k < NL; ++k) {
             if (l0 + k < S.n_lights) lighting(lights + 6ull * (l0 + k), ldir[k][0], ldir[k][1], ldir[k][2], ldn[k], ((in_shadow >> k) & 1u) != 0u);
           }
-        }
+        };
+        uint32_t l0 = 0u;
+        if constexpr (RTC_SHADOW_BATCH >= 2)
+          for (; l0 + 2u <= S.n_lights; l0 += 2u) batch(std::integral_constant<int, 2>{}, l0);
+        for (; l0 < S.n_lights; ++l0) batch(std::integral_constant<int, 1>{}, l0);
       } else {
         for (uint32_t li = 0; li < S.n_lights; ++li) {
           const double* __restrict__ L = lights + 6ull * li;
