@@ -82,12 +82,6 @@ __shared__ DevStats* rtc_prof_stats;  // (diagnostic builds: where the walks add
 #define RTC_WALK_ADD(slot, n) do { } while (0)
 #endif
 
-#ifndef RTC_FUSED_SHADOWS
-#define RTC_FUSED_SHADOWS 1  // worlds without groups: all the shadow rays of a hit in one trace (trace_shadows)
-#endif
-#ifndef RTC_SHADOW_BATCH
-#define RTC_SHADOW_BATCH 2   // ... that many lights at a time
-#endif
 #ifndef RTC_LB2
 #define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -890,150 +884,6 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
   if constexpr (FLAT) {
     if (stride > 1u) vis.merge_group(stride);  // (a cooperative trace: every lane of the group leaves with the group's result)
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// All the shadow rays of ONE hit in one trace.  World.shadeHit (world.zig:89-96) calls isShadowed (world.zig:126-154)
-// once per light, and every one of those rays starts at comps.over_point: what depends on the origin alone is computed
-// once for all NL lights of a batch -
-//   phase 1: the read of a root's bounding sphere and oc = c - o, oc^2, oc^2 + S^2, oc^2 - r^2 of roots_kept() (8 of its
-//            15 packed operations); per light only b = oc . d, the discriminant and the comparisons; one survivor mask
-//            per light;
-//   phase 2: a root that survives for any light has the origin taken into its object space once (the point half of
-//            Ray.transform, ray.zig:30-32: row_pt x 3), per light only the direction half (row_vec x 3) and the exact
-//            test; a light that is shadowed drops out (ShadowVisitor::done()); a root that casts no shadow is skipped
-//            (its entries never count, world.zig:144-149).
-// The per-light results are the same any-entry reductions as before (order-free), the rays and tests bit for bit those of
-// trace<ShadowVisitor>; only the work shared between the lights is new.  Worlds without groups (WORLD >= 1).
-// Returns bit k = light k of the batch is shadowed; `want` bit k = light k's shadow ray is traced at all.
-// member / stride: a cooperative trace as in trace(): the lanes of the group hold the same hit, each takes every
-// stride-th batch of four roots for ALL lights, and the shadowed bits are merged at the end.
-// ------------------------------------------------------------------------------------------
-template <int NL, bool GROUPS>
-__device__ __forceinline__ void roots_kept_lights(const RootCullPair& R, const float fox, const float foy, const float foz,
-                                                  const float s2, const float (&fdx)[NL], const float (&fdy)[NL],
-                                                  const float (&fdz)[NL], const float (&fa)[NL], const float (&fts)[NL],
-                                                  uint32_t (&kept)[NL]) {
-  const Float2 ocx = R.cx - fox, ocy = R.cy - foy, ocz = R.cz - foz;
-  const Float2 oc2 = __builtin_elementwise_fma(ocx, ocx, __builtin_elementwise_fma(ocy, ocy, ocz * ocz));
-  const Float2 oc2s = oc2 + s2, ocr = oc2 - R.r2;
-#pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    const Float2 b = __builtin_elementwise_fma(ocx, Float2(fdx[k]), __builtin_elementwise_fma(ocy, Float2(fdy[k]), ocz * fdz[k]));
-    const Float2 T = oc2s * fts[k];  // 8e-6 * a * (oc^2 + S^2), see roots_kept()
-    const Float2 ac = ocr * fa[k];
-    const Float2 bb = b * b;
-    const Float2 disc = bb - ac;
-    uint32_t kk = 0u;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const bool miss = disc[e] < -T[e];
-      const bool line_only = GROUPS && (__builtin_bit_cast(uint32_t, static_cast<float>(R.r2[e])) & 1u) != 0u;
-      const bool behind = (ac[e] > T[e]) & (bb[e] > T[e]) & !line_only & (b[e] < 0.0f);  // entirely at t < 0
-      kk |= (miss | behind) ? 0u : (1u << e);
-    }
-    kept[k] = kk;
-  }
-}
-
-template <bool CSG, int WORLD, int NL>
-__device__ __forceinline__ uint32_t trace_shadows(const DevScene& S, const RootRec* __restrict__ recs,
-                                                  const RootCullPair* __restrict__ cull, const double ox, const double oy,
-                                                  const double oz, const double (&dir)[NL][3], const double (&dist)[NL],
-                                                  const uint32_t want, const uint32_t member = 0u, const uint32_t stride = 1u) {
-  static_assert(WORLD >= 1, "worlds without groups");
-  constexpr bool SIMPLE = WORLD == 2;
-  const float fox = static_cast<float>(ox), foy = static_cast<float>(oy), foz = static_cast<float>(oz);
-  const float s = __builtin_sqrtf(fox * fox + foy * foy + foz * foz) + S.cull_cmax;
-  const float s2 = s * s;
-  float fdx[NL], fdy[NL], fdz[NL], fa[NL], fts[NL];
-#pragma unroll
-  for (int k = 0; k < NL; ++k) {
-    fdx[k] = static_cast<float>(dir[k][0]);
-    fdy[k] = static_cast<float>(dir[k][1]);
-    fdz[k] = static_cast<float>(dir[k][2]);
-    fa[k] = fdx[k] * fdx[k] + fdy[k] * fdy[k] + fdz[k] * fdz[k];
-    fts[k] = 8e-6f * fa[k];
-  }
-  uint32_t shadowed = 0u;
-  for (uint32_t base = 0; base < S.n_roots; base += 64u) {
-    const uint32_t n = min(64u, S.n_roots - base);
-    unsigned long long m[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) m[k] = 0ull;
-    for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
-      const RootCullPair p0 = cull[(base + i) >> 1], p1 = cull[((base + i) >> 1) + 1u];
-      uint32_t k0[NL], k1[NL];
-      roots_kept_lights<NL, false>(p0, fox, foy, foz, s2, fdx, fdy, fdz, fa, fts, k0);
-      roots_kept_lights<NL, false>(p1, fox, foy, foz, s2, fdx, fdy, fdz, fa, fts, k1);
-#pragma unroll
-      for (int k = 0; k < NL; ++k) m[k] |= static_cast<unsigned long long>(k0[k] | (k1[k] << 2)) << i;
-    }
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      if (((want >> k) & 1u) == 0u) m[k] = 0ull;
-      if (n < 64u) m[k] &= (1ull << n) - 1ull;
-    }
-    auto range = [&](uint32_t lo, uint32_t hi) -> unsigned long long {  // bits of roots [lo, hi) that fall into this block
-      const uint32_t a = max(lo, base) - base, b = min(max(hi, base), base + 64u) - base;
-      const unsigned long long below_b = b >= 64u ? ~0ull : (1ull << b) - 1ull;
-      const unsigned long long below_a = a >= 64u ? ~0ull : (1ull << a) - 1ull;
-      return below_b & ~below_a;
-    };
-    // One kind at a time (see trace()); kind_tag 255: the other leaf kinds, by the record's own kind.
-    auto roots_of_kind = [&](auto kind_tag, const unsigned long long in_range) {
-      constexpr uint32_t KIND = decltype(kind_tag)::value;
-      for (;;) {
-        unsigned long long mm = 0ull;
-#pragma unroll
-        for (int k = 0; k < NL; ++k) mm |= ((shadowed >> k) & 1u) ? 0ull : m[k];
-        mm &= in_range;
-        if (mm == 0ull) break;
-        const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mm));
-        const unsigned long long clear = ~(1ull << bit);
-        uint32_t on = 0u;  // the lights whose ray has to be tested against this root
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-          on |= (static_cast<uint32_t>(m[k] >> bit) & 1u & ~(shadowed >> k)) << k;
-          m[k] &= clear;
-        }
-        const RootRec& R = recs[base + bit];
-        const uint32_t kf = R.kind_flags;
-        if (((kf >> 8) & 1u) == 0u) continue;  // casts no shadow: none of its entries counts
-        // Ray.transform, the origin's half: once for all lights
-        const double lox = row_pt(R.inv + 0, ox, oy, oz), loy = row_pt(R.inv + 4, ox, oy, oz), loz = row_pt(R.inv + 8, ox, oy, oz);
-        const CylParams cy = KIND == 255u ? CylParams{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u} : CylParams{0.0, 0.0, false};
-        const double* const tri = KIND == 255u ? S.tri + 9ull * R.geom : nullptr;
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-          if (((on >> k) & 1u) == 0u) continue;
-          const Ray lr{lox, loy, loz, row_vec(R.inv + 0, dir[k][0], dir[k][1], dir[k][2]),
-                       row_vec(R.inv + 4, dir[k][0], dir[k][1], dir[k][2]), row_vec(R.inv + 8, dir[k][0], dir[k][1], dir[k][2])};
-          const double limit = dist[k];
-          bool any = false;
-          leaf_entries<SIMPLE>(KIND == 255u ? (kf & 0xFFu) : KIND, cy, tri, lr,
-                               [&](double t, double, double) { any = any || (t >= 0.0 && t < limit); });
-          shadowed |= any ? (1u << k) : 0u;
-        }
-      }
-    };
-    const uint32_t k1 = S.n_root_planes, k2 = k1 + S.n_root_spheres, k3 = k2 + S.n_root_cubes;
-    roots_of_kind(std::integral_constant<uint32_t, 1u>{}, range(0u, k1));
-    roots_of_kind(std::integral_constant<uint32_t, 0u>{}, range(k1, k2));
-    roots_of_kind(std::integral_constant<uint32_t, 2u>{}, range(k2, k3));
-    if constexpr (!SIMPLE) roots_of_kind(std::integral_constant<uint32_t, 255u>{}, range(k3, S.n_roots));
-  }
-  if (stride > 1u) {  // a cooperative trace: any lane of the aligned group of `stride` lanes
-    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    uint32_t merged = 0u;
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const unsigned long long b = __ballot(((shadowed >> k) & 1u) != 0u);
-      merged |= (((b >> (lane & ~(stride - 1u))) & ((1ull << stride) - 1ull)) != 0ull) ? (1u << k) : 0u;
-    }
-    shadowed = merged;
-  }
-  return shadowed;
 }
 
 // Butterfly over an aligned group of eight lanes with DPP moves (one VALU instruction per dword and step, no LDS crossbar):
@@ -2317,9 +2167,49 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
       // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
       const bool shadow_matters = !(mat.diffuse == 0.0 && mat.specular == 0.0);
-      // Material.lighting (material.zig:40-74) for one light, added to the surface colour in light order (world.zig:89-96)
-      auto lighting = [&](const double* __restrict__ L, const double lvx, const double lvy, const double lvz,
-                          const double light_dot_normal, const bool shadowed) {
+      // (a cooperative iteration of a world with at most two lights deals them to the two halves of the ray's group: lanes
+      // 0-3 take light 0, lanes 4-7 light 1, each half tracing its shadow ray four lanes wide; the halves' terms are added
+      // below, (0 + l0) + (0 + l1): the reference's running sum of world.zig:89-96 to the bit.  With three or more lights
+      // the halves' partial sums would round differently from that running sum - and whether an iteration runs
+      // cooperatively depends on the schedule -, so there every lane of the group takes all lights, in order, with its
+      // shadow rays traced eight lanes wide: a pixel's colour never depends on how its iterations were run.)
+      const bool deal_lights = COOP && coop && S.n_lights <= 2u;
+      const uint32_t li_first = deal_lights ? (member >> 2) : 0u, li_step = deal_lights ? 2u : 1u;
+      const uint32_t s_member = deal_lights ? (member & 3u) : member, s_stride = deal_lights ? 4u : stride;
+      const unsigned calls_before = it_shadow_calls, traced_before = it_shadow_traced, share_before = it_share;
+      for (uint32_t li = li_first; li < S.n_lights; li += li_step) {
+        const double* __restrict__ L = lights + 6ull * li;
+        it_shadow_calls++;
+        // isShadowed (world.zig:127-131) and lighting's point_to_light (material.zig:51) share this
+        const double vx = L[0] - ovx, vy = L[1] - ovy, vz = L[2] - ovz;
+        const double distance = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);
+        double lvx = vx, lvy = vy, lvz = vz;
+        if (distance != 0.0) {
+          lvx = vx / distance;
+          lvy = vy / distance;
+          lvz = vz / distance;
+        }
+        // With light_dot_normal < 0 (light behind the surface) lighting() returns `ambient` shadowed
+        // or not (material.zig:62-73): that shadow ray cannot change the result either.
+        const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
+        bool shadowed = false;
+        if (shadow_matters && light_dot_normal >= 0.0) {
+          it_shadow_traced++;
+          it_share++;
+          ShadowVisitor sv;
+          sv.distance = distance;
+          Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
+          RTC_STAMP(3);
+          RTC_COUNT(2);
+          {
+            RTC_HIST_BEGIN();
+            trace<CSG, WORLD>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
+            RTC_HIST_END(1);
+          }
+          RTC_STAMP(4);
+          shadowed = sv.shadowed;
+        }
+        // Material.lighting (material.zig:40-74)
         const double er = color.r * L[3], eg = color.g * L[4], eb = color.b * L[5];  // effective_color
         const double ka = mat.ambient;
         double lr_ = er * ka, lg_ = eg * ka, lb_ = eb * ka;
@@ -2349,91 +2239,15 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         sr = sr + lr_;
         sg = sg + lg_;
         sb = sb + lb_;
-      };
-      // isShadowed (world.zig:127-131) and lighting's point_to_light (material.zig:51) share the vector to the light
-      auto to_light = [&](const double* __restrict__ L, double& lvx, double& lvy, double& lvz, double& distance) {
-        const double vx = L[0] - ovx, vy = L[1] - ovy, vz = L[2] - ovz;
-        distance = __builtin_sqrt((vx * vx + vy * vy) + vz * vz);
-        lvx = vx;
-        lvy = vy;
-        lvz = vz;
-        if (distance != 0.0) {
-          lvx = vx / distance;
-          lvy = vy / distance;
-          lvz = vz / distance;
-        }
-      };
-      if constexpr (FLAT && RTC_FUSED_SHADOWS) {
-        // Worlds without groups: the shadow rays of RTC_SHADOW_BATCH lights at a time in ONE trace (trace_shadows: they
-        // share their origin), then lighting() light by light in the reference's order.  A cooperative iteration splits
-        // World.objects over the ray's eight lanes for all lights at once; every lane then adds the same terms in the
-        // same order, so a pixel's colour does not depend on whether an iteration ran cooperatively.
-        auto batch = [&](auto nl_tag, const uint32_t l0) {
-          constexpr int NL = decltype(nl_tag)::value;
-          double ldir[NL][3], ldist[NL], ldn[NL];
-          uint32_t want = 0u;
-#pragma unroll
-          for (int k = 0; k < NL; ++k) {
-            ldir[k][0] = ldir[k][1] = ldir[k][2] = 0.0;
-            ldist[k] = ldn[k] = 0.0;
-            if (l0 + k < S.n_lights) {
-              to_light(lights + 6ull * (l0 + k), ldir[k][0], ldir[k][1], ldir[k][2], ldist[k]);
-              // With light_dot_normal < 0 (light behind the surface) lighting() returns `ambient` shadowed
-              // or not (material.zig:62-73): that shadow ray cannot change the result either.
-              ldn[k] = (ldir[k][0] * nx + ldir[k][1] * ny) + ldir[k][2] * nz;
-              it_shadow_calls++;
-              if (shadow_matters && ldn[k] >= 0.0) {
-                want |= 1u << k;
-                it_shadow_traced++;
-                it_share++;
-              }
-            }
-          }
-          uint32_t in_shadow = 0u;
-          if (want != 0u) {
-            RTC_STAMP(3);
-            RTC_COUNT(2);
-            RTC_HIST_BEGIN();
-            in_shadow = trace_shadows<CSG, WORLD, NL>(S, recs, cull, ovx, ovy, ovz, ldir, ldist, want, member, stride);
-            RTC_HIST_END(1);
-            RTC_STAMP(4);
-          }
-#pragma unroll
-          for (int k = 0; k < NL; ++k) {
-            if (l0 + k < S.n_lights) lighting(lights + 6ull * (l0 + k), ldir[k][0], ldir[k][1], ldir[k][2], ldn[k], ((in_shadow >> k) & 1u) != 0u);
-          }
-        };
-        uint32_t l0 = 0u;
-        if constexpr (RTC_SHADOW_BATCH >= 2)
-          for (; l0 + 2u <= S.n_lights; l0 += 2u) batch(std::integral_constant<int, 2>{}, l0);
-        for (; l0 < S.n_lights; ++l0) batch(std::integral_constant<int, 1>{}, l0);
-      } else {
-        for (uint32_t li = 0; li < S.n_lights; ++li) {
-          const double* __restrict__ L = lights + 6ull * li;
-          it_shadow_calls++;
-          double lvx, lvy, lvz, distance;
-          to_light(L, lvx, lvy, lvz, distance);
-          // With light_dot_normal < 0 (light behind the surface) lighting() returns `ambient` shadowed
-          // or not (material.zig:62-73): that shadow ray cannot change the result either.
-          const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
-          bool shadowed = false;
-          if (shadow_matters && light_dot_normal >= 0.0) {
-            it_shadow_traced++;
-            it_share++;
-            ShadowVisitor sv;
-            sv.distance = distance;
-            Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
-            RTC_STAMP(3);
-            RTC_COUNT(2);
-            {
-              RTC_HIST_BEGIN();
-              trace<CSG, WORLD>(S, recs, cull, sray, sv, it_overflow, trav_stack, member, stride);
-              RTC_HIST_END(1);
-            }
-            RTC_STAMP(4);
-            shadowed = sv.shadowed;
-          }
-          lighting(L, lvx, lvy, lvz, light_dot_normal, shadowed);
+      }
+      if constexpr (COOP) {
+        if (deal_lights) {  // the other half's light (lane i <-> 7 - i pairs the halves), and what it counted
+          sr = sr + group8_other<2>(sr);
+          sg = sg + group8_other<2>(sg);
+          sb = sb + group8_other<2>(sb);
+          it_shadow_calls += group8_other<2>(it_shadow_calls - calls_before);
+          it_shadow_traced += group8_other<2>(it_shadow_traced - traced_before);
+          it_share += group8_other<2>(it_share - share_before);
         }
       }
     }

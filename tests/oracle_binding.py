@@ -61,3 +61,145 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The oracle's OWN scene build (oracle/rtc_oracle_scene.hpp: scene.zig + obj.zig restated, no product code).
+# ---------------------------------------------------------------------------------------------------------------
+def decode_png(path):
+    """A PNG decoder of the harness's own (zlib only; 8-bit grey / RGB / palette / +alpha, non-interlaced): the oracle
+    has no zigimg and must not borrow the product's decoder.  Returns [h][w][3] float32 = channel / 255 as zigimg's
+    colour iterator yields it (canvas.zig:34-46 widens that to T)."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, palette = 8, b"", None
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        at += 12 + n
+        if kind == b"IHDR":
+            w, h, depth, ctype, _, _, interlace = struct.unpack(">IIBBBBB", body)
+            assert depth == 8 and interlace == 0
+        elif kind == b"PLTE":
+            palette = np.frombuffer(body, dtype=np.uint8).reshape(-1, 3)
+        elif kind == b"IDAT":
+            idat += body
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(h, 1 + w * ch)
+    out = np.zeros((h, w * ch), dtype=np.uint8)
+    prev = np.zeros(w * ch, dtype=np.int32)
+    for y in range(h):
+        f, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:  # sub, average, paeth: sequential in x
+            cur = np.zeros(w * ch, dtype=np.int32)
+            for i in range(w * ch):
+                a = cur[i - ch] if i >= ch else 0
+                b = prev[i]
+                c = prev[i - ch] if i >= ch else 0
+                if f == 1:
+                    pred = a
+                elif f == 3:
+                    pred = (a + b) // 2
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 255
+        out[y] = cur
+        prev = cur
+    px = out.reshape(h, w, ch)
+    if ctype == 3:
+        rgb = palette[px[:, :, 0]]
+    elif ctype in (0, 4):
+        rgb = np.repeat(px[:, :, :1], 3, axis=2)
+    else:
+        rgb = px[:, :, :3]
+    return (rgb.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+
+
+class BuiltScene:
+    """Scene JSON -> the oracle's own World and Camera (orc_built_*), and that tree in canonical depth-first order."""
+
+    def __init__(self, scene_json, data_dir, width=0, height=0, images=()):
+        rtc = importlib.import_module("ray-tracer-challenge_amd")
+        l = lib()
+        if not hasattr(l, "_built_ready"):
+            l.orc_built_create.argtypes = [C.POINTER(C.c_void_p)]
+            l.orc_built_destroy.argtypes = [C.c_void_p]
+            l.orc_built_destroy.restype = None
+            l.orc_built_add_image.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+            l.orc_built_parse.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32]
+            l.orc_built_counts.argtypes = [C.c_void_p, C.c_void_p]
+            l.orc_built_leaves.argtypes = [C.c_void_p] + [C.c_void_p] * 9
+            l.orc_built_nodes.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+            l.orc_built_material.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+            l.orc_built_material.restype = C.c_uint64
+            l.orc_built_lights.argtypes = [C.c_void_p, C.c_void_p]
+            l.orc_built_camera.argtypes = [C.c_void_p, C.POINTER(rtc.Camera)]
+            l.orc_built_render.argtypes = [C.c_void_p] + [C.c_uint32] * 7 + [C.c_void_p, C.c_void_p]
+            l._built_ready = True
+        self._b = C.c_void_p()
+        l.orc_built_create(C.byref(self._b))
+        for name in images:
+            px = np.ascontiguousarray(decode_png(os.path.join(data_dir, name)))
+            l.orc_built_add_image(self._b, name.encode(), px.shape[1], px.shape[0], px.ctypes.data)
+        if isinstance(scene_json, str):
+            scene_json = scene_json.encode()
+        if l.orc_built_parse(self._b, scene_json, data_dir.encode(), width, height) != 0:
+            raise RuntimeError("oracle scene: " + l.orc_last_error().decode())
+        counts = (C.c_uint64 * 8)()
+        l.orc_built_counts(self._b, counts)
+        (self.n_leaves, self.n_nodes, self.n_children, self.n_roots, self.n_lights, self.n_materials, self.first_id,
+         self.lines_ignored) = [int(c) for c in counts]
+
+    def tables(self):
+        """dict of numpy arrays, canonical order (see orc_built_leaves / orc_built_nodes)."""
+        l, n, m = lib(), self.n_leaves, self.n_nodes
+        t = {"kind": np.zeros(n, np.uint8), "id": np.zeros(n, np.uint64), "shadow": np.zeros(n, np.uint8),
+             "inv": np.zeros((n, 16)), "inv_t": np.zeros((n, 16)), "xf": np.zeros((n, 16)), "cyl": np.zeros((n, 3)),
+             "tri": np.zeros((n, 18)), "material": np.zeros(n, np.uint32),
+             "box": np.zeros((m, 6)), "op": np.zeros(m, np.uint8), "count": np.zeros(m, np.uint32),
+             "children": np.zeros(self.n_children, np.uint32), "roots": np.zeros(self.n_roots, np.uint32),
+             "lights": np.zeros((self.n_lights, 6))}
+        l.orc_built_leaves(self._b, *[t[k].ctypes.data for k in ("kind", "id", "shadow", "inv", "inv_t", "xf", "cyl", "tri", "material")])
+        l.orc_built_nodes(self._b, *[t[k].ctypes.data for k in ("box", "op", "count", "children", "roots")])
+        l.orc_built_lights(self._b, t["lights"].ctypes.data)
+        blobs = []
+        for i in range(self.n_materials):
+            size = l.orc_built_material(self._b, i, None, 0)
+            buf = (C.c_uint8 * size)()
+            l.orc_built_material(self._b, i, buf, size)
+            blobs.append(bytes(buf))
+        t["materials"] = blobs
+        return t
+
+    def camera(self):
+        rtc = importlib.import_module("ray-tracer-challenge_amd")
+        cam = rtc.Camera()
+        lib().orc_built_camera(self._b, C.byref(cam))
+        return cam
+
+    def render(self, max_depth=5, row_step=1, threads=0):
+        cam = self.camera()
+        out = np.full((cam.vsize, cam.hsize, 3), np.nan, dtype=np.float64)
+        counters = (C.c_uint64 * 8)()
+        if lib().orc_built_render(self._b, max_depth, 0, 0, cam.hsize, cam.vsize, row_step, threads, out.ctypes.data, counters) != 0:
+            raise RuntimeError("oracle: " + lib().orc_last_error().decode())
+        return out, dict(zip(COUNTER_NAMES, [int(c) for c in counters]))
+
+    def close(self):
+        if self._b:
+            lib().orc_built_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

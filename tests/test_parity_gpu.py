@@ -71,6 +71,29 @@ def test_scene_parity(rtc, scene, w, h, depth):
     assert stats["shadow_traced"] <= stats["shadow_calls"]
 
 
+@pytest.mark.parametrize("scene,w,h,depth", [("dragons.json", 96, 54, 5), ("teapot.json", 96, 54, 5), ("groups.json", 90, 30, 5),
+                                             ("csg_demo.json", 96, 54, 5), ("cover.json", 96, 54, 5)])
+def test_gpu_against_the_world_the_oracle_built_itself(rtc, scene, w, h, depth):
+    """Everywhere else in this file the oracle is fed the PRODUCT loader's description (common mode: a loader bug moves
+    both sides).  Here the oracle builds its own World from the scene JSON and OBJ bytes (oracle/rtc_oracle_scene.hpp,
+    no product code) and that render is what the GPU - fed the product loader's description - must match.  The two
+    builds are also compared table by table on the CPU (tests/test_oracle_scene_cpu.py)."""
+    import os
+    with open(os.path.join(rtc.SCENE_DIR, scene)) as f:
+        js = f.read()
+    hs = rtc.HostScene(js, rtc.DATA_DIR + os.sep)
+    gpu = rtc.GpuScene(hs.desc)
+    got = gpu.render(hs.camera(w, h), depth)
+    stats = gpu.stats()
+    built = ob.BuiltScene(js, rtc.DATA_DIR + os.sep, w, h)
+    want, counters = built.render(depth)
+    delta = np.abs(got - want)
+    print(f"{scene} {w}x{h}: GPU vs oracle-built world max|delta|={delta.max():.3e}")
+    assert delta.max() < TOL
+    assert stats["overflow"] == 0 and stats["primary"] == counters["primary"] == w * h
+    assert stats["secondary"] == counters["secondary"] and stats["shadow_calls"] == counters["shadow"]
+
+
 def test_tile_render_matches_full_frame(rtc):
     hs = rtc.HostScene.from_file("cover.json")
     cam = hs.camera(120, 90)
