@@ -279,7 +279,7 @@ struct BvhBuilder {
     // Up to two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
     // tests together), the four-wide nodes and the final schedule, measured at 1 / 2 / 3 leaves per node:
     // dragons 4K 2.78 / 2.72 / 2.73 ms, nefertiti 0.728 / 0.713 / 0.719 ms, teapot 0.382 / 0.357 / 0.368 ms.
-    const size_t max_leaf = static_cast<size_t>(std::min(8.0, std::max(1.0, rtcOptions().bvh_leaf)));
+    const size_t max_leaf = static_cast<size_t>(std::min(RTC_BVH8 ? 4.0 : 8.0, std::max(1.0, rtcOptions().bvh_leaf)));  // (an eight-wide node addresses at most four records per leaf child)
     if (count <= max_leaf) {
       const uint32_t at = static_cast<uint32_t>(leaves.size());
       for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
@@ -455,6 +455,161 @@ struct Bvh4Collapse {
     need = std::max(k, (k ? k - 1u : 0u) + deepest);
     out[me] = N;
     return me;
+  }
+};
+
+// Collapses a binary tree of BvhBuilder into EIGHT-wide compressed nodes (Bvh8Node, rtc_device.h): the children of a node
+// are its two children, the larger (by surface area) inner one of which is replaced by ITS two children until there are
+// eight or none is left to open.  Child boxes are the binary tree's FP32 boxes quantised OUTWARD (lower planes down, upper
+// planes up) on the node's grid, so whatever the binary tree enters, this one enters.  Inner children become consecutive
+// nodes, leaf children consecutive leaf records (out_leaves: the binary builder's leaf list re-ordered), both in slot
+// order; slots are dealt by octant around the node's centre (greedy assignment of the best remaining child / slot pair).
+// Every box must be finite: leaves without a finite bound stay out of the tree (RootRec::always_*).
+struct Bvh8Collapse {
+  const std::vector<BvhNode>& in;
+  const std::vector<uint32_t>& in_leaves;
+  std::vector<Bvh8Node>& out;
+  std::vector<uint32_t>& out_leaves;
+  uint32_t max_depth = 0;  // deepest node: the walk's stack holds at most one entry per level
+  bool ok = true;          // false: a quantised box failed to contain its child (never expected; checked, not assumed)
+  struct Kid {
+    const float* lo;
+    const float* hi;
+    uint32_t ref;
+  };
+  static bool inner(uint32_t ref) { return ref != RTC_NO_LEAF && !(ref & RTC_NODE_BIT); }
+  static double area(const Kid& k) {
+    const double x = static_cast<double>(k.hi[0]) - k.lo[0], y = static_cast<double>(k.hi[1]) - k.lo[1], z = static_cast<double>(k.hi[2]) - k.lo[2];
+    return (x < 0.0 || y < 0.0 || z < 0.0) ? 0.0 : 2.0 * (x * y + y * z + z * x);
+  }
+  uint32_t convertRoot(uint32_t n) {
+    const uint32_t me = static_cast<uint32_t>(out.size());
+    out.emplace_back();
+    fill(me, n, 1);
+    return me;
+  }
+  void fill(uint32_t me, uint32_t n, uint32_t depth) {
+    max_depth = std::max(max_depth, depth);
+    std::vector<Kid> kids;
+    auto add = [&](const BvhNode& N, int which) {
+      const uint32_t ref = which == 0 ? N.c0 : N.c1;
+      if (ref != RTC_NO_LEAF) kids.push_back({which == 0 ? N.lo0 : N.lo1, which == 0 ? N.hi0 : N.hi1, ref});
+    };
+    add(in[n], 0);
+    add(in[n], 1);
+    while (kids.size() < 8) {
+      int open = -1;
+      for (size_t i = 0; i < kids.size(); ++i)
+        if (inner(kids[i].ref) && (open < 0 || area(kids[i]) > area(kids[open]))) open = static_cast<int>(i);
+      if (open < 0) break;
+      const BvhNode& C = in[kids[open].ref];
+      kids.erase(kids.begin() + open);
+      add(C, 0);
+      add(C, 1);
+    }
+    Bvh8Node N;
+    std::memset(&N, 0, sizeof N);
+    for (int a = 0; a < 3; ++a)
+      for (int s = 0; s < 8; ++s) {  // empty slots: lo above hi, never entered
+        N.q[8 * a + s] = 255;
+        N.q[24 + 8 * a + s] = 0;
+      }
+    const size_t nk = kids.size();
+    // the node's grid: origin = lower corner of the union, step per axis = the power of two with 255 steps >= the extent
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = nk ? kids[0].lo[a] : 0.0;
+      hi[a] = nk ? kids[0].hi[a] : 0.0;
+      for (size_t i = 1; i < nk; ++i) {
+        lo[a] = std::fmin(lo[a], kids[i].lo[a]);
+        hi[a] = std::fmax(hi[a], kids[i].hi[a]);
+      }
+    }
+    const float origin[3] = {static_cast<float>(lo[0]), static_cast<float>(lo[1]), static_cast<float>(lo[2])};  // (floats already: exact)
+    double step[3];
+    uint8_t* const ebyte[3] = {&N.ex, &N.ey, &N.ez};
+    for (int a = 0; a < 3; ++a) {
+      const double extent = hi[a] - static_cast<double>(origin[a]);
+      int e = extent > 0.0 ? static_cast<int>(std::ceil(std::log2(extent / 255.0))) : -126;
+      e = std::max(-126, std::min(127, e));
+      while (e < 127 && std::ldexp(255.0, e) < extent) ++e;
+      step[a] = std::ldexp(1.0, e);
+      *ebyte[a] = static_cast<uint8_t>(e + 127);
+    }
+    N.ox = origin[0];
+    N.oy = origin[1];
+    N.oz = origin[2];
+    // slots by octant: cost(child, slot) = sum over axes of +-(child centre - node centre); best remaining pair first
+    int slot_of[8];
+    {
+      double centre[3], cost[8][8];
+      for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (lo[a] + hi[a]);
+      for (size_t i = 0; i < nk; ++i)
+        for (int s = 0; s < 8; ++s) {
+          double c = 0.0;
+          for (int a = 0; a < 3; ++a) {
+            const double off = 0.5 * (static_cast<double>(kids[i].lo[a]) + kids[i].hi[a]) - centre[a];
+            c += ((s >> a) & 1) ? off : -off;
+          }
+          cost[i][s] = c;
+        }
+      bool kid_done[8] = {}, slot_used[8] = {};
+      for (size_t round = 0; round < nk; ++round) {
+        int bi = -1, bs = -1;
+        for (size_t i = 0; i < nk; ++i)
+          for (int s = 0; s < 8; ++s)
+            if (!kid_done[i] && !slot_used[s] && (bi < 0 || cost[i][s] > cost[bi][bs])) {
+              bi = static_cast<int>(i);
+              bs = s;
+            }
+        kid_done[bi] = true;
+        slot_used[bs] = true;
+        slot_of[bi] = bs;
+      }
+    }
+    int kid_in[8];
+    for (int s = 0; s < 8; ++s) kid_in[s] = -1;
+    for (size_t i = 0; i < nk; ++i) kid_in[slot_of[i]] = static_cast<int>(i);
+    // quantise; inner children and leaf records in slot order
+    uint32_t n_inner = 0, n_recs = 0, lmask = 0;
+    const uint32_t leaf_base = static_cast<uint32_t>(out_leaves.size());
+    for (int s = 0; s < 8; ++s) {
+      if (kid_in[s] < 0) continue;
+      const Kid& K = kids[kid_in[s]];
+      for (int a = 0; a < 3; ++a) {
+        const double o = origin[a];
+        double ql = std::floor((static_cast<double>(K.lo[a]) - o) / step[a]);
+        double qh = std::ceil((static_cast<double>(K.hi[a]) - o) / step[a]);
+        ql = std::fmax(0.0, std::fmin(255.0, ql));
+        qh = std::fmax(0.0, std::fmin(255.0, qh));
+        if (!(o + ql * step[a] <= K.lo[a] && o + qh * step[a] >= K.hi[a])) ok = false;
+        N.q[8 * a + s] = static_cast<uint8_t>(ql);
+        N.q[24 + 8 * a + s] = static_cast<uint8_t>(qh);
+      }
+      if (inner(K.ref)) {
+        N.imask |= static_cast<uint8_t>(1u << s);
+        n_inner++;
+      } else {
+        const uint32_t first = (K.ref & ~RTC_NODE_BIT) >> 3, count = (K.ref & 7u) + 1u;
+        if (count > 4u || n_recs > 28u) ok = false;
+        N.meta[s] = static_cast<uint8_t>((n_recs << 2) | (count - 1u));
+        lmask |= 1u << s;
+        for (uint32_t k = 0; k < count; ++k) out_leaves.push_back(in_leaves[first + k]);
+        n_recs += count;
+      }
+    }
+    if (leaf_base >= (1u << 24)) ok = false;
+    N.leaf_base_lmask = (leaf_base & 0xFFFFFFu) | (lmask << 24);
+    const uint32_t child_base = static_cast<uint32_t>(out.size());
+    N.child_base = child_base;
+    out.resize(out.size() + n_inner);  // (invalidates references into `out`: N is a local copy)
+    out[me] = N;
+    uint32_t rank = 0;
+    for (int s = 0; s < 8; ++s) {
+      if (kid_in[s] < 0 || !inner(kids[kid_in[s]].ref)) continue;
+      fill(child_base + rank, kids[kid_in[s]].ref, depth + 1);
+      rank++;
+    }
   }
 };
 

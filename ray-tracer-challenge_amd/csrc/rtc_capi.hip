@@ -554,7 +554,10 @@ struct HostTables {
   std::vector<uint32_t> leaf_parent;
   std::vector<uint32_t> node_parent;
   std::vector<BvhNode> bvh_nodes;      // the binary SAH trees (host only)
-  std::vector<Bvh4Node> bvh4_nodes;    // ... collapsed to four children per node: what the kernel walks
+  std::vector<Bvh4Node> bvh4_nodes;    // ... collapsed to four children per node: what the kernel walks (RTC_BVH8 == 0)
+  std::vector<Bvh8Node> bvh8_nodes;    // ... or to eight compressed children per node (RTC_BVH8 == 1)
+  std::vector<uint32_t> bvh8_leaves;   // the leaf list in the eight-wide tree's order, then the groups' unbounded leaves
+  std::vector<uint2> root_always;      // per root: {first, count} of its unbounded leaves in bvh8_leaves
   bool chain_nested = false;           // every reference node box lies inside its parent's box
   std::vector<uint32_t> bvh_leaves;
   std::vector<uint32_t> node_info;
@@ -743,6 +746,8 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       R.kind_flags = RTC_ROOT_IS_GROUP | (opOf(n) != RTC_CSG_NONE ? RTC_ROOT_IS_CSG : 0u);
       R.index = n;
       R.geom = bvh_root_of[i];
+      R.always_first = T.root_always[i].x;
+      R.always_count = T.root_always[i].y;
       // every entry of the group lies on a line that passes the group's own box test
       const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
       const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
@@ -979,6 +984,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
   auto& node_parent = T.node_parent;
   auto& bvh_nodes = T.bvh_nodes;
   auto& bvh4_nodes = T.bvh4_nodes;
+  (void)bvh4_nodes;
   auto& bvh_leaves = T.bvh_leaves;
   auto& node_info = T.node_info;
   auto& node_range = T.node_range;
@@ -1042,6 +1048,9 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
   node_parent.assign(d.n_nodes, RTC_NO_LEAF);
   std::vector<uint32_t> bvh_root_of(d.n_roots, 0);
   std::vector<uint32_t> bvh2_root_of(d.n_roots, 0);
+  T.root_always.assign(d.n_roots, uint2{0u, 0u});
+  T.bvh8_nodes.clear();
+  T.bvh8_leaves.clear();
   bvh_mag = 0.0f;
   // ---- reference-tree bookkeeping for every node: parent, which child of its parent it is (a csg's left
   // is child 0), the contiguous range of depth-first leaves below it, and the csg UNITS: a csg whose parent
@@ -1163,15 +1172,36 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
         }
       }
     }
+#if RTC_BVH8
+    // Leaves (and csg units) without a finite bound - planes, cones - stay out of the tree: the walk visits them first,
+    // unconditionally, and every box of the tree is finite (the eight-wide nodes quantise their children's boxes).
+    std::vector<BvhPrim> unbounded;
+    {
+      std::vector<BvhPrim> bounded;
+      for (BvhPrim& p : items) (p.box.finite() ? bounded : unbounded).push_back(p);
+      items.swap(bounded);
+    }
+#endif
     BvhBuilder builder{bvh_nodes, bvh_leaves};
     bvh_root_of[i] = builder.buildRoot(std::move(items));
     bvh_mag = std::fmax(bvh_mag, builder.mag);
     bvh2_root_of[i] = bvh_root_of[i];
+#if RTC_BVH8
+    Bvh8Collapse wide{bvh_nodes, bvh_leaves, T.bvh8_nodes, T.bvh8_leaves};
+    bvh_root_of[i] = wide.convertRoot(bvh_root_of[i]);
+    if (!wide.ok) return fail(RTC_ERR_UNSUPPORTED, "root %u: its candidate BVH does not fit the eight-wide node encoding", i);
+    if (wide.max_depth + 1 > RTC_TRAV_STACK)
+      return fail(RTC_ERR_OVERFLOW, "root %u: its candidate BVH is %u levels deep, the kernel's traversal stack holds %d", i,
+                  wide.max_depth, RTC_TRAV_STACK);
+    T.root_always[i] = uint2{static_cast<uint32_t>(T.bvh8_leaves.size()), static_cast<uint32_t>(unbounded.size())};
+    for (const BvhPrim& p : unbounded) T.bvh8_leaves.push_back(p.leaf);
+#else
     uint32_t stack_need = 0;
     bvh_root_of[i] = Bvh4Collapse{bvh_nodes, bvh4_nodes}.convert(bvh_root_of[i], stack_need);
     if (stack_need + 1 > RTC_TRAV_STACK)
       return fail(RTC_ERR_OVERFLOW, "root %u: walking its candidate BVH can take %u stack entries, the kernel's traversal stack holds %d", i,
                   stack_need + 1, RTC_TRAV_STACK);
+#endif
   }
   if (rtcOptions().bvh_check != 0.0) {
     // diagnostic: every leaf once, every stored child box contains the world boxes below it
@@ -1239,6 +1269,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
     std::fprintf(stderr, "rtc bvh check: %zu nodes, %zu leaves in groups, %zu seen exactly once, %zu containment violations\n",
                  bvh_nodes.size(), in_groups, once, bad);
   }
+  if (T.bvh8_leaves.size() >= (1u << 24)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the eight-wide BVH's leaf addressing", T.bvh8_leaves.size());
   if (bvh_leaves.size() >= (1u << 28)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the BVH leaf-range encoding", bvh_leaves.size());
   buildRootTables(d, dfs_of, bvh_root_of, T);
   copyPlainTables(d, T);
@@ -1281,6 +1312,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   const auto& node_parent = T.node_parent;
   const auto& bvh4_nodes = T.bvh4_nodes;
   const auto& bvh_leaves = T.bvh_leaves;
+  (void)bvh_leaves;
   const auto& node_info = T.node_info;
   const auto& node_range = T.node_range;
   const auto& root_recs = T.root_recs;
@@ -1323,11 +1355,17 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   HIP_TRY(s->tab->node_box.upload(node_box));
   HIP_TRY(s->tab->node_kids.upload(node_kids));
   HIP_TRY(s->tab->bvh.upload(bvh4_nodes));
-  std::vector<BvhLeafRec> leaf_recs(bvh_leaves.size());
+  HIP_TRY(s->tab->bvh8.upload(T.bvh8_nodes));
+#if RTC_BVH8
+  const std::vector<uint32_t>& walk_leaves = T.bvh8_leaves;
+#else
+  const std::vector<uint32_t>& walk_leaves = bvh_leaves;
+#endif
+  std::vector<BvhLeafRec> leaf_recs(walk_leaves.size());
   for (size_t i = 0; i < leaf_recs.size(); ++i) {
     BvhLeafRec& L = leaf_recs[i];
     std::memset(&L, 0, sizeof L);
-    L.leaf = bvh_leaves[i];
+    L.leaf = walk_leaves[i];
     if (L.leaf & RTC_NODE_BIT) continue;  // a csg unit
     const uint4 m = leaf_meta[L.leaf];
     L.kind_flags = m.x;
@@ -1420,6 +1458,9 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   D.mat = s->tab->mat.p;
   D.pat = s->tab->pat.p;
   D.bvh = s->tab->bvh.p;
+  D.bvh8 = s->tab->bvh8.p;
+  D.n_bvh_nodes = static_cast<uint32_t>(RTC_BVH8 ? T.bvh8_nodes.size() : bvh4_nodes.size());
+  D.n_bvh_leaves = static_cast<uint32_t>(walk_leaves.size());
   D.bvh_leaf = s->tab->bvh_leaf.p;
   D.leaf_parent = s->tab->leaf_parent.p;
   D.node_parent = s->tab->node_parent.p;
@@ -1980,8 +2021,10 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
                  h.prof_t1 >> 24, h.prof_t1 & 0xFFFFFFull, h.prof_busy, h.stolen);
     std::fprintf(stderr, "rtc traces (invocations, lanes): closest %llu %llu | shadow %llu %llu | behind %llu %llu\n", h.prof2[0],
                  h.prof2[1], h.prof2[2], h.prof2[3], h.prof2[4], h.prof2[5]);
-    std::fprintf(stderr, "rtc walks: %llu lanes %llu node-steps %llu leaf-steps %llu lanes-at-nodes %llu lanes-at-leaves %llu | without a leaf: %llu walks %llu node-steps\n",
-                 h.prof4[0], h.prof4[1], h.prof4[2], h.prof4[3], h.prof4[4], h.prof4[5], h.prof4[6], h.prof4[7]);
+    // (prof4[7]: the four-wide walk counts the node steps of walks that reach no leaf; the eight-wide walk the references
+    // it refused to follow because they point outside the node / leaf tables - must be 0)
+    std::fprintf(stderr, "rtc walks: %llu lanes %llu node-steps %llu leaf-steps %llu lanes-at-nodes %llu lanes-at-leaves %llu | without a leaf: %llu walks | %s %llu\n",
+                 h.prof4[0], h.prof4[1], h.prof4[2], h.prof4[3], h.prof4[4], h.prof4[5], h.prof4[6], RTC_BVH8 ? "bad refs" : "their node-steps", h.prof4[7]);
     std::fprintf(stderr, "rtc trace cycles by lanes with a ray (1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64):");
     for (int k = 0; k < 3; ++k) {
       std::fprintf(stderr, " %s", k == 0 ? "closest" : k == 1 ? "| shadow" : "| behind");

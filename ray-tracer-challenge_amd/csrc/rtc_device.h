@@ -66,8 +66,9 @@ struct RootRec {
   uint32_t kind_flags;   // kind | casts_shadow<<8 | closed<<9 | is_group<<15
   uint32_t index;        // leaf index (depth-first) or group node index
   uint32_t material;
-  uint32_t geom;
-  double pad_[2];        // 144-byte stride: per-lane LDS reads of different records spread over the banks
+  uint32_t geom;         // a group: root node of its candidate BVH
+  uint32_t always_first, always_count;  // a group: BvhLeafRecs of the leaves below it that no box bounds (planes, cones): visited before the walk
+  uint32_t pad_[2];      // 144-byte stride: per-lane LDS reads of different records spread over the banks
 };
 #define RTC_ROOT_IS_GROUP 0x8000u
 #define RTC_ROOT_IS_CSG 0x4000u  // with IS_GROUP: the root is a csg unit, `index` its node
@@ -110,6 +111,29 @@ struct Bvh4Node {
   float lo[3][4], hi[3][4];  // [axis][child]; an unused slot has lo = +huge, hi = -huge (never entered)
   uint32_t c[4];             // as BvhNode::c0
   uint32_t pad_[4];
+};
+
+// What the kernel walks since round 4 (RTC_BVH8): the binary SAH tree collapsed to EIGHT children per node, the child
+// boxes quantised to 8 bits per plane on a grid anchored at the node's own FP32 box (origin + per-axis power-of-two
+// step, lower planes rounded down, upper planes up) - 80 bytes, five 16-byte fetches for eight children where the
+// four-wide node took seven for four.  Children are not referenced one by one: the inner children of a node are
+// consecutive nodes (in slot order) starting at child_base, its leaf children's records consecutive BvhLeafRecs starting
+// at leaf_base, so a whole node's worth of pending children is ONE stack entry (base + bit masks), and a child's index
+// is base + the number of set mask bits below its slot.  Slots are dealt by octant (slot bit 0 / 1 / 2 set: the child
+// lies towards +x / +y / +z of the node's centre), so that `slot XOR the ray's direction signs` is a front-to-back
+// order without any sorting.  (The layout follows Ylitie, Karras, Laine, "Efficient Incoherent Ray Traversal on GPUs
+// Through Compressed Wide BVHs", 2017, with explicit leaf ranges instead of triangle blocks.)
+#ifndef RTC_BVH8
+#define RTC_BVH8 1
+#endif
+struct Bvh8Node {              // 80 B = 5 x 16
+  float ox, oy, oz;            // origin of the quantisation grid: the node box's lower corner
+  uint8_t ex, ey, ez;          // per axis: the step as an IEEE exponent byte, step = bit_cast<float>(e << 23)
+  uint8_t imask;               // bit s: slot s holds an inner node
+  uint32_t child_base;         // node index of the first inner child
+  uint32_t leaf_base_lmask;    // bits 0..23: first BvhLeafRec of the leaf children; bits 24..31: bit s: slot s holds a leaf range
+  uint8_t meta[8];             // per slot with a leaf range: (offset from leaf_base) << 2 | (records - 1); records <= 4
+  uint8_t q[48];               // lo_x[8] lo_y[8] lo_z[8] hi_x[8] hi_y[8] hi_z[8]; an empty slot has lo = 255, hi = 0
 };
 
 // Everything a visit of one BVH leaf needs, in BVH order: one fetch where leaf index -> leaf_meta -> tri would be three
@@ -172,7 +196,9 @@ struct DevScene {
   const double* __restrict__ trin;      // [n_tris][9]
   const DevMaterial* __restrict__ mat;
   const DevPattern* __restrict__ pat;
-  const Bvh4Node* __restrict__ bvh;     // all groups' BVHs; RootRec::geom = root node of a group's BVH
+  const Bvh4Node* __restrict__ bvh;     // all groups' BVHs; RootRec::geom = root node of a group's BVH (RTC_BVH8 == 0)
+  const Bvh8Node* __restrict__ bvh8;    // ... as eight-wide compressed nodes (RTC_BVH8 == 1)
+  uint32_t n_bvh_nodes, n_bvh_leaves;   // sizes of bvh / bvh8 and bvh_leaf (the RTC_PROFILE build checks every reference against them)
   const BvhLeafRec* __restrict__ bvh_leaf; // the leaves referenced by the nodes' leaf ranges
   const uint32_t* __restrict__ leaf_parent;  // reference Group node directly above each leaf (RTC_NO_LEAF: none)
   const uint32_t* __restrict__ node_parent;  // reference Group above each Group node (RTC_NO_LEAF: none)

@@ -97,6 +97,7 @@ struct SceneTables {
   DevBuf<DevMaterial> mat;
   DevBuf<uint2> node_kids;
   DevBuf<Bvh4Node> bvh;
+  DevBuf<Bvh8Node> bvh8;
   DevBuf<BvhLeafRec> bvh_leaf;
   DevBuf<uint32_t> leaf_parent, node_parent, node_info;
   DevBuf<uint2> node_range;

@@ -729,6 +729,183 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
 #endif
 }
 
+#if RTC_BVH8
+// Walks the EIGHT-wide compressed candidate BVH of one group (Bvh8Node, rtc_device.h) with an FP32 copy of the ray.
+// Per node: five 16-byte fetches bring eight child boxes; a child plane is origin + q * step, so its ray parameter is
+// q * (step / d) + (origin - o) / d - one conversion and one FMA per plane, the per-node part computed once; the ray's
+// direction signs pick which of a child's two planes per axis is the near one; `margin` (see traverse_bvh's delta; the
+// FMA form rounds differently from (plane - o) / d, within a few ulps of the same magnitudes, so the margin is doubled)
+// widens every interval.  The pending children of a node are ONE stack entry - the first inner child's index, the hit
+// mask in front-to-back order (slot XOR direction signs) and the node's inner-child mask - so a node costs at most one
+// push, and the stack is as deep as the tree (a handful of entries, all in LDS).  While-while as before: lanes descend
+// until they hold leaf ranges, then all lanes that hold some run their exact FP64 leaf tests together.  A visitor for
+// which the first entry that counts ends the trace (kAnyHit) takes the children in slot order.
+// Leaves no box bounds (planes, cones: RootRec::always_*) are visited first, unconditionally.
+__device__ __forceinline__ uint32_t permute_by_octant(uint32_t x, uint32_t oct) {  // bit p of the result = bit (p ^ oct) of x (8 bits)
+  const uint32_t s1 = ((x & 0x55u) << 1) | ((x >> 1) & 0x55u);
+  x = (oct & 1u) ? s1 : x;
+  const uint32_t s2 = ((x & 0x33u) << 2) | ((x >> 2) & 0x33u);
+  x = (oct & 2u) ? s2 : x;
+  const uint32_t s4 = ((x & 0x0Fu) << 4) | ((x >> 4) & 0x0Fu);
+  return (oct & 4u) ? s4 : x;
+}
+
+template <bool CSG, class V>
+__device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t root, const uint32_t always_first,
+                                              const uint32_t always_count, const Ray& ray, V& vis, unsigned& overflow,
+                                              uint2* lds_stack) {
+  const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
+  float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
+  // a direction component of (nearly) zero: 1e-30 instead - every product below stays finite, and over any parameter
+  // range that matters the ray does not move by a rounding error's worth along that axis
+  dx = __builtin_copysignf(fmaxf(__builtin_fabsf(dx), 1e-30f), dx);
+  dy = __builtin_copysignf(fmaxf(__builtin_fabsf(dy), 1e-30f), dy);
+  dz = __builtin_copysignf(fmaxf(__builtin_fabsf(dz), 1e-30f), dz);
+  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+  const float delta = 1e-6f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
+  const float mx = delta * __builtin_fabsf(ix), my = delta * __builtin_fabsf(iy), mz = delta * __builtin_fabsf(iz);
+  const bool negx = dx < 0.0f, negy = dy < 0.0f, negz = dz < 0.0f;
+  const uint32_t oct = V::kAnyHit ? 0u : ((negx ? 1u : 0u) | (negy ? 2u : 0u) | (negz ? 4u : 0u));
+  const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
+  uint32_t cur_xf = 0xFFFFFFFFu;
+  Ray lr = ray;
+  auto visit = [&](uint32_t rec) {
+#ifdef RTC_PROFILE  // (diagnostic builds check every reference before it is followed: a wild one is counted and skipped)
+    if (rec >= S.n_bvh_leaves) {
+      RTC_WALK_ADD(7, 1);
+      return;
+    }
+#endif
+    const BvhLeafRec& L = S.bvh_leaf[rec];
+    if (CSG && (L.leaf & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
+      if constexpr (CSG) visit_csg(S, L.leaf & ~RTC_NODE_BIT, ray, vis, overflow);
+    } else {
+      visit_leaf(S, L, ray, degenerate, cur_xf, lr, vis);
+    }
+  };
+  for (uint32_t i = 0; i < always_count; ++i) visit(always_first + i);
+  // the stack: [entry][lane] in LDS (8 bytes per entry), the rest in scratch memory
+  typedef uint32_t Pair __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) Pair LdsPair;
+  LdsPair* const lds_top = (LdsPair*)lds_stack;
+  Pair stack[RTC_TRAV_STACK - RTC_LDS_TRAV];
+  int sp = 0;
+  // the group in hand: the root is inner child 0 of a node that is not there
+  // bits 0..7: children still to visit, front to back (bit p: slot p ^ oct); bits 8..15: the node's imask (by slot)
+  uint32_t g_base = root, g_bits = (1u << oct) | 0x0100u;  // (slot 0 of the node that is not there)
+  uint32_t l_base = 0u, l_hits = 0u, meta_lo = 0u, meta_hi = 0u;
+#ifdef RTC_PROFILE
+  unsigned long long pw_nodes = 0, pw_leaves = 0, pw_node_lanes = 0, pw_leaf_lanes = 0;
+  const unsigned long long pw_lanes = __builtin_popcountll(__ballot(true));
+#endif
+  for (;;) {
+    while (l_hits == 0u && !vis.done()) {
+      if ((g_bits & 0xFFu) == 0u) {
+        if (sp == 0) break;
+        --sp;
+        Pair e;
+        if (sp < RTC_LDS_TRAV) {
+          e = lds_top[sp * 64];
+        } else {
+          e = stack[sp - RTC_LDS_TRAV];
+        }
+        g_base = e.x;
+        g_bits = e.y;
+      }
+#ifdef RTC_PROFILE
+      pw_nodes += 1ull;
+      pw_node_lanes += __builtin_popcountll(__ballot(true));
+#endif
+      const uint32_t p = static_cast<uint32_t>(__builtin_ctz(g_bits));  // (the low byte is not empty)
+      g_bits &= g_bits - 1u;
+      const uint32_t slot = p ^ oct;
+      const uint32_t node = g_base + static_cast<uint32_t>(__builtin_popcount((g_bits >> 8) & ((1u << slot) - 1u)));
+      if ((g_bits & 0xFFu) != 0u) {  // its siblings wait
+        if (sp < RTC_TRAV_STACK) {
+          if (sp < RTC_LDS_TRAV) {
+            lds_top[sp * 64] = Pair{g_base, g_bits};
+          } else {
+            stack[sp - RTC_LDS_TRAV] = Pair{g_base, g_bits};
+          }
+          ++sp;
+        } else {
+          overflow = 1u;
+        }
+      }
+#ifdef RTC_PROFILE
+      if (node >= S.n_bvh_nodes) {
+        RTC_WALK_ADD(7, 1);
+        g_bits = 0u;
+        continue;
+      }
+#endif
+      const char* const at = reinterpret_cast<const char*>(S.bvh8) + node * static_cast<uint32_t>(sizeof(Bvh8Node));
+      const uint4 h0 = *reinterpret_cast<const uint4*>(at), h1 = *reinterpret_cast<const uint4*>(at + 16);
+      const uint4 qa = *reinterpret_cast<const uint4*>(at + 32), qb = *reinterpret_cast<const uint4*>(at + 48),
+                  qc = *reinterpret_cast<const uint4*>(at + 64);
+      // per node: step / d and (origin - o) / d, widened by the margin
+      const float sx = __builtin_bit_cast(float, (h0.w & 0xFFu) << 23) * ix;
+      const float sy = __builtin_bit_cast(float, ((h0.w >> 8) & 0xFFu) << 23) * iy;
+      const float sz = __builtin_bit_cast(float, ((h0.w >> 16) & 0xFFu) << 23) * iz;
+      const float bx = (__builtin_bit_cast(float, h0.x) - ox) * ix;
+      const float by = (__builtin_bit_cast(float, h0.y) - oy) * iy;
+      const float bz = (__builtin_bit_cast(float, h0.z) - oz) * iz;
+      const float bnx = bx - mx, bfx = bx + mx, bny = by - my, bfy = by + my, bnz = bz - mz, bfz = bz + mz;
+      // q = lo_x lo_y | lo_z hi_x | hi_y hi_z, eight bytes each: the near plane of an axis is the lower one for a ray that
+      // travels up that axis
+      const uint32_t nx0 = negx ? qb.z : qa.x, nx1 = negx ? qb.w : qa.y, fx0 = negx ? qa.x : qb.z, fx1 = negx ? qa.y : qb.w;
+      const uint32_t ny0 = negy ? qc.x : qa.z, ny1 = negy ? qc.y : qa.w, fy0 = negy ? qa.z : qc.x, fy1 = negy ? qa.w : qc.y;
+      const uint32_t nz0 = negz ? qc.z : qb.x, nz1 = negz ? qc.w : qb.y, fz0 = negz ? qb.x : qc.z, fz1 = negz ? qb.y : qc.w;
+      float lo_c, hi_c;
+      vis.box_limits(lo_c, hi_c);  // (once per node, not per child)
+      uint32_t hits = 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int sh = 8 * (k & 3);
+        auto q = [&](uint32_t w0, uint32_t w1) { return static_cast<float>(((k < 4 ? w0 : w1) >> sh) & 0xFFu); };
+        const float tnx = __builtin_fmaf(q(nx0, nx1), sx, bnx), tfx = __builtin_fmaf(q(fx0, fx1), sx, bfx);
+        const float tny = __builtin_fmaf(q(ny0, ny1), sy, bny), tfy = __builtin_fmaf(q(fy0, fy1), sy, bfy);
+        const float tnz = __builtin_fmaf(q(nz0, nz1), sz, bnz), tfz = __builtin_fmaf(q(fz0, fz1), sz, bfz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, lo_c));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, hi_c));
+        hits |= (tn <= tf) ? (1u << k) : 0u;
+      }
+      const uint32_t imask = h0.w >> 24;
+      const uint32_t inner = hits & imask;
+      g_base = h1.x;
+      g_bits = (V::kAnyHit ? inner : permute_by_octant(inner, oct)) | (imask << 8);
+      l_hits = hits & (h1.y >> 24);
+      l_base = h1.y & 0xFFFFFFu;
+      meta_lo = h1.z;
+      meta_hi = h1.w;
+    }
+    if (l_hits == 0u) break;  // nothing left (or the visitor is done)
+    while (l_hits != 0u) {
+      const uint32_t k = static_cast<uint32_t>(__builtin_ctz(l_hits));
+      l_hits &= l_hits - 1u;
+      const uint32_t m = ((k < 4u ? meta_lo : meta_hi) >> (8u * (k & 3u))) & 0xFFu;
+      const uint32_t first = l_base + (m >> 2), count = (m & 3u) + 1u;
+      for (uint32_t i = 0; i < count; ++i) {
+#ifdef RTC_PROFILE
+        pw_leaves += 1ull;
+        pw_leaf_lanes += __builtin_popcountll(__ballot(true));
+#endif
+        visit(first + i);
+      }
+    }
+  }
+#ifdef RTC_PROFILE  // walks of the wave, their lanes, wave steps at nodes / at leaves, lanes at nodes / at leaves (summed over the steps)
+  RTC_WALK_ADD(0, 1);
+  RTC_WALK_ADD(1, pw_lanes);
+  RTC_WALK_ADD(2, pw_nodes);
+  RTC_WALK_ADD(3, pw_leaves);
+  RTC_WALK_ADD(4, pw_node_lanes);
+  RTC_WALK_ADD(5, pw_leaf_lanes);
+  if (pw_leaves == 0ull) RTC_WALK_ADD(6, 1);  // walks that reach no leaf at all
+#endif
+}
+#endif  // RTC_BVH8
+
 // Conservative bounding-sphere rejection for one World.objects entry, in FP32.
 // Everything under the root lies inside the sphere (radius inflated and rounded up at upload), so if the
 // LINE misses the sphere the root contributes no entry at all; the visitor may additionally discard
@@ -876,7 +1053,11 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         if (CSG && (kf & RTC_ROOT_IS_CSG)) {
           if constexpr (CSG) visit_csg(S, R.index, ray, vis, overflow);
         } else {
+#if RTC_BVH8
+          traverse_bvh8<CSG>(S, R.geom, R.always_first, R.always_count, ray, vis, overflow, reinterpret_cast<uint2*>(lds_stack));
+#else
           traverse_bvh<CSG>(S, R.geom, ray, vis, overflow, lds_stack);
+#endif
         }
       }
     }  // while (mine)
@@ -936,6 +1117,8 @@ struct ClosestVisitor {
   // - the limit below, rounded up - and tf < -1e-4 (1 + |tf|) is tf < -1e-4 / (1 - 1e-4).
   __device__ __forceinline__ float far_limit() const { return (static_cast<float>(t) * 1.0001f + 1.0001e-4f) * 1.0002f; }
   __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
+  // (the same two rules as an interval a box's [tn, tf] must meet: traverse_bvh8)
+  __device__ __forceinline__ void box_limits(float& lo, float& hi) const { lo = -1.0002e-4f; hi = far_limit(); }
   __device__ __forceinline__ bool done() const { return false; }
   // Cooperative trace (render_body, COOP): the eight lanes of an aligned group hold the SAME ray and have each tested a
   // share of World.objects; the lexicographic min of their results - the reduction is symmetric, so after three butterfly
@@ -980,6 +1163,7 @@ struct ShadowVisitor {
   }
   __device__ __forceinline__ float far_limit() const { return (static_cast<float>(distance) * 1.0001f + 1.0001e-4f) * 1.0002f; }
   __device__ __forceinline__ bool cull_limits(float tn, float tf, float limit) const { return (tf < -1.0002e-4f) | (tn > limit); }
+  __device__ __forceinline__ void box_limits(float& lo, float& hi) const { lo = -1.0002e-4f; hi = far_limit(); }
   __device__ __forceinline__ bool done() const { return shadowed; }
   __device__ __forceinline__ void merge_group(uint32_t group) {  // any lane of the aligned group of eight (or four)
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -1055,6 +1239,7 @@ struct BehindVisitor {
   __device__ __forceinline__ bool cullf(float tn, float) const { return tn > 1e-4f * (1.0f + __builtin_fabsf(tn)); }
   __device__ __forceinline__ float far_limit() const { return 0.0f; }
   __device__ __forceinline__ bool cull_limits(float tn, float, float) const { return tn > 1.0002e-4f; }  // tn > 1e-4 / (1 - 1e-4)
+  __device__ __forceinline__ void box_limits(float& lo, float& hi) const { lo = -__builtin_inff(); hi = 1.0002e-4f; }
   __device__ __forceinline__ bool done() const { return false; }
   // (every root was tested by ONE lane of the group, so the entries of a leaf did arrive together; what is merged are the
   // lanes' flushed results: the latest open leaf, the latest one other than the hit leaf, the hit leaf's own state)
@@ -1608,7 +1793,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // across the whole loop.  In LDS (one 24-byte slot per lane) it costs a read and a write per iteration instead of
   // six VGPRs of a kernel at the 256-register limit.
   __shared__ double lds_acc[4][64][3];
-  __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : RTC_LDS_TRAV][64];  // per lane: the top of the BVH walk's stack
+  // per lane: the top of the BVH walk's stack (the eight-wide walk's entries are pairs of words)
+  __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : RTC_LDS_TRAV][RTC_BVH8 ? 128 : 64];
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -1662,7 +1848,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // roughly their shares of an iteration's time; a pixel behind glass costs several times a pixel on a wall per ray)
   uint32_t share_rays = 0u;
   double* const acc = lds_acc[threadIdx.x >> 6][threadIdx.x & 63u];
-  uint32_t* const trav_stack = FLAT ? nullptr : &lds_trav[threadIdx.x >> 6][0][threadIdx.x & 63u];
+  uint32_t* const trav_stack = FLAT ? nullptr : &lds_trav[threadIdx.x >> 6][0][(RTC_BVH8 ? 2u : 1u) * (threadIdx.x & 63u)];
   acc[0] = acc[1] = acc[2] = 0.0;
   unsigned n_primary = 0, n_secondary = 0, n_shadow_calls = 0, n_shadow_traced = 0, overflow = 0, n_stolen = 0;
   Pending cur;

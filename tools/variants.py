@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds variants of librtc_hip.so with extra compiler flags and runs a command against each (GPU box).
 
-    python tools/variants.py [--keep] "name=-DFLAG -DOTHER=2" "base=" ... -- <command ...>
+    python tools/variants.py [--keep] "name=-DFLAG -DOTHER=2" "base=" ... -- <command ...> [-- <another command ...>]
     e.g.  python tools/variants.py "base=" "nofuse=-DRTC_FUSED_SHADOWS=0" -- python tools/time_scenes.py --set configs
 
 Every variant is built into gpurun_out/variants/<name>/ (rtc_kernels.o, rtc_capi.o, librtc_hip.so, with copies of the host and
@@ -21,7 +21,13 @@ argv = [a for a in argv if a != "--keep"]
 if "--" not in argv:
     sys.exit(__doc__)
 cut = argv.index("--")
-variants, command = argv[:cut], argv[cut + 1:]
+variants, rest = argv[:cut], argv[cut + 1:]
+commands = [[]]
+for a in rest:
+    if a == "--":
+        commands.append([])
+    else:
+        commands[-1].append(a)
 rc = 0
 for v in variants:
     name, _, flags = v.partition("=")
@@ -37,10 +43,11 @@ for v in variants:
         src = os.path.join(PKG, "lib", lib)
         if os.path.exists(src): shutil.copy(src, out)
     env = dict(os.environ, RTC_LIB_DIR=out)
-    p = subprocess.run(command, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    for line in p.stdout.splitlines():
-        print(f"[{name}] {line}", flush=True)
-    rc = rc or p.returncode
+    for command in commands:
+        p = subprocess.run(command, cwd=REPO, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        for line in p.stdout.splitlines():
+            print(f"[{name}] {line}", flush=True)
+        rc = rc or p.returncode
     if not keep:
         for f in os.listdir(out):
             if f.endswith(".o"): os.remove(os.path.join(out, f))
