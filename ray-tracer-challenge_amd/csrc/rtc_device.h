@@ -74,9 +74,15 @@ struct RootRec {
 #define RTC_ROOT_IS_CSG 0x4000u  // with IS_GROUP: the root is a csg unit, `index` its node
 // Small-world limits: scenes within all four get their tables staged in LDS (50.7 KB per work-group with the mailbox);
 // anything larger runs the same kernel reading the tables from memory.
+#ifndef RTC_LDS_ROOTS
 #define RTC_LDS_ROOTS 128
+#endif
+#ifndef RTC_LDS_MATERIALS
 #define RTC_LDS_MATERIALS 64
+#endif
+#ifndef RTC_LDS_PATTERNS
 #define RTC_LDS_PATTERNS 48
+#endif
 // (the three-waves-per-SIMD variant of the simple kernel: 52 KB per work-group with two levels of pending rays.  That
 // is the most three work-groups can have: at 53 KB the occupancy query still says three per CU, the hardware runs two
 // and the third of the persistent work-groups starts when the others are done - cover 0.55 -> 0.75 ms)

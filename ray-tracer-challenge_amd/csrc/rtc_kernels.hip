@@ -859,16 +859,21 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
       float lo_c, hi_c;
       vis.box_limits(lo_c, hi_c);  // (once per node, not per child)
       uint32_t hits = 0u;
+      // children k and k + 4 are the two halves of packed FP32 FMAs (v_pk_fma_f32: 24 instructions instead of 48)
+      typedef float F2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int sh = 8 * (k & 3);
-        auto q = [&](uint32_t w0, uint32_t w1) { return static_cast<float>(((k < 4 ? w0 : w1) >> sh) & 0xFFu); };
-        const float tnx = __builtin_fmaf(q(nx0, nx1), sx, bnx), tfx = __builtin_fmaf(q(fx0, fx1), sx, bfx);
-        const float tny = __builtin_fmaf(q(ny0, ny1), sy, bny), tfy = __builtin_fmaf(q(fy0, fy1), sy, bfy);
-        const float tnz = __builtin_fmaf(q(nz0, nz1), sz, bnz), tfz = __builtin_fmaf(q(fz0, fz1), sz, bfz);
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, lo_c));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, hi_c));
-        hits |= (tn <= tf) ? (1u << k) : 0u;
+      for (int k = 0; k < 4; ++k) {
+        const int sh = 8 * k;
+        auto q2 = [&](uint32_t w0, uint32_t w1) { return F2{static_cast<float>((w0 >> sh) & 0xFFu), static_cast<float>((w1 >> sh) & 0xFFu)}; };
+        const F2 tnx = __builtin_elementwise_fma(q2(nx0, nx1), F2(sx), F2(bnx)), tfx = __builtin_elementwise_fma(q2(fx0, fx1), F2(sx), F2(bfx));
+        const F2 tny = __builtin_elementwise_fma(q2(ny0, ny1), F2(sy), F2(bny)), tfy = __builtin_elementwise_fma(q2(fy0, fy1), F2(sy), F2(bfy));
+        const F2 tnz = __builtin_elementwise_fma(q2(nz0, nz1), F2(sz), F2(bnz)), tfz = __builtin_elementwise_fma(q2(fz0, fz1), F2(sz), F2(bfz));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float tn = fmaxf(fmaxf(tnx[e], tny[e]), fmaxf(tnz[e], lo_c));
+          const float tf = fminf(fminf(tfx[e], tfy[e]), fminf(tfz[e], hi_c));
+          hits |= (tn <= tf) ? (1u << (k + 4 * e)) : 0u;
+        }
       }
       const uint32_t imask = h0.w >> 24;
       const uint32_t inner = hits & imask;
