@@ -49,7 +49,7 @@ struct RtcOptions {
   double pull_min_idle = 64.0;       // idle lanes before a wave pulls its next packet
   double blocks_per_cu = 0.0;        // cap on resident work-groups per CU
   double sched_tmin = 0.0;           // time up to which cheap chunks share a packet
-  double bvh_leaf = 2.0;             // leaves per candidate-BVH leaf
+  double bvh_leaf = RTC_BVH8 ? 1.0 : 2.0;  // leaves per candidate-BVH leaf (eight-wide tree, 1 / 2 / 3 / 4: dragons 4K 2.03 / 2.10 / 2.18 / 2.30 ms, nefertiti 0.522 / 0.534 / 0.548 / 0.562, teapot 0.264 / 0.265 / 0.263 / 0.272)
   double bvh_one_axis = 0.0;         // != 0: SAH on the longest axis only
   double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
   double host_bands = 0.0;           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
