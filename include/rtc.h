@@ -40,12 +40,13 @@
  *   - more than 64 csg nodes under one csg: RTC_ERR_UNSUPPORTED at create;
  *   - a lane's list of the intersections of one ray with one csg unit (the list
  *     Csg.filterIntersections works on, csg.zig:51-95) starts with 32 slots: when a
- *     frame needs more, rtc_render / rtc_render_rgba8 double them and render again
- *     (up to 1024; the handle keeps the longer lists), while the asynchronous
+ *     frame needs more, the frame itself says how many (the longest list any lane
+ *     wanted): rtc_render / rtc_render_rgba8 size the lists for that and render
+ *     again (up to 1024; the handle keeps the longer lists), while the asynchronous
  *     entry points count the lanes that ran out in rtc_stats::overflow - callers
- *     check rtc_get_stats (one synchronous render of the view sizes the lists);
- *     beyond 1024 entries, or a group tree deeper than the traversal stack:
- *     RTC_ERR_OVERFLOW, never a truncated image;
+ *     check rtc_get_stats and call rtc_grow_csg_lists, then render the frame again
+ *     (rtc_multi.h does that for its handles); beyond 1024 entries, or a group tree
+ *     deeper than the traversal stack: RTC_ERR_OVERFLOW, never a truncated image;
  *   - two leaves with the same Shape.id: RTC_ERR_UNSUPPORTED (identity in the
  *     containers walk is the leaf);
  *   - reproducibility: geometry and every branch are bit-identical from run to
@@ -367,11 +368,37 @@ int rtc_assemble_tiles_device(const double *d_gathered, uint32_t world, uint32_t
                               uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize,
                               double *d_canvas, void *hip_stream);
 
+/*
+ * A rank's compact tiles (as rtc_render_tile_list_device leaves them: d_tiles[k] is tile d_tile_list[k]) written
+ * straight to their places in a row-major canvas [vsize][hsize][3] - `canvas` being any memory the current device can
+ * write: device memory, or the caller's host canvas after rtc_canvas_register (pinned and mapped).  With a registered
+ * host canvas every GPU of a split frame sends its own share over its own host link; nothing funnels through rank 0
+ * (rtc_multi.h does this for its host forms).  Pixels of edge tiles outside the image are skipped.  The _rgba8 form
+ * clamps on the way (color.zig:61-71) into [vsize][hsize] RGBA8.  d_tile_list is device memory.  Asynchronous on
+ * `hip_stream` (not NULL), on the current device.  Needs no scene.  Replaces Canvas writes of camera.zig:119-121.
+ */
+int rtc_scatter_tile_list_device(const double *d_tiles, const uint32_t *d_tile_list, uint32_t n_tiles, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t hsize, uint32_t vsize, double *canvas, void *hip_stream);
+int rtc_scatter_tile_list_rgba8_device(const double *d_tiles, const uint32_t *d_tile_list, uint32_t n_tiles,
+                                       uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize, uint32_t *rgba,
+                                       void *hip_stream);
+
 /* Waits for the work enqueued on the handle's own stream. */
 int rtc_scene_synchronize(rtc_scene *scene);
 
 /* Counters of the last render that was enqueued on this handle (synchronises). */
 int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
+
+/*
+ * For callers of the asynchronous entry points, after a frame whose rtc_stats::overflow is not 0 on a scene with csg
+ * nodes (Csg.filterIntersections' list, csg.zig:51-95, is of any length in the reference; a lane's list here is a
+ * buffer): waits for the handle's last launch and, if what ran out was a csg intersection list, sizes the handle's lists
+ * for what that frame needed (in one step, up to 1024 entries).  RTC_OK: the lists are longer now (or nothing had
+ * overflowed) - render the frame again; RTC_ERR_OVERFLOW: the overflow was not a csg list's, or the lists are at their
+ * maximum; RTC_ERR_OUT_OF_MEMORY (at the next render): the longer lists do not fit, the handle keeps the old ones.
+ * rtc_render and rtc_render_rgba8 do this by themselves.
+ */
+int rtc_grow_csg_lists(rtc_scene *scene);
 
 /* Diagnostic: the name of the render kernel the last launch on this handle ran
  * (the name rocprofv3 shows - which variant is picked depends on what the world

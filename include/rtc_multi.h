@@ -47,6 +47,15 @@ void rtc_multi_destroy(rtc_multi *m);
  * Camera.render (camera.zig:80-125) of the whole image on all GPUs: rgb_out[y * hsize + x][0..2], host memory,
  * [vsize][hsize][3] doubles.  Synchronous.  Status codes and names as in rtc.h; RTC_ERR_NO_DEVICE carries RCCL
  * failures too.
+ * Where the frame goes depends on the canvas: a canvas the caller has handed to rtc_canvas_register (pinned, mapped
+ * into every GPU) is written IN PLACE BY EVERY RANK - each GPU sends its own tiles over its own host link
+ * (rtc_scatter_tile_list_device), no gather, nothing through GPU 0; a pageable canvas gets the frame the *_device forms
+ * produce (one RCCL gather to GPU 0) and one copy over GPU 0's link.  Same bytes either way.  (4K f64: 199 MB over one
+ * link is ~3.8 ms at the 53 GB/s measured; an eighth of it over each of eight links ~0.5 ms.)  rtc_multi_render_rgba8
+ * does the same with 4 bytes per pixel.
+ * A frame whose csg intersection lists ran out (rtc.h, limits) has them enlarged on the handles concerned
+ * (rtc_grow_csg_lists) and is rendered again here; the *_device forms report that frame's RTC_ERR_OVERFLOW once (at
+ * the next call that finishes its slot) and render the frames after it with the longer lists.
  */
 int rtc_multi_render(rtc_multi *m, const rtc_camera *cam, uint32_t max_depth, double *rgb_out);
 

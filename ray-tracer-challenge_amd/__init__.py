@@ -91,8 +91,8 @@ class Stats(C.Structure):
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
-               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
-               "rtc_status_name", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scatter_tile_list_device", "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
+               "rtc_status_name", "rtc_grow_csg_lists", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
@@ -157,6 +157,7 @@ def hip_lib():
         lib.rtc_assemble_tile_list_rgba8_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_uint32] * 4 + [C.c_void_p, C.c_void_p]
         lib.rtc_scene_synchronize.argtypes = [C.c_void_p]
         lib.rtc_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        lib.rtc_grow_csg_lists.argtypes = [C.c_void_p]
         lib.rtc_last_kernel_name.argtypes = [C.c_void_p]
         lib.rtc_last_kernel_name.restype = C.c_char_p
         lib.rtc_get_schedule.argtypes = [C.c_void_p, _u32p, C.c_size_t, _u32p]

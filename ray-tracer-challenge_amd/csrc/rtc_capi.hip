@@ -15,6 +15,11 @@
 #include "../../include/rtc.h"
 #include "rtc_device.h"
 
+extern "C" __global__ void rtc_scatter_tiles_kernel(const double* tiles, const uint32_t* tile_list, const uint32_t n_tiles, const uint32_t tile_w,
+                                                    const uint32_t tile_h, const uint32_t hsize, const uint32_t vsize, double* canvas);
+extern "C" __global__ void rtc_scatter_tiles_rgba8_kernel(const double* tiles, const uint32_t* tile_list, const uint32_t n_tiles,
+                                                          const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
+                                                          const uint32_t vsize, uint32_t* rgba);
 extern "C" __global__ void rtc_render_kernel(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                              const uint32_t max_depth, double* __restrict__ out,
                                              DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
@@ -324,18 +329,23 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   plan = SchedulePlan{};
   const uint32_t* mp = reinterpret_cast<const uint32_t*>(&map);
   std::vector<uint32_t> mkey(mp, mp + offsetof(DevPixelMap, n_units) / sizeof(uint32_t));
+  bool new_map = false;
   if (mkey != s->cost_key) {
     s->cost_key = mkey;
     s->sched_valid = false;
+    new_map = true;
   }
+  // Pixels of edge tiles that lie outside the image are never written by a launch, and rtc_chunk_cost_kernel sums whole
+  // tiles: they must read as zero.  A NEW pixel map (another tile list after a re-deal, another rectangle) re-uses the
+  // buffer with other tiles in the slots, so what the old map left there is cleared - on the stream, before the launch.
+  if (new_map && s->d_cost != nullptr && out_pixels <= s->cost_capacity)
+    HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
   if (out_pixels > s->cost_capacity) {
     HIP_TRY(hipEventSynchronize(s->launch_done));
     if (s->d_cost) (void)hipFree(s->d_cost);
     s->d_cost = nullptr;
     s->cost_capacity = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_cost), out_pixels * sizeof(uint32_t)));
-    // (pixels of edge tiles outside the image are never written by a launch, and rtc_chunk_cost_kernel sums whole tiles:
-    // they must read as zero, once is enough)
     HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
     s->cost_capacity = out_pixels;
   }
@@ -437,9 +447,19 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
       if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
       s->d_csg_buf = nullptr;
       s->csg_buf_capacity = 0;
-      HIP_TRY(hipMalloc(&s->d_csg_buf, need_csg));
+      if (hipMalloc(&s->d_csg_buf, need_csg) != hipSuccess) {
+        // The longer lists do not fit: the handle goes back to the length that last rendered (its buffer is allocated
+        // again by the next launch), so later renders work as before instead of failing for good.
+        (void)hipGetLastError();
+        s->d_csg_buf = nullptr;
+        const uint32_t wanted = s->dev.csg_entries;
+        s->dev.csg_entries = s->csg_entries_ok;
+        return fail(RTC_ERR_OUT_OF_MEMORY, "csg intersection lists of %u entries per lane need %zu bytes; the handle keeps %u entries", wanted,
+                    need_csg, s->csg_entries_ok);
+      }
       s->csg_buf_capacity = need_csg;
     }
+    s->csg_entries_ok = s->dev.csg_entries;
     s->dev.csg_buf = static_cast<CsgRec*>(s->d_csg_buf);
   }
   return RTC_OK;
@@ -1781,29 +1801,55 @@ int ensureFrame(rtc_scene* s, size_t doubles) {
 // A lane that ran out of traversal stack, pending-ray stack or csg list space has dropped work: the image is not the
 // reference's.  Say so instead of returning it (asynchronous callers check rtc_get_stats).
 int checkOverflow(rtc_scene* s) {
-  unsigned long long dropped = 0;
-  HIP_TRY(hipMemcpy(&dropped, &(s->d_stats + s->stats_parity)->overflow, sizeof dropped, hipMemcpyDeviceToHost));
-  if (dropped) return fail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", dropped);
+  // (overflow and csg_needed share the cache line of `overflow`: one copy)
+  struct {
+    unsigned long long dropped;
+    unsigned int csg_needed;
+  } h{0, 0};
+  const DevStats* st = s->d_stats + s->stats_parity;
+  static_assert(offsetof(DevStats, csg_needed) == offsetof(DevStats, overflow) + sizeof(unsigned long long), "one copy reads both");
+  HIP_TRY(hipMemcpy(&h, &st->overflow, sizeof(unsigned long long) + sizeof(unsigned int), hipMemcpyDeviceToHost));
+  s->csg_needed = h.csg_needed;
+  if (h.dropped) {
+    if (h.csg_needed)
+      return fail(RTC_ERR_OVERFLOW, "%llu lanes ran out of csg intersection list (%u entries; a list of up to %u was needed)", h.dropped,
+                  s->dev.csg_entries, h.csg_needed);
+    return fail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack", h.dropped);
+  }
   return RTC_OK;
 }
 
 // Csg.filterIntersections works on a list of any length (csg.zig:51-95); a lane's list here has DevScene::csg_entries
-// slots in HBM.  The synchronous entry points render again with twice the slots when a frame of a scene with csg nodes
-// reports an overflow (the traversal and pending-ray stacks are sized or refused at create, so the list is what was
-// short), up to RTC_CSG_ENTRIES_MAX; the handle keeps the larger list.  Returns true if another attempt is worth it.
+// slots in HBM.  A frame whose lists ran out says how long the longest one had to be (DevStats::csg_needed, read by
+// checkOverflow): the lists are sized for that in ONE step (the next power of two, up to RTC_CSG_ENTRIES_MAX) and the
+// handle keeps them.  Only a csg list's overflow is answered this way - a traversal or pending-ray stack that ran out is
+// not fixed by longer lists (those are sized or refused at create).  Returns true if another attempt is worth it.
 bool growCsgLists(rtc_scene* s) {
-  if (!s->has_csg || s->dev.csg_entries >= RTC_CSG_ENTRIES_MAX) return false;
-  s->dev.csg_entries *= 2u;
+  if (!s->has_csg || s->csg_needed <= s->dev.csg_entries || s->dev.csg_entries >= RTC_CSG_ENTRIES_MAX) return false;
+  uint32_t want = s->dev.csg_entries;
+  while (want < s->csg_needed && want < RTC_CSG_ENTRIES_MAX) want *= 2u;
+  s->dev.csg_entries = want;
+  s->csg_needed = 0;
   g_error.clear();
   return true;
 }
 
 }  // namespace
 
+int rtc_grow_csg_lists(rtc_scene* s) {
+  g_error.clear();
+  if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->launch_done));
+  const int ov = checkOverflow(s);
+  if (ov != RTC_ERR_OVERFLOW) return ov;  // (RTC_OK: nothing overflowed, nothing to do)
+  return growCsgLists(s) ? RTC_OK : ov;
+}
+
 int rtc_canvas_register(void* canvas, size_t bytes) {
   g_error.clear();
   if (!canvas || bytes == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "null canvas or no bytes");
-  HIP_TRY(hipHostRegister(canvas, bytes, hipHostRegisterPortable));
+  HIP_TRY(hipHostRegister(canvas, bytes, hipHostRegisterPortable | hipHostRegisterMapped));  // (mapped: every GPU of the node may write it)
   return RTC_OK;
 }
 
@@ -1958,6 +2004,34 @@ int rtc_assemble_tiles_device(const double* d_gathered, uint32_t world, uint32_t
   const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
   hipLaunchKernelGGL(rtc_assemble_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_gathered,
                      world, padded_tiles, tile_w, tile_h, hsize, vsize, d_canvas);
+  HIP_TRY(hipGetLastError());
+  return RTC_OK;
+}
+
+int rtc_scatter_tile_list_device(const double* d_tiles, const uint32_t* d_tile_list, uint32_t n_tiles, uint32_t tile_w,
+                                 uint32_t tile_h, uint32_t hsize, uint32_t vsize, double* canvas, void* hip_stream) {
+  g_error.clear();
+  if (!d_tiles || !d_tile_list || !canvas || !hip_stream) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_tiles == 0 || tile_w == 0 || tile_h == 0 || hsize == 0 || vsize == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "%u tiles of %ux%u, image %ux%u", n_tiles, tile_w, tile_h, hsize, vsize);
+  const size_t n = static_cast<size_t>(n_tiles) * tile_w * tile_h * 3u;
+  const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
+  hipLaunchKernelGGL(rtc_scatter_tiles_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_tiles, d_tile_list,
+                     n_tiles, tile_w, tile_h, hsize, vsize, canvas);
+  HIP_TRY(hipGetLastError());
+  return RTC_OK;
+}
+
+int rtc_scatter_tile_list_rgba8_device(const double* d_tiles, const uint32_t* d_tile_list, uint32_t n_tiles, uint32_t tile_w,
+                                       uint32_t tile_h, uint32_t hsize, uint32_t vsize, uint32_t* rgba, void* hip_stream) {
+  g_error.clear();
+  if (!d_tiles || !d_tile_list || !rgba || !hip_stream) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_tiles == 0 || tile_w == 0 || tile_h == 0 || hsize == 0 || vsize == 0)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "%u tiles of %ux%u, image %ux%u", n_tiles, tile_w, tile_h, hsize, vsize);
+  const size_t n = static_cast<size_t>(n_tiles) * tile_w * tile_h;
+  const uint32_t blocks = static_cast<uint32_t>(std::min<size_t>((n + 255) / 256, 256u * 64u));
+  hipLaunchKernelGGL(rtc_scatter_tiles_rgba8_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_tiles,
+                     d_tile_list, n_tiles, tile_w, tile_h, hsize, vsize, rgba);
   HIP_TRY(hipGetLastError());
   return RTC_OK;
 }

@@ -319,7 +319,8 @@ struct DevStats {
   alignas(128) unsigned long long secondary;
   alignas(128) unsigned long long shadow_calls;
   alignas(128) unsigned long long shadow_traced;
-  alignas(128) unsigned long long overflow;
+  alignas(128) unsigned long long overflow;  // lanes that ran out of a per-lane stack or csg list
+  unsigned int csg_needed;               // ... if a csg list was what ran out: the longest list any lane needed (an upper bound)
   unsigned int stolen;                   // rays handed from one lane to another (diagnostic)
 #ifdef RTC_PROFILE          // diagnostic builds only (cleared by a host memset there)
   unsigned long long prof[16];  // wave cycles per section

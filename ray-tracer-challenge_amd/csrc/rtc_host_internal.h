@@ -126,6 +126,8 @@ struct rtc_scene {
   bool simple3_ok = false;         // a simple world whose tables fit the three-waves-per-SIMD kernel's LDS (RTC_LDS3_*)
   void* d_csg_buf = nullptr;       // DevPixelMap::csg_buf, only for scenes with csg nodes
   size_t csg_buf_capacity = 0;     // bytes
+  uint32_t csg_entries_ok = RTC_CSG_ENTRIES;  // the list length the buffer was last allocated for (what a failed enlargement falls back to)
+  uint32_t csg_needed = 0;         // what the last checked frame said its longest csg list needed (0: no csg list ran out)
   uint32_t max_trav_stack = 0;
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1, blocks_per_cu_simple3 = 1;
   // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next

@@ -472,7 +472,7 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
                       (threadIdx.x & 63u);
   const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
   const uint2 range = S.node_range[unit];
-  uint32_t n = 0;
+  uint32_t n = 0, dropped = 0;
   uint32_t cur_xf = 0xFFFFFFFFu;
   Ray lr = ray;
   for (uint32_t leaf = range.x; leaf < range.x + range.y; ++leaf) {
@@ -494,8 +494,8 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
         boxes = chain_ok(S, S.leaf_parent[leaf], ray, t, degenerate);
       }
       if (!boxes) return;
-      if (n >= S.csg_entries) {
-        overflow = 1u;
+      if (n >= S.csg_entries) {  // the list is full: keep counting what it would have needed (the host sizes it by that)
+        ++dropped;
         return;
       }
       // insertion sort by t, stable (equal t: the later entry stays behind)
@@ -514,6 +514,9 @@ __device__ __noinline__ uint32_t csg_collect(const DevScene& S, uint32_t unit, c
       ++n;
     });
   }
+  // (the lane's overflow word: bit 0 = a per-lane stack ran out; bits 8 and up = entries a csg list needed, OR-ed over the
+  // lists that ran out: an upper bound of the longest, within a factor of two)
+  if (dropped != 0u) overflow |= (n + dropped) << 8;
   unsigned long long inl = 0ull, inr = 0ull;  // one bit per csg node of the unit (node_info slot, < 64)
   for (uint32_t i = 0; i < n; ++i) {
     const uint32_t leaf = buf[static_cast<size_t>(i) * 64u].leaf;
@@ -672,7 +675,7 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
       }
       if (entered == 0) continue;
       if (sp + entered > RTC_TRAV_STACK) {
-        overflow = 1u;
+        overflow |= 1u;
         continue;
       }
       // farthest first, so that the nearest child is popped first (children not entered carry +inf and sort to the front)
@@ -829,7 +832,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
           }
           ++sp;
         } else {
-          overflow = 1u;
+          overflow |= 1u;
         }
       }
 #ifdef RTC_PROFILE
@@ -2518,7 +2521,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           if (sp < stack_cap) {
             push_level(sp++, p);
           } else {
-            overflow = 1u;
+            overflow |= 1u;
           }
         }
       } else {
@@ -2574,7 +2577,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           if (sp < stack_cap) {
             push_level(sp++, yield.kid_later);
           } else {
-            overflow = 1u;
+            overflow |= 1u;
           }
         }
         if (yield.n_kids != 0u) {
@@ -2612,7 +2615,12 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (threadIdx.x < 6u) wg_sum[threadIdx.x] = 0ull;
     __syncthreads();  // (every wave of the group gets here: the loop above ends for all of them)
     const unsigned long long s_pri = wave_sum(n_primary), s_sec = wave_sum(n_secondary), s_shc = wave_sum(n_shadow_calls),
-                             s_sht = wave_sum(n_shadow_traced), s_ovf = wave_sum(overflow), s_stolen = wave_sum(n_stolen);
+                             s_sht = wave_sum(n_shadow_traced), s_ovf = wave_sum(overflow != 0u ? 1u : 0u), s_stolen = wave_sum(n_stolen);
+    if (__any((overflow >> 8) != 0u)) {  // a csg list ran out somewhere in the wave: what it needed (rare: straight to memory)
+      unsigned need = overflow >> 8;
+      for (int off = 32; off > 0; off >>= 1) need = max(need, static_cast<unsigned>(__shfl_xor(need, off, 64)));
+      if (lane == 0u) atomicMax(&stats->csg_needed, need);
+    }
     if (lane == 0u) {
       atomicAdd(&wg_sum[0], s_pri);
       atomicAdd(&wg_sum[1], s_sec);
@@ -2773,6 +2781,53 @@ rtc_assemble_list_rgba8_kernel(const uint32_t* __restrict__ gathered, const uint
     const uint32_t y = static_cast<uint32_t>(i / hsize), x = static_cast<uint32_t>(i - static_cast<size_t>(y) * hsize);
     const uint32_t slot = slot_of_tile[(y / tile_h) * tiles_x + x / tile_w];
     rgba[i] = gathered[(static_cast<size_t>(slot) * tile_h + y % tile_h) * tile_w + x % tile_w];
+  }
+}
+
+// A rank's compact tiles written straight to where they belong in a row-major canvas - the canvas being any memory the
+// device can write, in particular the caller's REGISTERED host canvas (rtc_canvas_register: pinned and mapped): every
+// GPU of a split frame then sends its own share over its own host link, 64-pixel rows at a time, instead of all shares
+// funnelling through GPU 0 and one link (rtc_multi.h, host forms).  tiles[k] is tile tile_list[k] of the tiling.
+// One thread per channel value; pixels of edge tiles outside the image are skipped.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_scatter_tiles_kernel(const double* __restrict__ tiles, const uint32_t* __restrict__ tile_list, const uint32_t n_tiles,
+                         const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize, const uint32_t vsize,
+                         double* __restrict__ canvas) {
+  const uint32_t tiles_x = (hsize + tile_w - 1u) / tile_w;
+  const size_t per_tile = static_cast<size_t>(tile_w) * tile_h * 3u, n = per_tile * n_tiles;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const uint32_t k = static_cast<uint32_t>(i / per_tile);
+    const uint32_t in = static_cast<uint32_t>(i - k * per_tile);
+    const uint32_t ly = in / (tile_w * 3u), lx3 = in - ly * (tile_w * 3u);
+    const uint32_t tile = tile_list[k], ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t y = ty * tile_h + ly, x3 = tx * tile_w * 3u + lx3;
+    if (y < vsize && x3 < hsize * 3u) __builtin_nontemporal_store(tiles[i], canvas + static_cast<size_t>(y) * hsize * 3u + x3);
+  }
+}
+
+// The same with the clamp of color.zig:61-71 on the way (rtc_rgba8_kernel): one thread per pixel, 4 bytes per pixel leave.
+extern "C" __global__ void __launch_bounds__(256)
+rtc_scatter_tiles_rgba8_kernel(const double* __restrict__ tiles, const uint32_t* __restrict__ tile_list, const uint32_t n_tiles,
+                               const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize, const uint32_t vsize,
+                               uint32_t* __restrict__ rgba) {
+  const uint32_t tiles_x = (hsize + tile_w - 1u) / tile_w;
+  const size_t per_tile = static_cast<size_t>(tile_w) * tile_h, n = per_tile * n_tiles;
+  auto clamp = [](double channel) -> uint32_t {
+    const double t = round(channel * 255);
+    if (!(t >= 0)) return 0u;
+    if (t > 255) return 255u;
+    return static_cast<uint32_t>(t);
+  };
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const uint32_t k = static_cast<uint32_t>(i / per_tile);
+    const uint32_t in = static_cast<uint32_t>(i - k * per_tile);
+    const uint32_t ly = in / tile_w, lx = in - ly * tile_w;
+    const uint32_t tile = tile_list[k], ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const uint32_t y = ty * tile_h + ly, x = tx * tile_w + lx;
+    if (y < vsize && x < hsize) {
+      const double r = tiles[3 * i], g = tiles[3 * i + 1], b = tiles[3 * i + 2];
+      __builtin_nontemporal_store(clamp(r) | (clamp(g) << 8) | (clamp(b) << 16) | 0xFF000000u, rgba + static_cast<size_t>(y) * hsize + x);
+    }
   }
 }
 

@@ -93,6 +93,8 @@ struct rtc_multi {
   uint32_t redeals_in_a_row = 0;   // (a re-deal that the very next frame's measurement did not confirm is done again, three times at most)
   rtc_camera balance_cam{};
   double max_over_mean = 0.0;
+  bool csg_grown = false;           // finishSlot enlarged csg lists after an overflow: the synchronous entry points render again
+  std::vector<uint32_t*> d_list;    // [n] a rank's tile list on its device (the direct host forms scatter by it)
 };
 
 namespace {
@@ -104,7 +106,25 @@ void setLists(rtc_multi* m) {
   for (uint32_t t = 0; t < m->n_tiles; ++t) m->tiles_of[m->rank_of[t]].push_back(t);  // increasing tile order = slot order
 }
 
+// The ranks' tile lists on their devices (for rtc_scatter_tile_list_device); called with every frame finished.
+int uploadLists(rtc_multi* m) {
+  if (m->d_list.size() != m->n) m->d_list.assign(m->n, nullptr);
+  for (uint32_t r = 0; r < m->n; ++r) {
+    M_HIP(hipSetDevice(m->dev[r]));
+    if (!m->d_list[r]) M_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_list[r]), std::max<size_t>(1, m->padded) * sizeof(uint32_t)));
+    if (!m->tiles_of[r].empty())
+      M_HIP(hipMemcpy(m->d_list[r], m->tiles_of[r].data(), m->tiles_of[r].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  return RTC_OK;
+}
+
 void freeFrameBuffers(rtc_multi* m) {
+  for (uint32_t r = 0; r < m->d_list.size(); ++r)
+    if (m->d_list[r]) {
+      (void)hipSetDevice(m->dev[r]);
+      (void)hipFree(m->d_list[r]);
+    }
+  m->d_list.clear();
   for (Slot& S : m->slot) {
     for (uint32_t r = 0; r < S.d_buf.size(); ++r)
       if (S.d_buf[r]) {
@@ -178,7 +198,7 @@ int sizeForUnguarded(rtc_multi* m, const rtc_camera& cam) {
   }
   setLists(m);
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
-  return RTC_OK;
+  return uploadLists(m);
 }
 
 // The RGBA8 side of the frame buffers (per slot and rank the clamped tiles, on device 0 the gathered ones and the ring of
@@ -222,6 +242,16 @@ int ensureRgbaBuffers(rtc_multi* m) {
   const int st = make();
   if (st != RTC_OK) undo();
   return st;
+}
+
+// Is `p` host memory the GPUs can write in place - a canvas the caller handed to rtc_canvas_register?
+bool registeredHost(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // (plain pageable memory: not an error)
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr;
 }
 
 int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal);
@@ -302,6 +332,7 @@ int rebalance(rtc_multi* m, uint32_t f, const rtc_camera& cam, bool confirm) {
   setLists(m);
   M_HIP(hipSetDevice(m->dev[0]));
   M_HIP(hipMemcpy(m->d_slot, m->slot_of.data(), m->n_tiles * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (const int st = uploadLists(m); st != RTC_OK) return st;
   m->max_over_mean = imbalance();
   m->balanced = true;
   m->frames_since_balance = 0;
@@ -335,7 +366,31 @@ int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal) {
   if (const int st = drainSlot(m, f); st != RTC_OK) return st;
   rtc_stats st;
   if (const int s = slotStats(m, f, &st); s != RTC_OK) return s;
-  if (st.overflow) return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list", (unsigned long long)st.overflow);
+  if (st.overflow) {
+    // A csg intersection list that ran out is made longer on EVERY handle (all slots, all ranks: the next frame may run
+    // anywhere) - rtc_grow_csg_lists sizes it for what the frame needed.  The synchronous entry points then render the
+    // frame again; the asynchronous ones report this frame's overflow once, and the frames after it have the longer lists.
+    bool grown = false, stuck = false;
+    for (uint32_t r = 0; r < m->n; ++r) {
+      if (m->tiles_of.size() > r && m->tiles_of[r].empty()) continue;
+      M_HIP(hipSetDevice(m->dev[r]));
+      rtc_stats rs;
+      M_RTC(rtc_get_stats(S.scene[r], &rs));
+      if (rs.overflow == 0) continue;
+      if (rtc_grow_csg_lists(S.scene[r]) == RTC_OK) {
+        grown = true;
+      } else {
+        stuck = true;
+      }
+    }
+    if (grown && !stuck) {
+      // the other handles follow: a render with the same lists would overflow there as well.  (They have no overflow of
+      // their own to size by: one synchronous pass over them is the frame they render next.)
+      m->csg_grown = true;
+    }
+    return mfail(RTC_ERR_OVERFLOW, "%llu lanes overflowed a per-lane stack or csg list%s", (unsigned long long)st.overflow,
+                 (grown && !stuck) ? " (the csg lists have been enlarged: render the frame again)" : "");
+  }
   m->frames_since_balance++;
   const rtc_camera cam = S.cam;
   const bool moved = std::memcmp(&cam, &m->balance_cam, sizeof cam) != 0;
@@ -349,13 +404,14 @@ int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal) {
 // rank 0 (each rank's send is ordered behind its render), one kernel un-permutes them into the next canvas of the ring
 // on device 0, on the slot's stream of rank 0.  Only the frame that last ran on this slot is waited for: with several
 // slots the frames before this one are still rendering.
-int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, bool rgba8, void** d_out, uint32_t* slot_out) {
+int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, bool rgba8, void** d_out, uint32_t* slot_out,
+                 void* host_out = nullptr) {
   if (!m || !cam) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   if (cam->hsize == 0 || cam->vsize == 0) return mfail(RTC_ERR_INVALID_ARGUMENT, "camera %ux%u", cam->hsize, cam->vsize);
   const uint32_t f = m->next_slot;
   if (const int st = finishSlot(m, f, true); st != RTC_OK) return st;
   if (const int st = sizeFor(m, *cam); st != RTC_OK) return st;
-  if (rgba8)
+  if (rgba8 && !host_out)
     if (const int st = ensureRgbaBuffers(m); st != RTC_OK) return st;
   Slot& S = m->slot[f];
   const size_t tile_pixels = static_cast<size_t>(m->padded) * kTile * kTile;
@@ -364,6 +420,23 @@ int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, bool r
     M_HIP(hipSetDevice(m->dev[r]));
     M_RTC(rtc_render_tile_list_device(S.scene[r], cam, max_depth, kTile, kTile, m->tiles_of[r].data(),
                                       static_cast<uint32_t>(m->tiles_of[r].size()), S.d_buf[r], S.stream[r]));
+    if (host_out) {
+      // The caller's canvas is registered (pinned, mapped into every GPU): each rank writes its own tiles straight to
+      // their places in it over its OWN host link - no gather, no un-permute, nothing through GPU 0's one link (at 4K:
+      // 199 MB over one link ~3.8 ms; an eighth of it over each of eight ~0.5 ms).  Camera.render's consumer is a host
+      // Canvas (camera.zig:80-102); the *_device forms keep the single RCCL gather.
+      void* dev_view = nullptr;
+      M_HIP(hipHostGetDevicePointer(&dev_view, host_out, 0));
+      const uint32_t mine = static_cast<uint32_t>(m->tiles_of[r].size());
+      if (rgba8) {
+        M_RTC(rtc_scatter_tile_list_rgba8_device(S.d_buf[r], m->d_list[r], mine, kTile, kTile, cam->hsize, cam->vsize,
+                                                 static_cast<uint32_t*>(dev_view), S.stream[r]));
+      } else {
+        M_RTC(rtc_scatter_tile_list_device(S.d_buf[r], m->d_list[r], mine, kTile, kTile, cam->hsize, cam->vsize,
+                                           static_cast<double*>(dev_view), S.stream[r]));
+      }
+      continue;
+    }
     // (an RGBA8 frame is clamped where it was rendered: 4 bytes per pixel go through the gather instead of 24)
     if (rgba8) M_RTC(rtc_rgba8_device(S.d_buf[r], tile_pixels, S.d_rgba_buf[r], S.stream[r]));
   }
@@ -371,6 +444,16 @@ int enqueueFrame(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, bool r
   S.cam = *cam;
   m->last_slot = f;
   m->next_slot = (f + 1u) % m->frames;
+  if (host_out) {  // every rank's stream ends with its own writes into the canvas: finishSlot drains them all
+    if (!m->virt)
+      for (uint32_t r = 0; r < m->n; ++r) {  // (the `sent` events of a gather that did not happen: nothing to wait for)
+        M_HIP(hipSetDevice(m->dev[r]));
+        M_HIP(hipEventRecord(S.sent[r], S.stream[r]));
+      }
+    *d_out = nullptr;
+    *slot_out = f;
+    return RTC_OK;
+  }
   const size_t slab = slabDoubles(m);
   if (!m->virt) {
     for (uint32_t r = 0; r < m->n; ++r) {
@@ -526,23 +609,37 @@ void rtc_multi_destroy(rtc_multi* m) {
 int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, double* rgb_out) {
   g_multi_error.clear();
   if (!rgb_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  void* d_canvas = nullptr;
-  uint32_t f = 0;
-  if (const int st = enqueueFrame(m, cam, max_depth, false, &d_canvas, &f); st != RTC_OK) return st;
-  M_HIP(hipMemcpyAsync(rgb_out, d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
-                       hipMemcpyDeviceToHost, m->slot[f].stream[0]));
-  return finishSlot(m, f, true);
+  for (int attempt = 0;; ++attempt) {  // (again while a frame's csg lists ran out and could be enlarged: each handle at most six times)
+    void* d_canvas = nullptr;
+    uint32_t f = 0;
+    void* const direct = registeredHost(rgb_out) ? rgb_out : nullptr;
+    if (const int st = enqueueFrame(m, cam, max_depth, false, &d_canvas, &f, direct); st != RTC_OK) return st;
+    if (!direct)  // (a pageable canvas: gathered to GPU 0, one copy over its link)
+      M_HIP(hipMemcpyAsync(rgb_out, d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
+                           hipMemcpyDeviceToHost, m->slot[f].stream[0]));
+    const int st = finishSlot(m, f, true);
+    if (st != RTC_ERR_OVERFLOW || !m->csg_grown || attempt >= 6 * static_cast<int>(m->frames)) return st;
+    m->csg_grown = false;
+    g_multi_error.clear();
+  }
 }
 
 int rtc_multi_render_rgba8(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, uint8_t* rgba_out) {
   g_multi_error.clear();
   if (!rgba_out) return mfail(RTC_ERR_INVALID_ARGUMENT, "null argument");
-  void* d_fb = nullptr;
-  uint32_t f = 0;
-  if (const int st = enqueueFrame(m, cam, max_depth, true, &d_fb, &f); st != RTC_OK) return st;
-  M_HIP(hipMemcpyAsync(rgba_out, d_fb, static_cast<size_t>(cam->hsize) * cam->vsize * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                       m->slot[f].stream[0]));
-  return finishSlot(m, f, true);
+  for (int attempt = 0;; ++attempt) {
+    void* d_fb = nullptr;
+    uint32_t f = 0;
+    void* const direct = registeredHost(rgba_out) ? rgba_out : nullptr;
+    if (const int st = enqueueFrame(m, cam, max_depth, true, &d_fb, &f, direct); st != RTC_OK) return st;
+    if (!direct)
+      M_HIP(hipMemcpyAsync(rgba_out, d_fb, static_cast<size_t>(cam->hsize) * cam->vsize * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           m->slot[f].stream[0]));
+    const int st = finishSlot(m, f, true);
+    if (st != RTC_ERR_OVERFLOW || !m->csg_grown || attempt >= 6 * static_cast<int>(m->frames)) return st;
+    m->csg_grown = false;
+    g_multi_error.clear();
+  }
 }
 
 int rtc_multi_render_rgba8_device(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, const uint32_t** d_rgba_out) {

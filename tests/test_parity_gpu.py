@@ -1112,6 +1112,122 @@ def test_csg_lists_longer_than_the_first_allocation(rtc):
     assert np.array_equal(gpu.render_rgba8(cam, 5), rtc.canvas_rgba8(got))
 
 
+def test_multi_gpu_host_output_written_by_every_rank(rtc):
+    """rtc_multi_render / _render_rgba8 into a REGISTERED host canvas (rtc_canvas_register: pinned and mapped): every rank
+    writes its own tiles straight to their places in the caller's canvas over its own host link (rtc_scatter_tile_list_*),
+    no gather, nothing through GPU 0.  Virtual ranks, one and three frame slots: the bytes are those of the gathered path
+    (an unregistered canvas) - exactly, the split is the same - and the oracle's image; the re-deal after the first frame
+    and a second image size go through the same path."""
+    hs = rtc.HostScene.from_file("cover.json")
+    osc = ob.OracleScene(hs.desc)
+    for frames in (1, 3):
+        multi = rtc.MultiGpu(hs.desc, 4, True, frames)
+        for (w, h) in ((400, 230), (130, 70)):
+            cam = hs.camera(w, h)
+            want = osc.render(cam, 5)[0]
+            direct = np.full((h, w, 3), -1.0)
+            direct8 = np.zeros((h, w, 4), dtype=np.uint8)
+            rtc.canvas_register(direct)
+            rtc.canvas_register(direct8)
+            try:
+                for frame in range(3):
+                    direct[:] = -1.0
+                    multi.render(cam, 5, direct)
+                    st = multi.stats()
+                    gathered = multi.render(cam, 5)                 # (a pageable canvas: the gather to GPU 0 and one copy)
+                    assert np.abs(direct - want).max() < TOL and st["overflow"] == 0
+                    assert np.abs(direct - gathered).max() < REPEAT_TOL
+                    multi.render_rgba8(cam, 5, direct8)
+                    assert np.array_equal(direct8, rtc.canvas_rgba8(gathered)) or \
+                        np.abs(direct8.astype(int) - rtc.canvas_rgba8(gathered).astype(int)).max() <= 1   # (a channel on a rounding edge)
+                    assert np.array_equal(direct8, multi.render_rgba8(cam, 5)) or \
+                        np.abs(direct8.astype(int) - multi.render_rgba8(cam, 5).astype(int)).max() <= 1
+            finally:
+                rtc.canvas_unregister(direct)
+                rtc.canvas_unregister(direct8)
+        multi.close()
+
+
+def test_multi_gpu_grows_csg_lists(rtc):
+    """The csg scene of test_csg_lists_longer_than_the_first_allocation through rtc_multi (virtual ranks, two frame
+    slots): a lane's list of 32 entries is too short for a ray through 20 nested spheres and a cube; the frame says how
+    long it had to be, every handle that overflowed gets lists of that length (rtc_grow_csg_lists), and the synchronous
+    entry points render again - the oracle's image, on every slot; the asynchronous form reports the overflow once and
+    renders the frames after it with the longer lists."""
+    import json
+    spheres = [{"type": {"sphere": {}}, "transform": [{"scale": [0.2 + 0.05 * i] * 3}]} for i in range(20)]
+    scene = {"camera": {"width": 96, "height": 96, "field-of-view": 0.6, "from": [0, 0, -6], "to": [0, 0, 0], "up": [0, 1, 0]},
+             "lights": [{"point-light": {"position": [-5, 5, -5], "intensity": [1, 1, 1]}}],
+             "objects": [{"type": {"csg": {"operation": "union", "left": {"type": {"group": spheres}},
+                                           "right": {"type": {"cube": {}}}}}}]}
+    hs = rtc.HostScene(json.dumps(scene))
+    cam = hs.camera()
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    multi = rtc.MultiGpu(hs.desc, 2, True, 2)
+    for frame in range(4):                                       # (both slots, before and after the re-deal)
+        got = multi.render(cam, 5)
+        st = multi.stats()
+        assert np.abs(got - want).max() < TOL, frame
+        assert [st["overflow"], st["secondary"], st["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]]
+    assert np.array_equal(multi.render_rgba8(cam, 5), rtc.canvas_rgba8(multi.render(cam, 5)))
+    multi.close()
+    # asynchronous: the first frame's overflow is reported (once) when its slot is finished; the lists are longer then
+    multi = rtc.MultiGpu(hs.desc, 2, True, 1)
+    multi.render_device(cam, 5)
+    with pytest.raises(rtc.RtcError) as e:
+        multi.synchronize()
+    assert "Overflow" in str(e.value) or "overflow" in str(e.value)
+    for _ in range(3):                                           # (a handle may need a second step: it sizes by its own share)
+        try:
+            multi.render_device(cam, 5)
+            multi.synchronize()
+            break
+        except rtc.RtcError:
+            continue
+    ptr = multi.render_device(cam, 5)
+    multi.synchronize()
+    got = np.empty_like(want)
+    import ctypes
+    assert ctypes.CDLL(None).hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(got.nbytes), 2) == 0
+    assert np.abs(got - want).max() < TOL and multi.stats()["overflow"] == 0
+    multi.close()
+
+
+def test_three_lights_same_bits_whatever_the_kernel_and_the_schedule(rtc):
+    """World.shadeHit adds the lights' contributions in light order (world.zig:89-96).  With three or more lights a sum
+    split over the halves of a cooperative group would round differently from that running sum, and whether an iteration
+    runs cooperatively depends on the schedule: the cooperative iteration (rtc_render_kernel_simple, small launches)
+    therefore deals lights to halves only when there are at most two.  Here: three and five lights on an opaque world
+    (every pixel's tree stays in one lane, so rtc.h promises bitwise reproducibility): the same bits from repeated
+    renders, from the two-wave cooperative kernel and from the three-wave kernel, and the oracle's image."""
+    import json
+    for n_lights in (3, 5, 2):
+        lights = [{"point-light": {"position": [-6 + 3 * i, 5 + i, -6 - i], "intensity": [0.5, 0.4 + 0.05 * i, 0.3]}} for i in range(n_lights)]
+        objects = [{"type": {"plane": {}}, "material": {"pattern": {"type": {"checkers": [{"type": {"solid": [1, 1, 1]}}, {"type": {"solid": [0.2, 0.2, 0.3]}}]}}, "specular": 0.4}},
+                   {"type": {"sphere": {}}, "transform": [{"translate": [0, 1, 0]}], "material": {"shininess": 30, "reflective": 0.3}},
+                   {"type": {"cube": {}}, "transform": [{"scale": [0.5, 0.5, 0.5]}, {"translate": [2, 0.5, 0.5]}], "material": {"reflective": 0.5, "diffuse": 0.6}}]
+        scene = {"camera": {"width": 72, "height": 40, "field-of-view": 0.9, "from": [0, 2.5, -7], "to": [0, 0.7, 0], "up": [0, 1, 0]},
+                 "lights": lights, "objects": objects}
+        hs = rtc.HostScene(json.dumps(scene))
+        cam = hs.camera()
+        want = ob.OracleScene(hs.desc).render(cam, 5)[0]
+        images = []
+        for simple3 in (None, 0):
+            if simple3 is not None:
+                rtc.set_option("simple3_min_chunks", simple3)
+            try:
+                gpu = rtc.GpuScene(hs.desc)
+                for frame in range(3):                            # estimate-scheduled, measured, steady
+                    images.append((gpu.render(cam, 5), gpu.last_kernel_name()))
+            finally:
+                rtc.set_option("simple3_min_chunks", -1)
+        kernels = {k for _, k in images}
+        assert kernels == {"rtc_render_kernel_simple", "rtc_render_kernel_simple3"}, kernels
+        for img, k in images:
+            assert np.abs(img - want).max() < TOL
+            assert np.array_equal(img, images[0][0]), (n_lights, k)
+
+
 def test_host_output_in_bands(rtc):
     """rtc_render cuts a large frame into horizontal bands (the lower ones on clones of the handle), each copied to the
     caller while the next renders: forced to three and four bands on small images - a rectangle that starts off the chunk
