@@ -135,6 +135,13 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
         stream.synchronize()
         out[name + "_ms"] = (time.perf_counter() - t0) * 1e3
         out[name + "_kernel_ms"] = ev[0].elapsed_time(ev[1])
+    # What the pages of a fresh canvas cost by themselves on this host (the floor under a one-shot render with host output,
+    # whatever the library does): a canvas-sized allocation touched once per page, nothing else.
+    probe = np.empty((H, W, 3), dtype=np.float64)
+    t0 = time.perf_counter()
+    probe.reshape(-1)[::512] = 0.0
+    out["host_first_touch_alone_ms"] = (time.perf_counter() - t0) * 1e3
+    del probe
     host_canvas = np.empty((H, W, 3), dtype=np.float64)   # the caller's Canvas.pixels: pageable host memory
     times = []
     for _ in range(4):
@@ -143,6 +150,15 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
         times.append((time.perf_counter() - t0) * 1e3)
     out["host_output_first_ms"] = times[0]                 # a one-shot render: the 24 B/pixel copy into pageable memory
     out["host_output_pageable_ms"] = sorted(times[1:])[1]  # ... and again into the same pageable canvas
+    # (times[0] is also the PROCESS's first device-to-host copy: the HIP runtime's one-time set-up of its pageable-copy
+    # path, ~7 ms of it - tools/first_copy_probe.py, profiles/r04/first_copy_probe.txt.)  A fresh canvas AFTER that - the
+    # second scene of a host that renders scene after scene, main.zig:52-99 - pays the pages only, and those are
+    # populated while the kernel runs (rtc_render's prefaultCanvas):
+    fresh = np.empty((H, W, 3), dtype=np.float64)
+    t0 = time.perf_counter()
+    g.render_into(cam, fresh, args.depth)
+    out["host_output_fresh_canvas_ms"] = (time.perf_counter() - t0) * 1e3
+    del fresh
     t0 = time.perf_counter()
     rtc.canvas_register(host_canvas)                       # an interactive host pins its canvas once (rtc_canvas_register)
     out["canvas_register_ms"] = (time.perf_counter() - t0) * 1e3
@@ -175,34 +191,42 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
     # (`value` is one frame after the other on one handle); what an N-way share of a frame gains from it is in
     # tools/scale_sim.py --inflight.
     g.close()
-    out["frames_in_flight_ms_per_frame"] = {}
-    for m in (1, 2, 3):
-        streams = [torch.cuda.Stream() for _ in range(m)]
-        gs = [rtc.GpuScene(hs.desc)]
-        gs += [gs[0].clone() for _ in range(m - 1)]
-        cv = [torch.empty((H, W, 3), dtype=torch.float64, device="cuda") for _ in range(m)]
-        for i in range(24 * m):
-            gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
-        torch.cuda.synchronize()
-        best, k = None, 30
-        for rep in range(3):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            for st in streams:
-                st.wait_event(a)
-            for i in range(k):
-                gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
-            for st in streams:
-                stream.wait_stream(st)
-            b.record(stream)
-            torch.cuda.synchronize()
-            t = a.elapsed_time(b) / k
-            best = t if best is None else min(best, t)
-        out["frames_in_flight_ms_per_frame"][str(m)] = best
-        for x in gs:
-            x.close()
+    out["frames_in_flight_ms_per_frame"] = {str(m): frames_in_flight_ms(rtc, torch, hs, args, stream, m) for m in (1, 2)}
     out["orbit"] = "%d frames, %.2f rad per frame, one handle, frames enqueued back to back; wall time / frames" % (frames, angle)
     return out
+
+
+def frames_in_flight_ms(rtc, torch, hs, args, stream, m, k=30):
+    """ms per frame with m independent frames IN FLIGHT: a scene handle and m - 1 clones (rtc_scene_clone), each on a stream
+    of its own, frames dealt round-robin - the work-groups of frame i + 1 start on the CUs frame i's last waves have left.
+    What the N > 1 lines are measured with (a rank keeps three frames in flight): timed here on ONE
+    GPU so that a scaling efficiency divides like by like (value_same_inflight).  Best of three passes of k frames."""
+    W, H = args.width, args.height
+    cam = hs.camera(W, H)
+    streams = [torch.cuda.Stream() for _ in range(m)]
+    gs = [rtc.GpuScene(hs.desc)]
+    gs += [gs[0].clone() for _ in range(m - 1)]
+    cv = [torch.empty((H, W, 3), dtype=torch.float64, device="cuda") for _ in range(m)]
+    for i in range(24 * m):
+        gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
+    torch.cuda.synchronize()
+    best = None
+    for rep in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for st in streams:
+            st.wait_event(a)
+        for i in range(k):
+            gs[i % m].render_device(cam, cv[i % m].data_ptr(), args.depth, None, streams[i % m].cuda_stream)
+        for st in streams:
+            stream.wait_stream(st)
+        b.record(stream)
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / k
+        best = t if best is None else min(best, t)
+    for x in gs:
+        x.close()
+    return best
 
 
 def algorithmic_flops(desc, hs, stats):
@@ -564,6 +588,20 @@ def main():
                        "timed_frames": "steady state of a STATIC view: the schedule was measured on this same frame by the two "
                                        "untimed setup launches; first_frame_ms / orbit_ms below are the other cases"},
         }
+        # Like for like across N: the N > 1 lines keep SPLIT_INFLIGHT frames in flight per rank (a share of a sub-millisecond
+        # frame cannot fill a GPU by itself), the one-GPU headline `value` is one frame after the other.  A scaling
+        # efficiency t(1) / (N t(N)) must divide figures of one kind: value_same_inflight is this N's throughput WITH
+        # SPLIT_INFLIGHT frames in flight - at N > 1 that is `value` itself (unless --inflight says otherwise), at N = 1 it
+        # is measured beside the headline (same scene handle pattern as the split path: a handle and its clones).
+        SPLIT_INFLIGHT = 3
+        if world == 1 and not args.tile_path:
+            same_ms = ms_per_step if M == SPLIT_INFLIGHT else frames_in_flight_ms(rtc, torch, hs, args, stream, SPLIT_INFLIGHT)
+            result["value_same_inflight"] = rays / (same_ms * 1e-3) / 1e6
+            result["config"]["same_inflight"] = {"frames_in_flight": SPLIT_INFLIGHT, "ms_per_frame": same_ms,
+                                                 "note": "throughput of this N with the frames in flight the N > 1 lines use; "
+                                                         "efficiency = value_same_inflight(N) / (N x value_same_inflight(1))"}
+        else:
+            result["value_same_inflight"] = result["value"] if M == SPLIT_INFLIGHT else None
         if world == 1 and not args.tile_path:
             ab = algorithmic_bytes(hs.desc, W, H)
             fl = algorithmic_flops(hs.desc, hs, stats)
@@ -571,6 +609,7 @@ def main():
             result["roofline"] = {
                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.scene, W, H, args.depth),
+                "traffic_ratio": (measured_traffic(args.scene, W, H, args.depth) or 0) / ab or None,  # traffic / algorithmic bytes: > 1 is spills and pending-ray records, not canvas
                 "traffic_source": "committed profile (profiles/traffic.json), not measured in this run",
                 "kernel": gpu.last_kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
@@ -595,10 +634,12 @@ def main():
             if fl is not None:
                 tf = fl / (kernel_ms * 1e-3) / 1e12
                 result["roofline_valu"] = {
-                    "bound": "valu_fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": tf / FP64_VECTOR_PEAK_TF, "algorithmic_flops": fl,
-                    "note": "flops of the REFERENCE algorithm (SURVEY 8(d) table: every ray tests every leaf); the "
-                            "kernel skips most of them by bounding-sphere rejection.  Peak counts an FMA as 2 "
+                    "bound": "valu_fp64", "reference_tflops": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
+                    "frac_of_reference_flops": tf / FP64_VECTOR_PEAK_TF, "algorithmic_flops": fl,
+                    "note": "reference_tflops / frac_of_reference_flops price the flops of the REFERENCE algorithm (SURVEY 8(d) "
+                            "table: every ray tests every leaf, every isShadowed call is a full intersect) over this kernel's "
+                            "time: a statement about the algorithm replaced, NOT a utilisation - the kernel skips most of those "
+                            "flops by bounding-sphere rejection.  The hardware figure is executed_frac.  Peak counts an FMA as 2 "
                             "flops; the path runs with FMA contraction OFF to round like the reference.",
                 }
                 ex = executed_flops(args.scene, W, H, args.depth)
@@ -609,7 +650,7 @@ def main():
                         "executed_note": "FP64 flops the kernel executes per launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 "
                                          "lanes x %.2f lanes active; %d of %d VALU wave-instructions are FP64 arithmetic), from "
                                          "the committed PMC pass %s over this run's kernel time: THIS is the hardware "
-                                         "utilisation, `frac` above prices the reference's brute-force flop count"
+                                         "utilisation, frac_of_reference_flops above prices the reference's brute-force flop count"
                                          % (ex["lanes_active"], ex["fp64_instructions"], ex["valu_instructions"], ex["source"]),
                     })
                     for k in ("valu_pipe_busy", "wave_cycles_waiting", "clock_source"):
@@ -617,6 +658,7 @@ def main():
                             result["roofline_valu"][k] = ex[k]
             if not args.no_extras:
                 result["config"].update(one_shot_and_moving_view(rtc, torch, hs, args, stream))
+                result["config"]["frames_in_flight_ms_per_frame"][str(SPLIT_INFLIGHT)] = same_ms
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)
                 result["config"]["gpu_vs_cpu_frame_time"] = result["cpu_baseline"]["ms_per_frame_extrapolated"] / ms_per_step

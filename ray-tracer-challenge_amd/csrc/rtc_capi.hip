@@ -13,6 +13,9 @@
 #include <vector>
 
 #include "../../include/rtc.h"
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include "rtc_device.h"
 
 extern "C" __global__ void rtc_scatter_tiles_kernel(const double* tiles, const uint32_t* tile_list, const uint32_t n_tiles, const uint32_t tile_w,
@@ -1908,6 +1911,35 @@ int ensureBands(rtc_scene* s, uint32_t bands) {
   return RTC_OK;
 }
 
+// A host canvas the process has never touched (a one-shot render: main.zig:92 renders every scene once into a fresh
+// Canvas) costs more in page faults than the frame costs to render and copy: the copy of a 1080p frame into untouched
+// pageable memory took 11 ms against 1.5 ms into the same pages afterwards.  The faults cannot be avoided - the pages are
+// the caller's, and nothing is remembered about them - but they need not wait for the GPU, nor be taken one trap at a
+// time by the runtime's copy: while the render kernels run, the caller's thread has the kernel populate the canvas's
+// pages in one call (MADV_POPULATE_WRITE; where the running kernel lacks it, one read-modify-write per page - the
+// contents stay).  Three sampled pages that are resident mean the canvas has been used before: nothing is done then.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+void prefaultCanvas(void* canvas, size_t bytes) {
+  const uintptr_t page = static_cast<uintptr_t>(sysconf(_SC_PAGESIZE));
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(canvas) + page - 1u) & ~(page - 1u);
+  const uintptr_t hi = (reinterpret_cast<uintptr_t>(canvas) + bytes) & ~(page - 1u);
+  if (hi < lo + 64u * page) return;  // (a small canvas: not worth a system call)
+  const uintptr_t probes[3] = {lo, lo + (((hi - lo) / 2u) & ~(page - 1u)), hi - page};
+  bool resident = true;
+  for (const uintptr_t q : probes) {
+    unsigned char vec = 0;
+    if (mincore(reinterpret_cast<void*>(q), page, &vec) != 0 || (vec & 1u) == 0u) resident = false;
+  }
+  if (resident) return;
+  if (madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_POPULATE_WRITE) == 0) return;
+  for (uintptr_t q = lo; q < hi; q += page) {
+    volatile unsigned char* b = reinterpret_cast<volatile unsigned char*>(q);
+    *b = *b;
+  }
+}
+
 int renderBanded(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                  double* rgb_out, uint32_t bands) {
   if (const int st = ensureBands(s, bands); st != RTC_OK) return st;
@@ -1922,6 +1954,7 @@ int renderBanded(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32
       if (st != RTC_OK) return st;
       HIP_TRY(hipEventRecord(s->band_done[b], s->stream));
     }
+    prefaultCanvas(rgb_out, 3ull * w * h * sizeof(double));  // (a first-use canvas: its page faults, under the renders)
     for (uint32_t b = 0; b < bands; ++b) {  // ... and behind each its copy, on the other
       HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->band_done[b], 0));
       HIP_TRY(hipMemcpyAsync(rgb_out + 3ull * w * row[b], s->d_frame + 3ull * w * row[b],
@@ -1954,6 +1987,7 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
     // (into pageable memory the copy runs at a fifth of the link's rate - 5.6 ms for a 1080p frame; a host that renders
     // frame after frame registers its canvas once: rtc_canvas_register)
     const size_t bytes = need * sizeof(double);
+    prefaultCanvas(rgb_out, bytes);  // (a first-use canvas: its page faults, while the kernel runs)
     HIP_TRY(hipMemcpyAsync(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const int ov = checkOverflow(s);
@@ -1983,6 +2017,7 @@ int rtc_render_rgba8(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, ui
     if (st != RTC_OK) return st;
     uint32_t* d_rgba = reinterpret_cast<uint32_t*>(s->d_frame + 3 * n);
     if (const int st2 = rtc_rgba8_device(s->d_frame, n, d_rgba, s->stream); st2 != RTC_OK) return st2;
+    prefaultCanvas(rgba_out, n * sizeof(uint32_t));
     HIP_TRY(hipMemcpyAsync(rgba_out, d_rgba, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     const int ov = checkOverflow(s);
