@@ -386,6 +386,12 @@ int rtc_scatter_tile_list_rgba8_device(const double *d_tiles, const uint32_t *d_
 /* Waits for the work enqueued on the handle's own stream. */
 int rtc_scene_synchronize(rtc_scene *scene);
 
+/* Diagnostic (tools/estimate_probe.py): for the pixel map of the handle's last scheduled launch, per 8x8 chunk what the
+ * first-frame estimate (rtc_estimate_kernel, for camera `cam`) says it costs and what the last measuring launch measured,
+ * both in the packer's ticks of 16 shader cycles.  Either array may be NULL.  Scheduling only: no result depends on it. */
+int rtc_get_chunk_times(rtc_scene *scene, const rtc_camera *cam, uint32_t *estimated, uint32_t *measured, size_t capacity,
+                        uint32_t *n_chunks);
+
 /* Counters of the last render that was enqueued on this handle (synchronises). */
 int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
 

@@ -91,7 +91,7 @@ class Stats(C.Structure):
 
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
-               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scatter_tile_list_device", "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_last_error",
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scatter_tile_list_device", "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times", "rtc_last_error",
                "rtc_status_name", "rtc_grow_csg_lists", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
@@ -161,6 +161,7 @@ def hip_lib():
         lib.rtc_last_kernel_name.argtypes = [C.c_void_p]
         lib.rtc_last_kernel_name.restype = C.c_char_p
         lib.rtc_get_schedule.argtypes = [C.c_void_p, _u32p, C.c_size_t, _u32p]
+        lib.rtc_get_chunk_times.argtypes = [C.c_void_p, C.POINTER(Camera), _u32p, _u32p, C.c_size_t, _u32p]
         lib.rtc_canvas_register.argtypes = [C.c_void_p, C.c_size_t]
         lib.rtc_canvas_unregister.argtypes = [C.c_void_p]
         lib.rtc_rgba8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -444,6 +445,15 @@ class GpuScene:
         out = np.empty((n.value, 16), dtype=np.uint32)
         _check_hip(hip_lib().rtc_get_schedule(self._s, out.ctypes.data_as(_u32p), out.size, C.byref(n)))
         return out[:n.value]
+
+    def chunk_times(self, cam):
+        """Diagnostic: (estimated, measured) ticks per 8x8 chunk of the last scheduled launch's pixel map (rtc_get_chunk_times)."""
+        n = C.c_uint32()
+        _check_hip(hip_lib().rtc_get_chunk_times(self._s, C.byref(cam), None, None, 0, C.byref(n)))
+        est, got = np.zeros(n.value, dtype=np.uint32), np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _check_hip(hip_lib().rtc_get_chunk_times(self._s, C.byref(cam), est.ctypes.data_as(_u32p), got.ctypes.data_as(_u32p), n.value, C.byref(n)))
+        return est, got
 
     def close(self):
         if self._s:

@@ -506,8 +506,44 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   // one stream; when the caller changes streams (rtc_render_device on its own stream, then rtc_render on the handle's),
   // the new stream first waits for everything the handle enqueued before (the event recorded at the end of launch()).
   if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
+  if (!s->kernel_warm && s->d_ray_stack != nullptr) {
+    // A handle's first launch: the render kernel goes to the stream ONCE WITH NO WORK before anything else.  The first
+    // dispatch of a kernel that needs scratch memory (every render kernel spills) stalls its queue while the runtime sets
+    // that memory up - 130 us between submission and start, measured in front of a 0.5 ms frame
+    // (profiles/r04/first_frame_api_trace.txt).  Submitted here, that set-up runs under the ~300 us of host-side
+    // allocations a first launch makes next (cost, schedule and measurement buffers), and the real kernels start when
+    // they are submitted.  n_units = 0: every wave's first pull finds the counter past the end and leaves; the launch
+    // counters it touches are the ones the next launch clears or finds zero.
+    s->kernel_warm = true;
+    DevPixelMap idle = map;
+    idle.order = nullptr;
+    idle.n_units_dev = nullptr;
+    idle.n_units = 0;
+    idle.cost = nullptr;
+    idle.packet_time = nullptr;
+    idle.ray_stack = static_cast<PendingRec*>(s->d_ray_stack);
+    idle.ray_stack_levels = 2;
+    idle.pull_min_idle = 64;
+    const KernelChoice kernel = renderKernel(s, map);
+    DevScene dev = s->dev;
+    dev.csg_buf = nullptr;
+    hipLaunchKernelGGL(kernel.fn, dim3(residentBlocks(s, map)), dim3(256), 0, stream, dev, devCamera(cam), idle, max_depth, d_out,
+                       s->d_stats + s->stats_parity, s->d_stats + (s->stats_parity ^ 1u));
+    HIP_TRY(hipGetLastError());
+  }
   SchedulePlan plan;
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
+  // Every allocation of this launch BEFORE anything is enqueued (the pending-ray levels are 59 MB at depth 5): a
+  // hipMalloc between the estimate's packer and the render kernel left the GPU idle for 150 us of a first frame
+  // (profiles/r04/first_frame_trace.txt).  enqueueRender finds the buffers in place.
+  {
+    DevPixelMap sized = map;
+    const uint32_t resident = residentBlocks(s, map);
+    // (the packet count of an estimate-scheduled launch is not known yet: at least a packet per resident wave whenever
+    // there are that many chunks - the same bound enqueueRender applies to n_units)
+    const uint32_t blocks = std::max(1u, std::min(resident, (std::max(map.n_units, map.n_chunks) + 3u) / 4u));
+    if (const int st = ensureScratch(s, sized, blocks, max_depth); st != RTC_OK) return st;
+  }
   if (plan.estimate) {
     DevPixelMap none = map_in;  // (no schedule ran before: the packer sees no packets and no times)
     none.order = nullptr;
@@ -870,7 +906,9 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       // heaviest cover chunk: 0.37 ms); a mesh by the depth of its BVH.  Only the order of magnitude matters: the first
       // frame measures, and the second runs on measurements.
       {
-        float w = 1500.0f * (1.0f + 0.5f * std::log2(1.0f + static_cast<float>(n_below)));
+        // (round 4, tools/estimate_probe.py: with 1500 the estimates of the five configs summed to 1.9 - 5.2 x what
+        // their first frames then measured - cheap chunks shared packets a third as often as they should; 600 centres them)
+        float w = 600.0f * (1.0f + 0.75f * std::log2(1.0f + static_cast<float>(n_below)));
         if (branches) w *= 25.0f;
         else if (refracts) w *= 4.0f;
         else if (reflects) w *= 3.0f;
@@ -1541,6 +1579,20 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
     }
   } guard{s};
   if (const int st = uploadTables(d, traits, tables, s); st != RTC_OK) return st;
+  {
+    // The pending-ray levels of a full-size launch at the reference's depth (camera.zig:118), allocated here with the
+    // rest of the scene: the first frame - the only one a host that renders a scene once ever sees - then starts
+    // without a 59 MB hipMalloc in front of it.  Another depth or launch size re-allocates at its first launch.
+    DevPixelMap full{};
+    full.n_chunks = 1u << 20;
+    const size_t need = static_cast<size_t>(residentBlocks(s, full)) * 4u * (5u + 2u) * 64u * 64u;
+    if (hipMalloc(&s->d_ray_stack, need) == hipSuccess) {
+      s->ray_stack_capacity = need;
+    } else {
+      (void)hipGetLastError();  // (not fatal here: the first launch asks again and reports)
+      s->d_ray_stack = nullptr;
+    }
+  }
   guard.s = nullptr;
   *out = s;
   return RTC_OK;
@@ -2096,6 +2148,47 @@ int rtc_get_schedule(rtc_scene* s, uint32_t* items, size_t capacity_items, uint3
   if (need > capacity_items || (need != 0 && !items))
     return fail(RTC_ERR_INVALID_ARGUMENT, "the schedule has %u packets of %u items", info.n_units, RTC_PACKET_ITEMS);
   HIP_TRY(hipMemcpy(items, s->d_sched[s->sched_cur], need * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return RTC_OK;
+}
+
+int rtc_get_chunk_times(rtc_scene* s, const rtc_camera* cam, uint32_t* estimated, uint32_t* measured, size_t capacity, uint32_t* n_chunks) {
+  g_error.clear();
+  if (!s || !cam || !n_chunks) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  *n_chunks = 0;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipEventSynchronize(s->launch_done));
+  if (s->cost_key.empty() || !s->d_chunk_time || s->pack_capacity == 0) return RTC_OK;  // nothing scheduled has run
+  DevPixelMap map{};
+  std::memcpy(&map, s->cost_key.data(), std::min(s->cost_key.size() * sizeof(uint32_t), sizeof map));
+  const uint32_t n = map.n_chunks;
+  *n_chunks = n;
+  if (n > s->pack_capacity) return fail(RTC_ERR_INVALID_ARGUMENT, "the pixel map has %u chunks, the buffers %u", n, s->pack_capacity);
+  if (!estimated && !measured) return RTC_OK;  // (a size query)
+  if (n > capacity) return fail(RTC_ERR_INVALID_ARGUMENT, "%u chunks, room for %zu", n, capacity);
+  if (measured) HIP_TRY(hipMemcpy(measured, s->d_chunk_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (estimated) {
+    uint32_t *d_est = nullptr, *d_time = nullptr;
+    DevChunkShape* d_shape = nullptr;
+    DevPackState* d_state = nullptr;
+    auto release = [&]() {
+      for (void* p : {static_cast<void*>(d_est), static_cast<void*>(d_time), static_cast<void*>(d_shape), static_cast<void*>(d_state)})
+        if (p) (void)hipFree(p);
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&d_est), n * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_time), n * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_shape), n * sizeof(DevChunkShape)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_state), sizeof(DevPackState)) != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return fail(RTC_ERR_OUT_OF_MEMORY, "scratch for %u chunks", n);
+    }
+    hipLaunchKernelGGL(rtc_estimate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, s->dev, devCamera(*cam), map, d_est, d_time,
+                       d_shape, d_state);
+    const hipError_t e1 = hipStreamSynchronize(s->stream);
+    const hipError_t e2 = e1 == hipSuccess ? hipMemcpy(estimated, d_est, n * sizeof(uint32_t), hipMemcpyDeviceToHost) : e1;
+    release();
+    HIP_TRY(e2);
+  }
   return RTC_OK;
 }
 

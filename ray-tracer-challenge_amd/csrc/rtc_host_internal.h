@@ -129,6 +129,7 @@ struct rtc_scene {
   uint32_t csg_entries_ok = RTC_CSG_ENTRIES;  // the list length the buffer was last allocated for (what a failed enlargement falls back to)
   uint32_t csg_needed = 0;         // what the last checked frame said its longest csg list needed (0: no csg list ran out)
   uint32_t max_trav_stack = 0;
+  bool kernel_warm = false;        // the handle's first launch has sent the render kernel ahead once with no work (launch())
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1, blocks_per_cu_simple3 = 1;
   // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next
   // launch runs; a measuring launch is followed by the packer's launches, which pack the other buffer from what the
