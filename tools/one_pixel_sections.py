@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where ONE wave's time goes when it renders one pixel (or a small rectangle) with the GPU to itself - the dependent
-chain that floors every small launch.  Needs a -DRTC_PROFILE build (tools/prof_sections.sh builds one):
+chain that floors every small launch.  Needs a -DRTC_PROFILE build (python tools/variants.py "prof=-DRTC_PROFILE" -- python tools/one_pixel_sections.py ...):
     python tools/one_pixel_sections.py cover.json 1920 1080 X Y W H [depth]"""
 import importlib, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where a wave's time goes, and what the group walks did (needs a -DRTC_PROFILE build: tools/prof_sections.sh):
+"""Where a wave's time goes, and what the group walks did (needs a -DRTC_PROFILE build: python tools/variants.py "prof=-DRTC_PROFILE" -- python tools/prof_sections.py ...):
 prof_sections.py dragons.json 3840 2160 [depth].  Shares only - the stamps slow the kernel down."""
 import importlib, os, re, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-wave timeline of one simulated rank's share (needs a -DRTC_PROFILE build; see tools/wave_log.sh)."""
+"""Per-wave timeline of one simulated rank's share (needs a -DRTC_PROFILE build: python tools/variants.py "prof=-DRTC_PROFILE" -- python tools/wave_log.py ...)."""
 import argparse, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
