@@ -764,7 +764,9 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
   dx = __builtin_copysignf(fmaxf(__builtin_fabsf(dx), 1e-30f), dx);
   dy = __builtin_copysignf(fmaxf(__builtin_fabsf(dy), 1e-30f), dy);
   dz = __builtin_copysignf(fmaxf(__builtin_fabsf(dz), 1e-30f), dz);
-  const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+  // (v_rcp_f32, one ulp: a relative 1.2e-7 on every parameter computed with it, an eighth of the margin below - and one
+  // instruction where the IEEE quotient takes ten, three times per walk)
+  const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
   const float delta = 1e-6f * (fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.bvh_mag);
   const float mx = delta * __builtin_fabsf(ix), my = delta * __builtin_fabsf(iy), mz = delta * __builtin_fabsf(iz);
   const bool negx = dx < 0.0f, negy = dy < 0.0f, negz = dz < 0.0f;
