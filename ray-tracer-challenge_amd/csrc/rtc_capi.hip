@@ -34,6 +34,10 @@ extern "C" __global__ void rtc_render_kernel_simple(const DevScene S, const DevC
                                                     DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
 extern "C" __global__ void rtc_render_kernel_simple3(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                      uint32_t max_depth, double* out, DevStats* stats, DevStats* next_stats);
+#if RTC_BVH8
+extern "C" __global__ void rtc_render_kernel3(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                                              double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+#endif
 extern "C" __global__ void rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                         const uint32_t max_depth, double* __restrict__ out,
                                                         DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
@@ -229,8 +233,24 @@ struct KernelChoice {
   const char* name;
 };
 #define RTC_KERNEL(k) KernelChoice{k, #k}
+// The general kernel at three waves per SIMD (rtc_render_kernel3): forced by option "waves3", else what the handle's
+// trial measured (KernelTune in launch()).
+bool usesGeneral3(const rtc_scene* s) {
+#if RTC_BVH8
+  if (!s->general3_ok) return false;
+  const double forced = rtcOptions().waves3;
+  if (forced >= 0.0) return forced != 0.0;
+  return s->use_general3;
+#else
+  (void)s;
+  return false;
+#endif
+}
 KernelChoice ldsKernel(const rtc_scene* s, const DevPixelMap& map) {
   if (usesSimple3(s, map)) return RTC_KERNEL(rtc_render_kernel_simple3);
+#if RTC_BVH8
+  if (usesGeneral3(s)) return RTC_KERNEL(rtc_render_kernel3);
+#endif
   if (s->simple_kernel) return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_simple_ext) : RTC_KERNEL(rtc_render_kernel_simple);
   if (s->flat_kernel) return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_flat_ext) : RTC_KERNEL(rtc_render_kernel_flat);
   return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_ext) : RTC_KERNEL(rtc_render_kernel);
@@ -244,6 +264,7 @@ KernelChoice renderKernel(const rtc_scene* s, const DevPixelMap& map) {
 // Work-groups of the launch's kernel that are resident at once, and the waves in them.
 uint32_t residentBlocks(const rtc_scene* s, const DevPixelMap& map) {
   if (usesSimple3(s, map)) return s->n_cus * s->blocks_per_cu_simple3;
+  if (tablesInLds(s) && usesGeneral3(s)) return s->n_cus * s->blocks_per_cu_general3;
   return s->n_cus * (tablesInLds(s) ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
 }
 double residentWaves(const rtc_scene* s, const DevPixelMap& map) { return 4.0 * residentBlocks(s, map); }
@@ -533,6 +554,70 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   }
   SchedulePlan plan;
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
+  // ---- two or three waves per SIMD for a world with groups: measured on the handle's own frames (KernelTune).  Once a
+  // pixel map's schedule is steady (a static view, nothing being measured), six of its frames alternate between
+  // rtc_render_kernel and rtc_render_kernel3 with HIP events around the render kernel; as soon as three frames of each
+  // have been timed (the events are polled, never waited for) the handle keeps the kernel whose fastest frame was
+  // at least 3 % faster, and measures one more frame so that the schedule is packed for that kernel's wave count.
+  // Results do not depend on the kernel (same code, other launch bounds and table sizes).  No trial with frames in
+  // flight (several handles share the GPU: a frame's time says little) or when option "waves3" forces a kernel.
+  int trial_slot = -1;
+  {
+    rtc_scene::KernelTune& T = s->tune;
+    const bool eligible = s->general3_ok && rtcOptions().waves3 < 0.0 && tablesInLds(s) &&
+                          !(s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) &&
+                          static_cast<double>(map.n_chunks) >= 4.0 * 4.0 * s->n_cus * s->blocks_per_cu_lds;
+    if (eligible && T.key != s->cost_key) {  // another pixel map: a trial of its own (the last choice stands until it ends)
+      T.key = s->cost_key;
+      T.state = 0;
+      T.frames = 0;
+      T.n[0] = T.n[1] = 0;
+      for (int& w : T.which) w = -1;
+    }
+    if (eligible && T.state == 1 && !(!plan.measure && !plan.estimate && map.order != nullptr)) s->use_general3 = false;  // (the view moved: the trial waits)
+    if (eligible && T.state != 2 && !plan.measure && !plan.estimate && map.order != nullptr) {
+      for (int k = 0; k < rtc_scene::KernelTune::kRing; ++k) {
+        if (T.which[k] < 0) continue;
+        const hipError_t q = hipEventQuery(T.ev[k][1]);
+        if (q == hipSuccess) {
+          float ms = 0.0f;
+          if (hipEventElapsedTime(&ms, T.ev[k][0], T.ev[k][1]) == hipSuccess) {
+            const int w = T.which[k];
+            T.best[w] = T.n[w] == 0 ? ms : std::min(T.best[w], ms);
+            T.n[w]++;
+          }
+          T.which[k] = -1;
+        } else {
+          (void)hipGetLastError();  // (hipErrorNotReady: the frame is still running)
+        }
+      }
+      if (T.n[0] >= rtc_scene::KernelTune::kSamples && T.n[1] >= rtc_scene::KernelTune::kSamples) {
+        s->use_general3 = T.best[1] < 0.97f * T.best[0];
+        T.state = 2;
+        if (s->use_general3) plan.measure = true;  // (re-packed for three waves per SIMD's worth of resident waves)
+      } else {
+        uint32_t pending[2] = {0, 0};
+        int free_slot = -1;
+        for (int k = 0; k < rtc_scene::KernelTune::kRing; ++k) {
+          if (T.which[k] >= 0) pending[T.which[k]]++;
+          else if (free_slot < 0) free_slot = k;
+        }
+        int w = static_cast<int>(T.frames & 1u);
+        if (T.n[w] + pending[w] >= rtc_scene::KernelTune::kSamples) w ^= 1;
+        if (free_slot >= 0 && T.n[w] + pending[w] < rtc_scene::KernelTune::kSamples) {
+          for (hipEvent_t& e : T.ev[free_slot])
+            if (!e) HIP_TRY(hipEventCreate(&e));
+          s->use_general3 = w == 1;
+          T.which[free_slot] = w;
+          T.frames++;
+          T.state = 1;
+          trial_slot = free_slot;
+        } else {
+          s->use_general3 = false;  // (all samples are in flight: an ordinary frame meanwhile)
+        }
+      }
+    }
+  }
   // Every allocation of this launch BEFORE anything is enqueued (the pending-ray levels are 59 MB at depth 5): a
   // hipMalloc between the estimate's packer and the render kernel left the GPU idle for 150 us of a first frame
   // (profiles/r04/first_frame_trace.txt).  enqueueRender finds the buffers in place.
@@ -559,7 +644,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   const bool timed = plan.measure && rtcOptions().pull_min_idle >= 64.0;
   map.packet_time = timed ? s->d_packet_time : nullptr;
   if (plan.measure && !timed) HIP_TRY(hipMemsetAsync(s->d_packet_time, 0, static_cast<size_t>(map.n_units) * sizeof(uint32_t), stream));
+  if (trial_slot >= 0) HIP_TRY(hipEventRecord(s->tune.ev[trial_slot][0], stream));
   if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
+  if (trial_slot >= 0) HIP_TRY(hipEventRecord(s->tune.ev[trial_slot][1], stream));
   if (plan.measure)
     if (const int st = packNextSchedule(s, cam, map, max_depth, stream, PackFrom::Measurement); st != RTC_OK) return st;
   HIP_TRY(hipEventRecord(s->launch_done, stream));
@@ -1486,6 +1573,8 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   }
   s->simple3_ok = s->simple_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
                   d.n_patterns <= RTC_LDS3_PATTERNS;
+  s->general3_ok = RTC_BVH8 && !s->flat_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
+                   d.n_patterns <= RTC_LDS3_PATTERNS && d.n_lights <= RTC_LDS_LIGHTS;
   HIP_TRY(s->tab->light.upload(light));
   if (const int st = initLaunchState(s); st != RTC_OK) return st;
   s->max_trav_stack = traits.max_stack;
@@ -1500,6 +1589,10 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     s->blocks_per_cu_lds = static_cast<uint32_t>(std::max(nb, 1));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel_simple3, 256, 0));
     s->blocks_per_cu_simple3 = static_cast<uint32_t>(std::max(nb, 1));
+#if RTC_BVH8
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, rtc_render_kernel3, 256, 0));
+    s->blocks_per_cu_general3 = static_cast<uint32_t>(std::max(nb, 1));
+#endif
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &nb, ext_kernel ? rtc_render_kernel_bigworld_ext : rtc_render_kernel_bigworld, 256, 0));
     s->blocks_per_cu_big = static_cast<uint32_t>(std::max(nb, 1));
@@ -1626,6 +1719,9 @@ int rtc_scene_clone(const rtc_scene* src, rtc_scene** out) {
   s->blocks_per_cu_lds = src->blocks_per_cu_lds;
   s->blocks_per_cu_big = src->blocks_per_cu_big;
   s->blocks_per_cu_simple3 = src->blocks_per_cu_simple3;
+  s->general3_ok = src->general3_ok;
+  s->blocks_per_cu_general3 = src->blocks_per_cu_general3;
+  s->use_general3 = src->use_general3;  // (a clone starts from what its source has measured; frames in flight run no trial of their own)
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = initLaunchState(s); st != RTC_OK) return st;
   guard.s = nullptr;
@@ -1650,6 +1746,9 @@ void rtc_scene_destroy(rtc_scene* s) {
     (void)hipStreamSynchronize(s->stream);
     (void)hipStreamDestroy(s->stream);
   }
+  for (auto& pair : s->tune.ev)
+    for (hipEvent_t& e : pair)
+      if (e) (void)hipEventDestroy(e);
   if (s->d_stats) (void)hipFree(s->d_stats);
   if (s->d_frame) (void)hipFree(s->d_frame);
   for (int b = 0; b < 2; ++b)
@@ -1925,7 +2024,7 @@ int rtc_set_option(const char* name, double value) {
   } table[] = {{"simple3_min_chunks", &o.simple3_min_chunks}, {"sched_off", &o.sched_off}, {"cut_above", &o.cut_above},
                {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
-               {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}};
+               {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
       *e.slot = value;

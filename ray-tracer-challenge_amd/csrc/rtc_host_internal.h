@@ -52,6 +52,7 @@ struct RtcOptions {
   double bvh_leaf = RTC_BVH8 ? 1.0 : 2.0;  // leaves per candidate-BVH leaf (eight-wide tree, 1 / 2 / 3 / 4: dragons 4K 2.03 / 2.10 / 2.18 / 2.30 ms, nefertiti 0.522 / 0.534 / 0.548 / 0.562, teapot 0.264 / 0.265 / 0.263 / 0.272)
   double bvh_one_axis = 0.0;         // != 0: SAH on the longest axis only
   double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
+  double waves3 = -1.0;              // the general kernel at three waves per SIMD: 1 always (where the tables fit), 0 never, < 0: measured per handle
   double host_bands = 0.0;           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
 };
 inline RtcOptions& rtcOptions() {
@@ -129,6 +130,20 @@ struct rtc_scene {
   uint32_t csg_entries_ok = RTC_CSG_ENTRIES;  // the list length the buffer was last allocated for (what a failed enlargement falls back to)
   uint32_t csg_needed = 0;         // what the last checked frame said its longest csg list needed (0: no csg list ran out)
   uint32_t max_trav_stack = 0;
+  // ---- the general kernel at two or at three waves per SIMD: measured, not guessed (launch(), KernelTune)
+  bool general3_ok = false;        // a world with groups, no csg / texture maps, whose tables fit the three-wave kernel's LDS
+  uint32_t blocks_per_cu_general3 = 1;
+  bool use_general3 = false;       // what launches run: the choice once the trial is over, the kernel under trial during it
+  struct KernelTune {
+    enum { kSamples = 3, kRing = 8 };
+    int state = 0;                 // 0: no trial yet for this pixel map, 1: trial running, 2: decided
+    uint32_t frames = 0;           // trial frames enqueued
+    float best[2] = {0.0f, 0.0f};  // fastest frame seen per kernel (two waves, three waves), ms
+    uint32_t n[2] = {0, 0};        // samples resolved per kernel
+    hipEvent_t ev[kRing][2] = {};  // timing events around the render kernel of the trial frames (created on first use)
+    int which[kRing] = {};         // which kernel a ring slot timed; -1: slot free / resolved
+    std::vector<uint32_t> key;     // the pixel map the trial belongs to
+  } tune;
   bool kernel_warm = false;        // the handle's first launch has sent the render kernel ahead once with no work (launch())
   uint32_t n_cus = 0, blocks_per_cu_lds = 1, blocks_per_cu_big = 1, blocks_per_cu_simple3 = 1;
   // ---- the schedule (DevPixelMap::order): two device buffers, used alternately.  d_sched[sched_cur] is what the next

@@ -753,7 +753,7 @@ __device__ __forceinline__ uint32_t permute_by_octant(uint32_t x, uint32_t oct) 
   return (oct & 4u) ? s4 : x;
 }
 
-template <bool CSG, class V>
+template <bool CSG, class V, int LDS_ENTRIES = RTC_LDS_TRAV>
 __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t root, const uint32_t always_first,
                                               const uint32_t always_count, const Ray& ray, V& vis, unsigned& overflow,
                                               uint2* lds_stack) {
@@ -793,7 +793,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
   typedef uint32_t Pair __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) Pair LdsPair;
   LdsPair* const lds_top = (LdsPair*)lds_stack;
-  Pair stack[RTC_TRAV_STACK - RTC_LDS_TRAV];
+  Pair stack[RTC_TRAV_STACK - LDS_ENTRIES];
   int sp = 0;
   // the group in hand: the root is inner child 0 of a node that is not there
   // bits 0..7: children still to visit, front to back (bit p: slot p ^ oct); bits 8..15: the node's imask (by slot)
@@ -809,10 +809,10 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
         if (sp == 0) break;
         --sp;
         Pair e;
-        if (sp < RTC_LDS_TRAV) {
+        if (sp < LDS_ENTRIES) {
           e = lds_top[sp * 64];
         } else {
-          e = stack[sp - RTC_LDS_TRAV];
+          e = stack[sp - LDS_ENTRIES];
         }
         g_base = e.x;
         g_bits = e.y;
@@ -827,10 +827,10 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
       const uint32_t node = g_base + static_cast<uint32_t>(__builtin_popcount((g_bits >> 8) & ((1u << slot) - 1u)));
       if ((g_bits & 0xFFu) != 0u) {  // its siblings wait
         if (sp < RTC_TRAV_STACK) {
-          if (sp < RTC_LDS_TRAV) {
+          if (sp < LDS_ENTRIES) {
             lds_top[sp * 64] = Pair{g_base, g_bits};
           } else {
-            stack[sp - RTC_LDS_TRAV] = Pair{g_base, g_bits};
+            stack[sp - LDS_ENTRIES] = Pair{g_base, g_bits};
           }
           ++sp;
         } else {
@@ -992,7 +992,7 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 // group hold the same ray; lane `member` of the group takes every stride-th batch of four roots through both phases, and
 // the group's visitors are merged at the end: what one lane does in five batches and three exact tests in a row, eight
 // lanes do in one of each - the instruction stream of a wave with few rays left is what bounds it.  (0, 1): one lane, all.
-template <bool CSG, int WORLD, class V>
+template <bool CSG, int WORLD, class V, int TRAV = RTC_LDS_TRAV>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
                                       const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow,
                                       uint32_t* lds_stack, const uint32_t member = 0u, const uint32_t stride = 1u) {
@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
           if constexpr (CSG) visit_csg(S, R.index, ray, vis, overflow);
         } else {
 #if RTC_BVH8
-          traverse_bvh8<CSG>(S, R.geom, R.always_first, R.always_count, ray, vis, overflow, reinterpret_cast<uint2*>(lds_stack));
+          traverse_bvh8<CSG, V, TRAV>(S, R.geom, R.always_first, R.always_count, ray, vis, overflow, reinterpret_cast<uint2*>(lds_stack));
 #else
           traverse_bvh<CSG>(S, R.geom, ray, vis, overflow, lds_stack);
 #endif
@@ -1804,7 +1804,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // six VGPRs of a kernel at the 256-register limit.
   __shared__ double lds_acc[4][64][3];
   // per lane: the top of the BVH walk's stack (the eight-wide walk's entries are pairs of words)
-  __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : RTC_LDS_TRAV][RTC_BVH8 ? 128 : 64];
+  // (the three-wave general kernel keeps two entries in LDS: the eight-wide walk's stack is as deep as the tree and
+  // mostly one or two entries long)
+  constexpr int TRAV = (WAVES == 3 && RTC_BVH8) ? 2 : RTC_LDS_TRAV;
+  __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : TRAV][RTC_BVH8 ? 128 : 64];
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -2188,7 +2191,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_COUNT(0);
     {
       RTC_HIST_BEGIN();
-      trace<CSG, WORLD>(S, recs, cull, ray, hv, it_overflow, trav_stack, member, stride);
+      trace<CSG, WORLD, ClosestVisitor, TRAV>(S, recs, cull, ray, hv, it_overflow, trav_stack, member, stride);
       RTC_HIST_END(0);
     }
     RTC_STAMP(2);
@@ -2242,7 +2245,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       RTC_COUNT(4);
       {
         RTC_HIST_BEGIN();
-        trace<CSG, WORLD>(S, recs, cull, ray, bv, it_overflow, trav_stack, member, stride);
+        trace<CSG, WORLD, BehindVisitor, TRAV>(S, recs, cull, ray, bv, it_overflow, trav_stack, member, stride);
         RTC_HIST_END(2);
       }
       RTC_STAMP(6);
@@ -2399,7 +2402,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, WORLD>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
+            trace<CSG, WORLD, ShadowVisitor, TRAV>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
@@ -2676,6 +2679,19 @@ rtc_render_kernel_simple3(const DevScene S, const DevCamera cam, const DevPixelM
                           double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
   render_body<true, false, 2, 3>(S, cam, map, max_depth, out, stats, next_stats);
 }
+
+// The general kernel at THREE waves per SIMD (168 VGPRs, ~195 of them spilled; the small LDS tables of the three-wave
+// simple kernel, two LDS entries of the walk's stack).  A frame that is mostly BVH walks waits as much as it issues at two
+// waves (dragons 4K: four shadow walks per hit on a black background: 2.10 -> 1.97 ms), a frame that is mostly shading
+// pays for the spills (teapot 0.27 -> 0.40): which of the two a scene is is MEASURED, not guessed - a handle times both
+// kernels on its own steady-state frames and keeps the faster (rtc_capi.hip, KernelTune).
+#if RTC_BVH8
+extern "C" __global__ void __launch_bounds__(256, 3)
+rtc_render_kernel3(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                   double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, false, 0, 3>(S, cam, map, max_depth, out, stats, next_stats);
+}
+#endif
 
 // The same two kernels with the csg and texture-map paths compiled in (template flag CSG), for scenes that
 // have csg nodes or texture maps.  Kept apart because the out-of-line calls cost the main loop ~150 spilled

@@ -1228,6 +1228,42 @@ def test_three_lights_same_bits_whatever_the_kernel_and_the_schedule(rtc):
             assert np.array_equal(img, images[0][0]), (n_lights, k)
 
 
+def test_general_kernel_at_three_waves_and_its_trial(rtc):
+    """rtc_render_kernel3 (the general kernel at three waves per SIMD: smaller LDS tables, two LDS entries of the walk's
+    stack) forced by option: the oracle's image and counters on meshes, nested groups, cones on a group's always-visited
+    list.  Then the measured choice: twelve frames of a static view large enough for the trial (frames alternate between
+    the two kernels while a handle times them) - every frame is the same image to the last bits, whatever kernel ran."""
+    torch = pytest.importorskip("torch")
+    rtc.set_option("waves3", 1)
+    try:
+        for scene, w, h in (("teapot.json", 192, 108), ("dragons.json", 192, 108), ("groups.json", 150, 50), ("nefertiti.json", 90, 150)):
+            got, want, stats, counters = _both(rtc, scene, w, h, 5)
+            assert np.abs(got - want).max() < TOL, scene
+            assert [stats["overflow"], stats["secondary"], stats["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]]
+        hs = rtc.HostScene.from_file("teapot.json")
+        gpu = rtc.GpuScene(hs.desc)
+        gpu.render(hs.camera(64, 64), 5)
+        assert gpu.last_kernel_name() == "rtc_render_kernel3"
+    finally:
+        rtc.set_option("waves3", -1)
+    hs = rtc.HostScene.from_file("teapot.json")
+    cam = hs.camera(1024, 576)
+    want = ob.OracleScene(hs.desc).render(cam, 5, row_step=24)[0]
+    rows = np.arange(0, 576, 24)
+    gpu = rtc.GpuScene(hs.desc)
+    buf = torch.zeros((576, 1024, 3), dtype=torch.float64, device="cuda")
+    kernels, first = set(), None
+    for frame in range(14):
+        gpu.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        img = buf.cpu().numpy()
+        kernels.add(gpu.last_kernel_name())
+        assert np.abs(img[rows] - want[rows]).max() < TOL and gpu.stats()["overflow"] == 0, frame
+        first = img if first is None else first
+        assert np.abs(img - first).max() < REPEAT_TOL, frame
+    assert kernels == {"rtc_render_kernel", "rtc_render_kernel3"}, kernels   # (the trial ran both)
+
+
 def test_host_output_in_bands(rtc):
     """rtc_render cuts a large frame into horizontal bands (the lower ones on clones of the handle), each copied to the
     caller while the next renders: forced to three and four bands on small images - a rectangle that starts off the chunk
