@@ -335,6 +335,10 @@ def main():
     ap.add_argument("--output", choices=("f64", "rgba8"), default="f64",
                     help="what a split frame is gathered as: the f64 Canvas (canvas.zig, the default), or the RGBA8 framebuffer of "
                          "lib.zig:146-153 - every rank clamps the tiles it rendered and 4 bytes per pixel cross xGMI instead of 24")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="rtc_set_option before anything is created (tuning / test options; no result depends on one) - the "
+                         "profiling scripts pin the kernel a handle's own trial would choose (waves3) so that every PMC pass "
+                         "counts the same kernel")
     ap.add_argument("--check", action="store_true", help="after timing, compare the last frame with a plain render")
     ap.add_argument("--rehearse", action="store_true",
                     help="N ranks on ONE GPU over gloo (tiles staged through host memory): exercises the N > 1 code "
@@ -371,6 +375,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    for opt in args.option:
+        name, _, value = opt.partition("=")
+        rtc.set_option(name, float(value))
     hs = rtc.HostScene.from_file(args.scene)
     cam = hs.camera(args.width, args.height)
     W, H = cam.hsize, cam.vsize
@@ -582,6 +589,7 @@ def main():
                                           "shadow_calls": stats["shadow_calls"], "shadow_traced": stats["shadow_traced"]},
                        "mrays_per_s_incl_shadow_traced": (rays + stats["shadow_traced"]) * args.steps / elapsed / 1e6,
                        "frames_in_flight": M,
+                       "options": args.option,
                        "output": "f64 canvas" if dist is None or args.output == "f64" else "RGBA8 framebuffer (clamped by the rank that rendered the tile, 4 B/pixel gathered)",
                        "settle_frames": args.settle_frames,
                        "ms_per_step_right_after_startup": cold_ms,

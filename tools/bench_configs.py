@@ -18,7 +18,7 @@ for scene, w, h, depth in CONFIGS:
     hs = rtc.HostScene.from_file(scene); cam = hs.camera(w, h); gpu = rtc.GpuScene(hs.desc)
     stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
     canvas = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
-    for _ in range(3):
+    for _ in range(40):   # (the schedule settles, a handle's two- / three-wave trial runs its six frames)
         gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
     gpu.render_device(cam, canvas.data_ptr(), depth, None, stream.cuda_stream); torch.cuda.synchronize()
     n = 5; ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
@@ -34,4 +34,5 @@ for scene, w, h, depth in CONFIGS:
     print(json.dumps({"scene": scene, "size": [w, h], "depth": depth, "gpu_ms": round(ms, 3),
                       "mrays_s": round((st["primary"] + st["secondary"]) / ms / 1e3, 1), "rays": st,
                       "cpu_ms_extrapolated": round(cpu_ms, 1), "cpu_threads": CPU_THREADS, "speedup": round(cpu_ms / ms, 1),
-                      "max_delta_sampled_rows": delta, "leaves": hs.desc.n_leaves, "nodes": hs.desc.n_nodes}), flush=True)
+                      "max_delta_sampled_rows": delta, "leaves": hs.desc.n_leaves, "nodes": hs.desc.n_nodes,
+                      "kernel": gpu.last_kernel_name()}), flush=True)

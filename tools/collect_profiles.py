@@ -26,10 +26,25 @@ for prefix, name, key in WORKLOADS:
     trace = glob.glob(os.path.join(src, prefix + "stats", "**", "*_kernel_trace.csv"), recursive=True)[0]
     with open(trace) as f, open(os.path.join(dst, f"kernel_trace_head_{name}.csv"), "w") as g:
         rows = f.readlines()
-        g.writelines([rows[0]] + [r for r in rows[1:] if "rtc_render_kernel" in r][:3])
-    pmc = summarize([os.path.join(src, prefix + d) for d in PASSES])
+        g.writelines([rows[0]] + [r for r in rows[1:] if "rtc_render_kernel" in r][-3:])
+    # the render kernel's launch durations from the trace: all dispatches (what --stats averages: it includes the one
+    # no-work dispatch a handle's first launch sends ahead, and the frames of the two- / three-wave trial) and the steady
+    # state (the kernel with the most dispatches, durations within a factor of two of their median)
+    import csv, statistics
+    durs = {}
+    for r in csv.DictReader(open(trace)):
+        if "rtc_render_kernel" in r["Kernel_Name"]:
+            durs.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    main = max(durs, key=lambda n: len(durs[n]))
+    med = statistics.median(durs[main])
+    steady = [d for d in durs[main] if 0.5 * med <= d <= 2.0 * med]
+    key["kernel_ms"] = {"kernel": main, "steady_mean": sum(steady) / len(steady), "steady_dispatches": len(steady),
+                        "all_mean": sum(durs[main]) / len(durs[main]), "all_dispatches": len(durs[main]),
+                        "other_kernels": {n: len(v) for n, v in durs.items() if n != main}}
+    rep = {}
+    pmc = summarize([os.path.join(src, prefix + d) for d in PASSES], report=rep)
     with open(os.path.join(dst, f"pmc_{name}.txt"), "w") as g:
-        g.write(f"# {key['scene']} {key['width']}x{key['height']} depth {key['depth']}: per-launch means over the dispatches of the render kernel; separate rocprofv3 --pmc passes (tools/profile_round.sh)\n")
+        g.write(f"# {key['scene']} {key['width']}x{key['height']} depth {key['depth']}: per-launch means over the steady-state dispatches of {rep.get('kernel')} (tools/pmc_summary.py); separate rocprofv3 --pmc passes (tools/profile_round.sh)\n")
         for k, v in sorted(pmc.items()):
             g.write(f"{k:32s} {v:18.1f}\n")
         valu = pmc.get("SQ_INSTS_VALU", 0.0)
@@ -46,7 +61,7 @@ for prefix, name, key in WORKLOADS:
                         pmc={k: round(v, 1) for k, v in sorted(pmc.items())},
                         source=f"profiles/{rnd}/pmc_{name}.txt (rocprofv3 --pmc, separate passes, per-launch mean)"))
     ks = open(os.path.join(dst, f"kernel_stats_{name}.csv")).read().splitlines()
-    row = [r for r in ks if "rtc_render_kernel" in r][0].replace('"', "").split(",")
+    row = [r for r in ks if key["kernel_ms"]["kernel"] + '"' in r or key["kernel_ms"]["kernel"] + "," in r][0].replace('"', "").split(",")
     print(name, "kernel", row[0], "avg ns", row[3], "calls", row[1], "| VALU", round(pmc.get("SQ_INSTS_VALU", 0) / 1e6, 1), "M",
           "FETCH", round(pmc["FETCH_SIZE"] / 1024, 1), "MiB WRITE", round(pmc["WRITE_SIZE"] / 1024, 1), "MiB")
 json.dump({"workloads": entries}, open(os.path.join(repo, "profiles", "traffic.json"), "w"), indent=1)
@@ -59,3 +74,5 @@ if os.path.exists(os.path.join(src, "configs.txt")):
         g.writelines(l for l in f if l.startswith("{"))
 if os.path.exists(os.path.join(src, "scale_sim.txt")):
     shutil.copy(os.path.join(src, "scale_sim.txt"), os.path.join(dst, "scale_sim_one_gpu.jsonl"))
+if os.path.exists(os.path.join(src, "scale_sim_inflight3.txt")):
+    shutil.copy(os.path.join(src, "scale_sim_inflight3.txt"), os.path.join(dst, "scale_sim_frames_in_flight.jsonl"))

@@ -5,7 +5,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 passes() {  # passes <prefix> <bench arguments...>
@@ -21,14 +21,16 @@ passes() {  # passes <prefix> <bench arguments...>
 }
 passes ""
 echo "cover passes done"
-passes d_ --scene dragons.json --width 3840 --height 2160
+# (dragons: its handles choose the three-wave kernel - profiles/r04/bvh8_experiments.md; pinned here so that every pass counts the same kernel)
+passes d_ --scene dragons.json --width 3840 --height 2160 --option waves3=1
 echo "dragons passes done"
-passes t_ --scene teapot.json
+passes t_ --scene teapot.json --option waves3=0
 echo "teapot passes done"
 python3 tools/bench_configs.py > $OUT/configs.txt 2> $OUT/configs.err
 echo "configs done"
 for s in cover dragons teapot; do
   case $s in dragons) A="--scene dragons.json --width 3840 --height 2160";; teapot) A="--scene teapot.json";; *) A="";; esac
   python3 tools/scale_sim.py $A --tiles 64 --reps 20 >> $OUT/scale_sim.txt 2>> $OUT/scale_sim.err || true
+  python3 tools/scale_sim.py $A --tiles 64 --worlds 4,8 --reps 20 --inflight 3 >> $OUT/scale_sim_inflight3.txt 2>> $OUT/scale_sim.err || true
 done
 echo "scale_sim done"
