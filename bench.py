@@ -603,8 +603,10 @@ def main():
         # is measured beside the headline (same scene handle pattern as the split path: a handle and its clones).
         SPLIT_INFLIGHT = 3
         if world == 1 and not args.tile_path:
-            same_ms = ms_per_step if M == SPLIT_INFLIGHT else frames_in_flight_ms(rtc, torch, hs, args, stream, SPLIT_INFLIGHT)
-            result["value_same_inflight"] = rays / (same_ms * 1e-3) / 1e6
+            # (--no-extras - the profiling passes - skips it: three concurrent frames would mix into the per-dispatch counters
+            # and durations of the kernel being profiled)
+            same_ms = ms_per_step if M == SPLIT_INFLIGHT else (None if args.no_extras else frames_in_flight_ms(rtc, torch, hs, args, stream, SPLIT_INFLIGHT))
+            result["value_same_inflight"] = None if same_ms is None else rays / (same_ms * 1e-3) / 1e6
             result["config"]["same_inflight"] = {"frames_in_flight": SPLIT_INFLIGHT, "ms_per_frame": same_ms,
                                                  "note": "throughput of this N with the frames in flight the N > 1 lines use; "
                                                          "efficiency = value_same_inflight(N) / (N x value_same_inflight(1))"}

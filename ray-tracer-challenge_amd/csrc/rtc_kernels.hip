@@ -2526,7 +2526,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           if (sp < stack_cap) {
             push_level(sp++, p);
           } else {
-            overflow |= 1u;
+            overflow = CSG ? (overflow | 1u) : 1u;
           }
         }
       } else {
@@ -2582,7 +2582,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           if (sp < stack_cap) {
             push_level(sp++, yield.kid_later);
           } else {
-            overflow |= 1u;
+            overflow = CSG ? (overflow | 1u) : 1u;
           }
         }
         if (yield.n_kids != 0u) {
@@ -2620,7 +2620,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     if (threadIdx.x < 6u) wg_sum[threadIdx.x] = 0ull;
     __syncthreads();  // (every wave of the group gets here: the loop above ends for all of them)
     const unsigned long long s_pri = wave_sum(n_primary), s_sec = wave_sum(n_secondary), s_shc = wave_sum(n_shadow_calls),
-                             s_sht = wave_sum(n_shadow_traced), s_ovf = wave_sum(overflow != 0u ? 1u : 0u), s_stolen = wave_sum(n_stolen);
+                             s_sht = wave_sum(n_shadow_traced), s_ovf = wave_sum(CSG ? (overflow != 0u ? 1u : 0u) : overflow), s_stolen = wave_sum(n_stolen);
+    if constexpr (CSG)  // (only the *_ext kernels can have a csg list to run out of)
     if (__any((overflow >> 8) != 0u)) {  // a csg list ran out somewhere in the wave: what it needed (rare: straight to memory)
       unsigned need = overflow >> 8;
       for (int off = 32; off > 0; off >>= 1) need = max(need, static_cast<unsigned>(__shfl_xor(need, off, 64)));
