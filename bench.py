@@ -123,9 +123,10 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
     sptr = stream.cuda_stream
     cam = hs.camera(W, H)
     canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+    t0 = time.perf_counter()
     g = rtc.GpuScene(hs.desc)
     torch.cuda.synchronize()
-    out = {}
+    out = {"scene_create_ms": (time.perf_counter() - t0) * 1e3}   # (not the process's first)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for name in ("first_frame", "second_frame"):
         t0 = time.perf_counter()
@@ -150,10 +151,10 @@ def one_shot_and_moving_view(rtc, torch, hs, args, stream):
         times.append((time.perf_counter() - t0) * 1e3)
     out["host_output_first_ms"] = times[0]                 # a one-shot render: the 24 B/pixel copy into pageable memory
     out["host_output_pageable_ms"] = sorted(times[1:])[1]  # ... and again into the same pageable canvas
-    # (times[0] is also the PROCESS's first device-to-host copy: the HIP runtime's one-time set-up of its pageable-copy
-    # path, ~7 ms of it - tools/first_copy_probe.py, profiles/r04/first_copy_probe.txt.)  A fresh canvas AFTER that - the
-    # second scene of a host that renders scene after scene, main.zig:52-99 - pays the pages only, and those are
-    # populated while the kernel runs (rtc_render's prefaultCanvas):
+    # (times[0] is the process's first LARGE device-to-host copy.  The HIP runtime's one-time set-up of its pageable-copy
+    # path, ~7 ms - tools/first_copy_probe.py, profiles/r04/first_copy_probe.txt - is not in it any more: the first
+    # rtc_scene_create on a device pays it with a 64 KB copy of its own, `scene_create_first_ms` / `scene_create_ms`.)
+    # A fresh canvas pays its pages, and those are populated while the kernel runs (rtc_render's prefaultCanvas):
     fresh = np.empty((H, W, 3), dtype=np.float64)
     t0 = time.perf_counter()
     g.render_into(cam, fresh, args.depth)
@@ -381,7 +382,9 @@ def main():
     hs = rtc.HostScene.from_file(args.scene)
     cam = hs.camera(args.width, args.height)
     W, H = cam.hsize, cam.vsize
+    t_create = time.perf_counter()
     gpu = rtc.GpuScene(hs.desc)                      # scene uploaded to HBM once (outside the timed region)
+    create_first_ms = (time.perf_counter() - t_create) * 1e3   # (the process's first: + the runtime's D2H set-up, ~7 ms)
     # A non-default torch stream: the C ABI treats a NULL stream as "the handle's own stream", and
     # torch's default stream IS the NULL stream; HIP events must sit on the stream the kernel runs on.
     stream = torch.cuda.Stream()
@@ -668,6 +671,7 @@ def main():
                             result["roofline_valu"][k] = ex[k]
             if not args.no_extras:
                 result["config"].update(one_shot_and_moving_view(rtc, torch, hs, args, stream))
+                result["config"]["scene_create_first_ms"] = create_first_ms
                 result["config"]["frames_in_flight_ms_per_frame"][str(SPLIT_INFLIGHT)] = same_ms
             if not args.no_cpu_baseline:
                 result["cpu_baseline"] = cpu_baseline(rtc, hs, cam, args.depth)

@@ -282,7 +282,12 @@ double cutAbove(const rtc_scene* s, const DevPixelMap& map) {
   // frame's waves fill in; cuts only where a chunk is two shares.  The slowest 8-way share of cover, three in flight:
   // 0.116 -> 0.109 ms per frame, 4-way 0.164 -> 0.146)
   if (s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) return 2.0;
-  return static_cast<double>(map.n_chunks) >= 4.0 * residentWaves(s, map) ? 1.5 : 1.0;
+  // One share, whatever the size of the launch.  (Up to round 3 a launch of four chunks per wave and more cut from 1.5
+  // shares on: reflection_and_refraction at depth 8 - a closed box of mirrors whose heaviest chunks cost 1.3-1.6 shares -
+  // then settled at 1.68 or at 1.90 ms depending on which side of 1.5 the first frame's noise put them, handle by handle;
+  // from 0.6 to 1.0 shares every handle settles at 1.685 (0.4: 1.77-1.92; gpurun_out/r4_rr_cut.txt).  The other
+  // scenes do not care: cover 0.514 / 0.516, teapot 0.267 / 0.266, dragons 1.911 / 1.912, csg_demo 2.57 / 2.49.)
+  return 1.0;
 }
 
 // Packets a device-packed schedule of this pixel map can have at most: one per chunk, and up to fifteen more for every
@@ -1648,6 +1653,23 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
 
 extern "C" {
 
+// The HIP runtime sets its device-to-host path for pageable memory up at the first such copy of 64 KB or more on a
+// device: 6.8 ms, whatever the size (profiles/r04/first_copy_probe.txt: a 4 KB copy does not trigger it, a 64 KB copy
+// pays all of it).  The first handle created on a device makes that copy - into a buffer of its own, from the ray
+// levels just allocated, whose contents do not matter - so that the set-up is part of creating a scene (next to the
+// runtime's own start-up, a hundred times longer) and not of the first rtc_render into a host canvas.
+static void warmHostCopies(const rtc_scene* s) {
+  static std::atomic<uint64_t> warmed{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !s->d_ray_stack || s->ray_stack_capacity < 65536u) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (warmed.fetch_or(uint64_t{1} << dev) & (uint64_t{1} << dev)) return;
+  std::vector<char> sink(65536, 0);
+  if (hipMemcpy(sink.data(), s->d_ray_stack, sink.size(), hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+}
+
 int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
   g_error.clear();
   if (!desc || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
@@ -1686,6 +1708,7 @@ int rtc_scene_create(const rtc_scene_desc* desc, rtc_scene** out) {
       s->d_ray_stack = nullptr;
     }
   }
+  warmHostCopies(s);
   guard.s = nullptr;
   *out = s;
   return RTC_OK;
