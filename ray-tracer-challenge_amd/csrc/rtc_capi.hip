@@ -180,11 +180,14 @@ DevCamera devCamera(const rtc_camera& c) {
   return d;
 }
 
+// Everything the handle has enqueued is done: its last launch, whatever stream it ran on, and the packer behind it.
+hipError_t handleIdle(const rtc_scene* s) { return hipEventSynchronize(s->launch_done); }
+
 // Both schedule buffers hold at least `words` words (16 per packet; maxPackets() of them).  Growing drops what the
 // buffers held.
 int ensureScheduleBuffers(rtc_scene* s, size_t words) {
   if (words <= s->sched_capacity) return RTC_OK;
-  HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be reading a buffer)
+  HIP_TRY(handleIdle(s));  // (the last launch may still be reading a buffer)
   for (int b = 0; b < 2; ++b) {
     if (s->d_sched[b]) (void)hipFree(s->d_sched[b]);
     s->d_sched[b] = nullptr;
@@ -310,7 +313,7 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
   // (a schedule with chunks cut into runs can have more packets than there are chunks: at most 16 parts each)
   const size_t need_pt = static_cast<size_t>(map.n_chunks) * 16u;
   if (need_pt > s->packet_time_capacity) {
-    HIP_TRY(hipEventSynchronize(s->launch_done));
+    HIP_TRY(handleIdle(s));
     if (s->d_packet_time) (void)hipFree(s->d_packet_time);
     s->d_packet_time = nullptr;
     s->packet_time_capacity = 0;
@@ -318,7 +321,7 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
     s->packet_time_capacity = need_pt;
   }
   if (map.n_chunks > s->pack_capacity) {
-    HIP_TRY(hipEventSynchronize(s->launch_done));
+    HIP_TRY(handleIdle(s));
     for (uint32_t** p : {&s->d_chunk_time, &s->d_sorted, &s->d_chunk_cost}) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
@@ -351,7 +354,24 @@ int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
 struct SchedulePlan {
   bool measure = false;   // this launch collects costs and packet times, and the next schedule is packed from them
   bool estimate = false;  // ... and is preceded by rtc_estimate_kernel + the packer: ITS schedule from the roots' bounds
+  bool moved = false;     // the view is not the one the schedule in use was measured with
 };
+
+// A camera a few frames of an orbit or a walk away from `b` (lib.zig:166-190: 0.01-0.1 rad, a step of the scene's scale):
+// the same image geometry, every entry of the rotation within 0.05, the position within 5 % of its distance from the
+// origin (+ 0.05).  What a schedule measured at `b` is still good for.
+bool nearbyView(const rtc_camera& a, const rtc_camera& b) {
+  if (a.hsize != b.hsize || a.vsize != b.vsize || a.half_width != b.half_width || a.half_height != b.half_height ||
+      a.pixel_size != b.pixel_size)
+    return false;
+  double t2 = 0.0;
+  for (int r = 0; r < 3; ++r) t2 += b.inv_view[4 * r + 3] * b.inv_view[4 * r + 3];
+  const double t_tol = 0.05 * std::sqrt(t2) + 0.05;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c)
+      if (!(std::fabs(a.inv_view[4 * r + c] - b.inv_view[4 * r + c]) <= (c == 3 ? t_tol : 0.05))) return false;
+  return true;
+}
 
 int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32_t max_depth, size_t out_pixels,
                    hipStream_t stream, SchedulePlan& plan) {
@@ -370,7 +390,7 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   if (new_map && s->d_cost != nullptr && out_pixels <= s->cost_capacity)
     HIP_TRY(hipMemsetAsync(s->d_cost, 0, out_pixels * sizeof(uint32_t), stream));
   if (out_pixels > s->cost_capacity) {
-    HIP_TRY(hipEventSynchronize(s->launch_done));
+    HIP_TRY(handleIdle(s));
     if (s->d_cost) (void)hipFree(s->d_cost);
     s->d_cost = nullptr;
     s->cost_capacity = 0;
@@ -393,7 +413,22 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
     return RTC_OK;
   }
   useSchedule(s, map);
-  plan.measure = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
+  // A view that moves is measured every frame: the schedule in use is one frame old.  Option "measure_every" = n measures
+  // a view that moves in small steps every n-th frame only (n - 1 of n frames then run without the measuring stores and
+  // without the 55 us of packer kernels behind them) - which pays where the cost of a chunk does not depend much on the
+  // view and loses badly where it does (orbiting at 0.01 rad per frame, every frame / every fourth: teapot 1080p
+  // 0.361 / 0.316 ms per frame, cover 0.577 / 0.795, dragons 4K 2.12 / 2.30: cover's glass and dragons' silhouettes move
+  // by pixels per frame, and a schedule three frames old is no better than the estimate's).  Hence n = 1.
+  // A jump to another view, another depth or image is measured at once whatever n.
+  plan.moved = std::memcmp(&cam, &s->sched_cam, sizeof cam) != 0 || max_depth != s->sched_depth;
+  if (!plan.moved) {
+    s->frames_unmeasured = 0;
+  } else {
+    const uint32_t every = static_cast<uint32_t>(std::max(1.0, rtcOptions().measure_every));
+    const bool near = max_depth == s->sched_depth && nearbyView(cam, s->sched_cam);
+    plan.measure = !near || ++s->frames_unmeasured >= every;
+    if (plan.measure) s->frames_unmeasured = 0;
+  }
   return RTC_OK;
 }
 
@@ -453,7 +488,7 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
 int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_depth) {
   const size_t need = static_cast<size_t>(blocks) * 4u * (max_depth + 2u) * 64u * 64u;
   if (need > s->ray_stack_capacity) {
-    HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
+    HIP_TRY(handleIdle(s));  // (the last launch may still be using the old buffer)
     if (s->d_ray_stack) (void)hipFree(s->d_ray_stack);
     s->d_ray_stack = nullptr;
     s->ray_stack_capacity = 0;
@@ -472,7 +507,7 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   if (s->has_csg) {
     const size_t need_csg = static_cast<size_t>(blocks) * 4u * s->dev.csg_entries * 64u * sizeof(CsgRec);
     if (need_csg > s->csg_buf_capacity) {
-      HIP_TRY(hipEventSynchronize(s->launch_done));  // (the last launch may still be using the old buffer)
+      HIP_TRY(handleIdle(s));  // (the last launch may still be using the old buffer)
       if (s->d_csg_buf) (void)hipFree(s->d_csg_buf);
       s->d_csg_buf = nullptr;
       s->csg_buf_capacity = 0;
@@ -579,8 +614,8 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       T.n[0] = T.n[1] = 0;
       for (int& w : T.which) w = -1;
     }
-    if (eligible && T.state == 1 && !(!plan.measure && !plan.estimate && map.order != nullptr)) s->use_general3 = false;  // (the view moved: the trial waits)
-    if (eligible && T.state != 2 && !plan.measure && !plan.estimate && map.order != nullptr) {
+    if (eligible && T.state == 1 && !(!plan.moved && !plan.estimate && map.order != nullptr)) s->use_general3 = false;  // (the view moved: the trial waits)
+    if (eligible && T.state != 2 && !plan.moved && !plan.estimate && map.order != nullptr) {
       for (int k = 0; k < rtc_scene::KernelTune::kRing; ++k) {
         if (T.which[k] < 0) continue;
         const hipError_t q = hipEventQuery(T.ev[k][1]);
@@ -652,6 +687,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   if (trial_slot >= 0) HIP_TRY(hipEventRecord(s->tune.ev[trial_slot][0], stream));
   if (const int st = enqueueRender(s, cam, map, max_depth, d_out, stream); st != RTC_OK) return st;
   if (trial_slot >= 0) HIP_TRY(hipEventRecord(s->tune.ev[trial_slot][1], stream));
+  // (The packer runs on the launch's own stream.  On a stream of its own, so that a frame ends with its render kernel -
+  // tried in round 4 -, every hand-over between the two queues cost more than the 55 us of packer kernels it took off
+  // the frame: cover orbiting 0.563 -> 0.81 ms per frame, first frame 0.79 -> 0.87.)
   if (plan.measure)
     if (const int st = packNextSchedule(s, cam, map, max_depth, stream, PackFrom::Measurement); st != RTC_OK) return st;
   HIP_TRY(hipEventRecord(s->launch_done, stream));
@@ -1863,7 +1901,7 @@ int rtc_render_tile_list_device(rtc_scene* s, const rtc_camera* cam, uint32_t ma
   hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
   if (s->h_tile_list.size() != n_my_tiles || std::memcmp(s->h_tile_list.data(), tiles, n_my_tiles * sizeof(uint32_t)) != 0) {
     if (n_my_tiles > s->tile_list_capacity) {
-      HIP_TRY(hipEventSynchronize(s->launch_done));
+      HIP_TRY(handleIdle(s));
       if (s->d_tile_list) (void)hipFree(s->d_tile_list);
       s->d_tile_list = nullptr;
       s->tile_list_capacity = 0;
@@ -1895,7 +1933,7 @@ int rtc_get_tile_costs(rtc_scene* s, double* cost_out, uint32_t n_regions) {
     return fail(RTC_ERR_INVALID_ARGUMENT, "no measured launch with %u regions on this handle (the last one had %u)", n_regions,
                 s->measured_regions);
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipEventSynchronize(s->launch_done));
+  HIP_TRY(handleIdle(s));
   const size_t n = static_cast<size_t>(s->measured_regions) * s->measured_chunks_per_region;
   std::vector<uint32_t> t(n);
   HIP_TRY(hipMemcpy(t.data(), s->d_chunk_time, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1966,7 +2004,7 @@ namespace {
 // The frame of a host-output render: device staging for w x h pixels.
 int ensureFrame(rtc_scene* s, size_t doubles) {
   if (doubles <= s->frame_capacity) return RTC_OK;
-  HIP_TRY(hipEventSynchronize(s->launch_done));
+  HIP_TRY(handleIdle(s));
   if (s->d_frame) (void)hipFree(s->d_frame);
   s->d_frame = nullptr;
   s->frame_capacity = 0;
@@ -2017,7 +2055,7 @@ int rtc_grow_csg_lists(rtc_scene* s) {
   g_error.clear();
   if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipEventSynchronize(s->launch_done));
+  HIP_TRY(handleIdle(s));
   const int ov = checkOverflow(s);
   if (ov != RTC_ERR_OVERFLOW) return ov;  // (RTC_OK: nothing overflowed, nothing to do)
   return growCsgLists(s) ? RTC_OK : ov;
@@ -2047,7 +2085,8 @@ int rtc_set_option(const char* name, double value) {
   } table[] = {{"simple3_min_chunks", &o.simple3_min_chunks}, {"sched_off", &o.sched_off}, {"cut_above", &o.cut_above},
                {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
-               {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3}};
+               {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3},
+               {"measure_every", &o.measure_every}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
       *e.slot = value;
@@ -2260,7 +2299,7 @@ int rtc_get_schedule(rtc_scene* s, uint32_t* items, size_t capacity_items, uint3
   if (!s || !n_packets) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   *n_packets = 0;
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipEventSynchronize(s->launch_done));
+  HIP_TRY(handleIdle(s));
   if (!s->sched_valid || !s->d_sched_info) return RTC_OK;
   DevSchedInfo info{};
   HIP_TRY(hipMemcpy(&info, s->d_sched_info + s->sched_cur, sizeof info, hipMemcpyDeviceToHost));
@@ -2278,7 +2317,7 @@ int rtc_get_chunk_times(rtc_scene* s, const rtc_camera* cam, uint32_t* estimated
   if (!s || !cam || !n_chunks) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   *n_chunks = 0;
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipEventSynchronize(s->launch_done));
+  HIP_TRY(handleIdle(s));
   if (s->cost_key.empty() || !s->d_chunk_time || s->pack_capacity == 0) return RTC_OK;  // nothing scheduled has run
   DevPixelMap map{};
   std::memcpy(&map, s->cost_key.data(), std::min(s->cost_key.size() * sizeof(uint32_t), sizeof map));
@@ -2318,7 +2357,7 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   g_error.clear();
   if (!s || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipEventSynchronize(s->launch_done));  // the last launch on this handle, whatever stream it ran on
+  HIP_TRY(handleIdle(s));  // the last launch on this handle, whatever stream it ran on
   const std::unique_ptr<DevStats> hp(new DevStats);  // large in diagnostic layouts: off the stack, and not shared between handles
   DevStats& h = *hp;
   HIP_TRY(hipMemcpy(&h, s->d_stats + s->stats_parity, sizeof h, hipMemcpyDeviceToHost));
@@ -2329,7 +2368,7 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   out->overflow = h.overflow;
   for (uint32_t b = 1; b < s->last_bands; ++b) {  // (a frame rtc_render cut into bands: the other bands' counters)
     rtc_scene* const o = s->band[b - 1];
-    HIP_TRY(hipEventSynchronize(o->launch_done));
+    HIP_TRY(handleIdle(o));
     HIP_TRY(hipMemcpy(&h, o->d_stats + o->stats_parity, sizeof h, hipMemcpyDeviceToHost));
     out->primary += h.primary;
     out->secondary += h.secondary;

@@ -53,6 +53,7 @@ struct RtcOptions {
   double bvh_one_axis = 0.0;         // != 0: SAH on the longest axis only
   double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
   double waves3 = -1.0;              // the general kernel at three waves per SIMD: 1 always (where the tables fit), 0 never, < 0: measured per handle
+  double measure_every = 1.0;        // a moving view is measured (and its schedule re-packed) every this many frames (see updateSchedule)
   double host_bands = 0.0;           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
 };
 inline RtcOptions& rtcOptions() {
@@ -158,6 +159,7 @@ struct rtc_scene {
   bool sched_valid = false;               // d_sched[sched_cur] holds a schedule for the pixel map `cost_key`
   rtc_camera sched_cam{};                 // the view (and depth) that schedule was measured with: another view measures again
   uint32_t sched_depth = 0;
+  uint32_t frames_unmeasured = 0;         // frames of a moving view since the last measured one (updateSchedule)
   uint32_t* d_chunk_time = nullptr;       // the packer's scratch: per-chunk times, sorted chunks
   uint32_t* d_sorted = nullptr;
   DevChunkShape* d_chunk_shape = nullptr; // per chunk: how its rays are spread over its pixels (for the chunks the packer cuts)

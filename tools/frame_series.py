@@ -36,10 +36,15 @@ for h in range(a.handles):
     g = rtc.GpuScene(hs.desc)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.frames + 1)]
     ev[0].record(stream)
+    cams = [cam, cam]
+    if a.wiggle != 0.0:   # (the two views are made before the frames are enqueued: the host's share is one call per frame)
+        hs.rotate_camera(a.wiggle); cams[0] = hs.camera(a.width, a.height)
+        hs.rotate_camera(-a.wiggle); cams[1] = hs.camera(a.width, a.height)
+    import time
+    host_t = [time.perf_counter()]
     for f in range(a.frames):
-        if a.wiggle != 0.0:
-            hs.rotate_camera(a.wiggle if f % 2 == 0 else -a.wiggle)
-            cam = hs.camera(a.width, a.height)
+        cam = cams[f % 2]
+        host_t.append(time.perf_counter())
         g.render_device(cam, canvas.data_ptr(), a.depth - (1 if f == a.remeasure_at else 0), None, stream.cuda_stream)
         ev[f + 1].record(stream)
     stream.synchronize()
@@ -52,5 +57,7 @@ for h in range(a.handles):
     print("  schedule: %d packets, %d items, %d of them part of a cut chunk (%d chunks cut), first packets' items %s; measured chunk ticks: total %d max %d" % (
         len(sch), len(items), int((pixels < 64).sum()), len(np.unique((items & 0xFFFFF)[pixels < 64])),
         [int((r != 0xFFFFFFFF).sum()) for r in sch[:8]], int(got.sum()), int(got.max())), flush=True)
+    if a.wiggle != 0.0:
+        print("  host, us between enqueues: " + " ".join("%.0f" % ((host_t[i + 1] - host_t[i]) * 1e6) for i in range(1, a.frames)))
     print("handle %d %s | %s | min %.3f median-of-last-20 %.3f last %.3f" % (
         h, g.last_kernel_name(), " ".join("%.3f" % x for x in t), min(t), statistics.median(t[-20:]), t[-1]), flush=True)
