@@ -1406,6 +1406,30 @@ def test_interactive_camera_loop(rtc):
     assert np.abs(frames[0] - frames[1]).max() > 1e-3 and np.abs(frames[1] - frames[2]).max() > 1e-3
 
 
+def test_moving_view_measured_every_nth_frame(rtc):
+    """Option "measure_every": a view that moves in small steps is measured (and its schedule re-packed) every n-th frame
+    only, a jump at once; the frames in between run on a schedule up to n - 1 frames old.  Results never depend on the
+    schedule: every frame of an orbit equals the frame a fresh handle renders of that view (to the last bits: the pixels
+    of cover whose ray trees are shared between lanes are summed with atomics), whatever n."""
+    hs = rtc.HostScene.from_file("cover.json")
+    W, H = 320, 200                                   # 1000 chunks: scheduled launches
+    cams = []
+    for step in range(9):
+        cams.append(hs.camera(W, H))
+        hs.rotate_camera(1.0 if step == 5 else 0.01)  # small steps, one jump
+    want = [rtc.GpuScene(hs.desc).render(c, 5) for c in cams]
+    try:
+        for every in (4, 1):
+            rtc.set_option("measure_every", every)
+            gpu = rtc.GpuScene(hs.desc)
+            for i, c in enumerate(cams):
+                got = gpu.render(c, 5)
+                assert np.abs(got - want[i]).max() < REPEAT_TOL, (every, i)
+                assert gpu.stats()["overflow"] == 0
+    finally:
+        rtc.set_option("measure_every", 1)
+
+
 def test_bench_multi_rank_path_rehearsal():
     """bench.py's N > 1 code path (tile split, gather, rtc_assemble_tiles_device, stats reduction, the JSON line) with
     two ranks on the ONE GPU of this box over gloo (--rehearse); real RCCL runs over N GPUs are the driver's."""
