@@ -76,7 +76,7 @@ extern "C" __global__ void rtc_pack_sort_kernel(const uint32_t* __restrict__ chu
 extern "C" __global__ void rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves,
                                                 const float t_min, const float cut_above, const int rounds,
                                                 const DevPackState* __restrict__ state, uint32_t* __restrict__ order_out,
-                                                DevSchedInfo* __restrict__ info);
+                                                DevSchedInfo* __restrict__ info, const int mix);
 extern "C" __global__ void rtc_rgba8_kernel(const double* __restrict__ canvas, const size_t n_pixels, uint32_t* __restrict__ rgba);
 extern "C" __global__ void rtc_assemble_list_kernel(const double* __restrict__ gathered, const uint32_t* __restrict__ slot_of_tile,
                                                     const uint32_t tile_w, const uint32_t tile_h, const uint32_t hsize,
@@ -470,7 +470,8 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
   hipLaunchKernelGGL(rtc_pack_sort_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_chunk_time, n, n_waves, t_min,
                      cut_above, rounds, s->d_chunk_shape, s->d_pack_state, s->d_sorted, s->d_sched[target]);
   hipLaunchKernelGGL(rtc_pack_emit_kernel, dim3((n + 1023u) / 1024u), dim3(1024), 0, stream, s->d_sorted, n, n_waves, t_min,
-                     cut_above, rounds, s->d_pack_state, s->d_sched[target], s->d_sched_info + target);
+                     cut_above, rounds, s->d_pack_state, s->d_sched[target], s->d_sched_info + target,
+                     static_cast<int>(rtcOptions().sched_mix));
   HIP_TRY(hipGetLastError());
   if (!unmeasured) {
     s->measured_regions = map.mode == 0u ? 1u : map.n_my_tiles;
@@ -2086,7 +2087,7 @@ int rtc_set_option(const char* name, double value) {
                {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
                {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3},
-               {"measure_every", &o.measure_every}};
+               {"measure_every", &o.measure_every}, {"sched_mix", &o.sched_mix}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
       *e.slot = value;

@@ -44,7 +44,18 @@
 // Diagnostic build only (-DRTC_PROFILE): wave time per section of the main loop, from s_memtime stamps,
 // summed into DevStats::prof.  Never defined in the shipped library; numbers from such a build are
 // shares, not run times (MI355X guide, "In-kernel stamps").
-#ifdef RTC_PROFILE
+// -DRTC_PROFILE -DRTC_PROFILE_LITE: only the per-wave log (lifetime, packets, time of the last fetch - DevStats::prof_log)
+// and the walk counters' bounds checks; no section stamps, so the frame runs at nearly its product speed.
+#if defined(RTC_PROFILE) && defined(RTC_PROFILE_LITE)
+#define RTC_STAMP(sec)                                                     \
+  do {                                                                     \
+    if ((sec) == 7) prof_t = __builtin_amdgcn_s_memtime();                 \
+    (void)prof_sec;                                                        \
+  } while (0)
+#define RTC_COUNT(slot) do { } while (0)
+#define RTC_HIST_BEGIN() do { } while (0)
+#define RTC_HIST_END(kind) do { } while (0)
+#elif defined(RTC_PROFILE)
 #define RTC_STAMP(sec)                                                     \
   do {                                                                     \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();          \
@@ -71,7 +82,10 @@
 #define RTC_HIST_END(kind) do { } while (0)
 #endif
 
-#ifdef RTC_PROFILE
+#if defined(RTC_PROFILE) && defined(RTC_PROFILE_LITE)
+__shared__ DevStats* rtc_prof_stats;
+#define RTC_WALK_ADD(slot, n) do { } while (0)
+#elif defined(RTC_PROFILE)
 __shared__ DevStats* rtc_prof_stats;  // (diagnostic builds: where the walks add their counts, DevStats::prof4)
 #define RTC_WALK_ADD(slot, n)                                                                              \
   do {                                                                                                      \
@@ -1902,6 +1916,8 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   unsigned long long prof_snap[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // prof_acc at the wave's last packet fetch
   unsigned long long prof3[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned prof_last_unit = 0, prof_first_unit = 0;
+  const unsigned long long prof_real0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long prof_real_fetch = prof_real0;
 #endif
   for (;;) {
     RTC_STAMP(0);
@@ -2034,6 +2050,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           prof_last_unit = c;
           prof_first_unit = static_cast<unsigned>((__builtin_amdgcn_s_memtime() - prof_start) >> 8);  // time of the last fetch
           prof_units += 1ull;
+          prof_real_fetch = __builtin_amdgcn_s_memrealtime();
           for (int i = 0; i < 16; ++i) prof_snap[i] = prof_acc[i];
           prof_snap[7] = prof_iters;
 #endif
@@ -2611,6 +2628,13 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     stats->prof_log[wid][2] = prof_units;
     stats->prof_log[wid][3] = (static_cast<unsigned long long>(prof_first_unit) << 32) | prof_last_unit;
     for (int i = 0; i < 16; ++i) stats->prof_last[wid][i] = prof_acc[i] - prof_snap[i];  // sections of the last packet
+#ifdef RTC_PROFILE_LITE
+    // (no sections in this mode: when the wave began, fetched its last packet and ended, by the 100 MHz clock all XCDs
+    // share - s_memtime is a counter per XCD)
+    stats->prof_last[wid][0] = prof_real0;
+    stats->prof_last[wid][1] = __builtin_amdgcn_s_memrealtime();
+    stats->prof_last[wid][2] = prof_real_fetch;
+#endif
   }
 #endif
   // The counters: summed over the wave, then over the work-group in LDS, one atomic per counter per work-group (each
@@ -3312,7 +3336,7 @@ rtc_pack_sort_kernel(const uint32_t* __restrict__ chunk_time, const uint32_t n_c
 extern "C" __global__ void __launch_bounds__(1024)
 rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunks, const float n_waves, const float t_min,
                      const float cut_above, const int rounds, const DevPackState* __restrict__ state,
-                     uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info) {
+                     uint32_t* __restrict__ order_out, DevSchedInfo* __restrict__ info, const int mix) {
   __shared__ PackLayout L;
   pack_layout(state, n_waves, t_min, cut_above, rounds, L);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3328,7 +3352,36 @@ rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunk
   const uint32_t j = i - L.cbase[k], kk = L.per_packet[k];
   if (L.parts[k] != 0u) return;  // (a cut class: rtc_pack_sort_kernel wrote its packets)
   if (j % kk != 0u) return;
-  const uint32_t p = state->parts_cursor + L.pbase[k] + j / kk;  // (behind the runs of the cut chunks)
+  uint32_t rank = L.pbase[k] + j / kk;  // longest first
+  if (mix != 0) {
+    // Behind the first packet of every wave the schedule alternates between its long and its short end - longest, shortest,
+    // second longest, second shortest ... - and ends in the middle of the range.
+    const uint32_t a = max(1u, static_cast<uint32_t>(mix) & 0xFFu), b = max(1u, (static_cast<uint32_t>(mix) >> 8) & 0xFFu);
+    const uint32_t mode = (static_cast<uint32_t>(mix) >> 16) & 0xFu;
+    const uint32_t keep = min(static_cast<uint32_t>(n_waves), L.n_packets);
+    if (rank >= keep) {
+      const uint32_t m = L.n_packets - keep, r = rank - keep;
+      if (mode == 1u) {  // (diagnostic: a fixed pseudo-random order)
+        uint32_t K = 7919u;
+        while (m % K == 0u || K % 2u == 0u) K += 2u;
+        uint32_t g0 = m, g1 = K;  // gcd
+        while (g1 != 0u) { const uint32_t t = g0 % g1; g0 = g1; g1 = t; }
+        if (g0 == 1u) rank = keep + static_cast<uint32_t>((static_cast<unsigned long long>(r) * K) % m);
+      } else {  // a packets from the long end, then b from the short end, and so on; what is left over (the middle) last
+        const uint32_t G = min((m * a / (a + b)) / a, (m - m * a / (a + b)) / b);
+        const uint32_t sa = G * a, sb = G * b;
+        if (r < sa) {
+          rank = keep + (r / a) * (a + b) + r % a;
+        } else if (r >= m - sb) {
+          const uint32_t c = m - 1u - r;
+          rank = keep + (c / b) * (a + b) + a + c % b;
+        } else {
+          rank = keep + G * (a + b) + (r - sa);
+        }
+      }
+    }
+  }
+  const uint32_t p = state->parts_cursor + rank;  // (behind the runs of the cut chunks)
   const uint32_t have = min(kk, state->cnt[k] - j);
   uint32_t items[RTC_PACKET_ITEMS];
 #pragma unroll
