@@ -3354,8 +3354,12 @@ rtc_pack_emit_kernel(const uint32_t* __restrict__ sorted, const uint32_t n_chunk
   if (j % kk != 0u) return;
   uint32_t rank = L.pbase[k] + j / kk;  // longest first
   if (mix != 0) {
-    // Behind the first packet of every wave the schedule alternates between its long and its short end - longest, shortest,
-    // second longest, second shortest ... - and ends in the middle of the range.
+    // Behind the first packet of every wave the schedule takes a packets from its long end, then b from its short end, and
+    // so on (5 : 3), and ends in the middle of the range.  Longest first throughout - rounds 2 and 3 - puts every wave's
+    // cheapest packets last, and by the per-wave log of the light profile build (tools/wave_ends.py) those ran several
+    // times longer at the end of a frame than the schedule had them down for: cover 1080p 0.517 -> 0.498 ms, teapot
+    // 0.268 -> 0.256, nefertiti 0.507 -> 0.490, dragons 4K 1.91 -> 1.89 with the same instructions and bytes
+    // (profiles/r04/schedule_order.txt; 1:1, blocks, a reserved short tail, a pseudo-random order: all worse).
     const uint32_t a = max(1u, static_cast<uint32_t>(mix) & 0xFFu), b = max(1u, (static_cast<uint32_t>(mix) >> 8) & 0xFFu);
     const uint32_t mode = (static_cast<uint32_t>(mix) >> 16) & 0xFu;
     const uint32_t keep = min(static_cast<uint32_t>(n_waves), L.n_packets);
