@@ -18,13 +18,18 @@ hs.rotate_camera(1e-7); cams = [hs.camera(w, h)]; hs.rotate_camera(-1e-7); cams.
 for f in range(12):
     g.render_device(cams[f % 2], canvas.data_ptr(), depth, None, stream.cuda_stream)
 torch.cuda.synchronize()
-sch = g.schedule()
-est, got = g.chunk_times(cams[1])
+sch = g.schedule()                     # packed from frame 11's measurement: what frame 12 runs
+est, got = g.chunk_times(cams[1])      # ... and that measurement
+g.render_device(cams[0], canvas.data_ptr(), depth, None, stream.cuda_stream)   # frame 12, measured as well
+torch.cuda.synchronize()
+est2, got2 = g.chunk_times(cams[0])    # what the packets of `sch` really took (a packet's time, shared among its items)
 valid = sch != 0xFFFFFFFF
 chunk = sch & 0xFFFFF
 pixels = ((sch >> 26) & 63) + 1
+whole = (pixels == 64)
 t_item = np.where(valid, got[np.minimum(chunk, len(got) - 1)] * (pixels / 64.0), 0.0)
 t_packet = t_item.sum(axis=1)
+t_actual = np.where(valid & whole, got2[np.minimum(chunk, len(got2) - 1)], 0.0).sum(axis=1)   # (packets of whole chunks only)
 n_items = valid.sum(axis=1)
 total = t_packet.sum()
 waves = 3072 if "3" in g.last_kernel_name() else 2048
@@ -34,5 +39,7 @@ n = len(sch)
 for k in range(20):
     a, b = n * k // 20, n * (k + 1) // 20
     tp = t_packet[a:b]
-    print("  packets %6d-%6d: items per packet %.2f, packet time mean %8.0f max %8.0f, %.1f %% of the frame's time" % (
-        a, b, n_items[a:b].mean(), tp.mean(), tp.max(), 100.0 * tp.sum() / total))
+    ok = (valid[a:b] & ~whole[a:b]).sum(axis=1) == 0      # packets without runs of cut chunks
+    ratio = t_actual[a:b][ok].sum() / max(1.0, tp[ok].sum())
+    print("  packets %6d-%6d: items per packet %.2f, packet time mean %8.0f max %8.0f, %.1f %% of the frame's time; the frame after: x %.2f" % (
+        a, b, n_items[a:b].mean(), tp.mean(), tp.max(), 100.0 * tp.sum() / total, ratio))
