@@ -355,6 +355,7 @@ struct SchedulePlan {
   bool measure = false;   // this launch collects costs and packet times, and the next schedule is packed from them
   bool estimate = false;  // ... and is preceded by rtc_estimate_kernel + the packer: ITS schedule from the roots' bounds
   bool moved = false;     // the view is not the one the schedule in use was measured with
+  bool near = false;      // ... but a small step away from it (nearbyView): an orbit, a walk
 };
 
 // A camera a few frames of an orbit or a walk away from `b` (lib.zig:166-190: 0.01-0.1 rad, a step of the scene's scale):
@@ -426,6 +427,7 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   } else {
     const uint32_t every = static_cast<uint32_t>(std::max(1.0, rtcOptions().measure_every));
     const bool near = max_depth == s->sched_depth && nearbyView(cam, s->sched_cam);
+    plan.near = near;
     plan.measure = !near || ++s->frames_unmeasured >= every;
     if (plan.measure) s->frames_unmeasured = 0;
   }
@@ -596,7 +598,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   SchedulePlan plan;
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
   // ---- two or three waves per SIMD for a world with groups: measured on the handle's own frames (KernelTune).  Once a
-  // pixel map's schedule is steady (a static view, nothing being measured), six of its frames alternate between
+  // pixel map has a measured schedule (a static view, or one that moves in small steps), six of its frames alternate between
   // rtc_render_kernel and rtc_render_kernel3 with HIP events around the render kernel; as soon as three frames of each
   // have been timed (the events are polled, never waited for) the handle keeps the kernel whose fastest frame was
   // at least 3 % faster, and measures one more frame so that the schedule is packed for that kernel's wave count.
@@ -615,8 +617,11 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       T.n[0] = T.n[1] = 0;
       for (int& w : T.which) w = -1;
     }
-    if (eligible && T.state == 1 && !(!plan.moved && !plan.estimate && map.order != nullptr)) s->use_general3 = false;  // (the view moved: the trial waits)
-    if (eligible && T.state != 2 && !plan.moved && !plan.estimate && map.order != nullptr) {
+    // (a view that moves in small steps - consecutive frames of an orbit cost the same - is as good as a still one: an
+    // interactive host whose camera never rests gets its trial too; a jump to another view makes the trial wait)
+    const bool steady = (!plan.moved || plan.near) && !plan.estimate && map.order != nullptr;
+    if (eligible && T.state == 1 && !steady) s->use_general3 = false;
+    if (eligible && T.state != 2 && steady) {
       for (int k = 0; k < rtc_scene::KernelTune::kRing; ++k) {
         if (T.which[k] < 0) continue;
         const hipError_t q = hipEventQuery(T.ev[k][1]);
