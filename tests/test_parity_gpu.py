@@ -439,6 +439,34 @@ def test_device_schedules_hand_out_every_pixel_once(rtc, scene, w, h, rect, expe
         assert min(runs) > 0, runs
 
 
+def test_every_order_of_the_packets_is_a_schedule(rtc):
+    """Option "sched_mix" = a | b << 8: behind every wave's first packet the schedule takes a packets from its long end,
+    then b from its short end, ... (rtc_pack_emit_kernel; 5 : 3 by default, 0 = longest first throughout).  Whatever the
+    ratio - also lopsided ones that leave a long middle over - every pixel is in exactly one item and the image is the same."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file("cover.json")
+    w, h = 1280, 720                                 # 14 400 chunks: several packets per wave
+    cam = hs.camera(w, h)
+    n_chunks = ((w + 7) // 8) * ((h + 7) // 8)
+    want = rtc.GpuScene(hs.desc).render(cam, 5)
+    canvas = torch.empty((h, w, 3), dtype=torch.float64, device="cuda")
+    try:
+        for mix in (0, 1 | 1 << 8, 5 | 3 << 8, 2 | 7 << 8, 16 | 1 << 8, 255 | 255 << 8):
+            rtc.set_option("sched_mix", mix)
+            gpu = rtc.GpuScene(hs.desc)
+            for launch in range(3):                  # estimate-packed, then packed from the measurement
+                canvas.fill_(float("nan"))
+                torch.cuda.synchronize()
+                gpu.render_device(cam, canvas.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
+                st = gpu.stats()
+                assert st["primary"] == w * h and st["overflow"] == 0, (mix, launch)
+                assert np.abs(canvas.cpu().numpy() - want).max() < REPEAT_TOL, (mix, launch)
+                _check_schedule(gpu.schedule(), n_chunks, (mix, launch))
+            gpu.close()
+    finally:
+        rtc.set_option("sched_mix", 5 | 3 << 8)
+
+
 def test_first_launches_write_every_pixel(rtc):
     """The first frame of a pixel map runs a schedule packed from rtc_estimate_kernel's guesses (which roots a chunk's
     pixels can see), the second one packed from the first's measurements.  Whatever the guesses, every pixel is handed
