@@ -426,7 +426,11 @@ int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, u
  * top-level spheres / planes / cubes runs the three-waves-per-SIMD kernel; 0 always, < 0 the library's choice),
  * "sched_off" (!= 0: no schedule, packet i is chunk i), "cut_above" (shares of a wave above which a chunk is cut into
  * runs of pixels; < 0 never, 0 the library's choice), "pack_rounds", "pull_min_idle", "blocks_per_cu", "sched_tmin",
- * "bvh_leaf", "bvh_one_axis", "bvh_check", "host_bands" (bands of a host-output frame, 1 .. 4; 0 by size).
+ * "bvh_leaf", "bvh_one_axis", "bvh_check", "host_bands" (bands of a host-output frame, 1 .. 4; 0 by size),
+ * "waves3" (the general kernel at three waves per SIMD: 1 always, 0 never, < 0 measured per handle),
+ * "sched_mix" (a | b << 8: behind every wave's first packet the schedule takes a packets from its long end, then b from
+ * its short end, ...; 0 longest first throughout), "measure_every" (a view that moves in small steps is measured
+ * every n-th frame; 1).
  * RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
  * (The library reads no environment variables.)
  */
