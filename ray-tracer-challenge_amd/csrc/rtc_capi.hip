@@ -216,6 +216,16 @@ double groupFloor(const rtc_scene* s) {
 // The render kernel of a scene whose tables fit in LDS.
 // The three-waves-per-SIMD form of the simple kernel pays when every wave has several packets to run (see the kernel):
 // from about four chunks per resident wave on (1280x720; tools/simple3_sweep.py).
+// Between one and four chunks per wave of the three-wave kernel neither kernel wins everywhere (1080p quarters and
+// ninths, two against three waves: cover 960x540 0.304 / 0.260 ms and 640x360 0.176 / 0.182, reflection_and_refraction
+// depth 8 0.741 / 0.768 and 0.556 / 0.500): the handle measures it, with the trial the worlds with groups use (KernelTune
+// in launch()).
+bool simple3Trial(const rtc_scene* s, const DevPixelMap& map) {
+  if (!s->simple3_ok || rtcOptions().simple3_min_chunks >= 0.0) return false;
+  if (s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) return false;  // (frames in flight: see usesSimple3)
+  const uint64_t per_wave = 4ull * s->n_cus * s->blocks_per_cu_simple3;
+  return map.n_chunks >= per_wave && map.n_chunks < 4ull * per_wave;
+}
 bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
   const double forced = rtcOptions().simple3_min_chunks;  // (tests reach the kernel at small sizes with 0: always)
   // (a scene with several handles - rtc_scene_clone - is rendered with frames in flight: the GPU is full of other frames'
@@ -223,7 +233,9 @@ bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
   // The slowest 8-way share of cover with three frames in flight: 0.125 -> 0.118 ms per frame, 4-way 0.177 -> 0.164)
   const bool in_flight = s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1;
   const uint64_t min_chunks = forced >= 0.0 ? static_cast<uint64_t>(forced) : (in_flight ? 1ull : 4ull) * 4u * s->n_cus * s->blocks_per_cu_simple3;
-  return s->simple3_ok && map.n_chunks >= min_chunks;
+  if (!s->simple3_ok) return false;
+  if (map.n_chunks >= min_chunks) return true;
+  return simple3Trial(s, map) && s->use_general3;  // (between one and four chunks per wave: what the handle's trial says)
 }
 
 bool tablesInLds(const rtc_scene* s) {
@@ -480,6 +492,7 @@ int packNextSchedule(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map
     s->measured_chunks_per_region = map.chunks_per_region;
   }
   s->sched_cur = target;
+  s->n_packs++;
   s->sched_valid = true;
   s->sched_cam = cam;
   s->sched_depth = max_depth;
@@ -598,29 +611,39 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   SchedulePlan plan;
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
   // ---- two or three waves per SIMD for a world with groups: measured on the handle's own frames (KernelTune).  Once a
-  // pixel map has a measured schedule (a static view, or one that moves in small steps), six of its frames alternate between
-  // rtc_render_kernel and rtc_render_kernel3 with HIP events around the render kernel; as soon as three frames of each
-  // have been timed (the events are polled, never waited for) the handle keeps the kernel whose fastest frame was
-  // at least 3 % faster, and measures one more frame so that the schedule is packed for that kernel's wave count.
+  // pixel map has a measured schedule (a static view, or one that moves in small steps), three of its frames are timed on
+  // the two-wave kernel and three on the three-wave kernel (rtc_render_kernel / rtc_render_kernel3; for a simple world's
+  // mid-sized launches rtc_render_kernel_simple / _simple3), each on a schedule packed for its own waves, with HIP events
+  // around the render kernel (polled, never waited for); the handle keeps the three-wave kernel if its fastest frame
+  // was at least 3 % faster.
   // Results do not depend on the kernel (same code, other launch bounds and table sizes).  No trial with frames in
   // flight (several handles share the GPU: a frame's time says little) or when option "waves3" forces a kernel.
   int trial_slot = -1;
   {
     rtc_scene::KernelTune& T = s->tune;
-    const bool eligible = s->general3_ok && rtcOptions().waves3 < 0.0 && tablesInLds(s) &&
-                          !(s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) &&
-                          static_cast<double>(map.n_chunks) >= 4.0 * 4.0 * s->n_cus * s->blocks_per_cu_lds;
+    const bool eligible = (s->general3_ok && rtcOptions().waves3 < 0.0 && tablesInLds(s) &&
+                           !(s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) &&
+                           static_cast<double>(map.n_chunks) >= 4.0 * 4.0 * s->n_cus * s->blocks_per_cu_lds) ||
+                          simple3Trial(s, map);  // (a simple world's launch of a size where neither of its kernels always wins)
     if (eligible && T.key != s->cost_key) {  // another pixel map: a trial of its own (the last choice stands until it ends)
       T.key = s->cost_key;
       T.state = 0;
       T.frames = 0;
       T.n[0] = T.n[1] = 0;
+      T.switched = false;
       for (int& w : T.which) w = -1;
     }
     // (a view that moves in small steps - consecutive frames of an orbit cost the same - is as good as a still one: an
     // interactive host whose camera never rests gets its trial too; a jump to another view makes the trial wait)
     const bool steady = (!plan.moved || plan.near) && !plan.estimate && map.order != nullptr;
-    if (eligible && T.state == 1 && !steady) s->use_general3 = false;
+    if (eligible && T.state == 1 && !steady) {  // (a jump to another view: the trial starts over when the view rests again)
+      s->use_general3 = false;
+      T.state = 0;
+      T.frames = 0;
+      T.n[0] = T.n[1] = 0;
+      T.switched = false;
+      for (int& w : T.which) w = -1;
+    }
     if (eligible && T.state != 2 && steady) {
       for (int k = 0; k < rtc_scene::KernelTune::kRing; ++k) {
         if (T.which[k] < 0) continue;
@@ -637,10 +660,25 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
           (void)hipGetLastError();  // (hipErrorNotReady: the frame is still running)
         }
       }
-      if (T.n[0] >= rtc_scene::KernelTune::kSamples && T.n[1] >= rtc_scene::KernelTune::kSamples) {
+      // The trial runs in phases, so that each kernel is timed on a schedule packed for ITS number of resident waves (a
+      // small launch's chunks are cut for the waves there are: the three-wave kernel on a two-wave schedule lost cover
+      // 960x540 by a margin it wins by on its own): three timed frames of the two-wave kernel on the schedule in use; one
+      // frame of the three-wave kernel that measures (its schedule is packed behind it); three timed frames of that; the
+      // decision - and, if the two-wave kernel stays, one more measuring frame for its schedule.
+      constexpr uint32_t kSamples = rtc_scene::KernelTune::kSamples;
+      if (T.n[0] >= kSamples && T.n[1] >= kSamples) {
         s->use_general3 = T.best[1] < 0.97f * T.best[0];
         T.state = 2;
-        if (s->use_general3) plan.measure = true;  // (re-packed for three waves per SIMD's worth of resident waves)
+        if (!s->use_general3) {
+          // Back to the two-wave kernel and to ITS schedule: the one its samples ran is still in the other buffer if
+          // nothing but the switch frame has packed since (a still view); a view that moves packs every frame anyway.
+          if (s->n_packs == T.packs_at_switch + 1u && !plan.measure) {
+            s->sched_cur = T.sched_before;
+            useSchedule(s, map);
+          } else {
+            plan.measure = true;
+          }
+        }
       } else {
         uint32_t pending[2] = {0, 0};
         int free_slot = -1;
@@ -648,18 +686,27 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
           if (T.which[k] >= 0) pending[T.which[k]]++;
           else if (free_slot < 0) free_slot = k;
         }
-        int w = static_cast<int>(T.frames & 1u);
-        if (T.n[w] + pending[w] >= rtc_scene::KernelTune::kSamples) w ^= 1;
-        if (free_slot >= 0 && T.n[w] + pending[w] < rtc_scene::KernelTune::kSamples) {
+        T.state = 1;
+        int timed = -1;  // which kernel this frame times, if any
+        if (T.n[0] + pending[0] < kSamples) {
+          s->use_general3 = false;
+          timed = 0;
+        } else if (!T.switched) {
+          s->use_general3 = true;  // (the switch: this frame runs the two-wave schedule and measures)
+          plan.measure = true;
+          T.switched = true;
+          T.sched_before = s->sched_cur;
+          T.packs_at_switch = s->n_packs;
+        } else {
+          s->use_general3 = true;
+          if (T.n[1] + pending[1] < kSamples) timed = 1;  // (else: every sample is in flight)
+        }
+        if (timed >= 0 && free_slot >= 0) {
           for (hipEvent_t& e : T.ev[free_slot])
             if (!e) HIP_TRY(hipEventCreate(&e));
-          s->use_general3 = w == 1;
-          T.which[free_slot] = w;
+          T.which[free_slot] = timed;
           T.frames++;
-          T.state = 1;
           trial_slot = free_slot;
-        } else {
-          s->use_general3 = false;  // (all samples are in flight: an ordinary frame meanwhile)
         }
       }
     }

@@ -142,6 +142,9 @@ struct rtc_scene {
     uint32_t frames = 0;           // trial frames enqueued
     float best[2] = {0.0f, 0.0f};  // fastest frame seen per kernel (two waves, three waves), ms
     uint32_t n[2] = {0, 0};        // samples resolved per kernel
+    bool switched = false;         // the frame that changes to the three-wave kernel (and measures for its schedule) has been enqueued
+    uint32_t sched_before = 0;     // ... the schedule buffer the two-wave samples ran, and how many schedules had been packed then
+    uint32_t packs_at_switch = 0;
     hipEvent_t ev[kRing][2] = {};  // timing events around the render kernel of the trial frames (created on first use)
     int which[kRing] = {};         // which kernel a ring slot timed; -1: slot free / resolved
     std::vector<uint32_t> key;     // the pixel map the trial belongs to
@@ -160,6 +163,7 @@ struct rtc_scene {
   bool sched_valid = false;               // d_sched[sched_cur] holds a schedule for the pixel map `cost_key`
   rtc_camera sched_cam{};                 // the view (and depth) that schedule was measured with: another view measures again
   uint32_t sched_depth = 0;
+  uint32_t n_packs = 0;                   // schedules packed on this handle so far
   uint32_t frames_unmeasured = 0;         // frames of a moving view since the last measured one (updateSchedule)
   uint32_t* d_chunk_time = nullptr;       // the packer's scratch: per-chunk times, sorted chunks
   uint32_t* d_sorted = nullptr;

@@ -1292,6 +1292,30 @@ def test_general_kernel_at_three_waves_and_its_trial(rtc):
     assert kernels == {"rtc_render_kernel", "rtc_render_kernel3"}, kernels   # (the trial ran both)
 
 
+def test_simple_world_trial_between_its_two_kernels(rtc):
+    """A simple world's launch of one to four chunks per wave (here 960x540) is rendered by whichever of
+    rtc_render_kernel_simple / _simple3 the handle's own trial found faster: fourteen frames of a static view run both,
+    and every frame is the same image to the last bits - the oracle's - whichever kernel ran."""
+    torch = pytest.importorskip("torch")
+    hs = rtc.HostScene.from_file("cover.json")
+    w, h = 960, 540
+    cam = hs.camera(w, h)
+    want = ob.OracleScene(hs.desc).render(cam, 5, row_step=27)[0]
+    rows = np.arange(0, h, 27)
+    gpu = rtc.GpuScene(hs.desc)
+    buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
+    kernels, first = set(), None
+    for frame in range(14):
+        gpu.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        img = buf.cpu().numpy()
+        kernels.add(gpu.last_kernel_name())
+        assert np.abs(img[rows] - want[rows]).max() < TOL and gpu.stats()["overflow"] == 0, frame
+        first = img if first is None else first
+        assert np.abs(img - first).max() < REPEAT_TOL, frame
+    assert kernels == {"rtc_render_kernel_simple", "rtc_render_kernel_simple3"}, kernels   # (the trial ran both)
+
+
 def test_host_output_in_bands(rtc):
     """rtc_render cuts a large frame into horizontal bands (the lower ones on clones of the handle), each copied to the
     caller while the next renders: forced to three and four bands on small images - a rectangle that starts off the chunk
