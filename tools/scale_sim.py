@@ -38,7 +38,7 @@ def main():
     sptr = stream.cuda_stream
 
     def timed(fn, handle=None):
-        for i in range(8):
+        for i in range(16):  # (the schedule settles, and a handle's two- / three-wave trial - ten frames - is over)
             fn()
             torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
