@@ -277,10 +277,25 @@ KernelChoice renderKernel(const rtc_scene* s, const DevPixelMap& map) {
 #undef RTC_KERNEL
 
 // Work-groups of the launch's kernel that are resident at once, and the waves in them.
-uint32_t residentBlocks(const rtc_scene* s, const DevPixelMap& map) {
+uint32_t residentBlocksAlone(const rtc_scene* s, const DevPixelMap& map) {
   if (usesSimple3(s, map)) return s->n_cus * s->blocks_per_cu_simple3;
   if (tablesInLds(s) && usesGeneral3(s)) return s->n_cus * s->blocks_per_cu_general3;
   return s->n_cus * (tablesInLds(s) ? s->blocks_per_cu_lds : s->blocks_per_cu_big);
+}
+// With frames in flight (a scene with several handles) a launch gets no more waves than one per three chunks: a rank's
+// share of a split frame - 4 050 chunks of cover at 8 ranks - spread over all 3 072 wave slots leaves every lane with a
+// pixel or two and nothing to refill it with (SQ_THREAD_CYCLES_VALU: 0.59 lanes active against 0.84 for the whole frame,
+// 1.48 x the wave-instructions per pixel), and the other frames in flight are there to fill the slots it leaves.  The
+// slowest 8-way share of cover, four frames in flight: 0.096 -> 0.070 ms per frame, teapot 0.036 -> 0.033; dragons 4K
+// (16 000 chunks per share) and whole frames are not affected (profiles/r04/frames_in_flight_sweeps.txt).
+uint32_t residentBlocks(const rtc_scene* s, const DevPixelMap& map) {
+  const uint32_t alone = residentBlocksAlone(s, map);
+  const double per_wave = rtcOptions().inflight_chunks_per_wave;
+  if (per_wave > 0.0 && s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) {
+    const uint32_t want = static_cast<uint32_t>(std::ceil(static_cast<double>(map.n_chunks) / per_wave / 4.0));
+    return std::max(16u, std::min(alone, want));
+  }
+  return alone;
 }
 double residentWaves(const rtc_scene* s, const DevPixelMap& map) { return 4.0 * residentBlocks(s, map); }
 
@@ -2139,7 +2154,8 @@ int rtc_set_option(const char* name, double value) {
                {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
                {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3},
-               {"measure_every", &o.measure_every}, {"sched_mix", &o.sched_mix}};
+               {"measure_every", &o.measure_every}, {"sched_mix", &o.sched_mix},
+               {"inflight_chunks_per_wave", &o.inflight_chunks_per_wave}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
       *e.slot = value;

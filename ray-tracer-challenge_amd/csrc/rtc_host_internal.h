@@ -54,6 +54,7 @@ struct RtcOptions {
   double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
   double waves3 = -1.0;              // the general kernel at three waves per SIMD: 1 always (where the tables fit), 0 never, < 0: measured per handle
   double sched_mix = 773.0;          // a | b << 8: behind every wave's first packet the schedule takes a packets from its long end, b from its short end, ... (5 : 3); 0: longest first throughout
+  double inflight_chunks_per_wave = 3.0;  // a launch of a scene with frames in flight runs on at most one wave per this many chunks (0: no cap)
   double measure_every = 1.0;        // a moving view is measured (and its schedule re-packed) every this many frames (see updateSchedule)
   double host_bands = 0.0;           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
 };
