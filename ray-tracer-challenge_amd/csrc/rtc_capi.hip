@@ -597,7 +597,11 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   // launch N + 1 clears the counters of launch N + 2: they must run one after the other.  Stream order gives that on
   // one stream; when the caller changes streams (rtc_render_device on its own stream, then rtc_render on the handle's),
   // the new stream first waits for everything the handle enqueued before (the event recorded at the end of launch()).
-  if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
+  if (s->last_stream != nullptr && stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
+  if (!s->stats_zeroed) {  // (the handle's first launch: both counter blocks, on this stream, in front of everything)
+    HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), stream));
+    s->stats_zeroed = true;
+  }
   if (!s->kernel_warm && s->d_ray_stack != nullptr) {
     // A handle's first launch: the render kernel goes to the stream ONCE WITH NO WORK before anything else.  The first
     // dispatch of a kernel that needs scratch memory (every render kernel spills) stalls its queue while the runtime sets
@@ -1550,17 +1554,22 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
 // Copies the tables into HBM and fills in the scene handle.
 // What a handle owns by itself (a clone has its own): its stream, the launch counters, the event launches on other
 // streams order themselves by.  Schedules, cost buffers, ray stacks follow on first use.
+// Nothing is enqueued here and no stream is made: the counters are zeroed by the handle's FIRST launch, on the stream
+// that launch comes on, and the handle's own stream exists from the first call that needs it (a NULL stream argument,
+// rtc_render's host forms).  The HIP runtime deals its few hardware queues to streams in the order of their first use: a
+// handle that used a stream of its own at creation took a queue away from the caller's streams, and two of a host's three
+// streams of frames in flight could end up on ONE queue, their frames one after the other (the slowest 8-way share of
+// cover, three in flight: 0.08 or 0.16 ms per frame depending on how many handles had been created before the streams
+// were first used; profiles/r04/frames_in_flight_sweeps.txt).
 int initLaunchState(rtc_scene* s) {
-  HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_stats), 2 * sizeof(DevStats)));
-  // Zeroed ON THE HANDLE'S STREAM, followed by the event every launch on another stream waits for (launch()): the
-  // first launch, whatever stream it comes on, finds the work counter at zero.  (A hipMemset here runs on the legacy
-  // stream, which a hipStreamNonBlocking stream does not wait for.)
-  HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), s->stream));
   HIP_TRY(hipEventCreateWithFlags(&s->launch_done, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(s->launch_done, s->stream));
-  s->last_stream = s->stream;
+  s->stats_zeroed = false;
+  s->last_stream = nullptr;
   return RTC_OK;
+}
+hipError_t ensureOwnStream(rtc_scene* s) {
+  return s->stream != nullptr ? hipSuccess : hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
 }
 
 int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostTables& T, rtc_scene* s) {
@@ -1907,6 +1916,7 @@ int rtc_render_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, u
   DevPixelMap map;
   st = buildPixelMapRect(*cam, x0, y0, w, h, map);
   if (st != RTC_OK) return st;
+  if (!hip_stream) HIP_TRY(ensureOwnStream(s));
   return launch(s, *cam, map, max_depth, d_rgb_out, static_cast<size_t>(w) * h,
                 hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
 }
@@ -1938,6 +1948,7 @@ int rtc_render_tiles_device(rtc_scene* s, const rtc_camera* cam, uint32_t max_de
   const uint64_t total_chunks = static_cast<uint64_t>(map.chunks_per_region) * n_my_tiles;
   if (total_chunks > 0x7FFFFFFFull) return fail(RTC_ERR_INVALID_ARGUMENT, "%llu chunks", (unsigned long long)total_chunks);
   map.n_chunks = static_cast<uint32_t>(total_chunks);
+  if (!hip_stream) HIP_TRY(ensureOwnStream(s));
   return launch(s, *cam, map, max_depth, d_rgb_out, static_cast<size_t>(n_my_tiles) * tile_w * tile_h,
                 hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream);
 }
@@ -1966,6 +1977,7 @@ int rtc_render_tile_list_device(rtc_scene* s, const rtc_camera* cam, uint32_t ma
     }
   }
   HIP_TRY(hipSetDevice(s->device));
+  if (!hip_stream) HIP_TRY(ensureOwnStream(s));
   hipStream_t stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->stream;
   if (s->h_tile_list.size() != n_my_tiles || std::memcmp(s->h_tile_list.data(), tiles, n_my_tiles * sizeof(uint32_t)) != 0) {
     if (n_my_tiles > s->tile_list_capacity) {
@@ -1977,7 +1989,7 @@ int rtc_render_tile_list_device(rtc_scene* s, const rtc_camera* cam, uint32_t ma
       s->tile_list_capacity = n_my_tiles;
     }
     // (launches of the old list may still be running on another stream: the copy is ordered like a launch)
-    if (stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
+    if (s->last_stream != nullptr && stream != s->last_stream) HIP_TRY(hipStreamWaitEvent(stream, s->launch_done, 0));
     s->h_tile_list.assign(tiles, tiles + n_my_tiles);
     HIP_TRY(hipMemcpyAsync(s->d_tile_list, s->h_tile_list.data(), n_my_tiles * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(s->launch_done, stream));
@@ -2225,6 +2237,7 @@ void prefaultCanvas(void* canvas, size_t bytes) {
 int renderBanded(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                  double* rgb_out, uint32_t bands) {
   if (const int st = ensureBands(s, bands); st != RTC_OK) return st;
+  HIP_TRY(ensureOwnStream(s));
   for (;;) {
     uint32_t row[RTC_MAX_HOST_BANDS + 1];
     for (uint32_t b = 0; b < bands; ++b) row[b] = static_cast<uint32_t>(static_cast<uint64_t>(h) * b / bands) & ~7u;  // (whole rows of chunks)
@@ -2262,6 +2275,7 @@ int rtc_render(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, uint32_t
   const size_t need = 3ull * w * h;
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = ensureFrame(s, need); st != RTC_OK) return st;
+  HIP_TRY(ensureOwnStream(s));
   if (const uint32_t bands = hostBands(w, h); bands > 1u) return renderBanded(s, cam, max_depth, x0, y0, w, h, rgb_out, bands);
   for (;;) {
     const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
@@ -2294,6 +2308,7 @@ int rtc_render_rgba8(rtc_scene* s, const rtc_camera* cam, uint32_t max_depth, ui
   const size_t n = static_cast<size_t>(w) * h;
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = ensureFrame(s, 3 * n + (n + 1) / 2); st != RTC_OK) return st;  // the f64 frame, then n u32 behind it
+  HIP_TRY(ensureOwnStream(s));
   for (;;) {
     const int st = rtc_render_device(s, cam, max_depth, x0, y0, w, h, s->d_frame, s->stream);
     if (st != RTC_OK) return st;
@@ -2357,7 +2372,7 @@ int rtc_scene_synchronize(rtc_scene* s) {
   g_error.clear();
   if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
   HIP_TRY(hipSetDevice(s->device));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->stream != nullptr) HIP_TRY(hipStreamSynchronize(s->stream));  // (no stream of its own yet: nothing was enqueued on it)
   return RTC_OK;
 }
 
@@ -2412,6 +2427,11 @@ int rtc_get_chunk_times(rtc_scene* s, const rtc_camera* cam, uint32_t* estimated
       release();
       return fail(RTC_ERR_OUT_OF_MEMORY, "scratch for %u chunks", n);
     }
+    if (ensureOwnStream(s) != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return fail(RTC_ERR_OUT_OF_MEMORY, "no stream");
+    }
     hipLaunchKernelGGL(rtc_estimate_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s->stream, s->dev, devCamera(*cam), map, d_est, d_time,
                        d_shape, d_state);
     const hipError_t e1 = hipStreamSynchronize(s->stream);
@@ -2427,6 +2447,10 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
   if (!s || !out) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(handleIdle(s));  // the last launch on this handle, whatever stream it ran on
+  if (!s->stats_zeroed) {  // (no launch yet: the counters have not even been cleared)
+    std::memset(out, 0, sizeof *out);
+    return RTC_OK;
+  }
   const std::unique_ptr<DevStats> hp(new DevStats);  // large in diagnostic layouts: off the stack, and not shared between handles
   DevStats& h = *hp;
   HIP_TRY(hipMemcpy(&h, s->d_stats + s->stats_parity, sizeof h, hipMemcpyDeviceToHost));

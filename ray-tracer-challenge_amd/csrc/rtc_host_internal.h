@@ -184,7 +184,8 @@ struct rtc_scene {
   size_t tile_list_capacity = 0;
   uint32_t tile_list_gen = 0;
   uint32_t measured_regions = 0, measured_chunks_per_region = 0;  // what d_chunk_time describes (rtc_get_tile_costs)
-  hipStream_t last_stream = nullptr;  // the stream of the last launch (or the handle's own, after create)
+  hipStream_t last_stream = nullptr;  // the stream of the last launch (none yet: nullptr)
+  bool stats_zeroed = false;          // the first launch has zeroed d_stats on its stream (initLaunchState)
   hipEvent_t launch_done = nullptr;   // recorded behind everything a launch enqueues; a launch on ANOTHER stream waits for it
   void* d_ray_stack = nullptr;     // DevPixelMap::ray_stack
   size_t ray_stack_capacity = 0;   // bytes

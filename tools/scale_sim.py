@@ -7,7 +7,7 @@ The render time of the slowest share bounds the N-GPU step from below (the gathe
 `compute_eff` = T(full frame) / (N * max_r T(share r)) is the part of the strong-scaling efficiency that the
 partition itself decides (load balance + per-launch fixed cost).  Real multi-GPU runs are the driver's.
 """
-import argparse, importlib, json, os, sys
+import argparse, os, importlib, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -52,16 +52,23 @@ def main():
     M = max(1, args.inflight)
     streams = [stream] + [torch.cuda.Stream() for _ in range(M - 1)]
 
+    # The M handles of a rank's frames in flight - a scene handle and M - 1 clones, as a host with frames in flight has
+    # them - are made ONCE and render every share in turn (another tile list is another pixel map: measured afresh).
+    # (A rank process has one such set for good; and the HIP runtime deals its hardware queues to streams in the order
+    # of their first use - the fewer streams come and go in between, the more a rehearsal looks like a rank.)
+    pool = []
+    if M > 1:
+        pool.append(rtc.GpuScene(hs.desc))
+        pool += [pool[0].clone() for _ in range(M - 1)]
+
     def timed_in_flight(make):
-        """make(base) -> (handle, fn(stream_ptr)) for one of M frames in flight: base None = a scene handle of its own,
-        else a clone of that handle (rtc_scene_clone), as a host with frames in flight would have it."""
+        """make(handle or None) -> (handle, fn(stream_ptr)) for one of M frames in flight (None: a scene handle of its own)."""
         if M == 1:
             h, fn = make(None)
             t = timed(lambda: fn(sptr), h)
             h.close()
             return t
-        hf = [make(None)]
-        hf += [make(hf[0][0]) for _ in range(M - 1)]
+        hf = [make(g) for g in pool]
         for i in range(8 * M):
             hf[i % M][1](streams[i % M].cuda_stream)
             torch.cuda.synchronize()
@@ -75,12 +82,10 @@ def main():
             stream.wait_stream(st)
         b.record(stream)
         torch.cuda.synchronize()
-        for h, _ in hf:
-            h.close()
         return a.elapsed_time(b) / (args.reps * M)
 
     def full_frame(base):
-        g = base.clone() if base is not None else rtc.GpuScene(hs.desc)
+        g = base if base is not None else rtc.GpuScene(hs.desc)
         canvas = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
         return g, lambda sp: g.render_device(cam, canvas.data_ptr(), args.depth, None, sp)
     t_full = timed_in_flight(full_frame)
@@ -105,10 +110,11 @@ def main():
                 mine = np.flatnonzero(rank_of == rank).astype(np.uint32)
 
                 def share(base, mine=mine):
-                    g = base.clone() if base is not None else rtc.GpuScene(hs.desc)
+                    g = base if base is not None else rtc.GpuScene(hs.desc)
                     buf = torch.zeros(((tx * ty + world - 1) // world, tile, tile, 3), dtype=torch.float64, device="cuda")
                     return g, lambda sp: g.render_tile_list_device(cam, buf.data_ptr(), tile, tile, mine, args.depth, sp)
                 tb.append(timed_in_flight(share))
+            if os.environ.get("SCALE_SIM_RANKS"): print("per rank:", " ".join("%.4f" % t for t in tb), flush=True)
             print(json.dumps({"tile": tile, "world": world, "ideal_ms": t_full / world,
                               "round_robin": {"max_ms": max(ts), "mean_ms": sum(ts) / world, "compute_eff": t_full / (world * max(ts))},
                               "by_measured_cost": {"max_ms": max(tb), "mean_ms": sum(tb) / world, "compute_eff": t_full / (world * max(tb))}}),
