@@ -295,8 +295,10 @@ int rtc_rgba8_device(const double *d_canvas, size_t n_pixels, uint32_t *d_rgba, 
 
 /*
  * Same, but `d_rgb_out` is device memory on the scene's device and the work is
- * enqueued on `hip_stream` (a hipStream_t; NULL = the handle's own stream)
- * without synchronising.  This is the entry point the multi-GPU driver uses
+ * enqueued on `hip_stream` (a hipStream_t; NULL = the handle's own stream, which
+ * is made at the first call that needs it: a host that always passes its streams
+ * keeps the device's few hardware queues for them - INTEGRATION.md, "Streams and
+ * hardware queues") without synchronising.  This is the entry point the multi-GPU driver uses
  * with device buffers owned by its RCCL communicator.
  */
 int rtc_render_device(rtc_scene *scene, const rtc_camera *cam, uint32_t max_depth,
@@ -383,7 +385,7 @@ int rtc_scatter_tile_list_rgba8_device(const double *d_tiles, const uint32_t *d_
                                        uint32_t tile_w, uint32_t tile_h, uint32_t hsize, uint32_t vsize, uint32_t *rgba,
                                        void *hip_stream);
 
-/* Waits for the work enqueued on the handle's own stream. */
+/* Waits for the work enqueued on the handle's own stream (nothing to wait for if it has never used one). */
 int rtc_scene_synchronize(rtc_scene *scene);
 
 /* Diagnostic (tools/estimate_probe.py): for the pixel map of the handle's last scheduled launch, per 8x8 chunk what the
