@@ -84,7 +84,7 @@
 
 #if defined(RTC_PROFILE) && defined(RTC_PROFILE_LITE)
 __shared__ DevStats* rtc_prof_stats;
-#define RTC_WALK_ADD(slot, n) do { } while (0)
+#define RTC_WALK_ADD(slot, n) do { (void)(n); } while (0)
 #elif defined(RTC_PROFILE)
 __shared__ DevStats* rtc_prof_stats;  // (diagnostic builds: where the walks add their counts, DevStats::prof4)
 #define RTC_WALK_ADD(slot, n)                                                                              \
