@@ -2877,11 +2877,12 @@ rtc_scatter_tiles_rgba8_kernel(const double* __restrict__ tiles, const uint32_t*
 // ------------------------------------------------------------------------------------------
 // The schedule of the NEXT frame, packed on the device from what THIS frame measured: no host in
 // the loop, so a moving camera (lib.zig:166-190) renders every frame with a schedule that is one frame old.  Policy:
-// longest first in classes of a quarter octave of measured time, image order (about) kept inside a class - neighbouring
-// chunks run at the same moment: same objects, same BVH nodes -, cheap chunks several to a packet, chunks above a wave's
-// fair share cut into runs of pixels, those packets first.  Small launches on the render's stream, every one a grid over
-// chunks or packets (a single work-group doing all of it took 180 us at 1080p: forty dependent round trips to memory;
-// this takes about 25):
+// classes of a quarter octave of measured time, image order (about) kept inside a class - neighbouring chunks run at the
+// same moment: same objects, same BVH nodes -, cheap chunks several to a packet, chunks above a wave's fair share cut
+// into runs of pixels, those packets first; then every wave's first packet, longest first; behind those the schedule
+// alternates between its long and its short end (rtc_pack_emit_kernel).  Small launches on the render's stream, every
+// one a grid over chunks or packets (a single work-group doing all of it took 180 us at 1080p: forty dependent round
+// trips to memory; these take 57 us together, profiles/HISTORY.md):
 //   rtc_chunk_cost_kernel  per chunk: the sum of the per-pixel ray counts and how the rays are spread (DevChunkShape);
 //                          clears what the next steps add into
 //   rtc_chunk_time_kernel  a packet's measured time, shared among its items by their cost; counts the runs of a chunk
