@@ -235,7 +235,7 @@ bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
   const uint64_t min_chunks = forced >= 0.0 ? static_cast<uint64_t>(forced) : (in_flight ? 1ull : 4ull) * 4u * s->n_cus * s->blocks_per_cu_simple3;
   if (!s->simple3_ok) return false;
   if (map.n_chunks >= min_chunks) return true;
-  return simple3Trial(s, map) && s->use_general3;  // (between one and four chunks per wave: what the handle's trial says)
+  return simple3Trial(s, map) && s->use_three_waves;  // (between one and four chunks per wave: what the handle's trial says)
 }
 
 bool tablesInLds(const rtc_scene* s) {
@@ -255,7 +255,7 @@ bool usesGeneral3(const rtc_scene* s) {
   if (!s->general3_ok) return false;
   const double forced = rtcOptions().waves3;
   if (forced >= 0.0) return forced != 0.0;
-  return s->use_general3;
+  return s->use_three_waves;
 #else
   (void)s;
   return false;
@@ -656,7 +656,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     // interactive host whose camera never rests gets its trial too; a jump to another view makes the trial wait)
     const bool steady = (!plan.moved || plan.near) && !plan.estimate && map.order != nullptr;
     if (eligible && T.state == 1 && !steady) {  // (a jump to another view: the trial starts over when the view rests again)
-      s->use_general3 = false;
+      s->use_three_waves = false;
       T.state = 0;
       T.frames = 0;
       T.n[0] = T.n[1] = 0;
@@ -686,9 +686,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
       // decision - and, if the two-wave kernel stays, one more measuring frame for its schedule.
       constexpr uint32_t kSamples = rtc_scene::KernelTune::kSamples;
       if (T.n[0] >= kSamples && T.n[1] >= kSamples) {
-        s->use_general3 = T.best[1] < 0.97f * T.best[0];
+        s->use_three_waves = T.best[1] < 0.97f * T.best[0];
         T.state = 2;
-        if (!s->use_general3) {
+        if (!s->use_three_waves) {
           // Back to the two-wave kernel and to ITS schedule: the one its samples ran is still in the other buffer if
           // nothing but the switch frame has packed since (a still view); a view that moves packs every frame anyway.
           if (s->n_packs == T.packs_at_switch + 1u && !plan.measure) {
@@ -708,16 +708,16 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
         T.state = 1;
         int timed = -1;  // which kernel this frame times, if any
         if (T.n[0] + pending[0] < kSamples) {
-          s->use_general3 = false;
+          s->use_three_waves = false;
           timed = 0;
         } else if (!T.switched) {
-          s->use_general3 = true;  // (the switch: this frame runs the two-wave schedule and measures)
+          s->use_three_waves = true;  // (the switch: this frame runs the two-wave schedule and measures)
           plan.measure = true;
           T.switched = true;
           T.sched_before = s->sched_cur;
           T.packs_at_switch = s->n_packs;
         } else {
-          s->use_general3 = true;
+          s->use_three_waves = true;
           if (T.n[1] + pending[1] < kSamples) timed = 1;  // (else: every sample is in flight)
         }
         if (timed >= 0 && free_slot >= 0) {
@@ -1859,7 +1859,7 @@ int rtc_scene_clone(const rtc_scene* src, rtc_scene** out) {
   s->blocks_per_cu_simple3 = src->blocks_per_cu_simple3;
   s->general3_ok = src->general3_ok;
   s->blocks_per_cu_general3 = src->blocks_per_cu_general3;
-  s->use_general3 = src->use_general3;  // (a clone starts from what its source has measured; frames in flight run no trial of their own)
+  s->use_three_waves = src->use_three_waves;  // (a clone starts from what its source has measured; frames in flight run no trial of their own)
   HIP_TRY(hipSetDevice(s->device));
   if (const int st = initLaunchState(s); st != RTC_OK) return st;
   guard.s = nullptr;

@@ -136,7 +136,7 @@ struct rtc_scene {
   // ---- the general kernel at two or at three waves per SIMD: measured, not guessed (launch(), KernelTune)
   bool general3_ok = false;        // a world with groups, no csg / texture maps, whose tables fit the three-wave kernel's LDS
   uint32_t blocks_per_cu_general3 = 1;
-  bool use_general3 = false;       // what launches run: the choice once the trial is over, the kernel under trial during it
+  bool use_three_waves = false;    // the three-wave form of the world's kernel (rtc_render_kernel3 / _simple3 at mid sizes): the choice once the trial is over, the kernel under trial during it
   struct KernelTune {
     enum { kSamples = 3, kRing = 8 };
     int state = 0;                 // 0: no trial yet for this pixel map, 1: trial running, 2: decided
