@@ -432,7 +432,8 @@ int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, u
  * "waves3" (the general kernel at three waves per SIMD: 1 always, 0 never, < 0 measured per handle),
  * "sched_mix" (a | b << 8: behind every wave's first packet the schedule takes a packets from its long end, then b from
  * its short end, ...; 0 longest first throughout), "measure_every" (a view that moves in small steps is measured
- * every n-th frame; 1).
+ * every n-th frame; 1), "inflight_chunks_per_wave" (a launch of a scene with several handles - frames in flight -
+ * runs on at most one wave per this many chunks; 3, 0 = no cap).
  * RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
  * (The library reads no environment variables.)
  */
