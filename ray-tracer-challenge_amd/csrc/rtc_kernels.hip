@@ -86,12 +86,13 @@
 __shared__ DevStats* rtc_prof_stats;
 #define RTC_WALK_ADD(slot, n) do { (void)(n); } while (0)
 #define RTC_OCC_ADD(slot, n) do { (void)(n); } while (0)
+#define RTC_KIND_ADD(slot, n) do { (void)(n); } while (0)
 #elif defined(RTC_PROFILE)
 __shared__ DevStats* rtc_prof_stats;
 // (diagnostic builds: the walks' and the occluder cache's counts - DevStats::prof4 and prof5 - are summed per wave in LDS
 // by the first active lane and added to the launch's counters when the wave ends: with an atomic per count and walk on
 // eight words of memory the diagnostic frame was eleven times the product's)
-__shared__ unsigned long long rtc_prof_counts[4][16];
+__shared__ unsigned long long rtc_prof_counts[4][40];
 #define RTC_PROF_ADD_(slot, n)                                                                                        \
   do {                                                                                                                 \
     const unsigned long long n_ = static_cast<unsigned long long>(n);                                                  \
@@ -100,9 +101,17 @@ __shared__ unsigned long long rtc_prof_counts[4][16];
   } while (0)
 #define RTC_WALK_ADD(slot, n) RTC_PROF_ADD_(slot, n)
 #define RTC_OCC_ADD(slot, n) RTC_PROF_ADD_(8 + (slot), n)
+#define RTC_KIND_ADD(slot, n) RTC_PROF_ADD_(16 + (slot), n)
 #else
 #define RTC_WALK_ADD(slot, n) do { } while (0)
 #define RTC_OCC_ADD(slot, n) do { } while (0)
+#define RTC_KIND_ADD(slot, n) do { } while (0)
+#endif
+
+// Bound experiments (WRONG images, right dependency chains; never set in the product): bit 0: no shadow ray is traced;
+// bit 1: the walks of shadow rays visit no leaf (what their node phase alone costs).
+#ifndef RTC_EXPERIMENT
+#define RTC_EXPERIMENT 0
 #endif
 
 #ifndef RTC_LB2
@@ -800,6 +809,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
   uint32_t cur_xf = 0xFFFFFFFFu;
   Ray lr = ray;
   auto visit = [&](uint32_t rec) {
+    if ((RTC_EXPERIMENT & 2) && V::kAnyHit) return;
 #ifdef RTC_PROFILE  // (diagnostic builds check every reference before it is followed: a wild one is counted and skipped)
     if (rec >= S.n_bvh_leaves) {
       RTC_WALK_ADD(7, 1);
@@ -949,6 +959,17 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
 #ifdef RTC_PROFILE  // walks of the wave, their lanes, wave steps at nodes / at leaves, lanes at nodes / at leaves (summed over the steps)
   RTC_OCC_ADD(5, pw_t_nodes);
   RTC_OCC_ADD(6, pw_t_leaves);
+  {  // the same by kind of trace: closest hit, shadow, containers
+    constexpr int K = 8 * (V::kAnyHit ? 1 : (V::kBehindOnly ? 2 : 0));
+    RTC_KIND_ADD(K + 0, 1);
+    RTC_KIND_ADD(K + 1, pw_lanes);
+    RTC_KIND_ADD(K + 2, pw_nodes);
+    RTC_KIND_ADD(K + 3, pw_leaves);
+    RTC_KIND_ADD(K + 4, pw_node_lanes);
+    RTC_KIND_ADD(K + 5, pw_leaf_lanes);
+    RTC_KIND_ADD(K + 6, pw_t_nodes);
+    RTC_KIND_ADD(K + 7, pw_t_leaves);
+  }
   RTC_WALK_ADD(0, 1);
   RTC_WALK_ADD(1, pw_lanes);
   RTC_WALK_ADD(2, pw_nodes);
@@ -1868,7 +1889,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   (void)next_stats;
   if (threadIdx.x == 0u) rtc_prof_stats = stats;
 #ifndef RTC_PROFILE_LITE
-  if (threadIdx.x < 64u) rtc_prof_counts[threadIdx.x >> 4][threadIdx.x & 15u] = 0ull;
+  if (threadIdx.x < 160u) rtc_prof_counts[threadIdx.x / 40u][threadIdx.x % 40u] = 0ull;
 #endif
   __syncthreads();
 #endif
@@ -2500,7 +2521,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         // or not (material.zig:62-73): that shadow ray cannot change the result either.
         const double light_dot_normal = (lvx * nx + lvy * ny) + lvz * nz;
         bool shadowed = false;
-        if (shadow_matters && light_dot_normal >= 0.0) {
+        if (shadow_matters && light_dot_normal >= 0.0 && !(RTC_EXPERIMENT & 1)) {
           it_shadow_traced++;
           it_share++;
           ShadowVisitor sv;
@@ -2749,6 +2770,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       atomicAdd(&stats->prof4[i], rtc_prof_counts[threadIdx.x >> 6][i]);
       atomicAdd(&stats->prof5[i], rtc_prof_counts[threadIdx.x >> 6][8 + i]);
     }
+    for (int i = 0; i < 24; ++i) atomicAdd(&stats->prof6[i], rtc_prof_counts[threadIdx.x >> 6][16 + i]);
 #endif
     const unsigned wid = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 4095u;
     stats->prof_log[wid][0] = prof_t - prof_start;

@@ -1,7 +1,3 @@
 set -e
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-rocprofv3 -L > gpurun_out/r5_counters_list.txt 2>&1 || true
-grep -i -o "SQC_[A-Z_0-9]*\|SQ_IFETCH[A-Z_0-9]*\|SQ_INST_CYCLES[A-Z_0-9]*\|SQ_WAIT_IFETCH[A-Z_]*" gpurun_out/r5_counters_list.txt | sort -u > gpurun_out/r5_sqc_names.txt
-bash tools/pmc_probe.sh "--scene dragons.json --width 3840 --height 2160 --option waves3=1" SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY > gpurun_out/r5_icache_dragons.txt 2>&1
-bash tools/pmc_probe.sh "" SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY > gpurun_out/r5_icache_cover.txt 2>&1
+python3 tools/variants.py "base=-DRTC_MAJOR_XF=0" "mxf=" "leaf128=-DRTC_MAJOR_XF=0 -DRTC_LEAF_PAD_WORDS=8" "leaf96=-DRTC_MAJOR_XF=0 -DRTC_LEAF_PAD_WORDS=0" "node96=-DRTC_MAJOR_XF=0 -DRTC_NODE_PAD_BYTES=16" "node128=-DRTC_MAJOR_XF=0 -DRTC_NODE_PAD_BYTES=48" -- python3 tools/time_scenes.py --scenes dragons,teapot,nefertiti,groups --check > gpurun_out/r5_layout.txt 2>&1

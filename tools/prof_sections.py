@@ -11,7 +11,7 @@ if os.environ.get("RTC_PROF_CHILD") != "1":
              "record", "normal", "pattern", "spawn", "counter", "items"]
     last = [l for l in text.splitlines() if l.startswith("rtc prof:")]
     for l in text.splitlines():
-        if l.startswith("frame") or l.startswith("rtc walks") or l.startswith("rtc traces") or l.startswith("rtc occluder"): print(l)
+        if l.startswith("frame") or l.startswith("rtc walks") or l.startswith("rtc trace") or l.startswith("rtc occluder"): print(l)
     if last:
         v = [int(x) for x in last[-1].split("|")[0].split()[2:18]]
         total = sum(v[i] for i in range(16) if i != 7)
