@@ -14,6 +14,7 @@
 #include <string>
 
 #include "rtc_oracle.hpp"
+#include "rtc_oracle_scene.hpp"
 
 using namespace orc;
 
@@ -918,6 +919,338 @@ static void cameraKats() {  // camera.zig:129-187
   expectColor("camera.zig:186", "render_center_pixel", w.colorAt(rc.rayForPixel(5, 5), 5), {0.38066, 0.47583, 0.2855});
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The oracle's OWN scene build (rtc_oracle_scene.hpp: the build-time halves of bounding_box.zig, group.zig, shape.zig,
+// parsing/obj.zig, parsing/scene.zig) against the reference's tests of those functions.  The product loader passes the
+// same vectors in tests/cpp/host_kat_main.cpp; tests/test_oracle_scene_cpu.py holds the two builds bit-equal on whole
+// scenes - these cases are what makes that comparison more than two restatements by one author agreeing.
+static bool bitEq(Tuple a, Tuple b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+static bool bitEq(const Matrix& a, const Matrix& b) {
+  for (int i = 0; i < 16; ++i)
+    if (a.d[i / 4][i % 4] != b.d[i / 4][i % 4]) return false;
+  return true;
+}
+
+static void sceneBoxKats() {  // bounding_box.zig:183-252, 362-423
+  namespace sc = orc::scene;
+  {
+    sc::Box box = sc::newBox();  // bounding_box.zig:183-190
+    sc::boxAdd(box, point(-5, 2, 0));
+    sc::boxAdd(box, point(7, 0, -3));
+    expectTrue("bounding_box.zig:183", "scene_add_points", bitEq(box.min, point(-5, 0, -3)) && bitEq(box.max, point(7, 2, 0)));
+  }
+  {
+    sc::Box b = sc::newBox();  // bounding_box.zig:192-236
+    b.min = point(5, -2, 0);
+    b.max = point(11, 4, 7);
+    const Tuple in[] = {point(5, -2, 0), point(11, 4, 7), point(8, 1, 3)};
+    const Tuple out[] = {point(3, 0, 3), point(8, -4, 3), point(8, 1, -1), point(13, 1, 3), point(8, 5, 3), point(8, 1, 8)};
+    bool ok = true;
+    for (const Tuple& p : in) ok = ok && sc::boxContainsPoint(b, p);
+    for (const Tuple& p : out) ok = ok && !sc::boxContainsPoint(b, p);
+    expectTrue("bounding_box.zig:192", "scene_contains_point", ok);
+    auto cb = [&](Tuple mn, Tuple mx) {  // bounding_box.zig:238-252
+      sc::Box o = sc::newBox();
+      o.min = mn;
+      o.max = mx;
+      return sc::boxContainsBox(b, o);
+    };
+    expectTrue("bounding_box.zig:238", "scene_contains_box",
+               cb(point(5, -2, 0), point(11, 4, 7)) && cb(point(6, -1, 1), point(10, 3, 6)) &&
+                   !cb(point(4, -3, -1), point(10, 3, 6)) && !cb(point(6, -1, 1), point(12, 5, 8)));
+  }
+  {
+    sc::Box unit = sc::newBox();  // bounding_box.zig:254-266
+    unit.min = point(-1, -1, -1);
+    unit.max = point(1, 1, 1);
+    const sc::Box tb = sc::boxTransform(unit, Matrix::identity().rotateY(PI / 4).rotateX(PI / 4));
+    expectTuple("bounding_box.zig:262", "scene_transform_min", tb.min, point(-1.41421, -1.7071, -1.7071), 1e-4);
+    expectTuple("bounding_box.zig:265", "scene_transform_max", tb.max, point(1.41421, 1.7071, 1.7071), 1e-4);
+  }
+  struct S { Tuple mn, mx, lmax, rmin; int line; const char* name; };
+  const S splits[] = {{point(-1, -4, -5), point(9, 6, 5), point(4, 6, 5), point(4, -4, -5), 365, "scene_split_cube"},
+                      {point(-1, -2, -3), point(9, 5.5, 3), point(4, 5.5, 3), point(4, -2, -3), 380, "scene_split_x_wide"},
+                      {point(-1, -2, -3), point(5, 8, 3), point(5, 3, 3), point(-1, 3, -3), 395, "scene_split_y_wide"},
+                      {point(-1, -2, -3), point(5, 3, 7), point(5, 3, 2), point(-1, -2, 2), 410, "scene_split_z_wide"}};
+  for (const S& c : splits) {
+    sc::Box b = sc::newBox(), l, r;
+    b.min = c.mn;
+    b.max = c.mx;
+    sc::boxSplit(b, l, r);
+    char where[48];
+    std::snprintf(where, sizeof where, "bounding_box.zig:%d", c.line);
+    expectTrue(where, c.name, bitEq(l.min, c.mn) && approxEqual(l.max, c.lmax) && approxEqual(r.min, c.rmin) && bitEq(r.max, c.mx));
+  }
+  {  // per-kind bounds: cylinder.zig:334-344, cone.zig:241-260, plane.zig:109-116, triangle.zig:198-208, shape.zig:638-654
+    Shape cyl = Shape::make(CYLINDER);
+    cyl.ymin = -5;
+    cyl.ymax = 3;
+    expectTrue("cylinder.zig:341", "scene_cylinder_bounds",
+               bitEq(sc::shapeBounds(cyl).min, point(-1, -5, -1)) && bitEq(sc::shapeBounds(cyl).max, point(1, 3, 1)));
+    Shape cone = Shape::make(CONE);
+    cone.ymin = -5;
+    cone.ymax = 3;
+    expectTrue("cone.zig:249", "scene_cone_bounds",
+               bitEq(sc::shapeBounds(cone).min, point(-5, -5, -5)) && bitEq(sc::shapeBounds(cone).max, point(5, 3, 5)));
+    const Shape pl = Shape::make(PLANE);
+    expectTrue("plane.zig:109", "scene_plane_bounds",
+               sc::shapeBounds(pl).min.x == -INF && sc::shapeBounds(pl).min.y == 0 && sc::shapeBounds(pl).max.z == INF);
+    const Shape tri = Shape::triangle(point(-3, 7, 2), point(6, 2, -4), point(2, -1, -1));
+    expectTrue("triangle.zig:198", "scene_triangle_bounds",
+               bitEq(sc::shapeBounds(tri).min, point(-3, -1, -4)) && bitEq(sc::shapeBounds(tri).max, point(6, 7, 2)));
+    Shape s = Shape::make(SPHERE);
+    sc::setTransform(s, Matrix::identity().scale(0.5, 2, 4).translate(1, -3, 5));
+    expectTuple("shape.zig:652", "scene_parent_space_min", sc::parentSpaceBounds(s).min, point(0.5, -5, 1));
+    expectTuple("shape.zig:653", "scene_parent_space_max", sc::parentSpaceBounds(s).max, point(1.5, -1, 9));
+  }
+}
+
+static void sceneGroupKats() {  // group.zig:219-381
+  namespace sc = orc::scene;
+  {  // group.zig:219-241: a group's box contains its children
+    Shape s = Shape::make(SPHERE);
+    sc::setTransform(s, Matrix::identity().scale(2, 2, 2).translate(2, 5, -3));
+    Shape c = Shape::make(CYLINDER);
+    c.ymin = -2;
+    c.ymax = 2;
+    sc::setTransform(c, Matrix::identity().scale(0.5, 1, 0.5).translate(-4, -1, 4));
+    Shape g = sc::newGroup();
+    sc::addChild(g, s);
+    sc::addChild(g, c);
+    expectTuple("group.zig:240", "scene_group_bounds_min", sc::shapeBounds(g).min, point(-4.5, -3, -5));
+    expectTuple("group.zig:241", "scene_group_bounds_max", sc::shapeBounds(g).max, point(4, 7, 4.5));
+  }
+  {  // group.zig:246-273 partitionChildren
+    Shape s1 = Shape::make(SPHERE);
+    sc::setTransform(s1, Matrix::identity().translate(-2, 0, 0));
+    Shape s2 = Shape::make(SPHERE);
+    sc::setTransform(s2, Matrix::identity().translate(2, 0, 0));
+    Shape s3 = Shape::make(SPHERE);
+    const size_t i1 = s1.id, i2 = s2.id, i3 = s3.id;
+    Shape g = sc::newGroup();
+    sc::addChild(g, s1);
+    sc::addChild(g, s2);
+    sc::addChild(g, s3);
+    std::vector<Shape> left, right;
+    sc::partitionChildren(g, left, right);
+    expectTrue("group.zig:270", "scene_partition",
+               g.children.size() == 1 && g.children[0].id == i3 && left.size() == 1 && left[0].id == i1 && right.size() == 1 &&
+                   right[0].id == i2);
+  }
+  {  // group.zig:275-292 makeSubgroup
+    Shape g = sc::newGroup();
+    std::vector<Shape> kids{Shape::make(SPHERE), Shape::make(SPHERE)};
+    sc::makeSubgroup(g, kids);
+    expectTrue("group.zig:291", "scene_make_subgroup",
+               g.children.size() == 1 && g.children[0].kind == GROUP && g.children[0].children.size() == 2);
+  }
+  {  // group.zig:294-330 divide(1)
+    Shape s1 = Shape::make(SPHERE);
+    sc::setTransform(s1, Matrix::identity().translate(-2, -2, 0));
+    Shape s2 = Shape::make(SPHERE);
+    sc::setTransform(s2, Matrix::identity().translate(-2, 2, 0));
+    Shape s3 = Shape::make(SPHERE);
+    sc::setTransform(s3, Matrix::identity().scale(4, 4, 4));
+    const size_t i1 = s1.id, i2 = s2.id, i3 = s3.id;
+    Shape g = sc::newGroup();
+    sc::addChild(g, s1);
+    sc::addChild(g, s2);
+    sc::addChild(g, s3);
+    sc::divide(g, 1);
+    bool ok = g.children.size() == 2 && g.children[0].id == i3 && g.children[1].kind == GROUP;
+    if (ok) {
+      const Shape& sub = g.children[1];
+      ok = sub.children.size() == 2 && sub.children[0].kind == GROUP && sub.children[0].children.size() == 1 &&
+           sub.children[0].children[0].id == i1 && sub.children[1].children.size() == 1 && sub.children[1].children[0].id == i2;
+    }
+    expectTrue("group.zig:313", "scene_divide_1", ok);
+  }
+  {  // group.zig:332-381 divide(3) with too few children at the top
+    Shape s1 = Shape::make(SPHERE);
+    sc::setTransform(s1, Matrix::identity().translate(-2, 0, 0));
+    Shape s2 = Shape::make(SPHERE);
+    sc::setTransform(s2, Matrix::identity().translate(2, 1, 0));
+    Shape s3 = Shape::make(SPHERE);
+    sc::setTransform(s3, Matrix::identity().translate(2, -1, 0));
+    Shape s4 = Shape::make(SPHERE);
+    const size_t i1 = s1.id, i2 = s2.id, i3 = s3.id, i4 = s4.id;
+    Shape sub = sc::newGroup();
+    sc::addChild(sub, s1);
+    sc::addChild(sub, s2);
+    sc::addChild(sub, s3);
+    Shape g = sc::newGroup();
+    sc::addChild(g, sub);
+    sc::addChild(g, s4);
+    sc::divide(g, 3);
+    bool ok = g.children.size() == 2 && g.children[0].kind == GROUP && g.children[0].children.size() == 2 && g.children[1].id == i4;
+    if (ok) {
+      const Shape& a = g.children[0].children[0];
+      const Shape& b = g.children[0].children[1];
+      ok = a.children.size() == 1 && a.children[0].id == i1 && b.children.size() == 2 && b.children[0].id == i2 &&
+           b.children[1].id == i3;
+    }
+    expectTrue("group.zig:363", "scene_divide_3", ok);
+  }
+  {  // group.zig:201-217, shape.zig:286-296: a group's transform goes to its leaves and its box is re-boxed
+    Shape s = Shape::make(SPHERE);
+    sc::setTransform(s, Matrix::identity().translate(5, 0, 0));
+    Shape g = sc::newGroup();
+    sc::addChild(g, s);
+    sc::setTransform(g, Matrix::identity().scale(2, 2, 2));
+    expectTrue("shape.zig:288", "scene_group_pushes_transform",
+               bitEq(g.transform, Matrix::identity()) &&
+                   bitEq(g.children[0].transform, Matrix::identity().scale(2, 2, 2).mul(Matrix::identity().translate(5, 0, 0))));
+    expectTuple("shape.zig:294", "scene_group_rebox_min", g.bmin, point(8, -2, -2));
+    expectTuple("shape.zig:294", "scene_group_rebox_max", g.bmax, point(12, 2, 2));
+  }
+}
+
+static void sceneObjKats() {  // parsing/obj.zig:288-544
+  namespace sc = orc::scene;
+  {
+    sc::ObjParser p;  // obj.zig:288-307
+    p.loadObj("There was a young lady named Bright\nwho traveled much faster than light.\nShe set out one day\nin a relative way,\nand came back the previous night.", {}, false);
+    expectTrue("obj.zig:306", "scene_ignored_lines", p.lines_ignored == 5);
+  }
+  {
+    sc::ObjParser p;  // obj.zig:309-340
+    p.loadObj("v -1 1 0\nv -1.0000 0.5000 0.0000\nv 1 0 0\nv 1 1 0", {}, false);
+    expectTrue("obj.zig:326", "scene_vertices",
+               p.lines_ignored == 0 && p.vertices().size() == 4 && bitEq(p.vertices()[0], point(-1, 1, 0)) &&
+                   bitEq(p.vertices()[1], point(-1, 0.5, 0)) && bitEq(p.vertices()[2], point(1, 0, 0)) &&
+                   bitEq(p.vertices()[3], point(1, 1, 0)));
+  }
+  {
+    sc::ObjParser p;  // obj.zig:342-374
+    p.loadObj("v -1 1 0\nv -1 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3\nf 1 3 4", {}, false);
+    const auto& c = p.defaultGroup().children;
+    expectTrue("obj.zig:361", "scene_faces",
+               p.lines_ignored == 0 && c.size() == 2 && bitEq(c[0].p1, p.vertices()[0]) && bitEq(c[0].p2, p.vertices()[1]) &&
+                   bitEq(c[0].p3, p.vertices()[2]) && bitEq(c[1].p1, p.vertices()[0]) && bitEq(c[1].p2, p.vertices()[2]) &&
+                   bitEq(c[1].p3, p.vertices()[3]));
+  }
+  {
+    sc::ObjParser p;  // obj.zig:376-411
+    p.loadObj("v -1 1 0\nv -1 0 0\nv 1 0 0\nv 1 1 0\nv 0 2 0\nf 1 2 3 4 5", {}, false);
+    const auto& c = p.defaultGroup().children;
+    expectTrue("obj.zig:395", "scene_fan_triangulation",
+               p.lines_ignored == 0 && c.size() == 3 && bitEq(c[0].p1, p.vertices()[0]) && bitEq(c[0].p2, p.vertices()[1]) &&
+                   bitEq(c[0].p3, p.vertices()[2]) && bitEq(c[1].p1, p.vertices()[0]) && bitEq(c[1].p2, p.vertices()[2]) &&
+                   bitEq(c[1].p3, p.vertices()[3]) && bitEq(c[2].p1, p.vertices()[0]) && bitEq(c[2].p2, p.vertices()[3]) &&
+                   bitEq(c[2].p3, p.vertices()[4]));
+  }
+  {
+    sc::ObjParser p;  // obj.zig:413-448 (triangles in groups), :450-480 (converting an OBJ file to a group)
+    p.loadObj("v -1 1 0\nv -1 0 0\nv 1 0 0\nv 1 1 0\ng FirstGroup\nf 1 2 3\ng SecondGroup\nf 1 3 4", {}, false);
+    const auto& c = p.defaultGroup().children;  // named groups are children of the default group, in file order
+    bool ok = p.lines_ignored == 0 && c.size() == 2 && c[0].kind == GROUP && c[1].kind == GROUP && c[0].children.size() == 1 &&
+              c[1].children.size() == 1;
+    if (ok)
+      ok = bitEq(c[0].children[0].p1, p.vertices()[0]) && bitEq(c[0].children[0].p2, p.vertices()[1]) &&
+           bitEq(c[0].children[0].p3, p.vertices()[2]) && bitEq(c[1].children[0].p1, p.vertices()[0]) &&
+           bitEq(c[1].children[0].p2, p.vertices()[2]) && bitEq(c[1].children[0].p3, p.vertices()[3]);
+    expectTrue("obj.zig:434", "scene_named_groups", ok);
+    const size_t g1 = ok ? c[0].id : 0, g2 = ok ? c[1].id : 0;
+    const Shape g = p.toGroup();
+    expectTrue("obj.zig:471", "scene_obj_to_group",
+               ok && g.kind == GROUP && g.children.size() == 2 && g.children[0].id == g1 && g.children[1].id == g2);
+  }
+  {
+    sc::ObjParser p;  // obj.zig:482-509
+    p.loadObj("vn 0 0 1\nvn 0.707 0 -0.707\nvn 1 2 3", {}, false);
+    expectTrue("obj.zig:498", "scene_normals",
+               p.lines_ignored == 0 && p.normals().size() == 3 && bitEq(p.normals()[0], vec3(0, 0, 1)) &&
+                   bitEq(p.normals()[1], vec3(0.707, 0, -0.707)) && bitEq(p.normals()[2], vec3(1, 2, 3)));
+  }
+  {
+    sc::ObjParser p;  // obj.zig:511-544
+    p.loadObj("v 0 1 0\nv -1 0 0\nv 1 0 0\nvn -1 0 0\nvn 1 0 0\nvn 0 1 0\nf 1//3 2//1 3//2\nf 1/0/3 2/102/1 3/14/2", {}, false);
+    const auto& c = p.defaultGroup().children;
+    bool ok = p.lines_ignored == 0 && c.size() == 2 && c[0].kind == SMOOTH_TRIANGLE && c[1].kind == SMOOTH_TRIANGLE;
+    if (ok)
+      ok = bitEq(c[0].p1, p.vertices()[0]) && bitEq(c[0].p2, p.vertices()[1]) && bitEq(c[0].p3, p.vertices()[2]) &&
+           bitEq(c[0].n1, p.normals()[2]) && bitEq(c[0].n2, p.normals()[0]) && bitEq(c[0].n3, p.normals()[1]) &&
+           bitEq(c[1].p1, c[0].p1) && bitEq(c[1].p2, c[0].p2) && bitEq(c[1].p3, c[0].p3) && bitEq(c[1].n1, c[0].n1) &&
+           bitEq(c[1].n2, c[0].n2) && bitEq(c[1].n3, c[0].n3);
+    expectTrue("obj.zig:532", "scene_faces_with_normals", ok);
+  }
+  {  // obj.zig:197-260: normalisation - offset = the box's centre, scale = half its longest extent; vertices (p - offset) / scale
+    sc::ObjParser p;
+    p.loadObj("v 0 0 0\nv 4 2 1\nf 1 2 2", {}, true);
+    expectTrue("obj.zig:257", "scene_normalize",
+               p.scale() == 2.0 && p.offset().x == 2.0 && p.offset().y == 1.0 && p.offset().z == 0.5 && p.vertices()[0].x == -1.0 &&
+                   p.vertices()[1].x == 1.0 && p.vertices()[0].w == 0.5);
+  }
+}
+
+static void sceneParseKats() {  // parsing/scene.zig:664-774
+  namespace sc = orc::scene;
+  const char* scene_json = R"({
+     "camera": { "width": 1280, "height": 1000, "field-of-view": 0.785,
+                 "from": [ -6, 6, -10 ], "to": [ 6, 0, 6 ], "up": [ -0.45, 1, 0 ] },
+     "objects": [ { "type": { "sphere": {} },
+                    "transform": [ { "translate": [1.0, 2.0, 3.0] }, { "scale": [0.5, 0.5, 0.5] } ],
+                    "material": { "pattern": { "type": { "stripes": [ { "type": { "solid": [1.0, 1.0, 1.0] } },
+                                                                       { "type": { "solid": [0.0, 0.0, 0.0] } } ] },
+                                               "transform": [ { "scale": [0.1, 0.1, 0.1] } ] },
+                                  "reflective": 0.5 } } ],
+     "lights": [ { "point-light": { "position": [-10.0, 10.0, -10.0], "intensity": [1.0, 1.0, 1.0] } } ] })";
+  sc::Files files;
+  files.load = [](const std::string&) -> std::string { throw std::runtime_error("no files"); };
+  files.image = [](const std::string&) -> UvImage { throw std::runtime_error("no images"); };
+  const auto built = sc::buildScene(scene_json, files);
+  Camera expected = Camera::make(1280, 1000, 0.785);
+  expected.setTransform(Matrix::viewTransform(point(-6, 6, -10), point(6, 0, 6), vec3(-0.45, 1, 0)));
+  const Camera& cam = built->camera;
+  expectTrue("scene.zig:724", "scene_camera",
+             cam.hsize == 1280 && cam.vsize == 1000 && cam.pixel_size == expected.pixel_size && cam.half_width == expected.half_width &&
+                 cam.half_height == expected.half_height && bitEq(cam.transform, expected.transform) && bitEq(cam.inverse, expected.inverse));
+  expectTrue("scene.zig:737", "scene_one_object", built->world.objects.size() == 1);
+  const Shape& o = built->world.objects.at(0);
+  expectTrue("scene.zig:726", "scene_object_transform",
+             o.kind == SPHERE && bitEq(o.transform, Matrix::identity().translate(1, 2, 3).scale(0.5, 0.5, 0.5)));
+  Pattern ep;
+  ep.setTransform(Matrix::identity().scale(0.1, 0.1, 0.1));
+  const Pattern& op = o.material.pattern;
+  expectTrue("scene.zig:740", "scene_pattern_transform", op.kind == PAT_STRIPES && bitEq(op.transform, ep.transform));
+  expectTrue("scene.zig:744", "scene_pattern_inverse", bitEq(op.inverse, ep.inverse));
+  expectTrue("scene.zig:748", "scene_material_ambient", o.material.ambient == 0.1);
+  expectTrue("scene.zig:752", "scene_material_reflective", o.material.reflective == 0.5);
+  expectTrue("scene.zig:756", "scene_stripes_a", op.a && op.a->kind == PAT_SOLID && op.a->rgb.r == 1.0 && op.a->rgb.g == 1.0 && op.a->rgb.b == 1.0);
+  expectTrue("scene.zig:760", "scene_stripes_b", op.b && op.b->kind == PAT_SOLID && op.b->rgb.r == 0.0 && op.b->rgb.g == 0.0 && op.b->rgb.b == 0.0);
+  expectTrue("scene.zig:770", "scene_light",
+             built->world.lights.size() == 1 && bitEq(built->world.lights[0].position, point(-10, 10, -10)) &&
+                 built->world.lights[0].intensity.r == 1.0 && built->world.lights[0].intensity.g == 1.0 &&
+                 built->world.lights[0].intensity.b == 1.0);
+  // scene.zig:440-546: from-definition inside a group; the group's transform and material reach the leaf, the
+  // definition's own and the use site's are applied inside out (scene.zig:455-546, shape.zig:286-296)
+  const char* defs = R"({"camera":{"width":2,"height":2,"field-of-view":1,"from":[0,0,-5],"to":[0,0,0],"up":[0,1,0]},"lights":[],
+    "shape-definitions":[{"name":"leg","value":{"type":{"sphere":{}},"transform":[{"scale":[2,2,2]}],"material":{"ambient":0.3}}}],
+    "objects":[{"type":{"group":[{"type":{"from-definition":"leg"},"transform":[{"translate":[1,0,0]}],"material":{"diffuse":0.4}}]},
+                "transform":[{"translate":[0,5,0]}],"material":{"specular":0.25}}]})";
+  const auto di = sc::buildScene(defs, files);
+  bool ok = di->world.objects.size() == 1 && di->world.objects[0].kind == GROUP && di->world.objects[0].children.size() == 1;
+  if (ok) {
+    const Shape& leaf = di->world.objects[0].children[0];
+    const Matrix want = Matrix::identity().translate(0, 5, 0).mul(
+        Matrix::identity().translate(1, 0, 0).mul(Matrix::identity().scale(2, 2, 2).mul(Matrix::identity())));
+    ok = bitEq(leaf.transform, want) && leaf.material.ambient == 0.3 && leaf.material.diffuse == 0.4 && leaf.material.specular == 0.25;
+  }
+  expectTrue("scene.zig:455", "scene_from_definition_in_group", ok);
+  auto fails = [&](const std::string& js) {
+    try {
+      (void)sc::buildScene(js, files);
+    } catch (const std::exception&) {
+      return true;
+    }
+    return false;
+  };
+  const std::string cam_json = R"("camera":{"width":2,"height":2,"field-of-view":1,"from":[0,0,-5],"to":[0,0,0],"up":[0,1,0]},"lights":[])";
+  expectTrue("scene.zig:493", "scene_unknown_definition", fails("{" + cam_json + R"(,"objects":[{"type":{"from-definition":"nope"}}]})"));
+  expectTrue("scene.zig:203", "scene_missing_field", fails(R"({"lights":[],"objects":[]})"));
+}
+
 int main() {
   tupleKats();
   matrixKats();
@@ -939,6 +1272,10 @@ int main() {
   powKats();
   worldKats();
   cameraKats();
+  sceneBoxKats();
+  sceneGroupKats();
+  sceneObjKats();
+  sceneParseKats();
   std::printf("KAT-SUMMARY total=%d failed=%d\n", g_total, g_failed);
   return g_failed ? 1 : 0;
 }

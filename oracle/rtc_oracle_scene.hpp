@@ -466,6 +466,12 @@ class ObjParser {  // obj.zig:11-286
   }
   Shape toGroup() { return std::move(default_group_); }  // obj.zig:281-283
   size_t lines_ignored = 0;
+  // (what the reference's tests look at: parser.vertices / normals / default_group, obj.zig:288-544 - oracle/kat_main.cpp)
+  const std::vector<Tuple>& vertices() const { return vertices_; }
+  const std::vector<Tuple>& normals() const { return normals_; }
+  const Shape& defaultGroup() const { return default_group_; }
+  Tuple offset() const { return offset_; }
+  double scale() const { return scale_; }
 
  private:
   Shape default_group_;
