@@ -388,12 +388,6 @@ int rtc_scatter_tile_list_rgba8_device(const double *d_tiles, const uint32_t *d_
 /* Waits for the work enqueued on the handle's own stream (nothing to wait for if it has never used one). */
 int rtc_scene_synchronize(rtc_scene *scene);
 
-/* Diagnostic (tools/estimate_probe.py): for the pixel map of the handle's last scheduled launch, per 8x8 chunk what the
- * first-frame estimate (rtc_estimate_kernel, for camera `cam`) says it costs and what the last measuring launch measured,
- * both in the packer's ticks of 16 shader cycles.  Either array may be NULL.  Scheduling only: no result depends on it. */
-int rtc_get_chunk_times(rtc_scene *scene, const rtc_camera *cam, uint32_t *estimated, uint32_t *measured, size_t capacity,
-                        uint32_t *n_chunks);
-
 /* Counters of the last render that was enqueued on this handle (synchronises). */
 int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
 
@@ -408,36 +402,8 @@ int rtc_get_stats(rtc_scene *scene, rtc_stats *out);
  */
 int rtc_grow_csg_lists(rtc_scene *scene);
 
-/* Diagnostic: the name of the render kernel the last launch on this handle ran
- * (the name rocprofv3 shows - which variant is picked depends on what the world
- * contains and on the size of the launch); "" before the first launch.  Static storage.
- * (After an rtc_render that went to the host in bands, this, rtc_get_schedule and
- * rtc_get_tile_costs describe the frame's first band; rtc_get_stats the whole frame.) */
-const char *rtc_last_kernel_name(const rtc_scene *scene);
-
-/* Diagnostic: the schedule the NEXT launch of the handle's current pixel map would run - the order in which the
- * persistent waves are handed pixels (results never depend on it) - as `*n_packets` rows of 16 items; an item is
- * chunk | first_pixel << 20 | (pixels - 1) << 26 (pixels of an 8x8 chunk in row-major order), 0xFFFFFFFF = none.
- * Synchronises.  `*n_packets` = 0 when the handle has no schedule (no launch yet, or a launch of fewer than 64 chunks).
- * RTC_ERR_INVALID_ARGUMENT if `capacity_items` is too small (`*n_packets` says how many rows there are). */
-int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, uint32_t *n_packets);
-
-/*
- * Tuning and test options, process-wide; none changes a rendered value.  Read when a scene is created (bvh_*,
- * blocks_per_cu) or a launch is enqueued (the rest).  Names: "simple3_min_chunks" (chunks from which a world of
- * top-level spheres / planes / cubes runs the three-waves-per-SIMD kernel; 0 always, < 0 the library's choice),
- * "sched_off" (!= 0: no schedule, packet i is chunk i), "cut_above" (shares of a wave above which a chunk is cut into
- * runs of pixels; < 0 never, 0 the library's choice), "pack_rounds", "pull_min_idle", "blocks_per_cu", "sched_tmin",
- * "bvh_leaf", "bvh_one_axis", "bvh_check", "host_bands" (bands of a host-output frame, 1 .. 4; 0 by size),
- * "waves3" (the general kernel at three waves per SIMD: 1 always, 0 never, < 0 measured per handle),
- * "sched_mix" (a | b << 8: behind every wave's first packet the schedule takes a packets from its long end, then b from
- * its short end, ...; 0 longest first throughout), "measure_every" (a view that moves in small steps is measured
- * every n-th frame; 1), "inflight_chunks_per_wave" (a launch of a scene with several handles - frames in flight -
- * runs on at most one wave per this many chunks; 3, 0 = no cap).
- * RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
- * (The library reads no environment variables.)
- */
-int rtc_set_option(const char *name, double value);
+/* (Diagnostics and tuning - rtc_set_option, rtc_get_schedule, rtc_get_chunk_times, rtc_last_kernel_name - are declared in
+ * rtc_diag.h: a host that binds the render path does not need them.) */
 
 /* Thread-local, static storage; "" when the last call on this thread succeeded. */
 const char *rtc_last_error(void);

@@ -87,7 +87,6 @@ pub extern fn rtc_render_device(scene: *RtcScene, cam: *const RtcCamera, max_dep
 pub extern fn rtc_canvas_register(canvas: *anyopaque, bytes: usize) c_int; // pin a canvas that is rendered into again and again ...
 pub extern fn rtc_canvas_unregister(canvas: *anyopaque) c_int; // ... and drop the pin BEFORE the canvas is freed
 pub extern fn rtc_rgba8_device(d_canvas: [*]const f64, n_pixels: usize, d_rgba: [*]u32, hip_stream: ?*anyopaque) c_int;
-pub extern fn rtc_set_option(name: [*:0]const u8, value: f64) c_int; // tuning / test options; the library reads no environment
 pub extern fn rtc_scene_synchronize(scene: *RtcScene) c_int;
 pub extern fn rtc_get_stats(scene: *RtcScene, out: *RtcStats) c_int;
 pub extern fn rtc_grow_csg_lists(scene: *RtcScene) c_int; // after an asynchronous frame whose stats.overflow != 0 on a csg scene: longer lists, render again
@@ -95,11 +94,14 @@ pub extern fn rtc_scatter_tile_list_device(d_tiles: [*]const f64, d_tile_list: [
                                            hsize: u32, vsize: u32, canvas: [*]f64, hip_stream: ?*anyopaque) c_int; // a rank's tiles straight into a (registered host) canvas
 pub extern fn rtc_scatter_tile_list_rgba8_device(d_tiles: [*]const f64, d_tile_list: [*]const u32, n_tiles: u32, tile_w: u32, tile_h: u32,
                                                  hsize: u32, vsize: u32, rgba: [*]u32, hip_stream: ?*anyopaque) c_int;
+pub extern fn rtc_last_error() [*:0]const u8;
+pub extern fn rtc_status_name(status: c_int) [*:0]const u8;
+
+// include/rtc_diag.h (diagnostics and tuning: not needed to render; the same library exports them)
+pub extern fn rtc_set_option(name: [*:0]const u8, value: f64) c_int; // tuning / test options; the library reads no environment
 pub extern fn rtc_get_chunk_times(scene: *RtcScene, cam: *const RtcCamera, estimated: ?[*]u32, measured: ?[*]u32, capacity: usize, n_chunks: *u32) c_int; // diagnostic
 pub extern fn rtc_last_kernel_name(scene: *const RtcScene) [*:0]const u8;
 pub extern fn rtc_get_schedule(scene: *RtcScene, items: ?[*]u32, capacity_items: usize, n_packets: *u32) c_int;
-pub extern fn rtc_last_error() [*:0]const u8;
-pub extern fn rtc_status_name(status: c_int) [*:0]const u8;
 
 // include/rtc_multi.h (librtc_multi.so: all GPUs of the node behind one call, one ncclGather per frame)
 pub const RtcMulti = opaque {};

@@ -89,10 +89,14 @@ class Stats(C.Structure):
                 ("shadow_traced", C.c_uint64), ("overflow", C.c_uint64)]
 
 
+# (include/rtc.h: what a host binds ...)
 RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_render", "rtc_render_rgba8", "rtc_render_device",
                "rtc_render_tiles_device", "rtc_assemble_tiles_device", "rtc_render_tile_list_device", "rtc_get_tile_costs",
-               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scatter_tile_list_device", "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times", "rtc_last_error",
-               "rtc_status_name", "rtc_grow_csg_lists", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device", "rtc_set_option"]
+               "rtc_assign_tiles", "rtc_assemble_tile_list_device", "rtc_assemble_tile_list_rgba8_device", "rtc_scatter_tile_list_device",
+               "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error", "rtc_status_name",
+               "rtc_grow_csg_lists", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device"]
+# (... and include/rtc_diag.h: diagnostics and tuning, for the tests, bench.py and tools/)
+RTC_DIAG_SYMBOLS = ["rtc_set_option", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
@@ -478,7 +482,7 @@ def canvas_unregister(array):
 
 
 def set_option(name, value):
-    """rtc_set_option: a process-wide tuning / test option of the library (include/rtc.h lists them)."""
+    """rtc_set_option: a process-wide tuning / test option of the library (include/rtc_diag.h lists them)."""
     _check_hip(hip_lib().rtc_set_option(name.encode(), float(value)))
 
 

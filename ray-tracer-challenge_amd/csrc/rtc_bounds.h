@@ -279,7 +279,7 @@ struct BvhBuilder {
     // Up to two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
     // tests together), the four-wide nodes and the final schedule, measured at 1 / 2 / 3 leaves per node:
     // dragons 4K 2.78 / 2.72 / 2.73 ms, nefertiti 0.728 / 0.713 / 0.719 ms, teapot 0.382 / 0.357 / 0.368 ms.
-    const size_t max_leaf = static_cast<size_t>(std::min(RTC_BVH8 ? 4.0 : 8.0, std::max(1.0, rtcOptions().bvh_leaf)));  // (an eight-wide node addresses at most four records per leaf child)
+    const size_t max_leaf = static_cast<size_t>(std::min(RTC_BVH8 ? 4.0 : 8.0, std::max(1.0, static_cast<double>(rtcOptions().bvh_leaf))));  // (an eight-wide node addresses at most four records per leaf child)
     if (count <= max_leaf) {
       const uint32_t at = static_cast<uint32_t>(leaves.size());
       for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);

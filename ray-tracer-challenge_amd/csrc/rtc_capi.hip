@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/rtc.h"
+#include "../../include/rtc_diag.h"
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -220,6 +221,10 @@ double groupFloor(const rtc_scene* s) {
 // ninths, two against three waves: cover 960x540 0.304 / 0.260 ms and 640x360 0.176 / 0.182, reflection_and_refraction
 // depth 8 0.741 / 0.768 and 0.556 / 0.500): the handle measures it, with the trial the worlds with groups use (KernelTune
 // in launch()).
+// Three waves per SIMD for this launch: the kernel under trial while a trial frame is being enqueued, else the handle's
+// decision (KernelTune in launch()).
+bool threeWaves(const rtc_scene* s) { return s->trial_live ? s->trial_three : s->use_three_waves; }
+
 bool simple3Trial(const rtc_scene* s, const DevPixelMap& map) {
   if (!s->simple3_ok || rtcOptions().simple3_min_chunks >= 0.0) return false;
   if (s->tab && s->tab->handles.load(std::memory_order_relaxed) > 1) return false;  // (frames in flight: see usesSimple3)
@@ -235,7 +240,7 @@ bool usesSimple3(const rtc_scene* s, const DevPixelMap& map) {
   const uint64_t min_chunks = forced >= 0.0 ? static_cast<uint64_t>(forced) : (in_flight ? 1ull : 4ull) * 4u * s->n_cus * s->blocks_per_cu_simple3;
   if (!s->simple3_ok) return false;
   if (map.n_chunks >= min_chunks) return true;
-  return simple3Trial(s, map) && s->use_three_waves;  // (between one and four chunks per wave: what the handle's trial says)
+  return simple3Trial(s, map) && threeWaves(s);  // (between one and four chunks per wave: what the handle's trial says)
 }
 
 bool tablesInLds(const rtc_scene* s) {
@@ -255,7 +260,7 @@ bool usesGeneral3(const rtc_scene* s) {
   if (!s->general3_ok) return false;
   const double forced = rtcOptions().waves3;
   if (forced >= 0.0) return forced != 0.0;
-  return s->use_three_waves;
+  return threeWaves(s);
 #else
   (void)s;
   return false;
@@ -327,6 +332,17 @@ size_t maxPackets(const rtc_scene* s, const DevPixelMap& map) {
   return static_cast<size_t>(map.n_chunks) + 15u * std::min<size_t>(map.n_chunks, waves);
 }
 
+// ... and whichever of the world's kernels runs: the schedule buffers are sized for the larger of the two- and the
+// three-wave kernel's resident waves, so that the frame on which a trial changes kernels packs into buffers that are
+// already there (sized for the kernel in use only, that frame's schedule overran the documented bound and the next launch
+// re-allocated - a host-blocking wait inside rtc_render_device, a re-estimated frame and the trial started over).
+size_t maxPacketsAnyKernel(const rtc_scene* s, const DevPixelMap& map) {
+  uint32_t blocks = residentBlocksAlone(s, map);
+  if (s->simple3_ok) blocks = std::max(blocks, s->n_cus * s->blocks_per_cu_simple3);
+  if (s->general3_ok && tablesInLds(s)) blocks = std::max(blocks, s->n_cus * s->blocks_per_cu_general3);
+  return std::max(maxPackets(s, map), static_cast<size_t>(map.n_chunks) + 15u * std::min<size_t>(map.n_chunks, 4u * static_cast<size_t>(blocks)));
+}
+
 // The measured schedule in use, into a launch's pixel map.
 void useSchedule(const rtc_scene* s, DevPixelMap& map) {
   map.order = s->d_sched[s->sched_cur];
@@ -336,7 +352,7 @@ void useSchedule(const rtc_scene* s, DevPixelMap& map) {
 
 // Everything a measuring launch and the packer behind it write to.
 int ensureMeasureBuffers(rtc_scene* s, const DevPixelMap& map) {
-  if (const int st = ensureScheduleBuffers(s, maxPackets(s, map) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
+  if (const int st = ensureScheduleBuffers(s, maxPacketsAnyKernel(s, map) * RTC_PACKET_ITEMS); st != RTC_OK) return st;
   // (a schedule with chunks cut into runs can have more packets than there are chunks: at most 16 parts each)
   const size_t need_pt = static_cast<size_t>(map.n_chunks) * 16u;
   if (need_pt > s->packet_time_capacity) {
@@ -452,7 +468,7 @@ int updateSchedule(rtc_scene* s, const rtc_camera& cam, DevPixelMap& map, uint32
   if (!plan.moved) {
     s->frames_unmeasured = 0;
   } else {
-    const uint32_t every = static_cast<uint32_t>(std::max(1.0, rtcOptions().measure_every));
+    const uint32_t every = static_cast<uint32_t>(std::max(1.0, static_cast<double>(rtcOptions().measure_every)));
     const bool near = max_depth == s->sched_depth && nearbyView(cam, s->sched_cam);
     plan.near = near;
     plan.measure = !near || ++s->frames_unmeasured >= every;
@@ -532,10 +548,12 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   // 3.29 / 3.24 / 3.16 / 3.05 / 2.84 ms, dragons 4K 8.33 / 7.99 / 7.59 / 7.18 / 6.60 ms: a wave that finishes its
   // packet before it starts the next keeps neighbouring pixels (the same objects, materials, BVH paths) together;
   // the lanes that run out early are fed by the work sharing of step 2a, not by pixels of another chunk.
-  const uint32_t pull_min = static_cast<uint32_t>(std::max(1.0, rtcOptions().pull_min_idle));
+  const uint32_t pull_min = static_cast<uint32_t>(std::max(1.0, static_cast<double>(rtcOptions().pull_min_idle)));
   map.pull_min_idle = std::max(1u, std::min(64u, pull_min));
   s->dev.csg_buf = nullptr;
   if (s->has_csg) {
+    if (s->tab)  // (what another handle of this scene - a clone, a frame in flight - has already grown its lists to)
+      s->dev.csg_entries = std::max(s->dev.csg_entries, std::min<uint32_t>(RTC_CSG_ENTRIES_MAX, s->tab->csg_entries_wanted.load(std::memory_order_relaxed)));
     const size_t need_csg = static_cast<size_t>(blocks) * 4u * s->dev.csg_entries * 64u * sizeof(CsgRec);
     if (need_csg > s->csg_buf_capacity) {
       HIP_TRY(handleIdle(s));  // (the last launch may still be using the old buffer)
@@ -549,6 +567,7 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
         s->d_csg_buf = nullptr;
         const uint32_t wanted = s->dev.csg_entries;
         s->dev.csg_entries = s->csg_entries_ok;
+        if (s->tab) s->tab->csg_entries_wanted.store(s->csg_entries_ok, std::memory_order_relaxed);  // (nobody else tries that length either)
         return fail(RTC_ERR_OUT_OF_MEMORY, "csg intersection lists of %u entries per lane need %zu bytes; the handle keeps %u entries", wanted,
                     need_csg, s->csg_entries_ok);
       }
@@ -602,7 +621,9 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     HIP_TRY(hipMemsetAsync(s->d_stats, 0, 2 * sizeof(DevStats), stream));
     s->stats_zeroed = true;
   }
-  if (!s->kernel_warm && s->d_ray_stack != nullptr) {
+  const bool send_ahead = !s->kernel_warm && s->d_ray_stack != nullptr;
+  s->kernel_warm = true;  // (the FIRST launch only, whether or not the empty dispatch can be sent: on a later launch it would be pointless and would count into the previous launch's block)
+  if (send_ahead) {
     // A handle's first launch: the render kernel goes to the stream ONCE WITH NO WORK before anything else.  The first
     // dispatch of a kernel that needs scratch memory (every render kernel spills) stalls its queue while the runtime sets
     // that memory up - 130 us between submission and start, measured in front of a 0.5 ms frame
@@ -610,7 +631,6 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     // allocations a first launch makes next (cost, schedule and measurement buffers), and the real kernels start when
     // they are submitted.  n_units = 0: every wave's first pull finds the counter past the end and leaves; the launch
     // counters it touches are the ones the next launch clears or finds zero.
-    s->kernel_warm = true;
     DevPixelMap idle = map;
     idle.order = nullptr;
     idle.n_units_dev = nullptr;
@@ -627,6 +647,7 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
                        s->d_stats + s->stats_parity, s->d_stats + (s->stats_parity ^ 1u));
     HIP_TRY(hipGetLastError());
   }
+  s->trial_live = false;  // (set again below if this launch is a frame of a running trial)
   SchedulePlan plan;
   if (const int st = updateSchedule(s, cam, map, max_depth, out_pixels, stream, plan); st != RTC_OK) return st;
   // ---- two or three waves per SIMD for a world with groups: measured on the handle's own frames (KernelTune).  Once a
@@ -656,7 +677,6 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
     // interactive host whose camera never rests gets its trial too; a jump to another view makes the trial wait)
     const bool steady = (!plan.moved || plan.near) && !plan.estimate && map.order != nullptr;
     if (eligible && T.state == 1 && !steady) {  // (a jump to another view: the trial starts over when the view rests again)
-      s->use_three_waves = false;
       T.state = 0;
       T.frames = 0;
       T.n[0] = T.n[1] = 0;
@@ -707,17 +727,18 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
         }
         T.state = 1;
         int timed = -1;  // which kernel this frame times, if any
+        s->trial_live = true;
         if (T.n[0] + pending[0] < kSamples) {
-          s->use_three_waves = false;
+          s->trial_three = false;
           timed = 0;
         } else if (!T.switched) {
-          s->use_three_waves = true;  // (the switch: this frame runs the two-wave schedule and measures)
+          s->trial_three = true;  // (the switch: this frame runs the two-wave schedule and measures)
           plan.measure = true;
           T.switched = true;
           T.sched_before = s->sched_cur;
           T.packs_at_switch = s->n_packs;
         } else {
-          s->use_three_waves = true;
+          s->trial_three = true;
           if (T.n[1] + pending[1] < kSamples) timed = 1;  // (else: every sample is in flight)
         }
         if (timed >= 0 && free_slot >= 0) {
@@ -2125,6 +2146,10 @@ bool growCsgLists(rtc_scene* s) {
   while (want < s->csg_needed && want < RTC_CSG_ENTRIES_MAX) want *= 2u;
   s->dev.csg_entries = want;
   s->csg_needed = 0;
+  if (s->tab) {  // (every handle of the scene follows at its next launch: ensureScratch)
+    uint32_t seen = s->tab->csg_entries_wanted.load(std::memory_order_relaxed);
+    while (seen < want && !s->tab->csg_entries_wanted.compare_exchange_weak(seen, want, std::memory_order_relaxed)) {}
+  }
   g_error.clear();
   return true;
 }
@@ -2136,6 +2161,7 @@ int rtc_grow_csg_lists(rtc_scene* s) {
   if (!s) return fail(RTC_ERR_INVALID_ARGUMENT, "null scene");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(handleIdle(s));
+  if (!s->stats_zeroed) return RTC_OK;  // (no launch yet: the counters have not even been cleared - nothing overflowed)
   const int ov = checkOverflow(s);
   if (ov != RTC_ERR_OVERFLOW) return ov;  // (RTC_OK: nothing overflowed, nothing to do)
   return growCsgLists(s) ? RTC_OK : ov;
@@ -2161,16 +2187,16 @@ int rtc_set_option(const char* name, double value) {
   RtcOptions& o = rtcOptions();
   const struct {
     const char* name;
-    double* slot;
+    RtcOption* slot;
   } table[] = {{"simple3_min_chunks", &o.simple3_min_chunks}, {"sched_off", &o.sched_off}, {"cut_above", &o.cut_above},
                {"pack_rounds", &o.pack_rounds}, {"pull_min_idle", &o.pull_min_idle}, {"blocks_per_cu", &o.blocks_per_cu},
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
                {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3},
                {"measure_every", &o.measure_every}, {"sched_mix", &o.sched_mix},
-               {"inflight_chunks_per_wave", &o.inflight_chunks_per_wave}};
+               {"inflight_chunks_per_wave", &o.inflight_chunks_per_wave}, {"build_threads", &o.build_threads}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
-      *e.slot = value;
+      e.slot->set(value);
       return RTC_OK;
     }
   return fail(RTC_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);

@@ -39,24 +39,32 @@ int fail(int status, const char* fmt, ...) {
     }                                                                                         \
   } while (0)
 
-// Tuning and test options (rtc_set_option, include/rtc.h): process-wide, read when a scene is created or a launch is
-// enqueued; none changes a result.  0 / negative = the library's own choice.
+// Tuning and test options (rtc_set_option, include/rtc_diag.h): process-wide, read when a scene is created or a launch is
+// enqueued; none changes a result.  0 / negative = the library's own choice.  Every option is an atomic double (relaxed:
+// an option is one independent number): a host thread may set one while another thread's launch reads it.
+struct RtcOption {
+  std::atomic<double> v;
+  RtcOption(double d) : v(d) {}
+  operator double() const { return v.load(std::memory_order_relaxed); }
+  void set(double d) { v.store(d, std::memory_order_relaxed); }
+};
 struct RtcOptions {
-  double simple3_min_chunks = -1.0;  // chunks from which a simple world runs the three-wave kernel (0: always)
-  double sched_off = 0.0;            // != 0: no schedule at all (packet i is chunk i)
-  double cut_above = 0.0;            // shares of a wave above which a chunk is cut into runs (< 0: never)
-  double pack_rounds = 3.0;          // rounds of rtc_pack_extra_kernel
-  double pull_min_idle = 64.0;       // idle lanes before a wave pulls its next packet
-  double blocks_per_cu = 0.0;        // cap on resident work-groups per CU
-  double sched_tmin = 0.0;           // time up to which cheap chunks share a packet
-  double bvh_leaf = RTC_BVH8 ? 1.0 : 2.0;  // leaves per candidate-BVH leaf (eight-wide tree, 1 / 2 / 3 / 4: dragons 4K 2.03 / 2.10 / 2.18 / 2.30 ms, nefertiti 0.522 / 0.534 / 0.548 / 0.562, teapot 0.264 / 0.265 / 0.263 / 0.272)
-  double bvh_one_axis = 0.0;         // != 0: SAH on the longest axis only
-  double bvh_check = 0.0;            // != 0: host self-check of the candidate BVH at create (stderr)
-  double waves3 = -1.0;              // the general kernel at three waves per SIMD: 1 always (where the tables fit), 0 never, < 0: measured per handle
-  double sched_mix = 773.0;          // a | b << 8: behind every wave's first packet the schedule takes a packets from its long end, b from its short end, ... (5 : 3); 0: longest first throughout
-  double inflight_chunks_per_wave = 3.0;  // a launch of a scene with frames in flight runs on at most one wave per this many chunks (0: no cap)
-  double measure_every = 1.0;        // a moving view is measured (and its schedule re-packed) every this many frames (see updateSchedule)
-  double host_bands = 0.0;           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
+  RtcOption simple3_min_chunks{-1.0};  // chunks from which a simple world runs the three-wave kernel (0: always)
+  RtcOption sched_off{0.0};            // != 0: no schedule at all (packet i is chunk i)
+  RtcOption cut_above{0.0};            // shares of a wave above which a chunk is cut into runs (< 0: never)
+  RtcOption pack_rounds{3.0};          // rounds of rtc_pack_extra_kernel
+  RtcOption pull_min_idle{64.0};       // idle lanes before a wave pulls its next packet
+  RtcOption blocks_per_cu{0.0};        // cap on resident work-groups per CU
+  RtcOption sched_tmin{0.0};           // time up to which cheap chunks share a packet
+  RtcOption bvh_leaf{RTC_BVH8 ? 1.0 : 2.0};  // leaves per candidate-BVH leaf (eight-wide tree, 1 / 2 / 3 / 4: dragons 4K 2.03 / 2.10 / 2.18 / 2.30 ms, nefertiti 0.522 / 0.534 / 0.548 / 0.562, teapot 0.264 / 0.265 / 0.263 / 0.272)
+  RtcOption bvh_one_axis{0.0};         // != 0: SAH on the longest axis only
+  RtcOption bvh_check{0.0};            // != 0: host self-check of the candidate BVH at create (stderr)
+  RtcOption waves3{-1.0};              // the general kernel at three waves per SIMD: 1 always (where the tables fit), 0 never, < 0: measured per handle
+  RtcOption sched_mix{773.0};          // a | b << 8: behind every wave's first packet the schedule takes a packets from its long end, b from its short end, ... (5 : 3); 0: longest first throughout
+  RtcOption inflight_chunks_per_wave{3.0};  // a launch of a scene with frames in flight runs on at most one wave per this many chunks (0: no cap)
+  RtcOption measure_every{1.0};        // a moving view is measured (and its schedule re-packed) every this many frames (see updateSchedule)
+  RtcOption host_bands{0.0};           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
+  RtcOption build_threads{0.0};        // threads of rtc_scene_create's candidate-BVH build (one top-level group each); 0: as many as the host allows, up to 8
 };
 inline RtcOptions& rtcOptions() {
   static RtcOptions options;
@@ -90,6 +98,9 @@ struct Sphere {
 // (rtc_scene_clone: one handle per frame in flight) share one copy; freed with the last of them.
 struct SceneTables {
   std::atomic<int> handles{0};  // handles that share this copy: more than one = frames in flight (kernel choice, rtc_capi.hip)
+  // the csg list length any handle of this scene has grown to (rtc_grow_csg_lists): the others - clones, one per frame in
+  // flight - take it over at their next launch instead of overflowing, growing and rendering again one by one
+  std::atomic<uint32_t> csg_entries_wanted{0};
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;
@@ -136,7 +147,9 @@ struct rtc_scene {
   // ---- the general kernel at two or at three waves per SIMD: measured, not guessed (launch(), KernelTune)
   bool general3_ok = false;        // a world with groups, no csg / texture maps, whose tables fit the three-wave kernel's LDS
   uint32_t blocks_per_cu_general3 = 1;
-  bool use_three_waves = false;    // the three-wave form of the world's kernel (rtc_render_kernel3 / _simple3 at mid sizes): the choice once the trial is over, the kernel under trial during it
+  bool use_three_waves = false;    // the three-wave form of the world's kernel (rtc_render_kernel3 / _simple3 at mid sizes): what the handle's last finished trial DECIDED (clones inherit this, nothing else)
+  bool trial_live = false;         // the launch being enqueued is a frame of a running trial ...
+  bool trial_three = false;        // ... of this kernel; anything that ends or suspends the trial (a clone made, another pixel map, an option) falls back to the decision
   struct KernelTune {
     enum { kSamples = 3, kRing = 8 };
     int state = 0;                 // 0: no trial yet for this pixel map, 1: trial running, 2: decided

@@ -245,13 +245,28 @@ int ensureRgbaBuffers(rtc_multi* m) {
 }
 
 // Is `p` host memory the GPUs can write in place - a canvas the caller handed to rtc_canvas_register?
-bool registeredHost(const void* p) {
-  hipPointerAttribute_t attr;
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-    (void)hipGetLastError();  // (plain pageable memory: not an error)
+// All of it: the frame's first AND last byte (a canvas registered for fewer bytes than the frame has, or a pointer into
+// a smaller pinned allocation, would send every rank's scatter kernel past the mapped range - a GPU memory fault, not an
+// error code); anything else takes the gather path.
+bool registeredHost(const void* p, size_t bytes) {
+  auto mapped = [](const void* q) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, q) != hipSuccess) {
+      (void)hipGetLastError();  // (plain pageable memory: not an error)
+      return false;
+    }
+    return attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr;
+  };
+  if (bytes == 0 || !mapped(p)) return false;
+  if (!mapped(static_cast<const char*>(p) + bytes - 1)) return false;
+  // one registration (or allocation) from the first byte to the last: device views of both ends are as far apart as the bytes
+  void *d0 = nullptr, *d1 = nullptr;
+  if (hipHostGetDevicePointer(&d0, const_cast<void*>(p), 0) != hipSuccess ||
+      hipHostGetDevicePointer(&d1, const_cast<char*>(static_cast<const char*>(p)) + bytes - 1, 0) != hipSuccess) {
+    (void)hipGetLastError();
     return false;
   }
-  return attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr;
+  return static_cast<char*>(d1) - static_cast<char*>(d0) == static_cast<ptrdiff_t>(bytes - 1);
 }
 
 int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal);
@@ -367,9 +382,12 @@ int finishSlot(rtc_multi* m, uint32_t f, bool may_redeal) {
   rtc_stats st;
   if (const int s = slotStats(m, f, &st); s != RTC_OK) return s;
   if (st.overflow) {
-    // A csg intersection list that ran out is made longer on EVERY handle (all slots, all ranks: the next frame may run
-    // anywhere) - rtc_grow_csg_lists sizes it for what the frame needed.  The synchronous entry points then render the
-    // frame again; the asynchronous ones report this frame's overflow once, and the frames after it have the longer lists.
+    // A csg intersection list that ran out is made longer on the handles that overflowed - rtc_grow_csg_lists sizes it for
+    // what the frame needed - and the other slots' handles of the same rank (clones: they share the scene's tables) take the
+    // new length over at their next launch (SceneTables::csg_entries_wanted) instead of overflowing and growing one by one;
+    // a rank that has not overflowed yet grows when a re-deal hands it the tiles that need it.  The synchronous entry
+    // points then render the frame again; the asynchronous ones report this frame's overflow once, and the frames after
+    // it have the longer lists.
     bool grown = false, stuck = false;
     for (uint32_t r = 0; r < m->n; ++r) {
       if (m->tiles_of.size() > r && m->tiles_of[r].empty()) continue;
@@ -612,7 +630,8 @@ int rtc_multi_render(rtc_multi* m, const rtc_camera* cam, uint32_t max_depth, do
   for (int attempt = 0;; ++attempt) {  // (again while a frame's csg lists ran out and could be enlarged: each handle at most six times)
     void* d_canvas = nullptr;
     uint32_t f = 0;
-    void* const direct = registeredHost(rgb_out) ? rgb_out : nullptr;
+    const size_t frame_bytes = cam ? static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double) : 0u;
+    void* const direct = registeredHost(rgb_out, frame_bytes) ? rgb_out : nullptr;
     if (const int st = enqueueFrame(m, cam, max_depth, false, &d_canvas, &f, direct); st != RTC_OK) return st;
     if (!direct)  // (a pageable canvas: gathered to GPU 0, one copy over its link)
       M_HIP(hipMemcpyAsync(rgb_out, d_canvas, static_cast<size_t>(cam->hsize) * cam->vsize * 3u * sizeof(double),
@@ -630,7 +649,8 @@ int rtc_multi_render_rgba8(rtc_multi* m, const rtc_camera* cam, uint32_t max_dep
   for (int attempt = 0;; ++attempt) {
     void* d_fb = nullptr;
     uint32_t f = 0;
-    void* const direct = registeredHost(rgba_out) ? rgba_out : nullptr;
+    const size_t frame_bytes = cam ? static_cast<size_t>(cam->hsize) * cam->vsize * sizeof(uint32_t) : 0u;
+    void* const direct = registeredHost(rgba_out, frame_bytes) ? rgba_out : nullptr;
     if (const int st = enqueueFrame(m, cam, max_depth, true, &d_fb, &f, direct); st != RTC_OK) return st;
     if (!direct)
       M_HIP(hipMemcpyAsync(rgba_out, d_fb, static_cast<size_t>(cam->hsize) * cam->vsize * sizeof(uint32_t), hipMemcpyDeviceToHost,

@@ -20,6 +20,17 @@ def test_header_symbols_are_exported(rtc):
         assert getattr(lib, n) is not None
 
 
+def test_diagnostics_live_in_their_own_header(rtc):
+    """include/rtc.h is what a Zig host binds; rtc_set_option and the three diagnostic getters are declared in
+    include/rtc_diag.h only (and exported by the same library)."""
+    diag = _declared_functions(os.path.join(REPO, "include", "rtc_diag.h"))
+    assert set(diag) == set(rtc.RTC_DIAG_SYMBOLS), diag
+    assert not set(diag) & set(_declared_functions(os.path.join(REPO, "include", "rtc.h")))
+    lib = rtc.hip_lib()
+    for n in diag:
+        assert getattr(lib, n) is not None
+
+
 def test_host_symbols_are_exported(rtc):
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "rtc_host.h")).read(), flags=re.S)
     names = sorted(set(re.findall(r"\b(rtch_[a-z_0-9]+)\s*\(", text)))
@@ -41,7 +52,7 @@ def test_multi_symbols_are_exported(rtc):
 def test_headers_are_valid_c():
     """include/*.h is a C ABI: every header compiles as strict C99 on its own (a Zig @cImport or a C host sees this)."""
     import subprocess
-    for name in ("rtc.h", "rtc_host.h", "rtc_multi.h"):
+    for name in ("rtc.h", "rtc_diag.h", "rtc_host.h", "rtc_multi.h"):
         r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only",
                             os.path.join(REPO, "include", name)], capture_output=True, text=True)
         assert r.returncode == 0, (name, r.stderr)
@@ -122,7 +133,7 @@ def test_create_rejects_bad_scenes_without_gpu(rtc):
 
 
 def test_diagnostic_entry_points_refuse_null_handles(rtc):
-    """rtc_get_schedule / rtc_last_kernel_name (diagnostics of include/rtc.h) check their arguments before they touch the
+    """rtc_get_schedule / rtc_last_kernel_name (diagnostics of include/rtc_diag.h) check their arguments before they touch the
     device: callable on a box without one."""
     import ctypes as C
     lib = rtc.hip_lib()
@@ -157,7 +168,8 @@ def test_zig_binding_matches_the_header():
         zf = re.findall(r"(\w+):", zig[i:zig.index("};", i)])
         assert cf == zf, (zig_name, cf, zf)
     # extern functions: declared in a header, same arity
-    headers = re.sub(r"/\*.*?\*/", "", header + open(os.path.join(repo, "include", "rtc_multi.h")).read(), flags=re.S)
+    headers = re.sub(r"/\*.*?\*/", "", header + open(os.path.join(repo, "include", "rtc_multi.h")).read() +
+                     open(os.path.join(repo, "include", "rtc_diag.h")).read(), flags=re.S)
     externs = re.findall(r"pub extern fn (\w+)\(([^)]*)\)", zig)
     assert len(externs) >= 10
     for fn, params in externs:

@@ -1256,6 +1256,17 @@ def test_three_lights_same_bits_whatever_the_kernel_and_the_schedule(rtc):
             assert np.array_equal(img, images[0][0]), (n_lights, k)
 
 
+def _one_trial_only(names, three):
+    """The frames a handle's trial ran on its three-wave kernel are ONE run: the frame that changes kernels packs its
+    schedule into buffers that were sized for either kernel, so nothing is re-allocated, no frame is re-estimated and the
+    trial does not start over (sized for the kernel in use only, the first trial of every handle was aborted
+    and run again - a second run of three-wave frames a few frames after the first)."""
+    idx = [i for i, n in enumerate(names) if n == three]
+    assert idx and idx == list(range(idx[0], idx[-1] + 1)), names
+    assert idx[0] == 4, names          # the estimate-scheduled frame, three timed two-wave frames, then the switch
+    assert len(idx) >= 4, names        # the switch frame and three timed three-wave frames
+
+
 def test_general_kernel_at_three_waves_and_its_trial(rtc):
     """rtc_render_kernel3 (the general kernel at three waves per SIMD: smaller LDS tables, two LDS entries of the walk's
     stack) forced by option: the oracle's image and counters on meshes, nested groups, cones on a group's always-visited
@@ -1280,16 +1291,32 @@ def test_general_kernel_at_three_waves_and_its_trial(rtc):
     rows = np.arange(0, 576, 24)
     gpu = rtc.GpuScene(hs.desc)
     buf = torch.zeros((576, 1024, 3), dtype=torch.float64, device="cuda")
-    kernels, first = set(), None
+    kernels, first, names = set(), None, []
     for frame in range(14):
         gpu.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         img = buf.cpu().numpy()
         kernels.add(gpu.last_kernel_name())
+        names.append(gpu.last_kernel_name())
         assert np.abs(img[rows] - want[rows]).max() < TOL and gpu.stats()["overflow"] == 0, frame
         first = img if first is None else first
         assert np.abs(img - first).max() < REPEAT_TOL, frame
     assert kernels == {"rtc_render_kernel", "rtc_render_kernel3"}, kernels   # (the trial ran both)
+    _one_trial_only(names, "rtc_render_kernel3")
+    # a clone made in the middle of another handle's trial inherits that handle's DECISION, never the kernel under trial
+    gpu2 = rtc.GpuScene(hs.desc)
+    for frame in range(6):   # (estimate, three two-wave samples, the switch, one three-wave sample: mid-trial)
+        gpu2.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    assert gpu2.last_kernel_name() == "rtc_render_kernel3"
+    clone = gpu2.clone()
+    clone.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert clone.last_kernel_name() == "rtc_render_kernel", clone.last_kernel_name()   # (nothing decided yet: two waves)
+    gpu2.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)   # (frames in flight now: no trial, the decision)
+    torch.cuda.synchronize()
+    assert gpu2.last_kernel_name() == "rtc_render_kernel", gpu2.last_kernel_name()
+    assert np.abs(buf.cpu().numpy()[rows] - want[rows]).max() < TOL
 
 
 def test_simple_world_trial_between_its_two_kernels(rtc):
@@ -1304,16 +1331,18 @@ def test_simple_world_trial_between_its_two_kernels(rtc):
     rows = np.arange(0, h, 27)
     gpu = rtc.GpuScene(hs.desc)
     buf = torch.zeros((h, w, 3), dtype=torch.float64, device="cuda")
-    kernels, first = set(), None
+    kernels, first, names = set(), None, []
     for frame in range(14):
         gpu.render_device(cam, buf.data_ptr(), 5, None, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         img = buf.cpu().numpy()
         kernels.add(gpu.last_kernel_name())
+        names.append(gpu.last_kernel_name())
         assert np.abs(img[rows] - want[rows]).max() < TOL and gpu.stats()["overflow"] == 0, frame
         first = img if first is None else first
         assert np.abs(img - first).max() < REPEAT_TOL, frame
     assert kernels == {"rtc_render_kernel_simple", "rtc_render_kernel_simple3"}, kernels   # (the trial ran both)
+    _one_trial_only(names, "rtc_render_kernel_simple3")
 
 
 def test_host_output_in_bands(rtc):
