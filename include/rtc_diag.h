@@ -53,6 +53,13 @@ int rtc_get_schedule(rtc_scene *scene, uint32_t *items, size_t capacity_items, u
 int rtc_get_chunk_times(rtc_scene *scene, const rtc_camera *cam, uint32_t *estimated, uint32_t *measured, size_t capacity,
                         uint32_t *n_chunks);
 
+/* Diagnostic (tests/test_build_threads_cpu.py, tools/): the HOST half of rtc_scene_create by itself - validation and the
+ * device tables (depth-first leaf order, bounding spheres, the candidate BVHs and their eight-wide form) - without a
+ * device: `*digest` = a 64-bit FNV-1a hash over the tables the kernel walks (eight-wide nodes, leaf list, root records,
+ * bounding spheres, reference-tree parents), `*build_ms` = the wall time of the table build.  Either may be NULL.  What
+ * "build_threads" must not change. */
+int rtc_diag_build_tables(const rtc_scene_desc *desc, uint64_t *digest, double *build_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,7 +96,7 @@ RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_
                "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error", "rtc_status_name",
                "rtc_grow_csg_lists", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device"]
 # (... and include/rtc_diag.h: diagnostics and tuning, for the tests, bench.py and tools/)
-RTC_DIAG_SYMBOLS = ["rtc_set_option", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times"]
+RTC_DIAG_SYMBOLS = ["rtc_set_option", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times", "rtc_diag_build_tables"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
@@ -170,6 +170,7 @@ def hip_lib():
         lib.rtc_canvas_unregister.argtypes = [C.c_void_p]
         lib.rtc_rgba8_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.rtc_set_option.argtypes = [C.c_char_p, C.c_double]
+        lib.rtc_diag_build_tables.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
         _hip = lib
     return _hip
 
@@ -479,6 +480,13 @@ def canvas_register(array):
 
 def canvas_unregister(array):
     _check_hip(hip_lib().rtc_canvas_unregister(array.ctypes.data))
+
+
+def build_tables_digest(desc):
+    """rtc_diag_build_tables: (digest, ms) of the host half of rtc_scene_create for a scene description - no device needed."""
+    digest, ms = C.c_uint64(0), C.c_double(0.0)
+    _check_hip(hip_lib().rtc_diag_build_tables(C.byref(desc), C.byref(digest), C.byref(ms)))
+    return digest.value, ms.value
 
 
 def set_option(name, value):

@@ -1,6 +1,7 @@
 // rtc_bounds.h — conservative world-space bounds of leaves and roots, and the builder of the candidate BVH
 // (DESIGN.md section 3): everything here only ever REMOVES work that provably contributes no entry.
 #pragma once
+#include <thread>
 #include "rtc_host_internal.h"
 
 namespace {
@@ -237,7 +238,7 @@ struct BvhBuilder {
     if (static_cast<double>(f) < v) f = std::nextafterf(f, INFINITY);
     return f;
   }
-  void storeBox(const Aabb& b, float lo[3], float hi[3]) {
+  static void storeBox(const Aabb& b, float lo[3], float hi[3], float& mag) {
     if (!b.finite()) {
       for (int k = 0; k < 3; ++k) {
         lo[k] = -kHuge;
@@ -273,18 +274,15 @@ struct BvhBuilder {
     }
     return b;
   }
-  // returns the child reference for prims[first, first+count)
-  uint32_t build(size_t first, size_t count, uint32_t depth = 1) {
-    max_depth = std::max(max_depth, depth);
+  static size_t maxLeaf() {
     // Up to two leaves per BVH leaf.  With the kernel's while-while traversal (all lanes run their exact FP64 leaf
     // tests together), the four-wide nodes and the final schedule, measured at 1 / 2 / 3 leaves per node:
     // dragons 4K 2.78 / 2.72 / 2.73 ms, nefertiti 0.728 / 0.713 / 0.719 ms, teapot 0.382 / 0.357 / 0.368 ms.
-    const size_t max_leaf = static_cast<size_t>(std::min(RTC_BVH8 ? 4.0 : 8.0, std::max(1.0, static_cast<double>(rtcOptions().bvh_leaf))));  // (an eight-wide node addresses at most four records per leaf child)
-    if (count <= max_leaf) {
-      const uint32_t at = static_cast<uint32_t>(leaves.size());
-      for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
-      return RTC_NODE_BIT | (at << 3) | static_cast<uint32_t>(count - 1);
-    }
+    return static_cast<size_t>(std::min(RTC_BVH8 ? 4.0 : 8.0, std::max(1.0, static_cast<double>(rtcOptions().bvh_leaf))));  // (an eight-wide node addresses at most four records per leaf child)
+  }
+  // Sorts prims[first, first + count) into the two sides of the cheapest of the 45 candidate planes (16-bin SAH on three
+  // axes; the median of the longest axis where no plane separates anything) and returns where the second side begins.
+  size_t split(size_t first, size_t count) {
     // centroid bounds
     double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t i = first; i < first + count; ++i)
@@ -354,24 +352,82 @@ struct BvhBuilder {
       std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
                        [&](const BvhPrim& a, const BvhPrim& b) { return a.c[axis] < b.c[axis]; });
     }
+    return mid;
+  }
+  // returns the child reference for prims[first, first+count)
+  uint32_t build(size_t first, size_t count, uint32_t depth = 1) {
+    max_depth = std::max(max_depth, depth);
+    const size_t max_leaf = maxLeaf();
+    if (count <= max_leaf) {
+      const uint32_t at = static_cast<uint32_t>(leaves.size());
+      for (size_t i = first; i < first + count; ++i) leaves.push_back(prims[i].leaf);
+      return RTC_NODE_BIT | (at << 3) | static_cast<uint32_t>(count - 1);
+    }
+    const size_t mid = split(first, count);
     const uint32_t me = static_cast<uint32_t>(nodes.size());
     nodes.emplace_back();
     const Aabb b0 = boundsOf(first, mid - first), b1 = boundsOf(mid, first + count - mid);
     const uint32_t c0 = build(first, mid - first, depth + 1);
     const uint32_t c1 = build(mid, first + count - mid, depth + 1);
     BvhNode& N = nodes[me];
-    storeBox(b0, N.lo0, N.hi0);
-    storeBox(b1, N.lo1, N.hi1);
+    storeBox(b0, N.lo0, N.hi0, mag);
+    storeBox(b1, N.lo1, N.hi1, mag);
     N.c0 = c0;
     N.c1 = c1;
     N.pad_[0] = N.pad_[1] = 0;
     return me;
   }
+  // The same tree, built by several threads (one leaf per BVH leaf only - the default): a subtree over `count` leaves
+  // then has exactly count - 1 nodes and its leaves are the next `count` entries of the leaf list, so every node and
+  // leaf has its place before it exists - the node of prims[first, first + count) at `node_at`, its left subtree behind
+  // it, its right subtree behind that, leaf k of the builder at leaf_base + k - and subtrees can be built side by side
+  // into a table sized in advance: node for node what build() appends one after the other.  `spawn`: levels at which the
+  // left subtree goes to a thread of its own.
+  struct Sub {
+    uint32_t ref, depth;
+    float mag;
+  };
+  Sub buildFixed(size_t first, size_t count, uint32_t depth, uint32_t node_at, uint32_t leaf_base, int spawn) {
+    if (count == 1) {
+      leaves[leaf_base + first] = prims[first].leaf;
+      return {RTC_NODE_BIT | (static_cast<uint32_t>(leaf_base + first) << 3), depth, 0.0f};
+    }
+    const size_t mid = split(first, count);
+    const size_t lc = mid - first, rc = first + count - mid;
+    const Aabb b0 = boundsOf(first, lc), b1 = boundsOf(mid, rc);
+    Sub l, r;
+    if (spawn > 0 && count >= 4096) {
+      std::thread left([&]() { l = buildFixed(first, lc, depth + 1, node_at + 1u, leaf_base, spawn - 1); });
+      r = buildFixed(mid, rc, depth + 1, node_at + static_cast<uint32_t>(lc), leaf_base, spawn - 1);
+      left.join();
+    } else {
+      l = buildFixed(first, lc, depth + 1, node_at + 1u, leaf_base, 0);
+      r = buildFixed(mid, rc, depth + 1, node_at + static_cast<uint32_t>(lc), leaf_base, 0);
+    }
+    float m = std::fmax(l.mag, r.mag);
+    BvhNode& N = nodes[node_at];
+    storeBox(b0, N.lo0, N.hi0, m);
+    storeBox(b1, N.lo1, N.hi1, m);
+    N.c0 = l.ref;
+    N.c1 = r.ref;
+    N.pad_[0] = N.pad_[1] = 0;
+    return {node_at, std::max(l.depth, r.depth), m};
+  }
+  uint32_t buildTree(int spawn) {  // prims[0, size): build(), or its several-threads form where that pays
+    if (spawn <= 0 || maxLeaf() != 1 || prims.size() < 8192) return build(0, prims.size());
+    const uint32_t node_at = static_cast<uint32_t>(nodes.size()), leaf_base = static_cast<uint32_t>(leaves.size());
+    nodes.resize(nodes.size() + prims.size() - 1);
+    leaves.resize(leaves.size() + prims.size());
+    const Sub t = buildFixed(0, prims.size(), 1, node_at, leaf_base, spawn);
+    max_depth = std::max(max_depth, t.depth);
+    mag = std::fmax(mag, t.mag);
+    return t.ref;
+  }
   // root node index of a BVH over `items` (always a node, so the kernel can start from a node)
-  uint32_t buildRoot(std::vector<BvhPrim> items) {
+  uint32_t buildRoot(std::vector<BvhPrim> items, int spawn = 0) {
     prims = std::move(items);
     const uint32_t me = static_cast<uint32_t>(nodes.size());
-    if (prims.size() > 4) return build(0, prims.size());
+    if (prims.size() > 4) return buildTree(spawn);
     nodes.emplace_back();
     BvhNode N;
     std::memset(&N, 0, sizeof N);
@@ -381,7 +437,7 @@ struct BvhBuilder {
     }
     N.c0 = N.c1 = RTC_NO_LEAF;  // empty child
     if (!prims.empty()) {
-      storeBox(boundsOf(0, prims.size()), N.lo0, N.hi0);
+      storeBox(boundsOf(0, prims.size()), N.lo0, N.hi0, mag);
       N.c0 = build(0, prims.size());
     }
     nodes[me] = N;

@@ -2,6 +2,8 @@
 // the flat scene, upload to HBM, kernel launches.  No torch types, no CPU render path: every
 // entry point either runs the HIP kernel or fails with an rtc_status.
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -9,11 +11,13 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
 #include "../../include/rtc.h"
 #include "../../include/rtc_diag.h"
+#include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -1259,6 +1263,21 @@ void copyPlainTables(const rtc_scene_desc& d, HostTables& T) {
 }
 
 // The flat device tables of a validated scene.
+// Threads of the table build when the host does not say (option "build_threads"): what the process may use - its CPU
+// affinity and, in a container, its cgroup's CPU quota (a GPU box here: 256 hardware threads, a quota of 16) - up to 16.
+size_t defaultBuildThreads() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+    long long quota = 0, period = 0;
+    if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+      n = std::min<unsigned>(n, static_cast<unsigned>(std::max<long long>(1, quota / period)));
+    std::fclose(f);
+  }
+  return std::min(16u, n);
+}
+
 int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& T) {
   (void)traits;
   auto& leaf_meta = T.leaf_meta;
@@ -1430,10 +1449,41 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
     p.leaf = RTC_NODE_BIT | n;
     return p;
   };
+  // One candidate BVH per top-level group.  The groups' trees are independent, and the build - a 16-bin SAH over the
+  // world boxes of every leaf below the group, then the eight-wide collapse - is most of rtc_scene_create for a mesh
+  // scene (dragons.json: 141 k leaves in six groups): every group is built by itself, into tables of its own with
+  // indices that start at zero, on up to eight threads (option "build_threads"), and the tables are then joined in
+  // World.objects order with the indices moved by where each group's part begins - exactly the tables one thread
+  // building group after group into shared vectors makes (tests/test_build_threads_cpu.py holds the two bit-equal).
+  struct GroupBuild {
+    std::vector<BvhNode> nodes;       // binary tree, local indices
+    std::vector<uint32_t> leaves;     // its leaf list
+    std::vector<Bvh8Node> nodes8;     // eight-wide tree, local indices
+    std::vector<uint32_t> leaves8;    // its leaf records' leaves, then the group's unbounded leaves
+    uint32_t n_tree_leaves8 = 0, n_unbounded = 0;
+    uint32_t root2 = 0, root8 = 0;
+    float mag = 0.0f;
+    int status = RTC_OK;              // RTC_ERR_UNSUPPORTED: the eight-wide encoding; RTC_ERR_OVERFLOW: too deep
+    uint32_t depth = 0;
+  };
+  std::vector<uint32_t> group_roots;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     const uint32_t r = d.roots[i];
     if (!(r & RTC_CHILD_NODE_BIT)) continue;
     if (opOf(r & ~RTC_CHILD_NODE_BIT) != RTC_CSG_NONE) continue;
+    group_roots.push_back(i);
+  }
+  std::vector<GroupBuild> built(group_roots.size());
+  // (threads: one group each while there are groups, and what is left over inside a group's own build - a single mesh,
+  // nefertiti.json, has all of them: BvhBuilder::buildFixed)
+  const double threads_asked = rtcOptions().build_threads;
+  const size_t threads_total = threads_asked >= 1.0 ? static_cast<size_t>(threads_asked) : defaultBuildThreads();
+  const size_t group_threads = std::max<size_t>(1, std::min(built.size(), threads_total));
+  int spawn_levels = 0;
+  while ((group_threads << (spawn_levels + 1)) <= threads_total) ++spawn_levels;
+  auto buildGroup = [&](size_t g) {
+    GroupBuild& G = built[g];
+    const uint32_t r = d.roots[group_roots[g]];
     std::vector<BvhPrim> items;
     std::vector<uint32_t> todo{r & ~RTC_CHILD_NODE_BIT};
     while (!todo.empty()) {
@@ -1466,19 +1516,88 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
       items.swap(bounded);
     }
 #endif
-    BvhBuilder builder{bvh_nodes, bvh_leaves};
-    bvh_root_of[i] = builder.buildRoot(std::move(items));
-    bvh_mag = std::fmax(bvh_mag, builder.mag);
-    bvh2_root_of[i] = bvh_root_of[i];
+    BvhBuilder builder{G.nodes, G.leaves};
+    G.root2 = builder.buildRoot(std::move(items), spawn_levels);
+    G.mag = builder.mag;
 #if RTC_BVH8
-    Bvh8Collapse wide{bvh_nodes, bvh_leaves, T.bvh8_nodes, T.bvh8_leaves};
-    bvh_root_of[i] = wide.convertRoot(bvh_root_of[i]);
-    if (!wide.ok) return fail(RTC_ERR_UNSUPPORTED, "root %u: its candidate BVH does not fit the eight-wide node encoding", i);
-    if (wide.max_depth + 1 > RTC_TRAV_STACK)
-      return fail(RTC_ERR_OVERFLOW, "root %u: its candidate BVH is %u levels deep, the kernel's traversal stack holds %d", i,
-                  wide.max_depth, RTC_TRAV_STACK);
-    T.root_always[i] = uint2{static_cast<uint32_t>(T.bvh8_leaves.size()), static_cast<uint32_t>(unbounded.size())};
-    for (const BvhPrim& p : unbounded) T.bvh8_leaves.push_back(p.leaf);
+    Bvh8Collapse wide{G.nodes, G.leaves, G.nodes8, G.leaves8};
+    G.root8 = wide.convertRoot(G.root2);
+    G.depth = wide.max_depth;
+    if (!wide.ok) {
+      G.status = RTC_ERR_UNSUPPORTED;
+      return;
+    }
+    if (wide.max_depth + 1 > RTC_TRAV_STACK) {
+      G.status = RTC_ERR_OVERFLOW;
+      return;
+    }
+    G.n_tree_leaves8 = static_cast<uint32_t>(G.leaves8.size());
+    G.n_unbounded = static_cast<uint32_t>(unbounded.size());
+    for (const BvhPrim& p : unbounded) G.leaves8.push_back(p.leaf);
+#endif
+  };
+  {
+    const size_t n_threads = group_threads;
+    if (n_threads <= 1) {
+      for (size_t g = 0; g < built.size(); ++g) buildGroup(g);
+    } else {
+      std::atomic<size_t> next{0};
+      std::vector<std::thread> workers;
+      for (size_t t = 0; t < n_threads; ++t)
+        workers.emplace_back([&]() {
+          for (size_t g = next.fetch_add(1); g < built.size(); g = next.fetch_add(1)) buildGroup(g);
+        });
+      for (std::thread& w : workers) w.join();
+    }
+  }
+  {
+    size_t n2 = 0, l2 = 0, n8 = 0, l8 = 0;
+    for (const GroupBuild& G : built) {
+      n2 += G.nodes.size();
+      l2 += G.leaves.size();
+      n8 += G.nodes8.size();
+      l8 += G.leaves8.size();
+    }
+    bvh_nodes.reserve(bvh_nodes.size() + n2);
+    bvh_leaves.reserve(bvh_leaves.size() + l2);
+    T.bvh8_nodes.reserve(T.bvh8_nodes.size() + n8);
+    T.bvh8_leaves.reserve(T.bvh8_leaves.size() + l8);
+  }
+  for (size_t g = 0; g < built.size(); ++g) {  // joined in World.objects order
+    GroupBuild& G = built[g];
+    const uint32_t i = group_roots[g];
+#if RTC_BVH8
+    if (G.status == RTC_ERR_UNSUPPORTED) return fail(RTC_ERR_UNSUPPORTED, "root %u: its candidate BVH does not fit the eight-wide node encoding", i);
+    if (G.status == RTC_ERR_OVERFLOW)
+      return fail(RTC_ERR_OVERFLOW, "root %u: its candidate BVH is %u levels deep, the kernel's traversal stack holds %d", i, G.depth,
+                  RTC_TRAV_STACK);
+#endif
+    const uint32_t node_off = static_cast<uint32_t>(bvh_nodes.size()), leaf_off = static_cast<uint32_t>(bvh_leaves.size());
+    auto moved2 = [&](uint32_t ref) -> uint32_t {  // a child reference of the binary tree, local -> joined
+      if (ref == RTC_NO_LEAF) return ref;
+      if (ref & RTC_NODE_BIT) return RTC_NODE_BIT | ((((ref & ~RTC_NODE_BIT) >> 3) + leaf_off) << 3) | (ref & 7u);
+      return ref + node_off;
+    };
+    for (BvhNode N : G.nodes) {
+      N.c0 = moved2(N.c0);
+      N.c1 = moved2(N.c1);
+      bvh_nodes.push_back(N);
+    }
+    bvh_leaves.insert(bvh_leaves.end(), G.leaves.begin(), G.leaves.end());
+    bvh_mag = std::fmax(bvh_mag, G.mag);
+    bvh2_root_of[i] = bvh_root_of[i] = G.root2 + node_off;
+#if RTC_BVH8
+    const uint32_t node8_off = static_cast<uint32_t>(T.bvh8_nodes.size()), leaf8_off = static_cast<uint32_t>(T.bvh8_leaves.size());
+    if (static_cast<uint64_t>(leaf8_off) + G.leaves8.size() >= (1u << 24))
+      return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the eight-wide BVH's leaf addressing", leaf8_off + G.leaves8.size());
+    for (Bvh8Node N : G.nodes8) {
+      N.child_base += node8_off;
+      N.leaf_base_lmask = (((N.leaf_base_lmask & 0xFFFFFFu) + leaf8_off) & 0xFFFFFFu) | (N.leaf_base_lmask & 0xFF000000u);
+      T.bvh8_nodes.push_back(N);
+    }
+    T.bvh8_leaves.insert(T.bvh8_leaves.end(), G.leaves8.begin(), G.leaves8.end());
+    bvh_root_of[i] = G.root8 + node8_off;
+    T.root_always[i] = uint2{leaf8_off + G.n_tree_leaves8, G.n_unbounded};
 #else
     uint32_t stack_need = 0;
     bvh_root_of[i] = Bvh4Collapse{bvh_nodes, bvh4_nodes}.convert(bvh_root_of[i], stack_need);
@@ -1486,6 +1605,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
       return fail(RTC_ERR_OVERFLOW, "root %u: walking its candidate BVH can take %u stack entries, the kernel's traversal stack holds %d", i,
                   stack_need + 1, RTC_TRAV_STACK);
 #endif
+    G = GroupBuild{};  // (the group's own tables are not needed any more)
   }
   if (rtcOptions().bvh_check != 0.0) {
     // diagnostic: every leaf once, every stored child box contains the world boxes below it
@@ -2178,6 +2298,43 @@ int rtc_canvas_unregister(void* canvas) {
   g_error.clear();
   if (!canvas) return fail(RTC_ERR_INVALID_ARGUMENT, "null canvas");
   HIP_TRY(hipHostUnregister(canvas));
+  return RTC_OK;
+}
+
+int rtc_diag_build_tables(const rtc_scene_desc* desc, uint64_t* digest, double* build_ms) {
+  g_error.clear();
+  if (!desc) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  SceneTraits traits;
+  if (const int st = validateScene(*desc, traits); st != RTC_OK) return st;
+  HostTables tables;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (const int st = buildTables(*desc, traits, tables); st != RTC_OK) return st;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (build_ms) *build_ms = ms;
+  if (digest) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t bytes) {
+      const unsigned char* b = static_cast<const unsigned char*>(p);
+      for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    auto vec = [&](const auto& v) {
+      const uint64_t n = v.size();
+      mix(&n, sizeof n);
+      if (!v.empty()) mix(v.data(), v.size() * sizeof(v[0]));
+    };
+    vec(tables.bvh8_nodes);
+    vec(tables.bvh8_leaves);
+    vec(tables.bvh_nodes);
+    vec(tables.bvh_leaves);
+    vec(tables.root_recs);
+    vec(tables.root_cull);
+    vec(tables.root_always);
+    vec(tables.leaf_meta);
+    vec(tables.leaf_parent);
+    vec(tables.node_parent);
+    mix(&tables.bvh_mag, sizeof tables.bvh_mag);
+    *digest = h;
+  }
   return RTC_OK;
 }
 

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""What rtc_scene_create costs for the mesh scenes: the host half by itself (rtc_diag_build_tables: validation,
+depth-first order, bounds, the candidate BVHs on `build_threads` threads, the eight-wide collapse) and the whole create
+(+ leaf records, upload), single-threaded and with the library's own thread count.  python tools/create_time.py [scene ...]"""
+import importlib, os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+rtc = importlib.import_module("ray-tracer-challenge_amd")
+scenes = sys.argv[1:] or ["dragons.json", "nefertiti.json", "teapot.json", "cover.json"]
+warm = rtc.GpuScene(rtc.HostScene.from_file("fresnel.json").desc)  # (the process's first create carries the HIP runtime's start-up)
+for scene in scenes:
+    hs = rtc.HostScene.from_file(scene)
+    for threads in (1, 0):
+        rtc.set_option("build_threads", threads)
+        tables = min(rtc.build_tables_digest(hs.desc)[1] for _ in range(5))
+        creates = []
+        for _ in range(5):
+            t = time.perf_counter()
+            g = rtc.GpuScene(hs.desc)
+            creates.append((time.perf_counter() - t) * 1e3)
+            del g
+        print(f"{scene:16s} build_threads {threads or 'default':>7}: tables {tables:7.1f} ms, rtc_scene_create {min(creates):7.1f} ms (min of 5)", flush=True)
+rtc.set_option("build_threads", 0)
