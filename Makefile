@@ -33,8 +33,12 @@ oracle:
 $(LIB):
 	mkdir -p $(LIB)
 
-$(LIB)/rtc_kernels.o: $(PKG)/csrc/rtc_kernels.hip $(PKG)/csrc/rtc_device.h | $(LIB)
-	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+# (the compiler's resource-usage remarks of the product build are kept: lib/kernel_resources.json - registers, spills,
+# scratch bytes per lane, LDS of every kernel - is what bench.py quotes as roofline.scratch_bytes_per_lane)
+$(LIB)/rtc_kernels.o: $(PKG)/csrc/rtc_kernels.hip $(PKG)/csrc/rtc_device.h tools/kernel_resources.py | $(LIB)
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o $@ $< 2> $(LIB)/rtc_kernels.remarks || (grep -v "remark:" $(LIB)/rtc_kernels.remarks >&2; exit 1)
+	@grep -v "remark:\|remarks generated\|\^\|^ *[0-9]* |" $(LIB)/rtc_kernels.remarks >&2 || true
+	python3 tools/kernel_resources.py --from-remarks $(LIB)/rtc_kernels.remarks --json $(LIB)/kernel_resources.json
 
 $(LIB)/rtc_capi.o: $(PKG)/csrc/rtc_capi.hip $(wildcard $(PKG)/csrc/*.h) include/rtc.h | $(LIB)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<

@@ -99,6 +99,36 @@ def executed_flops(scene, width, height, depth):
     return out
 
 
+def kernel_resources(kernel_name):
+    """Registers, spills, scratch bytes per lane and LDS of the kernel that ran, from the compiler's resource-usage remarks
+    of the build that is loaded (lib/kernel_resources.json, written by the Makefile beside librtc_hip.so)."""
+    try:
+        lib_dir = os.environ.get("RTC_LIB_DIR", os.path.join(REPO, "ray-tracer-challenge_amd", "lib"))
+        return json.load(open(os.path.join(lib_dir, "kernel_resources.json"))).get(kernel_name)
+    except (OSError, ValueError):
+        return None
+
+
+def what_binds(ex, res):
+    """The keys VERDICT r04 item 5 asks for INSIDE `roofline` (the driver keeps that object): what binds the kernel - not
+    HBM - by the committed counters (`ex`: executed_flops()) and the compiler's figures for the kernel that ran (`res`)."""
+    out = {"binding": "valu_issue"}
+    if ex is not None:
+        out["lanes_active"] = ex["lanes_active"]
+        if "valu_pipe_busy" in ex:
+            out["valu_issuing"] = ex["valu_pipe_busy"]
+            out["waves_waiting"] = ex["wave_cycles_waiting"]
+            # issue-bound when a SIMD's vector pipe issues in most of the kernel's cycles; else the waves wait (dependent
+            # fetches of the BVH walk, spill reloads) more than they issue
+            out["binding"] = "valu_issue" if ex["valu_pipe_busy"] >= 0.75 else "valu_issue+latency"
+        out["counters_source"] = ex.get("source")
+    if res is not None:
+        out["scratch_bytes_per_lane"] = res.get("scratch_bytes_per_lane")
+        out["vgprs_spilled"] = res.get("vgprs_spilled")
+        out["waves_per_simd"] = res.get("waves_per_simd")
+    return out
+
+
 def reference_traversal_bytes(width, height, counters, rows_sampled, rows_total):
     """24 W H + sum over rays [56 bbox tests + 72 triangle tests + 72 smooth-triangle hits + 128 transforms
     applied], from the ORACLE's counters of the reference's own traversal (the F7 tree, every isShadowed ray a full
@@ -626,14 +656,19 @@ def main():
                 "traffic_source": "committed profile (profiles/traffic.json), not measured in this run",
                 "kernel": gpu.last_kernel_name(), "kernel_ms": kernel_ms, "algorithmic_bytes": ab,
                 "scene_bytes_touched_by_reference_traversal": scene_bytes_touched(hs.desc, stats),
-                "note": "HBM is NOT what binds this kernel: the compulsory traffic is the canvas (24*W*H B) plus "
+                "note": "HBM is NOT what binds this kernel (`binding`, `executed_fp64_frac`, `lanes_active`, `valu_issuing`, "
+                        "`scratch_bytes_per_lane` in this object say what does): the compulsory traffic is the canvas (24*W*H B) plus "
                         "a few KB of scene tables that live in LDS; the binding limit is per-wave FP64 issue "
                         "latency, see roofline_valu.  `traffic` is FETCH_SIZE*2 + WRITE_SIZE of profiles/ (separate "
                         "PMC passes): fabric-side requests of the L2s, mostly the lanes' pending-ray stacks and "
                         "register spills cycling through L2 into the Infinity Cache (DESIGN.md section 5), not canvas "
                         "bytes.",
             }
-            ex_only = executed_flops(args.scene, W, H, args.depth) if fl is None else None
+            ex_any = executed_flops(args.scene, W, H, args.depth)
+            result["roofline"].update(what_binds(ex_any, kernel_resources(gpu.last_kernel_name())))
+            if ex_any is not None:  # (the hardware figure, in the object the driver keeps: executed FP64 flops over THIS run's kernel time)
+                result["roofline"]["executed_fp64_frac"] = ex_any["flops"] / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF
+            ex_only = ex_any if fl is None else None
             if ex_only is not None:   # a scene with groups: no per-ray flop table applies; the executed figure alone
                 etf = ex_only["flops"] / (kernel_ms * 1e-3) / 1e12
                 result["roofline_valu"] = {"bound": "valu_fp64", "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",

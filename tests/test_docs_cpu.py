@@ -46,3 +46,18 @@ def test_evidence_files_exist_and_agree():
         live, traced = b["roofline"]["kernel_ms"], w["kernel_ms"]["steady_mean"]
         assert abs(live - traced) / traced < 0.10, (scene, live, traced)
         assert b["roofline"]["kernel"] == w["kernel_ms"]["kernel"], (scene, b["roofline"]["kernel"], w["kernel_ms"]["kernel"])
+
+
+def test_design_states_the_real_gpu_test_count():
+    """DESIGN.md section 7 says how many tests the GPU suite has; the sentence is held to what pytest collects (round 4's
+    said 159 where the driver ran 162)."""
+    import re
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests"), "-m", "gpu", "--collect-only", "-q"],
+                         capture_output=True, text=True, cwd=REPO).stdout
+    m = re.search(r"(\d+)/\d+ tests collected", out)
+    assert m, out[-400:]
+    said = re.search(r"\*\*GPU suite\*\* \((\d+) tests", open(os.path.join(REPO, "DESIGN.md")).read())
+    assert said, "DESIGN.md: the 'GPU suite (N tests' sentence is gone"
+    assert int(said.group(1)) == int(m.group(1)), (said.group(1), m.group(1))
