@@ -2664,8 +2664,7 @@ int rtc_get_stats(rtc_scene* s, rtc_stats* out) {
     // it refused to follow because they point outside the node / leaf tables - must be 0)
     std::fprintf(stderr, "rtc walks: %llu lanes %llu node-steps %llu leaf-steps %llu lanes-at-nodes %llu lanes-at-leaves %llu | without a leaf: %llu walks | %s %llu\n",
                  h.prof4[0], h.prof4[1], h.prof4[2], h.prof4[3], h.prof4[4], h.prof4[5], h.prof4[6], RTC_BVH8 ? "bad refs" : "their node-steps", h.prof4[7]);
-    std::fprintf(stderr, "rtc occluder cache: shadow rays %llu | cached tests %llu | answered %llu | wave-level shadow iterations %llu, without a trace %llu | walk cycles at nodes %llu at leaves %llu\n",
-                 h.prof5[0], h.prof5[1], h.prof5[2], h.prof5[3], h.prof5[4], h.prof5[5], h.prof5[6]);
+    std::fprintf(stderr, "rtc walk cycles: at nodes %llu at leaves %llu\n", h.prof5[5], h.prof5[6]);
     for (int k = 0; k < 3; ++k)
       std::fprintf(stderr, "rtc walks of %s traces: %llu lanes %llu node-steps %llu leaf-steps %llu lanes-at-nodes %llu lanes-at-leaves %llu cycles-at-nodes %llu cycles-at-leaves %llu\n",
                    k == 0 ? "closest" : k == 1 ? "shadow" : "containers", h.prof6[8 * k], h.prof6[8 * k + 1], h.prof6[8 * k + 2], h.prof6[8 * k + 3],

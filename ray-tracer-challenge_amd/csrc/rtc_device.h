@@ -326,7 +326,7 @@ struct DevStats {
   unsigned long long prof[16];  // wave cycles per section
   unsigned long long prof2[8];  // trace invocations (wave level) and active lanes: closest, shadow, behind
   unsigned long long prof3[21]; // wave cycles in traces by lanes with a ray: [closest, shadow, behind][1-2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64]
-  unsigned long long prof5[8];  // occluder cache: shadow rays, lanes that ran the cached test, lanes it answered, wave-level shadow iterations, those of them that needed no trace
+  unsigned long long prof5[8];  // [5], [6]: wave cycles of all group walks at nodes / at leaves (the other slots: free)
   unsigned long long prof6[24]; // group walks by kind of trace [closest, shadow, containers][walks, lanes, node steps, leaf steps, lanes at nodes, lanes at leaves, wave cycles at nodes, at leaves]
   unsigned long long prof4[8];  // group walks: walks of a wave, their lanes, wave steps at nodes, at leaves, lanes at nodes, at leaves (summed over the steps), walks that reach no leaf, their node steps
   unsigned long long prof_t0, prof_t1, prof_busy;  // shortest / longest / summed wave lifetime

@@ -85,11 +85,11 @@
 #if defined(RTC_PROFILE) && defined(RTC_PROFILE_LITE)
 __shared__ DevStats* rtc_prof_stats;
 #define RTC_WALK_ADD(slot, n) do { (void)(n); } while (0)
-#define RTC_OCC_ADD(slot, n) do { (void)(n); } while (0)
+#define RTC_AUX_ADD(slot, n) do { (void)(n); } while (0)
 #define RTC_KIND_ADD(slot, n) do { (void)(n); } while (0)
 #elif defined(RTC_PROFILE)
 __shared__ DevStats* rtc_prof_stats;
-// (diagnostic builds: the walks' and the occluder cache's counts - DevStats::prof4 and prof5 - are summed per wave in LDS
+// (diagnostic builds: the walks' counts and cycles - DevStats::prof4, prof5, prof6 - are summed per wave in LDS
 // by the first active lane and added to the launch's counters when the wave ends: with an atomic per count and walk on
 // eight words of memory the diagnostic frame was eleven times the product's)
 __shared__ unsigned long long rtc_prof_counts[4][40];
@@ -100,11 +100,11 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
       rtc_prof_counts[threadIdx.x >> 6][slot] += n_;                                                                   \
   } while (0)
 #define RTC_WALK_ADD(slot, n) RTC_PROF_ADD_(slot, n)
-#define RTC_OCC_ADD(slot, n) RTC_PROF_ADD_(8 + (slot), n)
+#define RTC_AUX_ADD(slot, n) RTC_PROF_ADD_(8 + (slot), n)
 #define RTC_KIND_ADD(slot, n) RTC_PROF_ADD_(16 + (slot), n)
 #else
 #define RTC_WALK_ADD(slot, n) do { } while (0)
-#define RTC_OCC_ADD(slot, n) do { } while (0)
+#define RTC_AUX_ADD(slot, n) do { } while (0)
 #define RTC_KIND_ADD(slot, n) do { } while (0)
 #endif
 
@@ -746,10 +746,8 @@ __device__ __forceinline__ void traverse_bvh(const DevScene& S, uint32_t root, c
 #endif
       const BvhLeafRec& L = S.bvh_leaf[first + i];
       if (CSG && (L.leaf & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
-        vis.set_rec(RTC_NO_LEAF);
         if constexpr (CSG) visit_csg(S, L.leaf & ~RTC_NODE_BIT, ray, vis, overflow);
       } else {
-        vis.set_rec(first + i);
         visit_leaf(S, L, ray, degenerate, cur_xf, lr, vis);
       }
     }
@@ -818,10 +816,8 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
 #endif
     const BvhLeafRec& L = S.bvh_leaf[rec];
     if (CSG && (L.leaf & RTC_NODE_BIT)) {  // a csg unit inside the group (only the *_ext kernels have this path)
-      vis.set_rec(RTC_NO_LEAF);
       if constexpr (CSG) visit_csg(S, L.leaf & ~RTC_NODE_BIT, ray, vis, overflow);
     } else {
-      vis.set_rec(rec);
       visit_leaf(S, L, ray, degenerate, cur_xf, lr, vis);
     }
   };
@@ -957,8 +953,8 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
 #endif
   }
 #ifdef RTC_PROFILE  // walks of the wave, their lanes, wave steps at nodes / at leaves, lanes at nodes / at leaves (summed over the steps)
-  RTC_OCC_ADD(5, pw_t_nodes);
-  RTC_OCC_ADD(6, pw_t_leaves);
+  RTC_AUX_ADD(5, pw_t_nodes);
+  RTC_AUX_ADD(6, pw_t_leaves);
   {  // the same by kind of trace: closest hit, shadow, containers
     constexpr int K = 8 * (V::kAnyHit ? 1 : (V::kBehindOnly ? 2 : 0));
     RTC_KIND_ADD(K + 0, 1);
@@ -1168,7 +1164,6 @@ struct ClosestVisitor {
   uint32_t cur_root = RTC_NO_LEAF;
   double u = 0.0, v = 0.0;
   __device__ __forceinline__ void set_root(uint32_t r) { cur_root = r; }
-  __device__ __forceinline__ void set_rec(uint32_t) {}
   static constexpr bool kFrontOnly = true;    // entries with t < 0 never matter
   static constexpr bool kBehindOnly = false;
   __device__ __forceinline__ double t_limit() const { return t; }
@@ -1223,20 +1218,12 @@ struct ShadowVisitor {
   static constexpr bool kAnyHit = true;  // the first entry that counts ends the trace: visiting order is free
   double distance;
   bool shadowed = false;
-  // The occluder cache (render_body, the lights loop): what is being tested - a World.objects index, or RTC_NODE_BIT | the
-  // BvhLeafRec of a leaf inside a group; RTC_NO_LEAF: something that is not remembered (a leaf of a csg unit) - and what
-  // ended the trace.
-  uint32_t cur = RTC_NO_LEAF, occluder = RTC_NO_LEAF;
-  __device__ __forceinline__ void set_root(uint32_t r) { cur = r; }
-  __device__ __forceinline__ void set_rec(uint32_t r) { cur = r == RTC_NO_LEAF ? r : (RTC_NODE_BIT | r); }
+  __device__ __forceinline__ void set_root(uint32_t) {}
   static constexpr bool kFrontOnly = true;
   static constexpr bool kBehindOnly = false;
   __device__ __forceinline__ double t_limit() const { return distance; }
   __device__ __forceinline__ void entry(uint32_t, uint32_t casts_shadow, uint32_t, double et, double, double) {
-    if (et >= 0.0 && et < distance && casts_shadow) {
-      shadowed = true;
-      occluder = cur;
-    }
+    if (et >= 0.0 && et < distance && casts_shadow) shadowed = true;
   }
   __device__ __forceinline__ bool relevant(uint32_t, uint32_t casts_shadow, double et) const {
     return et >= 0.0 && et < distance && casts_shadow;
@@ -1254,44 +1241,6 @@ struct ShadowVisitor {
     shadowed = ((__ballot(shadowed) >> (lane & ~(group - 1u))) & ((1ull << group) - 1ull)) != 0ull;
   }
 };
-
-// The occluder cache's test (render_body, the lights loop).  isShadowed (world.zig:126-154) is an EXISTENCE predicate: any
-// entry with 0 <= t < distance on a shadow-casting leaf.  Neighbouring pixels' shadow rays to one light are mostly
-// stopped by the same leaf, so a lane remembers, per light, what ended its last shadow trace to it and runs the exact
-// reference test on THAT first - the same arithmetic the trace would run on it (Shape.intersect + localIntersect, and
-// for a leaf inside a group the replay of the reference's box chain): if it yields an entry that counts, the reference's
-// list has that entry too and the answer is `true` whatever else is in the world; if not, nothing is known and the
-// trace runs as before.  Results cannot depend on it.
-// OFF: measured in round 5 (profiles/r05/occluder_cache.md) - 8 % of the remembered occluders answer on dragons (1.4 % of its
-// shadow rays: most of them reach their light, and a lane's consecutive pixels are further apart than a triangle is wide),
-// a lane that is answered waits for the longest walk of its wave anyway, and the extra inlined leaf test costs the
-// three-wave general kernel 66 more spilled registers: cover -1.1 %, every other scene +1 %, dragons +5 %.
-#ifndef RTC_OCC_CACHE
-#define RTC_OCC_CACHE 0
-#endif
-#define RTC_OCC_LIGHTS 4  // lights with a cache entry per lane (the others' shadow rays are traced as before)
-template <int WORLD>
-__device__ __forceinline__ void occluder_pretest(const DevScene& S, const RootRec* __restrict__ recs, const uint32_t what,
-                                                 const Ray& ray, ShadowVisitor& vis) {
-  constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
-  if (!FLAT && (what & RTC_NODE_BIT)) {  // a leaf inside a group, by its record in the candidate BVH
-    const uint32_t rec = what & ~RTC_NODE_BIT;
-    const bool degenerate = (__builtin_fabs(ray.dx) < 1e-5) | (__builtin_fabs(ray.dy) < 1e-5) | (__builtin_fabs(ray.dz) < 1e-5);
-    uint32_t cur_xf = 0xFFFFFFFFu;
-    Ray lr = ray;
-    vis.set_rec(rec);
-    visit_leaf(S, S.bvh_leaf[rec], ray, degenerate, cur_xf, lr, vis);
-    return;
-  }
-  const RootRec& R = recs[what];  // a top-level leaf (groups and csg units are never remembered)
-  const uint32_t kf = R.kind_flags;
-  const Ray lr = xform_ray(R.inv, ray);
-  const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
-  const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
-  vis.set_root(what);
-  leaf_entries<SIMPLE>(kf & 0xFFu, cy, SIMPLE ? nullptr : S.tri + 9ull * R.geom, lr,
-                       [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
-}
 
 // The containers walk of PreComputations.new (world.zig:229-255), as a reduction.
 // Entries before the hit in the sorted list are exactly those with t < 0.  A leaf with an
@@ -1318,7 +1267,6 @@ struct BehindVisitor {
   bool hit_open = false;
   uint32_t hit_dups = 0;
   __device__ __forceinline__ void set_root(uint32_t) {}
-  __device__ __forceinline__ void set_rec(uint32_t) {}
 
   __device__ __forceinline__ void flush() {
     if (cur != RTC_NO_LEAF && (cur_cnt & 1u)) {
@@ -1924,16 +1872,6 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   // mostly one or two entries long)
   constexpr int TRAV = (WAVES == 3 && RTC_BVH8) ? 2 : RTC_LDS_TRAV;
   __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : TRAV][RTC_BVH8 ? 128 : 64];
-  // The occluder cache (occluder_pretest): per lane and light what ended the lane's last shadow trace to that light.  A
-  // world without groups remembers World.objects indices (tables in LDS: below 128) - the four lights' bytes in one
-  // register; a world with groups a word per light in LDS.
-  constexpr bool OCC = RTC_OCC_CACHE != 0;
-  __shared__ uint32_t lds_occ[(OCC && !FLAT) ? 4 : 1][(OCC && !FLAT) ? RTC_OCC_LIGHTS : 1][64];
-  uint32_t occ_bytes = 0xFFFFFFFFu;
-  if constexpr (OCC && !FLAT) {
-#pragma unroll
-    for (int i = 0; i < RTC_OCC_LIGHTS; ++i) lds_occ[threadIdx.x >> 6][i][threadIdx.x & 63u] = RTC_NO_LEAF;
-  }
   const RootRec* __restrict__ recs = S.root_recs;
   const RootCullPair* __restrict__ cull = S.root_cull;
   const DevMaterial* __restrict__ mats = S.mat;
@@ -2529,41 +2467,10 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           Ray sray{ovx, ovy, ovz, lvx, lvy, lvz};
           RTC_STAMP(3);
           RTC_COUNT(2);
-          if constexpr (OCC) {  // what stopped this lane's last shadow ray to this light, first
-            if (li < RTC_OCC_LIGHTS) {
-              uint32_t what;
-              if constexpr (FLAT) {
-                what = (occ_bytes >> (8u * li)) & 0xFFu;
-                if (what == 0xFFu) what = RTC_NO_LEAF;
-              } else {
-                what = lds_occ[threadIdx.x >> 6][li][threadIdx.x & 63u];
-              }
-              if (what != RTC_NO_LEAF) {
-                occluder_pretest<WORLD>(S, recs, what, sray, sv);
-                RTC_OCC_ADD(1, __builtin_popcountll(__ballot(true)));         // lanes that ran the test
-                RTC_OCC_ADD(2, __builtin_popcountll(__ballot(sv.shadowed)));  // ... and were answered by it
-              }
-            }
-          }
-          RTC_OCC_ADD(0, __builtin_popcountll(__ballot(true)));  // shadow rays
-          RTC_OCC_ADD(3, 1);                                     // wave-level shadow iterations ...
-          if (!__any((COOP && coop) || !sv.shadowed)) RTC_OCC_ADD(4, 1);  // ... that need no trace at all
-          // (a cooperative trace runs for the whole group: a lane whose own test said `shadowed` skips its exact tests in
-          // there and the merge tells the others)
-          if ((COOP && coop) || !sv.shadowed) {
+          {
             RTC_HIST_BEGIN();
             trace<CSG, WORLD, ShadowVisitor, TRAV>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
             RTC_HIST_END(1);
-          }
-          if constexpr (OCC) {  // (RTC_NO_LEAF: nothing stopped it, or something that is not remembered)
-            if (li < RTC_OCC_LIGHTS) {
-              if constexpr (FLAT) {
-                const uint32_t b = sv.occluder < 0xFFu ? sv.occluder : 0xFFu;
-                occ_bytes = (occ_bytes & ~(0xFFu << (8u * li))) | (b << (8u * li));
-              } else {
-                lds_occ[threadIdx.x >> 6][li][threadIdx.x & 63u] = sv.occluder;
-              }
-            }
           }
           RTC_STAMP(4);
           shadowed = sv.shadowed;

@@ -1,3 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-python3 tools/variants.py "base=-DRTC_MAJOR_XF=0" "mxf=" "leaf128=-DRTC_MAJOR_XF=0 -DRTC_LEAF_PAD_WORDS=8" "leaf96=-DRTC_MAJOR_XF=0 -DRTC_LEAF_PAD_WORDS=0" "node96=-DRTC_MAJOR_XF=0 -DRTC_NODE_PAD_BYTES=16" "node128=-DRTC_MAJOR_XF=0 -DRTC_NODE_PAD_BYTES=48" -- python3 tools/time_scenes.py --scenes dragons,teapot,nefertiti,groups --check > gpurun_out/r5_layout.txt 2>&1
+python3 tools/create_time.py > gpurun_out/r5_create_time.txt 2>&1
+python3 tools/variants.py "lite=-DRTC_PROFILE -DRTC_PROFILE_LITE" -- python3 tools/wave_ends.py cover 1920 1080 5 -- python3 tools/wave_ends.py dragons 3840 2160 5 -- python3 tools/wave_ends.py teapot 1920 1080 5 > gpurun_out/r5_wave_ends.txt 2>&1
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/r5_bench_quick.json 2> gpurun_out/r5_bench_quick.err
