@@ -1034,6 +1034,8 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       R.geom = bvh_root_of[i];
       R.always_first = T.root_always[i].x;
       R.always_count = T.root_always[i].y;
+      static_assert(sizeof(Bvh8Node) <= sizeof R.inv && alignof(RootRec) >= 8, "the root node's copy lives in RootRec::inv");
+      if (!(R.kind_flags & RTC_ROOT_IS_CSG) && R.geom < T.bvh8_nodes.size()) std::memcpy(R.inv, &T.bvh8_nodes[R.geom], sizeof(Bvh8Node));
       // every entry of the group lies on a line that passes the group's own box test
       const double lo[3] = {d.node_min[3ull * n], d.node_min[3ull * n + 1], d.node_min[3ull * n + 2]};
       const double hi[3] = {d.node_max[3ull * n], d.node_max[3ull * n + 1], d.node_max[3ull * n + 2]};
@@ -1473,6 +1475,15 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
     if (opOf(r & ~RTC_CHILD_NODE_BIT) != RTC_CSG_NONE) continue;
     group_roots.push_back(i);
   }
+  // (the plain tables - transforms, triangles, normals, materials, patterns: copies of the caller's arrays that nothing
+  // below reads - are made beside the groups' builds, on a thread of their own)
+  std::thread plain_tables([&]() { copyPlainTables(d, T); });
+  struct JoinOnExit {
+    std::thread& t;
+    ~JoinOnExit() {
+      if (t.joinable()) t.join();
+    }
+  } plain_tables_joined{plain_tables};
   std::vector<GroupBuild> built(group_roots.size());
   // (threads: one group each while there are groups, and what is left over inside a group's own build - a single mesh,
   // nefertiti.json, has all of them: BvhBuilder::buildFixed)
@@ -1676,7 +1687,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
   if (T.bvh8_leaves.size() >= (1u << 24)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the eight-wide BVH's leaf addressing", T.bvh8_leaves.size());
   if (bvh_leaves.size() >= (1u << 28)) return fail(RTC_ERR_UNSUPPORTED, "%zu leaves inside groups exceed the BVH leaf-range encoding", bvh_leaves.size());
   buildRootTables(d, dfs_of, bvh_root_of, T);
-  copyPlainTables(d, T);
+  plain_tables.join();
   // Group boxes are unions of their children's boxes (group.zig:23-37), so they nest - unless a csg kept a stale box
   // (shape.zig:298-302) or the caller's tables are not the reference's.  Checked, not assumed: the kernel's chain
   // replay stops at the innermost box only if they do.

@@ -60,8 +60,8 @@ struct RootCullPair {
   typedef float Pair __attribute__((ext_vector_type(2)));
   Pair cx, cy, cz, r2;  // centre rounded to nearest, r2 rounded UP; phase 1 of the root loop is FP32
 };
-struct RootRec {
-  double inv[12];        // rows 0..2 of the leaf's inverse (unused for groups)
+struct alignas(16) RootRec {
+  double inv[12];        // rows 0..2 of the leaf's inverse; a group: a copy of the root Bvh8Node of its candidate BVH (80 bytes: a walk's first node comes from this record - in LDS - not from the node table)
   double ymin, ymax;     // cylinder / cone
   uint32_t kind_flags;   // kind | casts_shadow<<8 | closed<<9 | is_group<<15
   uint32_t index;        // leaf index (depth-first) or group node index

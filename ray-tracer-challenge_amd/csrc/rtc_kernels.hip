@@ -114,6 +114,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #define RTC_EXPERIMENT 0
 #endif
 
+#ifndef RTC_ROOT_NODE_IN_REC
+#define RTC_ROOT_NODE_IN_REC 1  // a group's World.objects record carries a copy of the root node of its candidate BVH (traverse_bvh8)
+#endif
 #ifndef RTC_LB2
 #define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -788,7 +791,7 @@ __device__ __forceinline__ uint32_t permute_by_octant(uint32_t x, uint32_t oct) 
 template <bool CSG, class V, int LDS_ENTRIES = RTC_LDS_TRAV>
 __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t root, const uint32_t always_first,
                                               const uint32_t always_count, const Ray& ray, V& vis, unsigned& overflow,
-                                              uint2* lds_stack) {
+                                              uint2* lds_stack, const uint4* __restrict__ root_node) {
   const float ox = static_cast<float>(ray.ox), oy = static_cast<float>(ray.oy), oz = static_cast<float>(ray.oz);
   float dx = static_cast<float>(ray.dx), dy = static_cast<float>(ray.dy), dz = static_cast<float>(ray.dz);
   // a direction component of (nearly) zero: 1e-30 instead - every product below stays finite, and over any parameter
@@ -831,6 +834,11 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
   // the group in hand: the root is inner child 0 of a node that is not there
   // bits 0..7: children still to visit, front to back (bit p: slot p ^ oct); bits 8..15: the node's imask (by slot)
   uint32_t g_base = root, g_bits = (1u << oct) | 0x0100u;  // (slot 0 of the node that is not there)
+  // Every walk's FIRST node - the group's root - is read from the group's World.objects record (RootRec::inv holds a copy
+  // of it: in LDS for every world whose tables fit) instead of from the node table in memory: a walk takes 3.3 node steps
+  // on dragons.json, each a gather of five 16-byte loads per lane through the CU's one vector-memory pipe (its data
+  // return path is busy in three cycles of four, profiles/r03/pmc_mem_dragons.txt) - the root's no longer is.
+  bool at_root = root_node != nullptr;
   uint32_t l_base = 0u, l_hits = 0u, meta_lo = 0u, meta_hi = 0u;
 #ifdef RTC_PROFILE
   unsigned long long pw_nodes = 0, pw_leaves = 0, pw_node_lanes = 0, pw_leaf_lanes = 0;
@@ -878,10 +886,22 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
         continue;
       }
 #endif
-      const char* const at = reinterpret_cast<const char*>(S.bvh8) + node * static_cast<uint32_t>(sizeof(Bvh8Node));
-      const uint4 h0 = *reinterpret_cast<const uint4*>(at), h1 = *reinterpret_cast<const uint4*>(at + 16);
-      const uint4 qa = *reinterpret_cast<const uint4*>(at + 32), qb = *reinterpret_cast<const uint4*>(at + 48),
-                  qc = *reinterpret_cast<const uint4*>(at + 64);
+      uint4 h0, h1, qa, qb, qc;
+      if (at_root) {
+        at_root = false;
+        h0 = root_node[0];
+        h1 = root_node[1];
+        qa = root_node[2];
+        qb = root_node[3];
+        qc = root_node[4];
+      } else {
+        const char* const at = reinterpret_cast<const char*>(S.bvh8) + node * static_cast<uint32_t>(sizeof(Bvh8Node));
+        h0 = *reinterpret_cast<const uint4*>(at);
+        h1 = *reinterpret_cast<const uint4*>(at + 16);
+        qa = *reinterpret_cast<const uint4*>(at + 32);
+        qb = *reinterpret_cast<const uint4*>(at + 48);
+        qc = *reinterpret_cast<const uint4*>(at + 64);
+      }
       // per node: step / d and (origin - o) / d, widened by the margin
       const float sx = __builtin_bit_cast(float, (h0.w & 0xFFu) << 23) * ix;
       const float sy = __builtin_bit_cast(float, ((h0.w >> 8) & 0xFFu) << 23) * iy;
@@ -1125,7 +1145,11 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
           if constexpr (CSG) visit_csg(S, R.index, ray, vis, overflow);
         } else {
 #if RTC_BVH8
-          traverse_bvh8<CSG, V, TRAV>(S, R.geom, R.always_first, R.always_count, ray, vis, overflow, reinterpret_cast<uint2*>(lds_stack));
+          // (the three-wave kernel only: measured with and without it, dragons 4K 1.884 -> 1.859 ms and groups 0.890 -> 0.875
+          // there; the two-wave kernel loses a per cent - teapot 0.256 -> 0.258, nefertiti 0.489 -> 0.495 -
+          // profiles/r05/walk_experiments.md)
+          traverse_bvh8<CSG, V, TRAV>(S, R.geom, R.always_first, R.always_count, ray, vis, overflow, reinterpret_cast<uint2*>(lds_stack),
+                                      (RTC_ROOT_NODE_IN_REC && TRAV == 2) ? reinterpret_cast<const uint4*>(R.inv) : nullptr);
 #else
           traverse_bvh<CSG>(S, R.geom, ray, vis, overflow, lds_stack);
 #endif
