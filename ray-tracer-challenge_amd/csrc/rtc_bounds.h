@@ -215,6 +215,18 @@ Aabb leafWorldBox(const rtc_scene_desc& d, uint32_t leaf) {
   return box;
 }
 
+#ifndef RTC_COLLAPSE_DP
+#define RTC_COLLAPSE_DP 1
+#endif
+#ifndef RTC_COLLAPSE_PRIM_COST
+#define RTC_COLLAPSE_PRIM_COST 4.0  // what testing a leaf record costs, in node steps (measured at 0.3 / 0.5 / 1 / 2 / 4 / 10 / 1000: dragons 4K 1.868 / 1.834 / 1.808 / 1.789 / 1.788 / 1.781 / 1.779 ms, teapot 0.2518 / 0.2500 / 0.2495 / 0.2495 / 0.2493 / 0.2527 / 0.2588, nefertiti 0.496 / 0.487 / 0.481 / 0.477 / 0.476 / 0.476 / 0.475)
+#endif
+#ifndef RTC_SAH_BINS
+#define RTC_SAH_BINS 32
+#endif
+#ifndef RTC_SAH_SWEEP
+#define RTC_SAH_SWEEP 16  // ranges of up to this many leaves are split by the exact (sorted sweep) surface-area heuristic
+#endif
 struct BvhPrim {
   Aabb box;        // may be non-finite: treated as unbounded
   double c[3];     // centroid (0 for unbounded)
@@ -283,6 +295,49 @@ struct BvhBuilder {
   // Sorts prims[first, first + count) into the two sides of the cheapest of the 45 candidate planes (16-bin SAH on three
   // axes; the median of the longest axis where no plane separates anything) and returns where the second side begins.
   size_t split(size_t first, size_t count) {
+#if RTC_SAH_SWEEP
+    // Small ranges: the exact surface-area heuristic - every one of the count - 1 positions of the range sorted along each
+    // axis (ties by leaf index: the order, and with it the tree, does not depend on where the range came from).
+    if (count <= RTC_SAH_SWEEP) {
+      bool all_finite = true;
+      for (size_t i = first; i < first + count; ++i) all_finite = all_finite && prims[i].box.finite();
+      if (all_finite) {
+        double best = INFINITY;
+        int best_axis = -1;
+        size_t best_pos = 0;
+        std::vector<uint32_t> order(count);
+        std::vector<double> right_area(count);
+        for (int ax = 0; ax < 3; ++ax) {
+          for (size_t i = 0; i < count; ++i) order[i] = static_cast<uint32_t>(i);
+          std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const BvhPrim &pa = prims[first + a], &pb = prims[first + b];
+            return pa.c[ax] < pb.c[ax] || (pa.c[ax] == pb.c[ax] && pa.leaf < pb.leaf);
+          });
+          Aabb acc;
+          for (size_t i = count; i-- > 1;) {
+            acc.merge(prims[first + order[i]].box);
+            right_area[i] = acc.area();
+          }
+          acc = Aabb{};
+          for (size_t i = 0; i + 1 < count; ++i) {
+            acc.merge(prims[first + order[i]].box);
+            const double cost = acc.area() * static_cast<double>(i + 1) + right_area[i + 1] * static_cast<double>(count - i - 1);
+            if (cost < best) {
+              best = cost;
+              best_axis = ax;
+              best_pos = i + 1;
+            }
+          }
+        }
+        if (best_axis >= 0) {
+          std::sort(prims.begin() + first, prims.begin() + first + count, [&](const BvhPrim& a, const BvhPrim& b) {
+            return a.c[best_axis] < b.c[best_axis] || (a.c[best_axis] == b.c[best_axis] && a.leaf < b.leaf);
+          });
+          return first + best_pos;
+        }
+      }
+    }
+#endif
     // centroid bounds
     double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (size_t i = first; i < first + count; ++i)
@@ -296,7 +351,7 @@ struct BvhBuilder {
       if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
     size_t mid = first + count / 2;
     bool split_done = false;
-    constexpr int kBins = 16;
+    constexpr int kBins = RTC_SAH_BINS;
     double best = INFINITY;
     int best_axis = -1, best_b = -1;
     auto binOf = [&](const BvhPrim& p, int ax) {
@@ -538,15 +593,111 @@ struct Bvh8Collapse {
     const double x = static_cast<double>(k.hi[0]) - k.lo[0], y = static_cast<double>(k.hi[1]) - k.lo[1], z = static_cast<double>(k.hi[2]) - k.lo[2];
     return (x < 0.0 || y < 0.0 || z < 0.0) ? 0.0 : 2.0 * (x * y + y * z + z * x);
   }
+  // ---- which descendants of a binary node become the (up to eight) children of its wide node.
+  // RTC_COLLAPSE_DP == 0: greedily - the node's two children, the larger (by surface area) inner one of which is replaced
+  // by ITS two children until there are eight or none is left to open.
+  // RTC_COLLAPSE_DP == 1: the cut that minimises the surface-area cost of the WIDE tree (Ylitie, Karras, Laine 2017,
+  // section 3.2), by dynamic programming over the binary tree: F(n, i) = the cheapest way to cover the subtree of n with
+  // at most i elements, an element being a wide inner node (its cost T(n) = area(n) + the cheapest cover of its two
+  // children with eight elements in all) or a leaf child of up to four records (cost kPrim * area(n) * records);
+  // F(n, 1) = min(T, leaf), F(n, i) = min(F(n, i - 1), min over k of F(left, k) + F(right, i - k)).
+  struct Cover {
+    float F[8];        // F(n, 1 .. 8)
+    uint8_t k[8];      // i >= 2: the left child's share of the split that gives F(n, i); 0: F(n, i) = F(n, i - 1)
+    uint8_t k_node;    // the left child's share of the eight elements when n becomes a wide inner node
+    uint8_t as_leaf;   // F(n, 1) is the leaf form
+    uint32_t first_leaf, records;  // the binary leaf list's entries below n (depth-first: contiguous)
+  };
+  std::vector<Cover> cover;  // per binary node (RTC_COLLAPSE_DP)
+  static constexpr double kPrim = RTC_COLLAPSE_PRIM_COST;
+  double areaOf(const float* lo, const float* hi) const { return area(Kid{lo, hi, 0u}); }
+  double coverCost(uint32_t ref, const float* lo, const float* hi, int i) const {  // F(child, i); a binary leaf reference is a leaf whatever i
+    if (ref == RTC_NO_LEAF) return 0.0;
+    if (ref & RTC_NODE_BIT) return kPrim * areaOf(lo, hi) * ((ref & 7u) + 1u);
+    return cover[ref].F[i - 1];
+  }
+  void prepareCover(uint32_t n, const float* lo, const float* hi) {  // post-order over the binary tree below n (its own box: lo, hi)
+    const BvhNode& N = in[n];
+    if (inner(N.c0)) prepareCover(N.c0, N.lo0, N.hi0);
+    if (inner(N.c1)) prepareCover(N.c1, N.lo1, N.hi1);
+    Cover& C = cover[n];
+    auto recordsOf = [&](uint32_t ref) -> uint32_t { return ref == RTC_NO_LEAF ? 0u : ((ref & RTC_NODE_BIT) ? (ref & 7u) + 1u : cover[ref].records); };
+    auto firstOf = [&](uint32_t ref) -> uint32_t { return (ref & RTC_NODE_BIT) ? ((ref & ~RTC_NODE_BIT) >> 3) : cover[ref].first_leaf; };
+    C.records = recordsOf(N.c0) + recordsOf(N.c1);
+    C.first_leaf = N.c0 != RTC_NO_LEAF ? firstOf(N.c0) : (N.c1 != RTC_NO_LEAF ? firstOf(N.c1) : 0u);
+    const bool contiguous = N.c0 != RTC_NO_LEAF && N.c1 != RTC_NO_LEAF && firstOf(N.c0) + recordsOf(N.c0) == firstOf(N.c1);
+    const double a = areaOf(lo, hi);
+    double node_cost = INFINITY;
+    C.k_node = 1;
+    for (int k = 1; k <= 7; ++k) {
+      const double v = coverCost(N.c0, N.lo0, N.hi0, k) + coverCost(N.c1, N.lo1, N.hi1, 8 - k);
+      if (v < node_cost) {
+        node_cost = v;
+        C.k_node = static_cast<uint8_t>(k);
+      }
+    }
+    node_cost += a;
+    const double leaf_cost = (contiguous && C.records <= 4u) ? kPrim * a * C.records : INFINITY;
+    C.as_leaf = leaf_cost < node_cost;
+    C.F[0] = static_cast<float>(std::fmin(node_cost, leaf_cost));
+    C.k[0] = 0;
+    for (int i = 2; i <= 8; ++i) {
+      double best = C.F[i - 2];
+      C.k[i - 1] = 0;
+      for (int k = 1; k < i; ++k) {
+        const double v = coverCost(N.c0, N.lo0, N.hi0, k) + coverCost(N.c1, N.lo1, N.hi1, i - k);
+        if (v < best) {
+          best = v;
+          C.k[i - 1] = static_cast<uint8_t>(k);
+        }
+      }
+      C.F[i - 1] = static_cast<float>(best);
+    }
+  }
+  void expand(uint32_t ref, const float* lo, const float* hi, int i, std::vector<Kid>& kids) const {  // the cover F(ref, i), element by element
+    if (ref == RTC_NO_LEAF) return;
+    if (ref & RTC_NODE_BIT) {
+      kids.push_back({lo, hi, ref});
+      return;
+    }
+    const Cover& C = cover[ref];
+    while (i > 1 && C.k[i - 1] == 0) --i;
+    if (i == 1) {
+      kids.push_back({lo, hi, C.as_leaf ? (RTC_NODE_BIT | (C.first_leaf << 3) | (C.records - 1u)) : ref});
+      return;
+    }
+    const BvhNode& N = in[ref];
+    expand(N.c0, N.lo0, N.hi0, C.k[i - 1], kids);
+    expand(N.c1, N.lo1, N.hi1, i - C.k[i - 1], kids);
+  }
   uint32_t convertRoot(uint32_t n) {
     const uint32_t me = static_cast<uint32_t>(out.size());
     out.emplace_back();
+#if RTC_COLLAPSE_DP
+    cover.assign(in.size(), Cover{});
+    {
+      const BvhNode& R = in[n];
+      float lo[3], hi[3];  // the root's own box: the union of its children's
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = std::fmin(R.c0 != RTC_NO_LEAF ? R.lo0[a] : INFINITY, R.c1 != RTC_NO_LEAF ? R.lo1[a] : INFINITY);
+        hi[a] = std::fmax(R.c0 != RTC_NO_LEAF ? R.hi0[a] : -INFINITY, R.c1 != RTC_NO_LEAF ? R.hi1[a] : -INFINITY);
+      }
+      prepareCover(n, lo, hi);
+    }
+#endif
     fill(me, n, 1);
     return me;
   }
   void fill(uint32_t me, uint32_t n, uint32_t depth) {
     max_depth = std::max(max_depth, depth);
     std::vector<Kid> kids;
+#if RTC_COLLAPSE_DP
+    {
+      const BvhNode& N = in[n];
+      expand(N.c0, N.lo0, N.hi0, cover[n].k_node, kids);
+      expand(N.c1, N.lo1, N.hi1, 8 - cover[n].k_node, kids);
+    }
+#else
     auto add = [&](const BvhNode& N, int which) {
       const uint32_t ref = which == 0 ? N.c0 : N.c1;
       if (ref != RTC_NO_LEAF) kids.push_back({which == 0 ? N.lo0 : N.lo1, which == 0 ? N.hi0 : N.hi1, ref});
@@ -563,6 +714,7 @@ struct Bvh8Collapse {
       add(C, 0);
       add(C, 1);
     }
+#endif
     Bvh8Node N;
     std::memset(&N, 0, sizeof N);
     for (int a = 0; a < 3; ++a)
