@@ -581,6 +581,7 @@ struct Bvh8Collapse {
   const std::vector<uint32_t>& in_leaves;
   std::vector<Bvh8Node>& out;
   std::vector<uint32_t>& out_leaves;
+  const std::vector<uint4>* leaf_meta = nullptr;  // per depth-first leaf: .x bit 8 = the shape casts a shadow (Bvh8Node::meta bit 7)
   uint32_t max_depth = 0;  // deepest node: the walk's stack holds at most one entry per level
   bool ok = true;          // false: a quantised box failed to contain its child (never expected; checked, not assumed)
   struct Kid {
@@ -802,6 +803,12 @@ struct Bvh8Collapse {
         if (count > 4u || n_recs > 28u) ok = false;
         N.meta[s] = static_cast<uint8_t>((n_recs << 2) | (count - 1u));
         lmask |= 1u << s;
+        bool dark = leaf_meta != nullptr;  // no shape of the range casts a shadow (a csg unit: not known here, it counts as casting)
+        for (uint32_t k = 0; k < count && dark; ++k) {
+          const uint32_t leaf = in_leaves[first + k];
+          dark = !(leaf & RTC_NODE_BIT) && leaf < leaf_meta->size() && (((*leaf_meta)[leaf].x >> 8) & 1u) == 0u;
+        }
+        if (dark) N.meta[s] |= 0x80u;
         for (uint32_t k = 0; k < count; ++k) out_leaves.push_back(in_leaves[first + k]);
         n_recs += count;
       }

@@ -1532,6 +1532,7 @@ int buildTables(const rtc_scene_desc& d, const SceneTraits& traits, HostTables& 
     G.mag = builder.mag;
 #if RTC_BVH8
     Bvh8Collapse wide{G.nodes, G.leaves, G.nodes8, G.leaves8};
+    wide.leaf_meta = &leaf_meta;
     G.root8 = wide.convertRoot(G.root2);
     G.depth = wide.max_depth;
     if (!wide.ok) {

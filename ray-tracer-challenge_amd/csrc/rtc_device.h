@@ -138,7 +138,7 @@ struct Bvh8Node {              // 80 B = 5 x 16
   uint8_t imask;               // bit s: slot s holds an inner node
   uint32_t child_base;         // node index of the first inner child
   uint32_t leaf_base_lmask;    // bits 0..23: first BvhLeafRec of the leaf children; bits 24..31: bit s: slot s holds a leaf range
-  uint8_t meta[8];             // per slot with a leaf range: (offset from leaf_base) << 2 | (records - 1); records <= 4
+  uint8_t meta[8];             // per slot with a leaf range: (offset from leaf_base) << 2 | (records - 1); records <= 4, offset <= 28; bit 7: none of the range's shapes casts a shadow (shadow traces skip the slot)
   uint8_t q[48];               // lo_x[8] lo_y[8] lo_z[8] hi_x[8] hi_y[8] hi_z[8]; an empty slot has lo = 255, hi = 0
 };
 

@@ -442,6 +442,9 @@ __device__ __forceinline__ void visit_leaf(const DevScene& S, const BvhLeafRec& 
   // (dragons 4K 2.30 -> 2.25 ms, nefertiti 0.565 -> 0.550; groups.json, whose leaves are cones and cylinders, pays 5 % for
   // triangle words it does not use)
   const BvhLeafRec L = Lm;
+  // isShadowed (world.zig:136-147) counts an entry only if its shape casts a shadow: a leaf that does not - a glass display
+  // case around a mesh - has nothing a shadow trace could use, whatever its test would say.
+  if (V::kAnyHit && ((L.kind_flags >> 8) & 1u) == 0u) return;
   const uint32_t leaf = L.leaf;
   const uint4 meta{L.kind_flags, L.xform, L.material, L.geom};
   if (meta.y != cur_xf) {  // Shape.intersect: ray.transform(_inverse_transform), shape.zig:314-318
@@ -939,6 +942,14 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
       g_base = h1.x;
       g_bits = (V::kAnyHit ? inner : permute_by_octant(inner, oct)) | (imask << 8);
       l_hits = hits & (h1.y >> 24);
+      if constexpr (V::kAnyHit) {
+        // (a shadow trace does not even fetch the records of a leaf range none of whose shapes casts a shadow: bit 7 of
+        // the range's meta byte, set at build time - in dragons.json the display case around every dragon is such a leaf
+        // and a child of its group's root node: every shadow walk through a group used to fetch and test it)
+        const uint32_t dark_lo = ((((h1.z >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+        const uint32_t dark_hi = ((((h1.w >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+        l_hits &= ~(dark_lo | (dark_hi << 4));
+      }
       l_base = h1.y & 0xFFFFFFu;
       meta_lo = h1.z;
       meta_hi = h1.w;
@@ -955,7 +966,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
       const uint32_t k = static_cast<uint32_t>(__builtin_ctz(l_hits));
       l_hits &= l_hits - 1u;
       const uint32_t m = ((k < 4u ? meta_lo : meta_hi) >> (8u * (k & 3u))) & 0xFFu;
-      const uint32_t first = l_base + (m >> 2), count = (m & 3u) + 1u;
+      const uint32_t first = l_base + ((m >> 2) & 31u), count = (m & 3u) + 1u;  // (bit 7: the range casts no shadow)
       for (uint32_t i = 0; i < count; ++i) {
 #ifdef RTC_PROFILE
         pw_leaves += 1ull;
@@ -1131,6 +1142,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       const RootRec& R = recs[base + bit];
       const uint32_t kf = R.kind_flags;
       if (FLAT || !(kf & RTC_ROOT_IS_GROUP)) {
+        if (!FLAT && V::kAnyHit && ((kf >> 8) & 1u) == 0u) continue;  // (a shadow trace: a shape that casts no shadow, see visit_leaf)
         const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
         const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
         const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;

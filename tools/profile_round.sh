@@ -5,7 +5,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 passes() {  # passes <prefix> <bench arguments...>

@@ -3,7 +3,7 @@
 # Usage: bash tools/profile_round_bench.sh r03
 set -e
 cd $GRAFT_REPO_ROOT
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/profiles_$R
 mkdir -p $OUT
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
