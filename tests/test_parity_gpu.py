@@ -942,6 +942,51 @@ def test_host_library_render_entry(rtc):
     assert np.abs(out - want).max() < TOL
 
 
+def test_shapes_that_cast_no_shadow_inside_groups(rtc):
+    """isShadowed (world.zig:136-147) counts an entry only if its shape casts a shadow.  Shadow traces skip such shapes
+    without testing them: a top-level leaf by its flag, a leaf inside a group by its record's flag, and a whole leaf range
+    of a group's BVH none of whose shapes casts one by a bit of the node (set at build time) - a display case around the
+    other shapes, as in dragons.json, every second sphere, and a flagged shape beside an unflagged one in one group.
+    The image (the shadows on the floor and between the shapes) and the counters are the oracle's on both general kernels."""
+    import json
+    def sphere(x, y, z, r, casts, **material):
+        o = {"type": {"sphere": {}}, "transform": [{"scale": [r, r, r]}, {"translate": [x, y, z]}],
+             "material": dict({"diffuse": 0.7, "specular": 0.3}, **material)}
+        if not casts:
+            o["casts-shadow"] = False
+        return o
+    kids = [sphere(-2.0 + 0.8 * (i % 6), 0.5 + 0.9 * (i // 6), 0.3 * (i % 3), 0.35, i % 2 == 0) for i in range(18)]
+    case = {"type": {"cube": {}}, "transform": [{"scale": [3.2, 1.6, 1.2]}, {"translate": [0, 1.4, 0.3]}], "casts-shadow": False,
+            "material": {"ambient": 0, "diffuse": 0.3, "specular": 0, "transparency": 0.7, "refractive-index": 1}}
+    scene = {"camera": {"width": 160, "height": 100, "field-of-view": 1.0, "from": [1.5, 3.5, -8], "to": [0, 1, 0], "up": [0, 1, 0]},
+             "lights": [{"point-light": {"position": [-6, 9, -6], "intensity": [0.7, 0.7, 0.7]}},
+                        {"point-light": {"position": [7, 6, -3], "intensity": [0.4, 0.4, 0.4]}}],
+             "objects": [{"type": {"plane": {}}, "material": {"diffuse": 0.8, "specular": 0}},
+                         {"type": {"group": kids + [case]}},
+                         {"type": {"cube": {}}, "transform": [{"scale": [0.5, 0.5, 0.5]}, {"translate": [3.5, 0.5, -1]}], "casts-shadow": False,
+                          "material": {"diffuse": 0.6}},
+                         {"type": {"group": [sphere(-3.5, 0.6, -1.5, 0.6, False), sphere(-3.3, 1.9, -1.5, 0.5, True)]}}]}
+    hs = rtc.HostScene(json.dumps(scene))
+    cam = hs.camera()
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    for waves3 in (0, 1):
+        rtc.set_option("waves3", waves3)
+        try:
+            gpu = rtc.GpuScene(hs.desc)
+            got = gpu.render(cam, 5)
+            st = gpu.stats()
+            assert gpu.last_kernel_name() == ("rtc_render_kernel3" if waves3 else "rtc_render_kernel")
+        finally:
+            rtc.set_option("waves3", -1)
+        assert np.abs(got - want).max() < TOL, waves3
+        assert [st["overflow"], st["secondary"], st["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]], waves3
+    # the flags matter: with every shape casting, the image differs (the case and the flagged spheres throw shadows)
+    for o in scene["objects"][1]["type"]["group"] + scene["objects"][2:3]:
+        o.pop("casts-shadow", None)
+    hs2 = rtc.HostScene(json.dumps(scene))
+    assert np.abs(ob.OracleScene(hs2.desc).render(cam, 5)[0] - want).max() > 1e-3
+
+
 def _random_scene(seed):
     """Random world through the JSON loader: every in-scope primitive, nested groups (some large enough to be
     divided), planes inside groups, glass inside glass, every pattern kind the kernel implements."""
