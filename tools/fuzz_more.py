@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off widening of tests/test_parity_gpu.py::test_random_scenes: the same generator over many more seeds
-(python tools/fuzz_more.py [first] [count] [depth]); prints the seeds that break parity or the ray counters."""
+(python tools/fuzz_more.py [first] [count] [depth] [name=value option ...], e.g. waves3=1 for the three-wave general
+kernel); prints the seeds that break parity or the ray counters."""
 import importlib, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -13,6 +14,8 @@ from test_parity_gpu import _random_scene, TOL
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for opt in sys.argv[4:]:
+    rtc.set_option(opt.split("=")[0], float(opt.split("=")[1]))
 bad, worst = [], 0.0
 for seed in range(first, first + count):
     hs = rtc.HostScene(_random_scene(seed)); cam = hs.camera()
