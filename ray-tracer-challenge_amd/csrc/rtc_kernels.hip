@@ -109,7 +109,8 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #endif
 
 // Bound experiments (WRONG images, right dependency chains; never set in the product): bit 0: no shadow ray is traced;
-// bit 1: the walks of shadow rays visit no leaf (what their node phase alone costs).
+// bit 1: the walks of shadow rays visit no leaf (what their node phase alone costs); bit 2: triangles are tested in FP32
+// (what VERDICT r04 item 2's pre-test could save at the very most: every exact test replaced, not a survivor left).
 #ifndef RTC_EXPERIMENT
 #define RTC_EXPERIMENT 0
 #endif
@@ -365,6 +366,24 @@ __device__ __forceinline__ void leaf_entries(uint32_t kind, const CylParams& cy,
     }
     default: {  // 4 triangle.zig:29-63, 5 triangle.zig:225-259 (Moller-Trumbore, left-handed cross)
       if constexpr (SIMPLE) break;
+      if constexpr ((RTC_EXPERIMENT & 4) != 0) {  // (bound experiment: what an FP32 triangle test in place of the exact one would buy at most)
+        const float p1x = static_cast<float>(T[0]), p1y = static_cast<float>(T[1]), p1z = static_cast<float>(T[2]);
+        const float e1x = static_cast<float>(T[3]), e1y = static_cast<float>(T[4]), e1z = static_cast<float>(T[5]);
+        const float e2x = static_cast<float>(T[6]), e2y = static_cast<float>(T[7]), e2z = static_cast<float>(T[8]);
+        const float dx = static_cast<float>(r.dx), dy = static_cast<float>(r.dy), dz = static_cast<float>(r.dz);
+        const float cx = dy * e2z - dz * e2y, cy_ = dz * e2x - dx * e2z, cz = dx * e2y - dy * e2x;
+        const float det = (e1x * cx + e1y * cy_) + e1z * cz;
+        if (__builtin_fabsf(det) < 1e-5f) break;
+        const float ff = 1.0f / det;
+        const float qx = static_cast<float>(r.ox) - p1x, qy = static_cast<float>(r.oy) - p1y, qz = static_cast<float>(r.oz) - p1z;
+        const float u = ff * ((qx * cx + qy * cy_) + qz * cz);
+        if (u < 0.0f || u > 1.0f) break;
+        const float ox = qy * e1z - qz * e1y, oy = qz * e1x - qx * e1z, oz = qx * e1y - qy * e1x;
+        const float v = ff * ((dx * ox + dy * oy) + dz * oz);
+        if (v < 0.0f || (u + v) > 1.0f) break;
+        f(static_cast<double>(ff * ((e2x * ox + e2y * oy) + e2z * oz)), static_cast<double>(u), static_cast<double>(v));
+        break;
+      }
       const double p1x = T[0], p1y = T[1], p1z = T[2];
       const double e1x = T[3], e1y = T[4], e1z = T[5];
       const double e2x = T[6], e2y = T[7], e2z = T[8];

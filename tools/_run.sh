@@ -1,10 +1,3 @@
 set -e
 cd $GRAFT_REPO_ROOT
-( python3 tools/fuzz_more.py 40000 1200 5 2>&1 | tail -4 ) > gpurun_out/r5_fuzz_groups.txt
-echo "groups depth 5 done"
-( python3 tools/fuzz_more.py 50000 300 8 2>&1 | tail -3 ) >> gpurun_out/r5_fuzz_groups.txt
-echo "groups depth 8 done"
-( python3 tools/fuzz_flat.py 3000 400 2>&1 | tail -4 ) > gpurun_out/r5_fuzz_flat.txt || true
-echo "flat done"
-( python3 tools/full_size_parity.py 2>&1 | tail -22 ) > gpurun_out/r5_full_size_parity.txt
-echo "full size done"
+python3 tools/variants.py "x0=" "x4=-DRTC_EXPERIMENT=4" -- python3 tools/time_scenes.py --scenes dragons,teapot,nefertiti > gpurun_out/r5_bound_fp32_tri.txt 2>&1
