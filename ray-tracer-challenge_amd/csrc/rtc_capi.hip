@@ -37,6 +37,10 @@ extern "C" __global__ void rtc_render_kernel_bigworld(const DevScene S, const De
 extern "C" __global__ void rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                     const uint32_t max_depth, double* __restrict__ out,
                                                     DevStats* __restrict__ stats, DevStats* __restrict__ next_stats);
+extern "C" __global__ void rtc_render_kernel_simple_b(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                      const uint32_t max_depth, double* out, DevStats* stats, DevStats* next_stats);
+extern "C" __global__ void rtc_render_kernel_simple3_b(const DevScene S, const DevCamera cam, const DevPixelMap map,
+                                                       const uint32_t max_depth, double* out, DevStats* stats, DevStats* next_stats);
 extern "C" __global__ void rtc_render_kernel_simple3(const DevScene S, const DevCamera cam, const DevPixelMap map,
                                                      uint32_t max_depth, double* out, DevStats* stats, DevStats* next_stats);
 #if RTC_BVH8
@@ -271,11 +275,13 @@ bool usesGeneral3(const rtc_scene* s) {
 #endif
 }
 KernelChoice ldsKernel(const rtc_scene* s, const DevPixelMap& map) {
-  if (usesSimple3(s, map)) return RTC_KERNEL(rtc_render_kernel_simple3);
+  // (a simple world that is mostly cubes: the kernels whose root loop rejects by world boxes - trace() in rtc_kernels.hip)
+  if (usesSimple3(s, map)) return s->box_cull ? RTC_KERNEL(rtc_render_kernel_simple3_b) : RTC_KERNEL(rtc_render_kernel_simple3);
 #if RTC_BVH8
   if (usesGeneral3(s)) return RTC_KERNEL(rtc_render_kernel3);
 #endif
-  if (s->simple_kernel) return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_simple_ext) : RTC_KERNEL(rtc_render_kernel_simple);
+  if (s->simple_kernel)
+    return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_simple_ext) : (s->box_cull ? RTC_KERNEL(rtc_render_kernel_simple_b) : RTC_KERNEL(rtc_render_kernel_simple));
   if (s->flat_kernel) return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_flat_ext) : RTC_KERNEL(rtc_render_kernel_flat);
   return s->ext_kernel ? RTC_KERNEL(rtc_render_kernel_ext) : RTC_KERNEL(rtc_render_kernel);
 }
@@ -615,6 +621,8 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   if (max_depth > RTC_MAX_DEPTH)
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
+  if (out_pixels > 0xFFFFFFFFull)  // (a lane hands a pending ray to a neighbour with its canvas pixel in 32 bits: render_body, step 2a)
+    return fail(RTC_ERR_INVALID_ARGUMENT, "%zu pixels in one launch: the kernel indexes at most 2^32", out_pixels);
   HIP_TRY(hipSetDevice(s->device));
   // Launches on one handle share its counters, work counter, pending-ray stacks, csg lists and schedule buffers, and
   // launch N + 1 clears the counters of launch N + 2: they must run one after the other.  Stream order gives that on
@@ -823,6 +831,10 @@ namespace {
 struct RootCull {  // host form of one bounding sphere; uploaded two to a RootCullPair
   float cx, cy, cz, r2;
 };
+struct RootBox {   // host form of one world box; uploaded two to a RootBoxPair.  lo > hi: never kept (table padding)
+  float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  float line_only = 0.0f;
+};
 
 // What validateScene learns about a scene on the way.
 struct SceneTraits {
@@ -850,6 +862,9 @@ struct HostTables {
   std::vector<uint2> node_range;
   std::vector<RootRec> root_recs;
   std::vector<RootCull> root_cull;
+  std::vector<RootBox> root_box;       // the same roots' world boxes (RootBoxPair: what the render kernels' root loop tests)
+  float cull_bmax = 0.0f;              // max |coordinate| of any finite root box
+  float cull_par = 0.0f;               // 1.2e-5 x the largest scale of any cube (DevScene::cull_par)
   std::vector<float> root_weight;      // per root (table order): what a chunk that looks at it costs (rtc_estimate_kernel)
   std::vector<double> xf;
   std::vector<DevPattern> pat;
@@ -861,7 +876,7 @@ struct HostTables {
   std::vector<double> node_box;
   std::vector<double> light;
   uint32_t n_live = 0;
-  uint32_t n_root_kind[3] = {0, 0, 0};  // planes, spheres, cubes at the head of root_recs (in that order)
+  uint32_t n_root_kind[3] = {0, 0, 0};  // spheres, planes, cubes at the head of root_recs (in that order)
   float bvh_mag = 0.0f;
   float cull_cmax = 0.0f;
 };
@@ -1019,6 +1034,8 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
   root_recs.assign(d.n_roots, RootRec{});
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
   root_cull.assign((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  T.root_box.assign((d.n_roots + 3u) & ~3u, RootBox{});
+  T.cull_bmax = 0.0f;
   T.root_weight.assign((d.n_roots + 3u) & ~3u, 0.0f);
   cull_cmax = 0.0f;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
@@ -1026,6 +1043,7 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
     std::memset(&R, 0, sizeof R);
     const uint32_t ref = d.roots[i];
     Sphere sp;
+    Aabb rb;                 // the same bound as a world box (not finite: no bound)
     bool line_only = false;  // entries may lie outside the bound: only "the line misses it" may cull
     if (ref & RTC_CHILD_NODE_BIT) {
       const uint32_t n = ref & ~RTC_CHILD_NODE_BIT;
@@ -1064,7 +1082,11 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       }
       line_only = cone_below;
       if (!csg_below) {
-        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) sp = sphereOfBox(I, lo, hi);
+        if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
+          sp = sphereOfBox(I, lo, hi);
+          rb.add(lo);
+          rb.add(hi);
+        }
       } else if (lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2]) {
         // A csg keeps the box it was built with when a transform is pushed through it (shape.zig:298-302),
         // so its leaves - and the entries they report - may lie outside it and outside the groups above.
@@ -1092,7 +1114,10 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
             }
           }
         }
-        if (bounded && all.finite()) sp = sphereOfBox(I, all.lo, all.hi);
+        if (bounded && all.finite()) {
+          sp = sphereOfBox(I, all.lo, all.hi);
+          rb = all;
+        }
       }
     } else {
       const uint8_t k = d.leaf_kind[ref];
@@ -1108,6 +1133,7 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       R.material = d.leaf_material[ref];
       R.geom = (k == RTC_TRIANGLE || k == RTC_SMOOTH_TRIANGLE) ? g : 0u;
       sp = leafSphere(d, ref);
+      rb = leafWorldBox(d, ref);
     }
     sp = inflate(sp);
     {
@@ -1144,6 +1170,27 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
         T.root_weight[i] = w;
       }
     }
+    {
+      // the box: inflated like the sphere, planes rounded outward to FP32; no finite bound (or a sphere that has none: the
+      // two tables say the same): -3e38 / +3e38, which every ray is inside of
+      RootBox& B = T.root_box[i];
+      B.line_only = line_only ? 1.0f : 0.0f;
+      bool ok = rb.finite() && sp.finite();
+      for (int k = 0; k < 3 && ok; ++k) {
+        const double pad = 1e-6 * (std::fabs(rb.lo[k]) + std::fabs(rb.hi[k])) + 1e-9;
+        B.lo[k] = BvhBuilder::down(rb.lo[k] - pad);
+        B.hi[k] = BvhBuilder::up(rb.hi[k] + pad);
+        ok = std::isfinite(B.lo[k]) && std::isfinite(B.hi[k]) && std::fabs(B.lo[k]) < 1.0e37f && std::fabs(B.hi[k]) < 1.0e37f;
+      }
+      if (ok) {
+        for (int k = 0; k < 3; ++k) T.cull_bmax = std::fmax(T.cull_bmax, std::fmax(std::fabs(B.lo[k]), std::fabs(B.hi[k])));
+      } else {
+        for (int k = 0; k < 3; ++k) {
+          B.lo[k] = -3.0e38f;
+          B.hi[k] = 3.0e38f;
+        }
+      }
+    }
     RootCull& C = root_cull[i];
     if (sp.finite()) {
       // FP32 copy: centre to nearest (its rounding is covered by the kernel's margin, which scales with
@@ -1167,14 +1214,14 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};
     }
   }
-  // Sorted by kind for the kernel's root loop (trace() phase 2 runs one kind at a time): planes, spheres, cubes, the
+  // Sorted by kind for the kernel's root loop (trace() phase 2 runs one kind at a time): spheres, planes, cubes, the
   // rest; World.objects order inside a kind.  The record carries everything that depends on the object's identity
   // (depth-first leaf index, material), so the table order is free.
   auto klass = [&](const RootRec& R) -> int {
     if (R.kind_flags & RTC_ROOT_IS_GROUP) return 3;
     switch (R.kind_flags & 0xFFu) {
-      case RTC_PLANE: return 0;
-      case RTC_SPHERE: return 1;
+      case RTC_SPHERE: return 0;  // (first: the head of the table is what the root loop rejects by bounding SPHERES - a sphere's own
+      case RTC_PLANE: return 1;   //  outline - and everything behind it by world boxes: trace())
       case RTC_CUBE: return 2;
       default: return 3;
     }
@@ -1184,18 +1231,36 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
   std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return klass(root_recs[a]) < klass(root_recs[b]); });
   std::vector<RootRec> recs2(d.n_roots);
   std::vector<RootCull> cull2(root_cull.size(), RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
+  std::vector<RootBox> box2(T.root_box.size(), RootBox{});
   std::vector<float> weight2(T.root_weight.size(), 0.0f);
   T.n_root_kind[0] = T.n_root_kind[1] = T.n_root_kind[2] = 0;
   for (uint32_t i = 0; i < d.n_roots; ++i) {
     recs2[i] = root_recs[perm[i]];
     cull2[i] = root_cull[perm[i]];
+    box2[i] = T.root_box[perm[i]];
     weight2[i] = T.root_weight[perm[i]];
     const int k = klass(recs2[i]);
     if (k < 3) T.n_root_kind[k]++;
   }
   root_recs.swap(recs2);
   root_cull.swap(cull2);
+  T.root_box.swap(box2);
   T.root_weight.swap(weight2);
+  // the reference's "parallel" rule for cubes (cube.zig:28-35): the largest scale of any cube of the scene, top-level or
+  // inside a group (Frobenius norm of its forward transform: at least its largest singular value)
+  double cube_scale = 0.0;
+  for (uint32_t l = 0; l < d.n_leaves; ++l) {
+    if (d.leaf_kind[l] != RTC_CUBE) continue;
+    double M[12];
+    if (!forwardOf(d.xf_inv + 16ull * d.leaf_xform[l], M)) {
+      cube_scale = INFINITY;
+      break;
+    }
+    double fro = 0.0;
+    for (int k = 0; k < 3; ++k) fro += M[4 * k] * M[4 * k] + M[4 * k + 1] * M[4 * k + 1] + M[4 * k + 2] * M[4 * k + 2];
+    cube_scale = std::fmax(cube_scale, std::sqrt(fro));
+  }
+  T.cull_par = static_cast<float>(std::fmin(1.2e-5 * cube_scale, 1.0e30));
 }
 
 // The tables that are the caller's arrays in the kernel's element layout.
@@ -1764,6 +1829,17 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     root_cull_pairs[i].r2 = {a.r2, b.r2};
   }
   HIP_TRY(s->tab->root_cull.upload(root_cull_pairs));
+  std::vector<RootBoxPair> root_box_pairs(T.root_box.size() / 2u);
+  for (size_t i = 0; i < root_box_pairs.size(); ++i) {
+    const RootBox &a = T.root_box[2 * i], &b = T.root_box[2 * i + 1];
+    for (int k = 0; k < 3; ++k) {
+      root_box_pairs[i].lo[k] = {a.lo[k], b.lo[k]};
+      root_box_pairs[i].hi[k] = {a.hi[k], b.hi[k]};
+    }
+    root_box_pairs[i].line_only = {a.line_only, b.line_only};
+    root_box_pairs[i].pad_ = {0.0f, 0.0f};
+  }
+  HIP_TRY(s->tab->root_box.upload(root_box_pairs));
   HIP_TRY(s->tab->root_weight.upload(T.root_weight));
   HIP_TRY(s->tab->kids.upload(kids));
   HIP_TRY(s->tab->leaf_meta.upload(leaf_meta));
@@ -1844,10 +1920,19 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
     if (d.roots[i] & RTC_CHILD_NODE_BIT) s->flat_kernel = s->simple_kernel = false;
     else if (d.leaf_kind[d.roots[i]] > RTC_CUBE) s->simple_kernel = false;
   }
+  {  // spheres against cubes among the top-level objects (planes have no bound either way)
+    uint32_t n_spheres = 0, n_cubes = 0;
+    for (uint32_t i = 0; i < d.n_roots; ++i) {
+      if (d.roots[i] & RTC_CHILD_NODE_BIT) continue;
+      n_spheres += d.leaf_kind[d.roots[i]] == RTC_SPHERE;
+      n_cubes += d.leaf_kind[d.roots[i]] == RTC_CUBE;
+    }
+    s->box_cull = n_cubes > n_spheres;
+  }
   s->simple3_ok = s->simple_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
-                  d.n_patterns <= RTC_LDS3_PATTERNS;
+                  d.n_patterns <= RTC_LDS3_PATTERNS && d.n_lights <= RTC_LDS3_LIGHTS;
   s->general3_ok = RTC_BVH8 && !s->flat_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
-                   d.n_patterns <= RTC_LDS3_PATTERNS && d.n_lights <= RTC_LDS_LIGHTS;
+                   d.n_patterns <= RTC_LDS3_PATTERNS && d.n_lights <= RTC_LDS3_LIGHTS;
   HIP_TRY(s->tab->light.upload(light));
   if (const int st = initLaunchState(s); st != RTC_OK) return st;
   s->max_trav_stack = traits.max_stack;
@@ -1875,6 +1960,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   DevScene& D = s->dev;
   D.root_recs = s->tab->root_recs.p;
   D.root_cull = s->tab->root_cull.p;
+  D.root_box = s->tab->root_box.p;
   D.root_weight = s->tab->root_weight.p;
   D.roots = s->tab->roots.p;
   D.leaf_meta = s->tab->leaf_meta.p;
@@ -1911,8 +1997,10 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   D.n_materials = d.n_materials;
   D.n_patterns = d.n_patterns;
   D.cull_cmax = cull_cmax;
-  D.n_root_planes = T.n_root_kind[0];
-  D.n_root_spheres = T.n_root_kind[1];
+  D.cull_bmax = T.cull_bmax;
+  D.cull_par = T.cull_par;
+  D.n_root_spheres = T.n_root_kind[0];
+  D.n_root_planes = T.n_root_kind[1];
   D.n_root_cubes = T.n_root_kind[2];
   return RTC_OK;
 }
@@ -2005,6 +2093,7 @@ int rtc_scene_clone(const rtc_scene* src, rtc_scene** out) {
   s->simple_kernel = src->simple_kernel;
   s->flat_kernel = src->flat_kernel;
   s->simple3_ok = src->simple3_ok;
+  s->box_cull = src->box_cull;
   s->max_trav_stack = src->max_trav_stack;
   s->n_cus = src->n_cus;
   s->blocks_per_cu_lds = src->blocks_per_cu_lds;
@@ -2340,6 +2429,7 @@ int rtc_diag_build_tables(const rtc_scene_desc* desc, uint64_t* digest, double* 
     vec(tables.bvh_leaves);
     vec(tables.root_recs);
     vec(tables.root_cull);
+    vec(tables.root_box);
     vec(tables.root_always);
     vec(tables.leaf_meta);
     vec(tables.leaf_parent);

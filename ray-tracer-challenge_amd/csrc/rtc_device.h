@@ -60,6 +60,19 @@ struct RootCullPair {
   typedef float Pair __attribute__((ext_vector_type(2)));
   Pair cx, cy, cz, r2;  // centre rounded to nearest, r2 rounded UP; phase 1 of the root loop is FP32
 };
+// The same bound as an axis-aligned WORLD-space box (round 5): what the render kernels' root loop tests since the box of an
+// axis-aligned cube IS the cube (its bounding sphere lets half of the rays through that miss it), a group's box is far
+// tighter than the sphere around it, and the interval a ray spends inside a box also says whether the root lies behind
+// the origin or beyond a shadow ray's light.  Two roots per record, plane by plane: [lo_x][lo_y][lo_z][hi_x][hi_y][hi_z],
+// each a pair of floats (root 0, root 1) - a lane reads the NEAR and the FAR plane of an axis from the offsets its ray's
+// direction signs pick (no selects, no min / max), and the two roots are the two halves of packed FP32 FMAs.  Planes
+// rounded outward; no finite bound: -3e38 / +3e38 (always kept); table padding: +3e38 / -3e38 (never kept).
+struct RootBoxPair {  // 64 B
+  typedef float Pair __attribute__((ext_vector_type(2)));
+  Pair lo[3], hi[3];
+  Pair line_only;  // != 0: entries of this root may lie outside its box (a cone in a group): only "the line misses the box" culls it
+  Pair pad_;
+};
 struct alignas(16) RootRec {
   double inv[12];        // rows 0..2 of the leaf's inverse; a group: a copy of the root Bvh8Node of its candidate BVH (80 bytes: a walk's first node comes from this record - in LDS - not from the node table)
   double ymin, ymax;     // cylinder / cone
@@ -88,7 +101,8 @@ struct alignas(16) RootRec {
 // and the third of the persistent work-groups starts when the others are done - cover 0.55 -> 0.75 ms)
 #define RTC_LDS3_ROOTS 32
 #define RTC_LDS3_MATERIALS 16
-#define RTC_LDS3_PATTERNS 22
+#define RTC_LDS3_PATTERNS 20
+#define RTC_LDS3_LIGHTS 8
 #define RTC_LDS_LIGHTS 16
 
 struct DevPattern {      // 144 B
@@ -192,7 +206,8 @@ struct __attribute__((aligned(32))) CsgRec {
 
 struct DevScene {
   const RootRec* __restrict__ root_recs;
-  const RootCullPair* __restrict__ root_cull;  // (n_roots + 3) / 4 * 2 pairs, padded with never-kept spheres
+  const RootCullPair* __restrict__ root_cull;  // (n_roots + 3) / 4 * 2 pairs, padded with never-kept spheres (rtc_estimate_kernel)
+  const RootBoxPair* __restrict__ root_box;    // the same roots' world boxes: what the render kernels' root loop tests
   const float* __restrict__ root_weight;       // per root: what a chunk that looks at it costs (rtc_estimate_kernel), in packer ticks
   const uint32_t* __restrict__ roots;
   const uint4* __restrict__ leaf_meta;
@@ -224,10 +239,13 @@ struct DevScene {
   const uint32_t* __restrict__ kids;
   const double* __restrict__ light;     // [n_lights][6]
   uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
-  // root_recs / root_cull are sorted by kind: [planes][spheres][cubes][every other leaf kind and the groups] (the
+  // root_recs / root_cull / root_box are sorted by kind: [spheres][planes][cubes][every other leaf kind and the groups] (the
   // order inside a kind is World.objects order; nothing depends on the table order, see trace())
   uint32_t n_root_planes, n_root_spheres, n_root_cubes;
   float cull_cmax;  // max over bounded roots of |centre|: scale of the FP32 rounding margin
+  float cull_bmax;  // max |coordinate| of any finite root box: scale of the box test's FP32 margin
+  float cull_par;   // 1.2e-5 x the largest scale of any cube in the scene: the reference's "parallel" rule (cube.zig:28-35 ignores a
+                    // direction component below 1e-5 in object space, so an entry may lie that far - times the ray parameter - outside the cube)
   float bvh_mag;    // max |coordinate| of any finite BVH box: scale of the FP32 traversal margin
   uint32_t chain_nested;  // every reference Group box lies inside its parent's: a ray that passes the innermost passes all
 };

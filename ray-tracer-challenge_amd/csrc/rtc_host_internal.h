@@ -104,6 +104,7 @@ struct SceneTables {
   DevBuf<uint32_t> roots, kids;
   DevBuf<RootRec> root_recs;
   DevBuf<RootCullPair> root_cull;
+  DevBuf<RootBoxPair> root_box;
   DevBuf<float> root_weight;
   DevBuf<uint4> leaf_meta;
   DevBuf<double> xf, tri, trin, node_box, light;
@@ -145,6 +146,7 @@ struct rtc_scene {
   uint32_t csg_needed = 0;         // what the last checked frame said its longest csg list needed (0: no csg list ran out)
   uint32_t max_trav_stack = 0;
   // ---- the general kernel at two or at three waves per SIMD: measured, not guessed (launch(), KernelTune)
+  bool box_cull = false;           // a simple world with more cubes than spheres at top level: its kernels reject roots by world boxes (rtc_render_kernel_simple_b / _simple3_b)
   bool general3_ok = false;        // a world with groups, no csg / texture maps, whose tables fit the three-wave kernel's LDS
   uint32_t blocks_per_cu_general3 = 1;
   bool use_three_waves = false;    // the three-wave form of the world's kernel (rtc_render_kernel3 / _simple3 at mid sizes): what the handle's last finished trial DECIDED (clones inherit this, nothing else)

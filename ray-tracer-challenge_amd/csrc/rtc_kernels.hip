@@ -118,6 +118,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #ifndef RTC_ROOT_NODE_IN_REC
 #define RTC_ROOT_NODE_IN_REC 1  // a group's World.objects record carries a copy of the root node of its candidate BVH (traverse_bvh8)
 #endif
+#ifndef RTC_MAIL_WIDE
+#define RTC_MAIL_WIDE 1
+#endif
 #ifndef RTC_LB2
 #define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -1058,6 +1061,10 @@ __device__ __forceinline__ RayF ray_f32(const Ray& r, float cmax) {
 }
 
 typedef float Float2 __attribute__((ext_vector_type(2)));
+struct CullTables {  // what phase 1 of the root loop reads (in LDS where the world's tables fit): one of the two
+  const RootCullPair* __restrict__ sphere;
+  const RootBoxPair* __restrict__ box;
+};
 
 // Phase 1 of the root loop for TWO roots: the arithmetic runs as packed FP32 (v_pk_fma_f32 & co: one instruction per
 // pair of roots), only the comparisons are per root.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.
@@ -1088,6 +1095,81 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
   return kept;
 }
 
+// ---- the same rejection with the roots' WORLD-SPACE BOXES (RootBoxPair, rtc_device.h; trace<BOX>, round 5).  A ray's parameter at a plane x = p is (p - o) / d = p * (1 / d) + (-o / d): one FMA per plane with the
+// per-ray part computed once, two roots per packed FMA; which of a box's two planes per axis is the near one is the
+// ray's business (its direction signs pick the offsets the planes are read from).  The interval [max of the near
+// parameters, min of the far ones] is where the LINE is inside the box: empty - no entry at all; entirely outside the
+// range in which an entry can matter to the visitor (behind the origin for the closest hit and for shadows, beyond the
+// light for shadows, in front of the origin for the containers pass) - none that matters.  Margins: every near
+// parameter is lowered and every far one raised by (delta + par) * |1 / d|, delta = 1e-6 (|o| + largest box coordinate)
+// for the FP32 arithmetic (see traverse_bvh8), par for the reference's "parallel" rule (DevScene::cull_par): a cube
+// ignores a direction component below 1e-5 in its object space, so one of its entries can lie up to 1e-5 x the ray
+// parameter x the cube's scale outside the cube along that axis.  NaNs keep (every comparison is "is it outside").
+struct RayB {
+  float ix, iy, iz;                       // 1 / d (a component of zero: 1e30 of its sign)
+  float cnx, cny, cnz, cfx, cfy, cfz;     // -o / d - margin (near planes), -o / d + margin (far planes)
+  uint32_t onx, ony, onz, ofx, ofy, ofz;  // byte offsets of the near / far planes' pairs in a RootBoxPair
+  float t_lo, t_hi;                       // the parameter range in which an entry can matter to the visitor
+};
+
+template <class V>
+__device__ __forceinline__ RayB ray_box(const Ray& r, const DevScene& S, const V& vis) {
+  RayB b;
+  const float ox = static_cast<float>(r.ox), oy = static_cast<float>(r.oy), oz = static_cast<float>(r.oz);
+  float dx = static_cast<float>(r.dx), dy = static_cast<float>(r.dy), dz = static_cast<float>(r.dz);
+  dx = __builtin_copysignf(fmaxf(__builtin_fabsf(dx), 1e-30f), dx);
+  dy = __builtin_copysignf(fmaxf(__builtin_fabsf(dy), 1e-30f), dy);
+  dz = __builtin_copysignf(fmaxf(__builtin_fabsf(dz), 1e-30f), dz);
+  b.ix = __builtin_amdgcn_rcpf(dx);
+  b.iy = __builtin_amdgcn_rcpf(dy);
+  b.iz = __builtin_amdgcn_rcpf(dz);
+  const float reach = fmaxf(fmaxf(__builtin_fabsf(ox), __builtin_fabsf(oy)), __builtin_fabsf(oz)) + S.cull_bmax;
+  const float slack = 1e-6f * reach + S.cull_par * (4.0f * reach);  // (4 x reach: no entry of a bounded root is further along a ray of about unit length)
+  const float mx = slack * __builtin_fabsf(b.ix), my = slack * __builtin_fabsf(b.iy), mz = slack * __builtin_fabsf(b.iz);
+  const float cx = -ox * b.ix, cy = -oy * b.iy, cz = -oz * b.iz;
+  b.cnx = cx - mx;
+  b.cny = cy - my;
+  b.cnz = cz - mz;
+  b.cfx = cx + mx;
+  b.cfy = cy + my;
+  b.cfz = cz + mz;
+  const bool nx = dx < 0.0f, ny = dy < 0.0f, nz = dz < 0.0f;
+  b.onx = nx ? 24u : 0u;
+  b.ofx = nx ? 0u : 24u;
+  b.ony = ny ? 32u : 8u;
+  b.ofy = ny ? 8u : 32u;
+  b.onz = nz ? 40u : 16u;
+  b.ofz = nz ? 16u : 40u;
+  vis.box_limits(b.t_lo, b.t_hi);
+  return b;
+}
+
+// Two roots.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.
+template <class V, bool GROUPS>
+__device__ __forceinline__ uint32_t roots_kept_box(const char* __restrict__ pair, const RayB& rb) {
+  const Float2 nx = *reinterpret_cast<const Float2*>(pair + rb.onx), ny = *reinterpret_cast<const Float2*>(pair + rb.ony),
+               nz = *reinterpret_cast<const Float2*>(pair + rb.onz);
+  const Float2 fx = *reinterpret_cast<const Float2*>(pair + rb.ofx), fy = *reinterpret_cast<const Float2*>(pair + rb.ofy),
+               fz = *reinterpret_cast<const Float2*>(pair + rb.ofz);
+  const Float2 tnx = __builtin_elementwise_fma(nx, Float2(rb.ix), Float2(rb.cnx)), tny = __builtin_elementwise_fma(ny, Float2(rb.iy), Float2(rb.cny)),
+               tnz = __builtin_elementwise_fma(nz, Float2(rb.iz), Float2(rb.cnz));
+  const Float2 tfx = __builtin_elementwise_fma(fx, Float2(rb.ix), Float2(rb.cfx)), tfy = __builtin_elementwise_fma(fy, Float2(rb.iy), Float2(rb.cfy)),
+               tfz = __builtin_elementwise_fma(fz, Float2(rb.iz), Float2(rb.cfz));
+  uint32_t kept = 0u;
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float tn = fmaxf(fmaxf(tnx[e], tny[e]), tnz[e]), tf = fminf(fminf(tfx[e], tfy[e]), tfz[e]);
+    bool culled = fmaxf(tn, rb.t_lo) > fminf(tf, rb.t_hi);  // the line misses the box, or meets it only where no entry matters
+    if constexpr (GROUPS) {
+      // (entries of this root may lie outside its box - a cone in a group: only the line's missing the box holds)
+      const float line_only = (*reinterpret_cast<const Float2*>(pair + 48))[e];
+      culled = line_only != 0.0f ? tn > tf : culled;
+    }
+    kept |= culled ? 0u : (1u << e);
+  }
+  return kept;
+}
+
 // World.intersect's loop over World.objects (world.zig:74), two-phase so that no load depends on a
 // previous one and no lane waits for roots only its neighbours need:
 //   phase 1 streams the 16-byte FP32 bounding spheres of up to 64 roots (wave-uniform addresses) and
@@ -1103,23 +1185,42 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 // group hold the same ray; lane `member` of the group takes every stride-th batch of four roots through both phases, and
 // the group's visitors are merged at the end: what one lane does in five batches and three exact tests in a row, eight
 // lanes do in one of each - the instruction stream of a wave with few rays left is what bounds it.  (0, 1): one lane, all.
-template <bool CSG, int WORLD, class V, int TRAV = RTC_LDS_TRAV>
+template <bool CSG, int WORLD, class V, int TRAV = RTC_LDS_TRAV, bool BOX = true>
 __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restrict__ recs,
-                                      const RootCullPair* __restrict__ cull, const Ray& ray, V& vis, unsigned& overflow,
+                                      const CullTables& cull, const Ray& ray, V& vis, unsigned& overflow,
                                       uint32_t* lds_stack, const uint32_t member = 0u, const uint32_t stride = 1u) {
   constexpr bool SIMPLE = WORLD == 2, FLAT = WORLD >= 1;
-  const RayF rf = ray_f32(ray, S.cull_cmax);
+  // Phase 1 rejects a root by its world BOX (BOX: every kernel that walks groups, the flat kernels, and the simple kernels
+  // of worlds that are mostly cubes) or by its bounding SPHERE (the simple kernels of worlds that are mostly spheres): a
+  // cube's box is the cube where its sphere lets through half of the rays that miss it, a group's box is far tighter than
+  // the sphere around it, and a box says whether a root lies beyond a shadow ray's light - but a sphere's bounding sphere
+  // is its own outline, which its box is 27 % wider than.  Measured, boxes against spheres: cover 0.497 -> 0.483 ms,
+  // cubes 0.803 -> 0.748, groups 0.879 -> 0.745, csg_demo 2.49 -> 2.34, dragons 4K 1.74 -> 1.70, cylinders 0.242 -> 0.230;
+  // reflection_and_refraction (seven spheres in a room of planes) 1.664 -> 1.738, skybox_demo 0.261 -> 0.272.  Both tests
+  // in one kernel - spheres by spheres, the rest by boxes - lose to either (cover 0.496, reflection_and_refraction 1.785:
+  // the three-wave kernel has no registers for two kinds of ray set-up): rtc_scene_create picks the kernel by what the
+  // world is made of (profiles/r05/root_cull_boxes.md).
+  const auto rf = [&]() {
+    if constexpr (BOX) return ray_box(ray, S, vis);
+    else return ray_f32(ray, S.cull_cmax);
+  }();
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
     unsigned long long mine = 0ull;
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
     for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
-      const RootCullPair p0 = cull[(base + i) >> 1], p1 = cull[((base + i) >> 1) + 1u];
-      const unsigned long long k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
+      unsigned long long k;
+      if constexpr (BOX) {
+        const char* const p0 = reinterpret_cast<const char*>(cull.box + ((base + i) >> 1));
+        k = roots_kept_box<V, !FLAT>(p0, rf) | (roots_kept_box<V, !FLAT>(p0 + sizeof(RootBoxPair), rf) << 2);
+      } else {
+        const RootCullPair p0 = cull.sphere[(base + i) >> 1], p1 = cull.sphere[((base + i) >> 1) + 1u];
+        k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
+      }
       mine |= k << i;
     }
     if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
-    // Phase 2, one kind at a time.  The table is sorted [planes][spheres][cubes][everything else] (rtc_scene_create), so
+    // Phase 2, one kind at a time.  The table is sorted [spheres][planes][cubes][everything else] (rtc_scene_create), so
     // a kind is a range of bits.  A wave that walks its lanes' survivors in table order runs the plane, the sphere AND
     // the cube code in almost every step (some lane holds one of each); kind by kind it runs each test's code only as
     // often as the lane with the most survivors of that kind needs it, and the compiler drops what a kind does not use
@@ -1148,9 +1249,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     // cover 0.730 -> 0.698; in the kernels that also carry the group traversal the three extra loops cost the mesh
     // scenes 1-2 % and their worlds have few top-level objects.)
     if constexpr (FLAT) {
-      const uint32_t k1 = S.n_root_planes, k2 = k1 + S.n_root_spheres, k3 = k2 + S.n_root_cubes;
-      leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(0u, k1));
-      leaves_of_kind(std::integral_constant<uint32_t, 0u>{}, mine & range(k1, k2));
+      const uint32_t k1 = S.n_root_spheres, k2 = k1 + S.n_root_planes, k3 = k2 + S.n_root_cubes;
+      leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(k1, k2));
+      leaves_of_kind(std::integral_constant<uint32_t, 0u>{}, mine & range(0u, k1));
       leaves_of_kind(std::integral_constant<uint32_t, 2u>{}, mine & range(k2, k3));
       if constexpr (SIMPLE) continue;  // (a simple world has nothing else)
       mine &= range(k3, S.n_roots);    // the other leaf kinds: cylinders, cones, triangles
@@ -1879,7 +1980,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // reflection / refraction children (one continues in registers, the other goes to the lane's stack).
 // Exit: the counter runs past n_chunks (`drained`) and no lane holds a ray; every wave reaches it.
 // ------------------------------------------------------------------------------------------
-template <bool LDS, bool CSG, int WORLD = 0, int WAVES = 2, bool COOP = false>
+template <bool LDS, bool CSG, int WORLD = 0, int WAVES = 2, bool COOP = false, bool BOX = true>
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
@@ -1905,12 +2006,19 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   constexpr int N_ROOTS = WAVES == 3 ? RTC_LDS3_ROOTS : RTC_LDS_ROOTS, N_MATS = WAVES == 3 ? RTC_LDS3_MATERIALS : RTC_LDS_MATERIALS,
                 N_PATS = WAVES == 3 ? RTC_LDS3_PATTERNS : RTC_LDS_PATTERNS;
   __shared__ RootRec lds_recs[LDS ? N_ROOTS : 1];
-  __shared__ RootCullPair lds_cull[LDS ? N_ROOTS / 2 : 1];
+  __shared__ RootCullPair lds_cull[(LDS && !BOX) ? N_ROOTS / 2 : 1];  // phase 1 of the root loop: bounding spheres ...
+  __shared__ RootBoxPair lds_box[(LDS && BOX) ? N_ROOTS / 2 : 1];     // ... or world boxes (trace())
   __shared__ DevMaterial lds_mat[LDS ? N_MATS : 1];
   __shared__ DevPattern lds_pat[LDS ? N_PATS : 1];
-  __shared__ double lds_light[LDS ? 6 * RTC_LDS_LIGHTS : 1];
+  constexpr int N_LIGHTS = WAVES == 3 ? RTC_LDS3_LIGHTS : RTC_LDS_LIGHTS;
+  __shared__ double lds_light[LDS ? 6 * N_LIGHTS : 1];
   // per wave: which pending ray (donor lane, level of its stack) an idle lane takes over, and the canvas pixel it belongs to
+  // (8 bytes an entry: donor lane | level << 8, canvas pixel - a launch has at most 2^32 pixels, checked in launch())
+#if RTC_MAIL_WIDE
   __shared__ uint4 lds_mail[4][64];
+#else
+  __shared__ uint2 lds_mail[4][64];
+#endif
   // The first LDS_LEVELS levels of every lane's stack of pending rays ([wave][level][quarter][lane], see
   // store_pending_lds); deeper levels are in the buffer in memory (DevPixelMap::ray_stack).  A lane's stack is empty
   // again after almost every pixel, so nearly every push and pop stays here: the pops no longer wait for memory and the
@@ -1928,7 +2036,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   constexpr int TRAV = (WAVES == 3 && RTC_BVH8) ? 2 : RTC_LDS_TRAV;
   __shared__ uint32_t lds_trav[FLAT ? 1 : 4][FLAT ? 1 : TRAV][RTC_BVH8 ? 128 : 64];
   const RootRec* __restrict__ recs = S.root_recs;
-  const RootCullPair* __restrict__ cull = S.root_cull;
+  CullTables cull{S.root_cull, S.root_box};
   const DevMaterial* __restrict__ mats = S.mat;
   const DevPattern* __restrict__ pats = S.pat;
   const double* __restrict__ lights = S.light;
@@ -1939,13 +2047,15 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
     };
     stage(lds_recs, S.root_recs, S.n_roots * (sizeof(RootRec) / 8u));
-    stage(lds_cull, S.root_cull, ((S.n_roots + 3u) & ~3u) / 2u * (sizeof(RootCullPair) / 8u));
+    if constexpr (BOX) stage(lds_box, S.root_box, ((S.n_roots + 3u) & ~3u) / 2u * (sizeof(RootBoxPair) / 8u));
+    else stage(lds_cull, S.root_cull, ((S.n_roots + 3u) & ~3u) / 2u * (sizeof(RootCullPair) / 8u));
     stage(lds_mat, S.mat, S.n_materials * (sizeof(DevMaterial) / 8u));
     stage(lds_pat, S.pat, S.n_patterns * (sizeof(DevPattern) / 8u));
     stage(lds_light, S.light, S.n_lights * 6u);
     __syncthreads();
     recs = lds_recs;
-    cull = lds_cull;
+    cull.sphere = lds_cull;
+    cull.box = lds_box;
     mats = lds_mat;
     pats = lds_pat;
     lights = lds_light;
@@ -1996,7 +2106,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * map.ray_stack_levels * 64u + lane;
   const int stack_cap = static_cast<int>(map.ray_stack_levels);
   int sp = 0, base = 0;
+#if RTC_MAIL_WIDE
   uint4* const mailbox = lds_mail[threadIdx.x >> 6];
+#else
+  uint2* const mailbox = lds_mail[threadIdx.x >> 6];
+#endif
   Quad2* const pend_wave = &lds_pend[threadIdx.x >> 6][0][0][0];  // level l of lane x: pend_wave + l * 256 + x
   // (the buffer in memory keeps a slot for every level; the first LDS_LEVELS of them are never touched)
   auto push_level = [&](int level, const Pending& p) {
@@ -2081,7 +2195,11 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         const uint32_t irank = bits_below(imask);
         const uint32_t drank = bits_below(dmask);
         if (donor && drank < pairs) {
+#if RTC_MAIL_WIDE
           mailbox[drank] = uint4{lane, static_cast<uint32_t>(base++), static_cast<uint32_t>(out_index), static_cast<uint32_t>(out_index >> 32)};
+#else
+          mailbox[drank] = uint2{lane | (static_cast<uint32_t>(base++) << 8), static_cast<uint32_t>(out_index)};
+#endif
           if (!shared) {
             // First hand-out of this pixel: from here on its shares are ADDED, so it starts from zero.  The canvas is
             // not cleared per launch (a pixel nobody shares is stored once); the store is at L2 before the taker —
@@ -2100,9 +2218,15 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (idle && irank < pairs) {
           // (the donor's slot is read here, in program order before any lane of the wave can push into it again)
+#if RTC_MAIL_WIDE
           const uint4 m = mailbox[irank];
           cur = load_level(static_cast<int>(m.y), m.x);
           out_index = static_cast<size_t>(m.z) | (static_cast<size_t>(m.w) << 32);
+#else
+          const uint2 m = mailbox[irank];
+          cur = load_level(static_cast<int>(m.x >> 8), m.x & 63u);
+          out_index = static_cast<size_t>(m.y);
+#endif
           have_cur = true;
           has_pixel = true;
           shared = true;
@@ -2313,7 +2437,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_COUNT(0);
     {
       RTC_HIST_BEGIN();
-      trace<CSG, WORLD, ClosestVisitor, TRAV>(S, recs, cull, ray, hv, it_overflow, trav_stack, member, stride);
+      trace<CSG, WORLD, ClosestVisitor, TRAV, BOX>(S, recs, cull, ray, hv, it_overflow, trav_stack, member, stride);
       RTC_HIST_END(0);
     }
     RTC_STAMP(2);
@@ -2367,7 +2491,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       RTC_COUNT(4);
       {
         RTC_HIST_BEGIN();
-        trace<CSG, WORLD, BehindVisitor, TRAV>(S, recs, cull, ray, bv, it_overflow, trav_stack, member, stride);
+        trace<CSG, WORLD, BehindVisitor, TRAV, BOX>(S, recs, cull, ray, bv, it_overflow, trav_stack, member, stride);
         RTC_HIST_END(2);
       }
       RTC_STAMP(6);
@@ -2524,7 +2648,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
           RTC_COUNT(2);
           {
             RTC_HIST_BEGIN();
-            trace<CSG, WORLD, ShadowVisitor, TRAV>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
+            trace<CSG, WORLD, ShadowVisitor, TRAV, BOX>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
             RTC_HIST_END(1);
           }
           RTC_STAMP(4);
@@ -2802,7 +2926,14 @@ rtc_render_kernel_bigworld(const DevScene S, const DevCamera cam, const DevPixel
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                          double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true, false, 2, 2, true>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, false, 2, 2, true, false>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
+// ... and the same kernel with the root loop's first phase on world boxes: the simple worlds that are mostly cubes (trace()).
+extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
+rtc_render_kernel_simple_b(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                           double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, false, 2, 2, true, true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // The `simple` kernel at THREE waves per SIMD (168 VGPRs; about a hundred values go to scratch memory, nearly all of them
@@ -2814,7 +2945,13 @@ rtc_render_kernel_simple(const DevScene S, const DevCamera cam, const DevPixelMa
 extern "C" __global__ void __launch_bounds__(256, 3)
 rtc_render_kernel_simple3(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                           double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true, false, 2, 3>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, false, 2, 3, false, false>(S, cam, map, max_depth, out, stats, next_stats);
+}
+
+extern "C" __global__ void __launch_bounds__(256, 3)
+rtc_render_kernel_simple3_b(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
+                            double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  render_body<true, false, 2, 3, false, true>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // The general kernel at THREE waves per SIMD (168 VGPRs, ~195 of them spilled; the small LDS tables of the three-wave
@@ -2844,7 +2981,7 @@ rtc_render_kernel_ext(const DevScene S, const DevCamera cam, const DevPixelMap m
 extern "C" __global__ void __launch_bounds__(256, RTC_LB2)
 rtc_render_kernel_simple_ext(const DevScene S, const DevCamera cam, const DevPixelMap map, const uint32_t max_depth,
                              double* __restrict__ out, DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
-  render_body<true, true, 2>(S, cam, map, max_depth, out, stats, next_stats);
+  render_body<true, true, 2, 2, false, false>(S, cam, map, max_depth, out, stats, next_stats);
 }
 
 // Worlds without groups or csg but with other leaf kinds at top level (cylinders, cones, triangles: cylinders.json,
