@@ -26,8 +26,9 @@ extern "C" {
  * its short end, ...; 0 longest first throughout), "measure_every" (a view that moves in small steps is measured
  * every n-th frame; 1), "inflight_chunks_per_wave" (a launch of a scene with several handles - frames in flight -
  * runs on at most one wave per this many chunks; 3, 0 = no cap), "build_threads" (threads rtc_scene_create builds the
- * groups' candidate BVHs with, one top-level group each; 0 = the library's choice, at most 8; the tables do not depend
- * on it).
+ * groups' candidate BVHs with, one top-level group each; 0 = the library's choice, at most 16; the tables do not depend
+ * on it), "box_cull" (read at create: a world of top-level spheres / planes / cubes runs the kernels whose root loop
+ * rejects by world boxes - 1 - or by bounding spheres - 0; < 0: boxes if it has more cubes than spheres).
  * RTC_ERR_INVALID_ARGUMENT for a name the library does not know.
  * (The library reads no environment variables.)
  */

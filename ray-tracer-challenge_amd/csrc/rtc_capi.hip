@@ -1928,6 +1928,7 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
       n_cubes += d.leaf_kind[d.roots[i]] == RTC_CUBE;
     }
     s->box_cull = n_cubes > n_spheres;
+    if (rtcOptions().box_cull >= 0.0) s->box_cull = rtcOptions().box_cull != 0.0;  // (tests and fuzzers reach either form on any world)
   }
   s->simple3_ok = s->simple_kernel && !ext_kernel && d.n_roots <= RTC_LDS3_ROOTS && d.n_materials <= RTC_LDS3_MATERIALS &&
                   d.n_patterns <= RTC_LDS3_PATTERNS && d.n_lights <= RTC_LDS3_LIGHTS;
@@ -2452,7 +2453,7 @@ int rtc_set_option(const char* name, double value) {
                {"sched_tmin", &o.sched_tmin}, {"bvh_leaf", &o.bvh_leaf}, {"bvh_one_axis", &o.bvh_one_axis},
                {"bvh_check", &o.bvh_check}, {"host_bands", &o.host_bands}, {"waves3", &o.waves3},
                {"measure_every", &o.measure_every}, {"sched_mix", &o.sched_mix},
-               {"inflight_chunks_per_wave", &o.inflight_chunks_per_wave}, {"build_threads", &o.build_threads}};
+               {"inflight_chunks_per_wave", &o.inflight_chunks_per_wave}, {"build_threads", &o.build_threads}, {"box_cull", &o.box_cull}};
   for (const auto& e : table)
     if (std::strcmp(e.name, name) == 0) {
       e.slot->set(value);

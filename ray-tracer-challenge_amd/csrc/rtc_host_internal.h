@@ -64,6 +64,7 @@ struct RtcOptions {
   RtcOption inflight_chunks_per_wave{3.0};  // a launch of a scene with frames in flight runs on at most one wave per this many chunks (0: no cap)
   RtcOption measure_every{1.0};        // a moving view is measured (and its schedule re-packed) every this many frames (see updateSchedule)
   RtcOption host_bands{0.0};           // bands rtc_render cuts a frame into (copy of band i under the render of band i + 1); 0: by size
+  RtcOption box_cull{-1.0};            // a simple world's kernels reject roots by world boxes (1) or bounding spheres (0); < 0: boxes if it has more cubes than spheres
   RtcOption build_threads{0.0};        // threads of rtc_scene_create's candidate-BVH build (one top-level group each); 0: as many as the host allows, up to 8
 };
 inline RtcOptions& rtcOptions() {

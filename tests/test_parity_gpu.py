@@ -987,6 +987,101 @@ def test_shapes_that_cast_no_shadow_inside_groups(rtc):
     assert np.abs(ob.OracleScene(hs2.desc).render(cam, 5)[0] - want).max() > 1e-3
 
 
+@pytest.mark.parametrize("scene,w,h,depth", [("cover.json", 320, 180, 5), ("reflection_and_refraction.json", 240, 135, 8), ("cubes.json", 240, 135, 5),
+                                            ("fresnel.json", 150, 150, 5), ("xyz.json", 200, 120, 5)])
+def test_simple_worlds_on_boxes_and_on_spheres(rtc, scene, w, h, depth):
+    """A simple world renders the oracle's image and counters whichever form of its kernels runs: roots rejected by their
+    bounding spheres (rtc_render_kernel_simple / _simple3) or by their world boxes (_simple_b / _simple3_b) - forced
+    either way by option, at two and at three waves per SIMD."""
+    hs = rtc.HostScene.from_file(scene)
+    cam = hs.camera(w, h)
+    want, counters = ob.OracleScene(hs.desc).render(cam, depth)
+    seen = set()
+    for box in (0, 1):
+        for three in (1e9, 0):
+            rtc.set_option("box_cull", box)
+            rtc.set_option("simple3_min_chunks", three)
+            try:
+                gpu = rtc.GpuScene(hs.desc)
+                got = gpu.render(cam, depth)
+                st = gpu.stats()
+                seen.add(gpu.last_kernel_name())
+            finally:
+                rtc.set_option("box_cull", -1)
+                rtc.set_option("simple3_min_chunks", -1)
+            assert np.abs(got - want).max() < TOL, (scene, box, three)
+            assert [st["overflow"], st["secondary"], st["shadow_calls"]] == [0, counters["secondary"], counters["shadow"]], (scene, box, three)
+    assert seen == {"rtc_render_kernel_simple", "rtc_render_kernel_simple3", "rtc_render_kernel_simple_b", "rtc_render_kernel_simple3_b"}, seen
+
+
+def _grazing_cubes_scene(variant):
+    """Axis-aligned cubes whose faces, edges and corners lie exactly on pixel rays and on the shadow rays of a light, cubes
+    stretched so far that the reference's "parallel" rule (cube.zig:28-35: a direction component below 1e-5 in object space
+    is ignored) applies to ordinary rays, a rotated cube: what a box test that is tight on whole faces has to get right.
+    variant: "simple" (top-level cubes and planes), "flat" (+ a cylinder), "group" (everything inside one group)."""
+    import json
+    def cube(sx, sy, sz, tx, ty, tz, extra=None, **material):
+        o = {"type": {"cube": {}}, "transform": [{"scale": [sx, sy, sz]}] + (extra or []) + [{"translate": [tx, ty, tz]}],
+             "material": dict({"diffuse": 0.7, "specular": 0.2, "reflective": 0.2}, **material)}
+        return o
+    objs = [
+        cube(1, 1, 1, 1, 0, 0),                    # face x = 0: the image's centre column looks along it
+        cube(1, 1, 1, -1, 2, 3),                   # edge x = 0, y = 1 behind it
+        cube(0.5, 0.5, 0.5, 0, -1.5, -2),          # top face y = -1: the centre row's rays pass just above / along it
+        cube(200000, 0.5, 0.5, 0, 3.5, 6),         # stretched 2e5 along x: d_obj_x = d_x / 2e5 < 1e-5 for every ray - the parallel rule
+        cube(0.5, 200000, 0.5, -4, 0, 8),          # ... and along y
+        cube(1, 1, 1, 3, 1, 4, extra=[{"rotate-y": 0.7853981633974483}, {"rotate-x": 0.6154797086703874}]),   # a corner towards the camera
+        cube(2, 0.01, 2, 0, -3, 2, transparency=0.5, **{"refractive-index": 1.3}),   # a thin glass slab: entries 0.02 apart
+    ]
+    floor = {"type": {"plane": {}}, "transform": [{"translate": [0, -4, 0]}], "material": {"diffuse": 0.8, "specular": 0}}
+    if variant == "flat":
+        objs.append({"type": {"cylinder": {"min": -1, "max": 1, "closed": True}}, "transform": [{"translate": [-3, -2, 1]}]})
+    if variant == "group":
+        objs = [{"type": {"group": objs}}]
+    # lights: in the plane of the first cube's face x = 0 and of the slab's top face; ordinary
+    lights = [{"point-light": {"position": [0, 6, -3], "intensity": [0.5, 0.5, 0.5]}},
+              {"point-light": {"position": [5, -2.99, -6], "intensity": [0.3, 0.3, 0.3]}},
+              {"point-light": {"position": [-7, 8, -5], "intensity": [0.4, 0.4, 0.4]}}]
+    return json.dumps({"camera": {"width": 121, "height": 81, "field-of-view": 1.2, "from": [0, 0, -10], "to": [0, 0, 0], "up": [0, 1, 0]},
+                       "lights": lights, "objects": objs + [floor]})
+
+
+@pytest.mark.parametrize("variant,kernel", [("simple", "rtc_render_kernel_simple_b"), ("flat", "rtc_render_kernel_flat"), ("group", "rtc_render_kernel")])
+def test_rays_along_cube_faces(rtc, variant, kernel):
+    """The root loop rejects World.objects entries (and the walk a group's leaves) by FP32 world boxes that are exactly as
+    large as an axis-aligned cube: rays that run along faces, through edges and corners, shadow rays in the plane of a
+    face, and cubes for which the reference ignores a direction component must all come out as in the oracle - whole image
+    and every counter, on the two- and (where there is one) the three-wave kernel, odd image size (a pixel centre on the axis)."""
+    hs = rtc.HostScene(_grazing_cubes_scene(variant))
+    cam = hs.camera()
+    want, counters = ob.OracleScene(hs.desc).render(cam, 5)
+    three = {"simple": ("simple3_min_chunks", 0), "group": ("waves3", 1)}.get(variant)
+    for force in (None, three):
+        if force is None and three is None and False:
+            continue
+        if force is not None:
+            rtc.set_option(force[0], force[1])
+        try:
+            gpu = rtc.GpuScene(hs.desc)
+            got = gpu.render(cam, 5)
+            st = gpu.stats()
+            name = gpu.last_kernel_name()
+        finally:
+            if force is not None:
+                rtc.set_option(force[0], -1)
+        if force is None:
+            assert name == kernel, name
+        elif variant == "simple":
+            assert name == "rtc_render_kernel_simple3_b", name
+        else:
+            assert name == "rtc_render_kernel3", name
+        delta = np.abs(got - want)
+        assert delta.max() < TOL, (variant, name, delta.max(), np.unravel_index(np.argmax(delta), delta.shape))
+        assert [st["overflow"], st["primary"], st["secondary"], st["shadow_calls"]] == [0, counters["primary"], counters["secondary"], counters["shadow"]], (variant, name)
+        if three is None:
+            break
+
+
 def _random_scene(seed):
     """Random world through the JSON loader: every in-scope primitive, nested groups (some large enough to be
     divided), planes inside groups, glass inside glass, every pattern kind the kernel implements."""

@@ -12,6 +12,8 @@ import test_parity_gpu as t
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 max_objects = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+for opt in sys.argv[4:]:   # name=value options, e.g. box_cull=1 simple3_min_chunks=0
+    rtc.set_option(opt.split("=")[0], float(opt.split("=")[1]))
 kernels = {}
 bad, worst = [], 0.0
 for seed in range(first, first + count):
