@@ -1108,7 +1108,7 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 struct RayB {
   float ix, iy, iz;                       // 1 / d (a component of zero: 1e30 of its sign)
   float cnx, cny, cnz, cfx, cfy, cfz;     // -o / d - margin (near planes), -o / d + margin (far planes)
-  uint32_t onx, ony, onz, ofx, ofy, ofz;  // byte offsets of the near / far planes' pairs in a RootBoxPair
+  uint32_t onx, ony, onz;                 // byte offsets of the near planes' pairs in a RootBoxPair (the far plane of an axis: the other of lo / hi)
   float t_lo, t_hi;                       // the parameter range in which an entry can matter to the visitor
 };
 
@@ -1135,11 +1135,8 @@ __device__ __forceinline__ RayB ray_box(const Ray& r, const DevScene& S, const V
   b.cfz = cz + mz;
   const bool nx = dx < 0.0f, ny = dy < 0.0f, nz = dz < 0.0f;
   b.onx = nx ? 24u : 0u;
-  b.ofx = nx ? 0u : 24u;
   b.ony = ny ? 32u : 8u;
-  b.ofy = ny ? 8u : 32u;
   b.onz = nz ? 40u : 16u;
-  b.ofz = nz ? 16u : 40u;
   vis.box_limits(b.t_lo, b.t_hi);
   return b;
 }
@@ -1149,8 +1146,9 @@ template <class V, bool GROUPS>
 __device__ __forceinline__ uint32_t roots_kept_box(const char* __restrict__ pair, const RayB& rb) {
   const Float2 nx = *reinterpret_cast<const Float2*>(pair + rb.onx), ny = *reinterpret_cast<const Float2*>(pair + rb.ony),
                nz = *reinterpret_cast<const Float2*>(pair + rb.onz);
-  const Float2 fx = *reinterpret_cast<const Float2*>(pair + rb.ofx), fy = *reinterpret_cast<const Float2*>(pair + rb.ofy),
-               fz = *reinterpret_cast<const Float2*>(pair + rb.ofz);
+  // (lo_x at 0, hi_x at 24: the far plane's offset is 24 - the near one's; y: 8 / 32 -> 40 - ; z: 16 / 40 -> 56 -)
+  const Float2 fx = *reinterpret_cast<const Float2*>(pair + (24u - rb.onx)), fy = *reinterpret_cast<const Float2*>(pair + (40u - rb.ony)),
+               fz = *reinterpret_cast<const Float2*>(pair + (56u - rb.onz));
   const Float2 tnx = __builtin_elementwise_fma(nx, Float2(rb.ix), Float2(rb.cnx)), tny = __builtin_elementwise_fma(ny, Float2(rb.iy), Float2(rb.cny)),
                tnz = __builtin_elementwise_fma(nz, Float2(rb.iz), Float2(rb.cnz));
   const Float2 tfx = __builtin_elementwise_fma(fx, Float2(rb.ix), Float2(rb.cfx)), tfy = __builtin_elementwise_fma(fy, Float2(rb.iy), Float2(rb.cfy)),

@@ -1,7 +1,5 @@
 set -e
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q > gpurun_out/r5_gpu6.log 2>&1 || true
-tail -4 gpurun_out/r5_gpu6.log
-( python3 tools/fuzz_flat.py 9000 500 7 box_cull=1 2>&1 | tail -3 ) > gpurun_out/r5_fuzz_box_simple.txt
-( python3 tools/fuzz_flat.py 9500 300 7 box_cull=1 simple3_min_chunks=0 2>&1 | tail -3 ) >> gpurun_out/r5_fuzz_box_simple.txt
-cat gpurun_out/r5_fuzz_box_simple.txt
+python3 tools/time_scenes.py --scenes cover,cubes,dragons,groups,cylinders > gpurun_out/r5_box5.txt 2>&1
+bash tools/pmc_probe.sh "" WRITE_SIZE >> gpurun_out/r5_box5.txt 2>&1
+bash tools/pmc_probe.sh "--option box_cull=0" WRITE_SIZE >> gpurun_out/r5_box5.txt 2>&1
