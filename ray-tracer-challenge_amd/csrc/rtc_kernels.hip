@@ -29,7 +29,8 @@
 //       - n1 / n2   = refractive index of the "open" leaf whose last entry before the hit
 //                     comes latest (see BehindVisitor), which is what the containers walk
 //                     of world.zig:229-255 evaluates to;
-//   * top-level World.objects: tables staged in LDS, an FP32 bounding-sphere pass over all of them, then each
+//   * top-level World.objects: tables staged in LDS, an FP32 pass over all of them (world boxes, or bounding spheres in the
+//     kernels of worlds that are mostly spheres), then each
 //     lane runs the exact FP64 test on its own survivors; groups: a candidate BVH (FP32, world space) proposes
 //     leaves, and a proposed leaf counts only if the ray passes the reference's own box test of every Group
 //     above it (chain_ok), so the entries that reach the reductions are exactly the reference's;
@@ -1170,7 +1171,7 @@ __device__ __forceinline__ uint32_t roots_kept_box(const char* __restrict__ pair
 
 // World.intersect's loop over World.objects (world.zig:74), two-phase so that no load depends on a
 // previous one and no lane waits for roots only its neighbours need:
-//   phase 1 streams the 16-byte FP32 bounding spheres of up to 64 roots (wave-uniform addresses) and
+//   phase 1 streams the FP32 bounds (world boxes or bounding spheres: BOX) of up to 64 roots (wave-uniform addresses) and
 //           leaves one survivor bit per root in a per-lane mask;
 //   phase 2 lets every lane walk the set bits of ITS OWN mask and run the exact reference test on
 //           the 144-byte-strided root records (per-lane LDS addresses; the stride spreads the banks).
@@ -1995,7 +1996,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 #endif
   __syncthreads();
 #endif
-  // Small-world tables (World.objects records + bounding spheres, materials, patterns, lights):
+  // Small-world tables (World.objects records + their FP32 bounds, materials, patterns, lights):
   // staged once per work-group into LDS, so neither the per-ray root loop nor the shading of a hit
   // chases pointers through memory.  Larger worlds run the same code on the tables in memory.
   // (WAVES: what the launch bounds leave room for per SIMD; a three-wave kernel has 53 KB of LDS per work-group: smaller
