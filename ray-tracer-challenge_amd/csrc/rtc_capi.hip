@@ -621,8 +621,6 @@ int launch(rtc_scene* s, const rtc_camera& cam, const DevPixelMap& map_in, uint3
   if (max_depth > RTC_MAX_DEPTH)
     return fail(RTC_ERR_INVALID_ARGUMENT, "max_depth %u exceeds the per-lane ray stack (%d)", max_depth, RTC_MAX_DEPTH);
   if (map.n_chunks == 0) return fail(RTC_ERR_INVALID_ARGUMENT, "nothing to render");
-  if (out_pixels > 0xFFFFFFFFull)  // (a lane hands a pending ray to a neighbour with its canvas pixel in 32 bits: render_body, step 2a)
-    return fail(RTC_ERR_INVALID_ARGUMENT, "%zu pixels in one launch: the kernel indexes at most 2^32", out_pixels);
   HIP_TRY(hipSetDevice(s->device));
   // Launches on one handle share its counters, work counter, pending-ray stacks, csg lists and schedule buffers, and
   // launch N + 1 clears the counters of launch N + 2: they must run one after the other.  Stream order gives that on

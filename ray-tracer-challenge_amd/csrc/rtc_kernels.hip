@@ -119,9 +119,6 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #ifndef RTC_ROOT_NODE_IN_REC
 #define RTC_ROOT_NODE_IN_REC 1  // a group's World.objects record carries a copy of the root node of its candidate BVH (traverse_bvh8)
 #endif
-#ifndef RTC_MAIL_WIDE
-#define RTC_MAIL_WIDE 1
-#endif
 #ifndef RTC_LB2
 #define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
 #endif
@@ -2012,12 +2009,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
   constexpr int N_LIGHTS = WAVES == 3 ? RTC_LDS3_LIGHTS : RTC_LDS_LIGHTS;
   __shared__ double lds_light[LDS ? 6 * N_LIGHTS : 1];
   // per wave: which pending ray (donor lane, level of its stack) an idle lane takes over, and the canvas pixel it belongs to
-  // (8 bytes an entry: donor lane | level << 8, canvas pixel - a launch has at most 2^32 pixels, checked in launch())
-#if RTC_MAIL_WIDE
   __shared__ uint4 lds_mail[4][64];
-#else
-  __shared__ uint2 lds_mail[4][64];
-#endif
   // The first LDS_LEVELS levels of every lane's stack of pending rays ([wave][level][quarter][lane], see
   // store_pending_lds); deeper levels are in the buffer in memory (DevPixelMap::ray_stack).  A lane's stack is empty
   // again after almost every pixel, so nearly every push and pop stays here: the pops no longer wait for memory and the
@@ -2105,11 +2097,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       (static_cast<size_t>(blockIdx.x) * 4u + (threadIdx.x >> 6)) * map.ray_stack_levels * 64u + lane;
   const int stack_cap = static_cast<int>(map.ray_stack_levels);
   int sp = 0, base = 0;
-#if RTC_MAIL_WIDE
   uint4* const mailbox = lds_mail[threadIdx.x >> 6];
-#else
-  uint2* const mailbox = lds_mail[threadIdx.x >> 6];
-#endif
   Quad2* const pend_wave = &lds_pend[threadIdx.x >> 6][0][0][0];  // level l of lane x: pend_wave + l * 256 + x
   // (the buffer in memory keeps a slot for every level; the first LDS_LEVELS of them are never touched)
   auto push_level = [&](int level, const Pending& p) {
@@ -2194,11 +2182,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         const uint32_t irank = bits_below(imask);
         const uint32_t drank = bits_below(dmask);
         if (donor && drank < pairs) {
-#if RTC_MAIL_WIDE
           mailbox[drank] = uint4{lane, static_cast<uint32_t>(base++), static_cast<uint32_t>(out_index), static_cast<uint32_t>(out_index >> 32)};
-#else
-          mailbox[drank] = uint2{lane | (static_cast<uint32_t>(base++) << 8), static_cast<uint32_t>(out_index)};
-#endif
           if (!shared) {
             // First hand-out of this pixel: from here on its shares are ADDED, so it starts from zero.  The canvas is
             // not cleared per launch (a pixel nobody shares is stored once); the store is at L2 before the taker —
@@ -2217,15 +2201,9 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (idle && irank < pairs) {
           // (the donor's slot is read here, in program order before any lane of the wave can push into it again)
-#if RTC_MAIL_WIDE
           const uint4 m = mailbox[irank];
           cur = load_level(static_cast<int>(m.y), m.x);
           out_index = static_cast<size_t>(m.z) | (static_cast<size_t>(m.w) << 32);
-#else
-          const uint2 m = mailbox[irank];
-          cur = load_level(static_cast<int>(m.x >> 8), m.x & 63u);
-          out_index = static_cast<size_t>(m.y);
-#endif
           have_cur = true;
           has_pixel = true;
           shared = true;
