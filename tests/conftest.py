@@ -19,6 +19,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The first `import torch` on a fresh box can take minutes while the image pages in (the per-test timeout below is
+    four): it happens here, before any test's clock runs - round 5 saw the suite's first test time out inside importlib
+    on a cold box and pass as usual a minute later."""
+    try:
+        sys.stderr.write("conftest: importing torch (slow on a fresh box)...\n")
+        sys.stderr.flush()
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def pytest_collection_modifyitems(config, items):
     # A hung kernel must not sit there silently: pytest-timeout (when installed) dumps the Python stacks and
     # ends the process, so the test that hung is named in the log.
