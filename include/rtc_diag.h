@@ -61,6 +61,14 @@ int rtc_get_chunk_times(rtc_scene *scene, const rtc_camera *cam, uint32_t *estim
  * "build_threads" must not change. */
 int rtc_diag_build_tables(const rtc_scene_desc *desc, uint64_t *digest, double *build_ms);
 
+/* Diagnostic (tests/test_root_boxes_cpu.py): the FP32 world boxes phase 1 of the render kernels' root loop tests
+ * (DESIGN.md section 3), as rtc_scene_create builds them, without a device: per table position i (the tables are sorted
+ * by kind) `boxes[7 i ...]` = lo x y z, hi x y z, line_only (no finite bound: -3e38 / +3e38), `world_index[i]` = the
+ * World.objects entry it belongs to, `scales` = {largest |coordinate| of a finite box, the "parallel rule" factor}:
+ * what the test needs to replay the kernel's arithmetic on the host.  Either array may be NULL (then only *n_roots). */
+int rtc_diag_root_boxes(const rtc_scene_desc *desc, float *boxes, uint32_t *world_index, uint32_t capacity, uint32_t *n_roots,
+                        float *scales);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,7 +96,7 @@ RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_
                "rtc_scatter_tile_list_rgba8_device", "rtc_scene_synchronize", "rtc_get_stats", "rtc_last_error", "rtc_status_name",
                "rtc_grow_csg_lists", "rtc_canvas_register", "rtc_canvas_unregister", "rtc_rgba8_device"]
 # (... and include/rtc_diag.h: diagnostics and tuning, for the tests, bench.py and tools/)
-RTC_DIAG_SYMBOLS = ["rtc_set_option", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times", "rtc_diag_build_tables"]
+RTC_DIAG_SYMBOLS = ["rtc_set_option", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times", "rtc_diag_build_tables", "rtc_diag_root_boxes"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
                 "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
 
@@ -487,6 +487,22 @@ def build_tables_digest(desc):
     digest, ms = C.c_uint64(0), C.c_double(0.0)
     _check_hip(hip_lib().rtc_diag_build_tables(C.byref(desc), C.byref(digest), C.byref(ms)))
     return digest.value, ms.value
+
+
+def root_boxes(desc):
+    """rtc_diag_root_boxes: (boxes [n][7] f32: lo, hi, line_only; world_index [n] u32; (cull_bmax, cull_par)) of a scene
+    description, as rtc_scene_create builds them - no device needed."""
+    lib = hip_lib()
+    n = C.c_uint32(0)
+    f32p = C.POINTER(C.c_float)
+    lib.rtc_diag_root_boxes.argtypes = [C.c_void_p, f32p, _u32p, C.c_uint32, _u32p, f32p]
+    _check_hip(lib.rtc_diag_root_boxes(C.byref(desc), None, None, 0, C.byref(n), None))
+    boxes = np.zeros((n.value, 7), dtype=np.float32)
+    order = np.zeros(n.value, dtype=np.uint32)
+    scales = np.zeros(2, dtype=np.float32)
+    _check_hip(lib.rtc_diag_root_boxes(C.byref(desc), boxes.ctypes.data_as(f32p), order.ctypes.data_as(_u32p), n.value, C.byref(n),
+                                       scales.ctypes.data_as(f32p)))
+    return boxes, order, (float(scales[0]), float(scales[1]))
 
 
 def set_option(name, value):

@@ -861,6 +861,7 @@ struct HostTables {
   std::vector<RootRec> root_recs;
   std::vector<RootCull> root_cull;
   std::vector<RootBox> root_box;       // the same roots' world boxes (RootBoxPair: what the render kernels' root loop tests)
+  std::vector<uint32_t> root_order;    // table position -> World.objects index (the tables are sorted by kind)
   float cull_bmax = 0.0f;              // max |coordinate| of any finite root box
   float cull_par = 0.0f;               // 1.2e-5 x the largest scale of any cube (DevScene::cull_par)
   std::vector<float> root_weight;      // per root (table order): what a chunk that looks at it costs (rtc_estimate_kernel)
@@ -1240,6 +1241,7 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
     const int k = klass(recs2[i]);
     if (k < 3) T.n_root_kind[k]++;
   }
+  T.root_order = perm;
   root_recs.swap(recs2);
   root_cull.swap(cull2);
   T.root_box.swap(box2);
@@ -2435,6 +2437,34 @@ int rtc_diag_build_tables(const rtc_scene_desc* desc, uint64_t* digest, double* 
     vec(tables.node_parent);
     mix(&tables.bvh_mag, sizeof tables.bvh_mag);
     *digest = h;
+  }
+  return RTC_OK;
+}
+
+int rtc_diag_root_boxes(const rtc_scene_desc* desc, float* boxes, uint32_t* world_index, uint32_t capacity, uint32_t* n_roots,
+                        float* scales) {
+  g_error.clear();
+  if (!desc || !n_roots) return fail(RTC_ERR_INVALID_ARGUMENT, "null argument");
+  SceneTraits traits;
+  if (const int st = validateScene(*desc, traits); st != RTC_OK) return st;
+  HostTables tables;
+  if (const int st = buildTables(*desc, traits, tables); st != RTC_OK) return st;
+  *n_roots = desc->n_roots;
+  if (scales) {
+    scales[0] = tables.cull_bmax;
+    scales[1] = tables.cull_par;
+  }
+  if (capacity < desc->n_roots) return (boxes || world_index) ? fail(RTC_ERR_INVALID_ARGUMENT, "%u roots, room for %u", desc->n_roots, capacity) : RTC_OK;
+  for (uint32_t i = 0; i < desc->n_roots; ++i) {
+    if (boxes) {
+      const RootBox& B = tables.root_box[i];
+      for (int k = 0; k < 3; ++k) {
+        boxes[7ull * i + k] = B.lo[k];
+        boxes[7ull * i + 3 + k] = B.hi[k];
+      }
+      boxes[7ull * i + 6] = B.line_only;
+    }
+    if (world_index) world_index[i] = tables.root_order[i];
   }
   return RTC_OK;
 }
