@@ -480,7 +480,7 @@ Shape parseObject(const Value& object, const InheritedState& inherited, const De
     st.material = material;
     st.casts_shadow = casts_shadow;
     parser.loadObj(obj, st, normalize);
-    shape = parser.toGroup();
+    shape = parser.takeGroup();
   } else if (t == "sphere") {
     requireVoid(payload, "sphere");
     shape = Shape::sphere();
@@ -609,34 +609,45 @@ SceneInfo parseScene(const std::string& scene_json, const FileLoader& load_file_
 // =========================================================================================
 namespace {
 
-// std.mem.tokenizeScalar: split on ONE delimiter byte, empty tokens skipped.
-std::vector<std::string> tokenize(const std::string& s, char delim) {
-  std::vector<std::string> out;
+// std.mem.tokenizeScalar: split on ONE delimiter byte, empty tokens skipped.  Tokens are views into the text (an OBJ
+// file is a few hundred thousand of them: no allocation per token).
+using Token = std::string_view;
+void tokenize(Token s, char delim, std::vector<Token>& out) {
+  out.clear();
   size_t i = 0;
   while (i < s.size()) {
     while (i < s.size() && s[i] == delim) ++i;
     size_t j = i;
     while (j < s.size() && s[j] != delim) ++j;
-    if (j > i) out.emplace_back(s, i, j - i);
+    if (j > i) out.push_back(s.substr(i, j - i));
     i = j;
   }
-  return out;
 }
 
 struct LineError {  // an error from the ObjParser.Error set or from parseFloat/parseInt
   const char* name;
 };
 
-double parseFloatToken(const std::string& tok) {  // std.fmt.parseFloat: whole token, no whitespace
+double parseFloatToken(Token tok) {  // std.fmt.parseFloat: whole token, no whitespace
   if (tok.empty() || std::isspace(static_cast<unsigned char>(tok[0]))) throw LineError{"InvalidCharacter"};
+  char small[64];
+  std::string big;
+  const char* text = small;
+  if (tok.size() < sizeof small) {  // strtod wants a terminated string
+    std::memcpy(small, tok.data(), tok.size());
+    small[tok.size()] = '\0';
+  } else {
+    big.assign(tok);
+    text = big.c_str();
+  }
   errno = 0;
   char* end = nullptr;
-  const double v = std::strtod(tok.c_str(), &end);
-  if (end != tok.c_str() + tok.size()) throw LineError{"InvalidCharacter"};
+  const double v = std::strtod(text, &end);
+  if (end != text + tok.size()) throw LineError{"InvalidCharacter"};
   return v;
 }
 
-size_t parseUsizeToken(const std::string& tok) {  // std.fmt.parseInt(usize, tok, 10)
+size_t parseUsizeToken(Token tok) {  // std.fmt.parseInt(usize, tok, 10)
   size_t i = 0;
   if (i < tok.size() && tok[i] == '+') ++i;
   if (i >= tok.size()) throw LineError{"InvalidCharacter"};
@@ -657,22 +668,21 @@ struct FaceVertex {
 };
 
 // obj.zig:85-99 — "v", "v/t", "v/t/n", "v//n"
-FaceVertex handleFaceHelper(const std::string& token) {
-  // std.mem.splitScalar keeps empty fields.
-  std::vector<std::string> parts;
-  size_t start = 0;
+FaceVertex handleFaceHelper(Token token) {
+  // std.mem.splitScalar keeps empty fields: field 0 is the vertex, field 2 (if there is one) the normal.
+  Token parts[3];
+  size_t n_parts = 0, start = 0;
   while (true) {
     const size_t p = token.find('/', start);
-    if (p == std::string::npos) {
-      parts.emplace_back(token, start);
-      break;
-    }
-    parts.emplace_back(token, start, p - start);
+    const Token part = p == Token::npos ? token.substr(start) : token.substr(start, p - start);
+    if (n_parts < 3) parts[n_parts] = part;
+    ++n_parts;
+    if (p == Token::npos) break;
     start = p + 1;
   }
   FaceVertex fv;
   fv.vertex_index = parseUsizeToken(parts[0]);
-  if (parts.size() < 3) return fv;  // no texture field, or no normal field
+  if (n_parts < 3) return fv;  // no texture field, or no normal field
   fv.normal_index = parseUsizeToken(parts[2]);
   return fv;
 }
@@ -681,11 +691,12 @@ FaceVertex handleFaceHelper(const std::string& token) {
 
 ObjParser::ObjParser() : default_group(Shape::group()) {}
 
-void ObjParser::handleLine(const std::string& line, const InheritedState& state) {
-  const std::vector<std::string> tokens = tokenize(line, ' ');
+void ObjParser::handleLine(std::string_view line, const InheritedState& state) {
+  std::vector<Token>& tokens = line_tokens_;
+  tokenize(line, ' ', tokens);
   if (tokens.empty()) throw LineError{"LineEmpty"};
-  const std::string& first = tokens[0];
-  auto tok = [&](size_t i, const char* err) -> const std::string& {
+  const Token first = tokens[0];
+  auto tok = [&](size_t i, const char* err) -> Token {
     if (i >= tokens.size()) throw LineError{err};
     return tokens[i];
   };
@@ -717,20 +728,17 @@ void ObjParser::handleLine(const std::string& line, const InheritedState& state)
       const Tuple& p1 = vertexAt(firstv.vertex_index);
       const Tuple& p2 = vertexAt(last.vertex_index);
       const Tuple& p3 = vertexAt(current.vertex_index);
-      Shape tri;
-      if (firstv.normal_index && last.normal_index && current.normal_index) {
-        tri = Shape::smoothTriangle(p1, p2, p3, normalAt(*firstv.normal_index), normalAt(*last.normal_index),
-                                    normalAt(*current.normal_index));
-      } else {
-        tri = Shape::triangle(p1, p2, p3);
-      }
+      Shape tri = (firstv.normal_index && last.normal_index && current.normal_index)
+                      ? Shape::smoothTriangle(p1, p2, p3, normalAt(*firstv.normal_index), normalAt(*last.normal_index),
+                                              normalAt(*current.normal_index))
+                      : Shape::triangle(p1, p2, p3);
       tri.material = state.material ? *state.material : Material{};  // copied into EVERY triangle
       tri.casts_shadow = state.casts_shadow ? *state.casts_shadow : true;
       activeGroup().addChild(std::move(tri));
       last = current;
     }
   } else if (first == "g") {  // obj.zig:152-169
-    const std::string& name = tok(1, "IncompleteNamedGroup");
+    const std::string name(tok(1, "IncompleteNamedGroup"));
     default_group.addChild(Shape::group());
     active_group_ = static_cast<long>(default_group.children.size()) - 1;
     named_groups[name] = static_cast<size_t>(active_group_);
@@ -740,13 +748,15 @@ void ObjParser::handleLine(const std::string& line, const InheritedState& state)
 }
 
 void ObjParser::loadObj(const std::string& obj, const InheritedState& state, bool normalize) {
-  const std::vector<std::string> lines = tokenize(obj, '\n');  // empty lines are skipped, never "ignored"
+  std::vector<Token> lines;
+  tokenize(obj, '\n', lines);  // empty lines are skipped, never "ignored"
 
   if (normalize) {  // obj.zig:198-271
     double min_x = kInf, min_y = kInf, min_z = kInf;
     double max_x = -kInf, max_y = -kInf, max_z = -kInf;
-    for (const std::string& line : lines) {
-      const std::vector<std::string> tokens = tokenize(line, ' ');
+    std::vector<Token> tokens;
+    for (const Token line : lines) {
+      tokenize(line, ' ', tokens);
       if (tokens.empty() || tokens[0] != "v") continue;
       auto coord = [&](size_t i) -> std::optional<double> {
         if (i >= tokens.size()) return std::nullopt;
@@ -778,7 +788,7 @@ void ObjParser::loadObj(const std::string& obj, const InheritedState& state, boo
     scale = scale_;
   }
 
-  for (const std::string& line : lines) {
+  for (const Token line : lines) {
     try {
       handleLine(line, state);
     } catch (const LineError&) {

@@ -6,6 +6,7 @@
 #include <map>
 #include <optional>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "rtc_scene.hpp"
@@ -36,6 +37,7 @@ class ObjParser {
   ObjParser();
   void loadObj(const std::string& obj, const InheritedState& state, bool normalize);  // obj.zig:191-279
   Shape toGroup() const { return default_group; }                                      // obj.zig:281-283
+  Shape takeGroup() { return std::move(default_group); }  // the same, for a parser that is done (no copy of a kilobyte per triangle)
 
   Shape default_group;
   std::map<std::string, size_t> named_groups;  // name -> index in default_group.children
@@ -48,7 +50,8 @@ class ObjParser {
  private:
   long active_group_ = -1;  // -1: default group, else index into default_group.children
   Shape& activeGroup() { return active_group_ < 0 ? default_group : default_group.children[active_group_]; }
-  void handleLine(const std::string& line, const InheritedState& state);
+  void handleLine(std::string_view line, const InheritedState& state);
+  std::vector<std::string_view> line_tokens_;  // (scratch of handleLine)
 };
 
 }  // namespace rtc

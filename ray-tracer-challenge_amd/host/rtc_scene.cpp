@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include <atomic>
+#include <memory>
 
 namespace rtc {
 
@@ -113,6 +114,85 @@ void Shape::makeSubgroup(std::vector<Shape> list) {
   addChild(std::move(sub));
 }
 
+// divide() of a group, planned before anything moves.  The reference's partitionChildren / makeSubgroup hand every
+// child down one level at a time (group.zig:85-135), and at every level partitionChildren asks each child for its
+// parentSpaceBounds again; here a Shape is a kilobyte, and dragons.json's 141 000 triangles sink through ~20 levels: 5 GB
+// of moves and 3 M box transforms, most of the 2 s its load took.  The plan runs the SAME steps in the SAME order on
+// (pointer, box) pairs - a child's parent-space box cannot change while its ancestors are partitioned: the subgroups in
+// between have identity transforms and a child is divided only after every partition above it - and the tree is then
+// built with one move per child.  Ids are drawn where the reference draws them (two per subgroup: its box, itself).
+namespace {
+
+struct DividePlan;
+struct DivideItem {
+  Shape* child = nullptr;   // a child the group already had ...
+  std::unique_ptr<DividePlan> sub;  // ... or a subgroup the division makes
+  BoundingBox box;          // parentSpaceBounds()
+};
+struct DividePlan {
+  size_t id = 0;
+  BoundingBox bbox;
+  std::vector<DivideItem> items;
+};
+
+void planDivide(DividePlan& g, size_t threshold) {
+  if (g.items.size() >= threshold) {
+    std::vector<DivideItem> left, right, keep;  // partitionChildren (group.zig:85-115)
+    const auto halves = g.bbox.split();
+    for (DivideItem& it : g.items) {
+      if (halves.first.containsBox(it.box)) {
+        left.push_back(std::move(it));
+      } else if (halves.second.containsBox(it.box)) {
+        right.push_back(std::move(it));
+      } else {
+        keep.push_back(std::move(it));
+      }
+    }
+    g.items = std::move(keep);
+    auto make_subgroup = [&](std::vector<DivideItem>& list) {  // makeSubgroup (group.zig:117-135)
+      if (list.empty()) return;
+      auto sub = std::make_unique<DividePlan>();
+      (void)nextShapeId();  // Shape::group(): the box's id, then the group's
+      sub->id = nextShapeId();
+      for (const DivideItem& it : list) sub->bbox.merge(it.box);  // addChild
+      sub->items = std::move(list);
+      DivideItem item;
+      item.box = sub->bbox.transform(Matrix4::identity());  // the subgroup's parentSpaceBounds()
+      item.sub = std::move(sub);
+      g.bbox.merge(item.box);  // addChild
+      g.items.push_back(std::move(item));
+    };
+    make_subgroup(left);
+    make_subgroup(right);
+  }
+  for (DivideItem& it : g.items) {
+    if (it.sub) {
+      planDivide(*it.sub, threshold);
+    } else {
+      it.child->divide(threshold);
+    }
+  }
+}
+
+void buildDivided(Shape& g, DividePlan& plan) {
+  g.bbox = plan.bbox;
+  g.children.clear();
+  g.children.reserve(plan.items.size());
+  for (DivideItem& it : plan.items) {
+    if (it.sub) {
+      Shape sub;  // Shape::group() with the ids planDivide drew
+      sub.kind = ShapeKind::Group;
+      sub.id = it.sub->id;
+      buildDivided(sub, *it.sub);
+      g.children.push_back(std::move(sub));
+    } else {
+      g.children.push_back(std::move(*it.child));
+    }
+  }
+}
+
+}  // namespace
+
 void Shape::divide(size_t threshold) {
   if (kind == ShapeKind::Csg) {  // shape.zig:393-396
     children[0].divide(threshold);
@@ -120,12 +200,21 @@ void Shape::divide(size_t threshold) {
     return;
   }
   if (kind != ShapeKind::Group) return;
-  if (children.size() >= threshold) {
-    auto parts = partitionChildren();
-    if (!parts.first.empty()) makeSubgroup(std::move(parts.first));
-    if (!parts.second.empty()) makeSubgroup(std::move(parts.second));
+  if (children.size() < threshold) {  // nothing to partition (shape.zig:376-390 goes straight to the children)
+    for (Shape& child : children) child.divide(threshold);
+    return;
   }
-  for (Shape& child : children) child.divide(threshold);
+  DividePlan plan;
+  plan.bbox = bbox;
+  plan.items.resize(children.size());
+  for (size_t i = 0; i < children.size(); ++i) {
+    plan.items[i].child = &children[i];
+    plan.items[i].box = children[i].parentSpaceBounds();
+  }
+  planDivide(plan, threshold);
+  std::vector<Shape> old = std::move(children);  // (the plan points into it)
+  children = std::vector<Shape>();
+  buildDivided(*this, plan);
 }
 
 size_t Shape::leafCount() const {
