@@ -223,7 +223,7 @@ static void cubeKats() {  // cube.zig:126-209
                        {point(-0.6, 0.3, 1), vec3(0, 0, 1)},  {point(0.4, 0.4, -1), vec3(0, 0, -1)},
                        {point(1, 1, 1), vec3(1, 0, 0)},       {point(-1, -1, -1), vec3(-1, 0, 0)}};
   i = 0;
-  for (const N& n : normals) expectTuple("cube.zig:198", "normal_" + std::to_string(i++), c.normalAt(n.p, {}), n.n);
+  for (const N& n : normals) expectTuple("cube.zig:200", "normal_" + std::to_string(i++), c.normalAt(n.p, {}), n.n);
 }
 
 static void cylinderKats() {  // cylinder.zig:136-332
@@ -260,7 +260,7 @@ static void cylinderKats() {  // cylinder.zig:136-332
                     {point(0, -1, -2), vec3(0, 1, 1), 2}};
   i = 0;
   for (const C& c : caps)
-    expectTrue("cylinder.zig:271", "closed_caps_" + std::to_string(i++), cc.intersect({c.o, normalized(c.d)}).size() == c.count);
+    expectTrue("cylinder.zig:273", "closed_caps_" + std::to_string(i++), cc.intersect({c.o, normalized(c.d)}).size() == c.count);
   const N capn[] = {{point(0, 1, 0), vec3(0, -1, 0)},   {point(0.5, 1, 0), vec3(0, -1, 0)}, {point(0, 1, 0.5), vec3(0, -1, 0)},
                     {point(0, 2, 0), vec3(0, 1, 0)},    {point(0.5, 2, 0), vec3(0, 1, 0)},  {point(0, 2, 0.5), vec3(0, 1, 0)}};
   i = 0;
@@ -306,16 +306,16 @@ static void triangleKats() {  // triangle.zig:83-196, 289-342
   expectTuple("triangle.zig:107", "normalAt", t.normalAt(point(-0.5, 0.75, 0), {}), t.normal);
   expectTs("triangle.zig:118", "parallel", t.intersect({point(0, -1, -2), vec3(0, 1, 0)}), {});
   expectTs("triangle.zig:133", "miss_p1p3", t.intersect({point(1, 1, -2), vec3(0, 0, 1)}), {});
-  expectTs("triangle.zig:148", "miss_p1p2", t.intersect({point(-1, 1, -2), vec3(0, 0, 1)}), {});
-  expectTs("triangle.zig:163", "miss_p2p3", t.intersect({point(0, -1, -2), vec3(0, 0, 1)}), {});
-  expectTs("triangle.zig:178", "strike", t.intersect({point(0, 0.5, -2), vec3(0, 0, 1)}), {2.0}, 0.0);
+  expectTs("triangle.zig:149", "miss_p1p2", t.intersect({point(-1, 1, -2), vec3(0, 0, 1)}), {});
+  expectTs("triangle.zig:165", "miss_p2p3", t.intersect({point(0, -1, -2), vec3(0, 0, 1)}), {});
+  expectTs("triangle.zig:181", "strike", t.intersect({point(0, 0.5, -2), vec3(0, 0, 1)}), {2.0}, 0.0);
   const Shape st = Shape::smoothTriangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0), vec3(0, 1, 0), vec3(-1, 0, 0),
                                          vec3(1, 0, 0));
   const Intersections xs = st.intersect({point(-0.2, 0.3, -2), vec3(0, 0, 1)});
   expectTrue("triangle.zig:305", "smooth_hit", xs.size() == 1);
   if (xs.size() == 1) {
     expectNear("triangle.zig:315", "smooth_u", xs[0].u, 0.45);
-    expectNear("triangle.zig:316", "smooth_v", xs[0].v, 0.25);
+    expectNear("triangle.zig:315", "smooth_v", xs[0].v, 0.25);
   }
   Intersection i{1.0, &st, 0.45, 0.25};
   expectTuple("triangle.zig:323", "smooth_normal", st.normalAt(point(0, 0, 0), i), vec3(-0.5547, 0.83205, 0));
@@ -344,12 +344,12 @@ static void groupAndBoxKats() {  // group.zig:163-223, bounding_box.zig:254-360
   const Intersections xs = g.intersect({point(0, 0, -5), vec3(0, 0, 1)});
   bool ok = xs.size() == 4;
   if (ok) ok = xs[0].object->id == s2.id && xs[1].object->id == s2.id && xs[2].object->id == s1.id && xs[3].object->id == s1.id;
-  expectTrue("group.zig:175", "nonempty_group_order", ok);
+  expectTrue("group.zig:177", "nonempty_group_order", ok);
   // transformed group: group scale(2) pushed onto child translate(5,0,0) (group.zig:201-216)
   Shape ts = Shape::make(SPHERE);
   ts.setTransform(Matrix::identity().scale(2, 2, 2).mul(Matrix::identity().translate(5, 0, 0)));
   const Shape tg = groupOf({ts}, point(8, -2, -2), point(12, 2, 2));
-  expectTrue("group.zig:201", "transformed_group", tg.intersect({point(10, 0, -10), vec3(0, 0, 1)}).size() == 2);
+  expectTrue("group.zig:206", "transformed_group", tg.intersect({point(10, 0, -10), vec3(0, 0, 1)}).size() == 2);
 
   auto boxHit = [](Tuple mn, Tuple mx, Tuple o, Tuple d) {
     Shape b = Shape::make(BOUNDING_BOX);
@@ -367,7 +367,7 @@ static void groupAndBoxKats() {  // group.zig:163-223, bounding_box.zig:254-360
                     {point(2, 2, 0), vec3(-1, 0, 0), false}};
   int i = 0;
   for (const B& b : unit)
-    expectTrue("bounding_box.zig:283", "aabb_unit_" + std::to_string(i++),
+    expectTrue("bounding_box.zig:289", "aabb_unit_" + std::to_string(i++),
                boxHit(point(-1, -1, -1), point(1, 1, 1), b.o, b.d) == b.r);
   const B nc[] = {{point(15, 1, 2), vec3(-1, 0, 0), true}, {point(-5, -1, 4), vec3(1, 0, 0), true},
                   {point(7, 6, 5), vec3(0, -1, 0), true},  {point(9, -5, 6), vec3(0, 1, 0), true},
@@ -378,7 +378,7 @@ static void groupAndBoxKats() {  // group.zig:163-223, bounding_box.zig:254-360
                   {point(12, 5, 4), vec3(-1, 0, 0), false}};
   i = 0;
   for (const B& b : nc)
-    expectTrue("bounding_box.zig:343", "aabb_noncubic_" + std::to_string(i++),
+    expectTrue("bounding_box.zig:347", "aabb_noncubic_" + std::to_string(i++),
                boxHit(point(5, -2, 0), point(11, 4, 7), b.o, b.d) == b.r);
 }
 
@@ -390,8 +390,8 @@ static void nestedGroupKats() {  // shape.zig:560-617 (transforms pushed to the 
   Shape s2 = Shape::make(SPHERE);
   s2.setTransform(Matrix::identity().rotateY(PI / 2).mul(Matrix::identity().scale(1, 2, 3).mul(Matrix::identity().translate(5, 0, 0))));
   const double r3 = 1.0 / std::sqrt(3.0);
-  expectTuple("shape.zig:582", "normal_to_world", s2.normalToWorld(vec3(r3, r3, r3)), vec3(0.28571, 0.42857, -0.85714));
-  expectTuple("shape.zig:605", "normal_on_child", s2.normalAt(point(1.7321, 1.1547, -5.5774), {}),
+  expectTuple("shape.zig:583", "normal_to_world", s2.normalToWorld(vec3(r3, r3, r3)), vec3(0.28571, 0.42857, -0.85714));
+  expectTuple("shape.zig:607", "normal_on_child", s2.normalAt(point(1.7321, 1.1547, -5.5774), {}),
               vec3(0.2857, 0.42854, -0.85716));
 }
 
@@ -678,13 +678,13 @@ static void csgKats() {  // csg.zig:143-258
     const Shape* s2 = &c.children[1];
     const Intersections xs{{1.0, s1}, {2.0, s2}, {3.0, s1}, {4.0, s2}};
     const Intersections r = csgFilter(c, xs);
-    expectTrue("csg.zig:221-223", "filter_op" + std::to_string(f.op),
+    expectTrue("csg.zig:214", "filter_op" + std::to_string(f.op),
                r.size() == 2 && r[0].t == xs[f.x0].t && r[0].object == xs[f.x0].object && r[1].t == xs[f.x1].t &&
                    r[1].object == xs[f.x1].object);
   }
   {  // csg.zig:228-240
     Shape c = makeCsg(Shape::make(SPHERE), Shape::make(CUBE), CSG_UNION);
-    expectTrue("csg.zig:239", "ray_misses_csg", c.intersect({point(0, 2, -5), vec3(0, 0, 1)}).empty());
+    expectTrue("csg.zig:223", "ray_misses_csg", c.intersect({point(0, 2, -5), vec3(0, 0, 1)}).empty());
   }
   {  // csg.zig:242-258
     Shape s2 = Shape::make(SPHERE);
@@ -844,7 +844,7 @@ static void worldKats() {  // world.zig:293-892
     expectColor("world.zig:721", "refracted_depth_0", w2.refractedColor(c2, 0), {0, 0, 0}, 0.0);
     const Intersections xs3{{-RS2, &w2.objects[0]}, {RS2, &w2.objects[0]}};
     const PreComputations c3 = PreComputations::make(xs3[1], {point(0, 0, RS2), vec3(0, 1, 0)}, xs3);
-    expectColor("world.zig:746", "total_internal_reflection", w2.refractedColor(c3, 5), {0, 0, 0}, 0.0);
+    expectColor("world.zig:725", "total_internal_reflection", w2.refractedColor(c3, 5), {0, 0, 0}, 0.0);
   }
   {  // Recursive refraction, world.zig:751-807
     World w1 = World::defaultWorld();
@@ -949,14 +949,14 @@ static void sceneBoxKats() {  // bounding_box.zig:183-252, 362-423
     bool ok = true;
     for (const Tuple& p : in) ok = ok && sc::boxContainsPoint(b, p);
     for (const Tuple& p : out) ok = ok && !sc::boxContainsPoint(b, p);
-    expectTrue("bounding_box.zig:192", "scene_contains_point", ok);
+    expectTrue("bounding_box.zig:193", "scene_contains_point", ok);
     auto cb = [&](Tuple mn, Tuple mx) {  // bounding_box.zig:238-252
       sc::Box o = sc::newBox();
       o.min = mn;
       o.max = mx;
       return sc::boxContainsBox(b, o);
     };
-    expectTrue("bounding_box.zig:238", "scene_contains_box",
+    expectTrue("bounding_box.zig:242", "scene_contains_box",
                cb(point(5, -2, 0), point(11, 4, 7)) && cb(point(6, -1, 1), point(10, 3, 6)) &&
                    !cb(point(4, -3, -1), point(10, 3, 6)) && !cb(point(6, -1, 1), point(12, 5, 8)));
   }
@@ -986,7 +986,7 @@ static void sceneBoxKats() {  // bounding_box.zig:183-252, 362-423
     Shape cyl = Shape::make(CYLINDER);
     cyl.ymin = -5;
     cyl.ymax = 3;
-    expectTrue("cylinder.zig:341", "scene_cylinder_bounds",
+    expectTrue("cylinder.zig:342", "scene_cylinder_bounds",
                bitEq(sc::shapeBounds(cyl).min, point(-1, -5, -1)) && bitEq(sc::shapeBounds(cyl).max, point(1, 3, 1)));
     Shape cone = Shape::make(CONE);
     cone.ymin = -5;
@@ -1251,6 +1251,104 @@ static void sceneParseKats() {  // parsing/scene.zig:664-774
   expectTrue("scene.zig:203", "scene_missing_field", fails(R"({"lights":[],"objects":[]})"));
 }
 
+// The reference tests that had no vector of their own until round 5's audit (tests/test_reference_test_index.py holds every
+// `test "..."` block of the reference's files to at least one KAT inside its line range).  Most are one-liners - a constructor,
+// a default, a bounds() - which is why they were passed over; they are the reference's all the same.
+static void auditKats() {
+  namespace sc = orc::scene;
+  auto nearM = [](const Matrix& a, const Matrix& b) {  // Matrix.approxEqual (matrix.zig: every element within the tolerance)
+    for (int i = 0; i < 16; ++i)
+      if (!(std::fabs(a.d[i / 4][i % 4] - b.d[i / 4][i % 4]) < 1e-5)) return false;
+    return true;
+  };
+  {  // csg.zig:143-154 CSG is created with an operation and two shapes (the scene builder's constructor)
+    const Shape s1 = Shape::make(SPHERE), s2 = Shape::make(CUBE);
+    const Shape c = sc::newCsg(s1, s2, CSG_UNION);
+    expectTrue("csg.zig:143", "scene_csg_creation", c.kind == CSG && c.csg_op == CSG_UNION && c.children.size() == 2 &&
+                                                        c.children[0].id == s1.id && c.children[0].kind == SPHERE &&
+                                                        c.children[1].id == s2.id && c.children[1].kind == CUBE);
+  }
+  {  // ray.zig:37-41 Ray creation
+    const Ray r{point(1, 2, 3), vec3(4, 5, 6)};
+    expectTrue("ray.zig:37", "ray_creation", bitEq(r.origin, point(1, 2, 3)) && bitEq(r.direction, vec3(4, 5, 6)));
+  }
+  {  // shape.zig:441-448 Id uniqueness; :450-462 Creation
+    const Shape s1 = Shape::make(SPHERE), s2 = Shape::make(SPHERE), s3 = Shape::make(TEST_SHAPE);
+    expectTrue("shape.zig:441", "id_uniqueness", s1.id != s2.id && s2.id != s3.id && s3.id != s1.id);
+    Shape s = Shape::make(TEST_SHAPE);
+    expectTrue("shape.zig:452", "default_transform", bitEq(s.transform, Matrix::identity()));
+    s.setTransform(Matrix::identity().translate(2, 3, 4));
+    expectTrue("shape.zig:456", "set_transform", nearM(s.transform, Matrix::identity().translate(2, 3, 4)));
+    expectTrue("shape.zig:459", "set_transform_inverse", nearM(s.inverse, Matrix::identity().translate(-2, -3, -4)));
+  }
+  {  // bounds() of the kinds whose tests are three lines: sphere.zig:186, cube.zig:211, shape.zig:631, cylinder.zig:334
+    auto unit = [](ShapeKind k) {
+      const sc::Box b = sc::shapeBounds(Shape::make(k));
+      return bitEq(b.min, point(-1, -1, -1)) && bitEq(b.max, point(1, 1, 1));
+    };
+    expectTrue("sphere.zig:186", "scene_sphere_bounds", unit(SPHERE));
+    expectTrue("cube.zig:211", "scene_cube_bounds", unit(CUBE));
+    expectTrue("shape.zig:631", "scene_test_shape_bounds", unit(TEST_SHAPE));
+    const sc::Box c = sc::shapeBounds(Shape::make(CYLINDER));
+    expectTrue("cylinder.zig:334", "scene_unbounded_cylinder_bounds", bitEq(c.min, point(-1, -INF, -1)) && bitEq(c.max, point(1, INF, 1)));
+  }
+  {  // triangle.zig:289-299 Constructing a smooth triangle; :344-357 its bounding box
+    const Shape t = Shape::smoothTriangle(point(0, 1, 0), point(-1, 0, 0), point(1, 0, 0), vec3(0, 1, 0), vec3(-1, 0, 0), vec3(1, 0, 0));
+    expectTrue("triangle.zig:289", "smooth_construction",
+               bitEq(t.p1, point(0, 1, 0)) && bitEq(t.p2, point(-1, 0, 0)) && bitEq(t.p3, point(1, 0, 0)) &&
+                   bitEq(t.n1, vec3(0, 1, 0)) && bitEq(t.n2, vec3(-1, 0, 0)) && bitEq(t.n3, vec3(1, 0, 0)));
+    const Shape b = Shape::smoothTriangle(point(-3, 7, 2), point(6, 2, -4), point(2, -1, -1), vec3(0, 0, 0), vec3(0, 0, 0), vec3(0, 0, 0));
+    expectTrue("triangle.zig:344", "scene_smooth_triangle_bounds",
+               bitEq(sc::shapeBounds(b).min, point(-3, -1, -4)) && bitEq(sc::shapeBounds(b).max, point(6, 7, 2)));
+  }
+  {  // group.zig:139-147 Creating a new group; :149-161 Adding a child to a group
+    Shape g = sc::newGroup();
+    expectTrue("group.zig:139", "scene_new_group", bitEq(g.transform, Matrix::identity()) && g.children.empty());
+    const Shape s = Shape::make(TEST_SHAPE);
+    sc::addChild(g, s);
+    expectTrue("group.zig:149", "scene_add_child", g.children.size() == 1 && g.children[0].id == s.id && g.children[0].kind == TEST_SHAPE &&
+                                                        bitEq(g.children[0].transform, s.transform));
+  }
+  {  // gradient.zig:59-77 Gradient (the two ends), :79-103 RadialGradient
+    const Color white{1, 1, 1}, black{0, 0, 0};
+    const Pattern sw = solidPattern(white), sb = solidPattern(black);
+    Pattern gr;
+    gr.kind = PAT_GRADIENT;
+    gr.a = &sw;
+    gr.b = &sb;
+    expectColor("gradient.zig:69", "gradient_0", gr.patternAt(point(0, 0, 0)), white, 0.0);
+    expectColor("gradient.zig:75", "gradient_0.75", gr.patternAt(point(0.75, 0, 0)), {0.25, 0.25, 0.25}, 0.0);
+    Pattern rad;
+    rad.kind = PAT_RADIAL_GRADIENT;
+    rad.a = &sw;
+    rad.b = &sb;
+    const struct { Tuple p; double want; double tol; } rows[] = {
+        {point(0, 0, 0), 1.0, 0.0},    {point(0.25, 0, 0), 0.75, 0.0}, {point(0.5, 0, 0), 0.5, 0.0}, {point(0.75, 0, 0), 0.25, 0.0},
+        {point(0, 0, 0.25), 0.75, 0.0}, {point(0, 0, 0.5), 0.5, 0.0},   {point(0.353553, 0, 0.353553), 0.5, 1e-5}};
+    int i = 0;
+    for (const auto& r : rows)
+      expectColor(("gradient.zig:" + std::to_string(89 + 2 * i)).c_str(), "radial_gradient_" + std::to_string(i), rad.patternAt(r.p),
+                  {r.want, r.want, r.want}, r.tol), ++i;
+  }
+  {  // texture_map.zig:432-442 Identifying the face of a cube from a point: six faces of one colour each
+    const Color cols[6] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {0, 1, 1}, {1, 0, 1}};  // front, back, left, right, up, down
+    Pattern solid[6];
+    TextureMap cube;
+    cube.mapping = TEX_CUBIC;
+    for (int f = 0; f < 6; ++f) {
+      solid[f] = solidPattern(cols[f]);
+      cube.faces[f].kind = UV_ALIGN_CHECK;
+      for (int k = 0; k < 5; ++k) cube.faces[f].sub[k] = &solid[f];
+    }
+    const struct { Tuple p; int face; const char* name; } rows[] = {
+        {point(-1, 0.5, -0.25), 2, "face_left"}, {point(1.1, -0.75, 0.8), 3, "face_right"}, {point(0.1, 0.6, 0.9), 0, "face_front"},
+        {point(-0.7, 0, -2), 1, "face_back"},    {point(0.5, 1, 0.9), 4, "face_up"},        {point(-0.2, -1.3, 1.1), 5, "face_down"}};
+    int i = 0;
+    for (const auto& r : rows)
+      expectColor(("texture_map.zig:" + std::to_string(436 + i)).c_str(), r.name, cube.patternAt(r.p, point(0, 0, 0)), cols[r.face], 0.0), ++i;
+  }
+}
+
 int main() {
   tupleKats();
   matrixKats();
@@ -1276,6 +1374,7 @@ int main() {
   sceneGroupKats();
   sceneObjKats();
   sceneParseKats();
+  auditKats();
   std::printf("KAT-SUMMARY total=%d failed=%d\n", g_total, g_failed);
   return g_failed ? 1 : 0;
 }

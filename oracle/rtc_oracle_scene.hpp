@@ -272,8 +272,9 @@ inline void setGroupBox(Shape& s, const Box& b) {
 // a group or csg returns a copy of its _bbox (no id).
 inline Box shapeBounds(const Shape& s) {
   switch (s.kind) {
-    case SPHERE:  // sphere.zig:55-63
-    case CUBE: {  // cube.zig:99-107
+    case SPHERE:      // sphere.zig:55-63
+    case TEST_SHAPE:  // shape.zig:429-437
+    case CUBE: {      // cube.zig:99-107
       Box b = newBox();
       b.min = point(-1.0, -1.0, -1.0);
       b.max = point(1.0, 1.0, 1.0);

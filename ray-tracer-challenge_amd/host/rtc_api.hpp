@@ -1,7 +1,7 @@
 // rtc_api.hpp — host-side mirror of the reference's public interface for the path:
 //
 //   Camera(T).render(self, allocator, world) !Canvas(T)     camera.zig:80-102
-//   Canvas(T).new / getPixelPointer / ppm                   canvas.zig:25-46, 132-147, 181-254
+//   Canvas(T).new / getPixelPointer / ppm / fromPpm         canvas.zig:25-46, 132-147, 181-254, 48-121
 //   Renderer (scene kept alive between renders)             lib.zig:41-190 ("preheated")
 //
 // Same names and argument meaning as the reference; the body of render() is a
@@ -39,6 +39,9 @@ struct Canvas {  // canvas.zig:16-22
     return &pixels[y * width + x];
   }
   std::string ppm() const;                 // canvas.zig:181-254 — P3, 70-column wrap
+  // canvas.zig:48-121 — a P3 file back into a canvas; throws Error named like the reference's ParseError /
+  // parseInt / parseFloat errors (InvalidMagicNumber, InvalidDimensions, InvalidScale, InvalidCharacter, Overflow)
+  static Canvas fromPpm(const std::string& ppm);
   std::vector<uint8_t> rgba8() const;      // lib.zig:146-153 — clamp()'d RGBA, alpha 255
 };
 

@@ -10,6 +10,7 @@
 //   canvas.zig:258-303                           -> Canvas::ppm
 // Output format is the same as oracle/kat_main.cpp: "KAT <where> <name> PASS|FAIL".
 #include <cstdio>
+#include <cstring>
 #include <string>
 
 #include "../../ray-tracer-challenge_amd/host/rtc_api.hpp"
@@ -96,14 +97,14 @@ static void boxKats() {
   bool ok = true;
   for (const Tuple& p : in) ok = ok && b2.containsPoint(p);
   for (const Tuple& p : outp) ok = ok && !b2.containsPoint(p);
-  report("bounding_box.zig:192", "contains_point", ok);
+  report("bounding_box.zig:193", "contains_point", ok);
   auto cb = [&](Tuple mn, Tuple mx) {
     BoundingBox o;
     o.min = mn;
     o.max = mx;
     return b2.containsBox(o);
   };
-  report("bounding_box.zig:238", "contains_box",
+  report("bounding_box.zig:242", "contains_box",
          cb(Tuple::point(5, -2, 0), Tuple::point(11, 4, 7)) && cb(Tuple::point(6, -1, 1), Tuple::point(10, 3, 6)) &&
              !cb(Tuple::point(4, -3, -1), Tuple::point(10, 3, 6)) && !cb(Tuple::point(6, -1, 1), Tuple::point(12, 5, 8)));
   BoundingBox unit;
@@ -123,14 +124,15 @@ static void boxKats() {
     b.min = s.mn;
     b.max = s.mx;
     const auto h = b.split();
-    report("bounding_box.zig:362", "split_" + std::to_string(i++),
+    report(("bounding_box.zig:" + std::to_string(365 + 15 * i)).c_str(), "split_" + std::to_string(i),   // the four tests at :365, :380, :395, :410
            h.first.min.bitEqual(s.mn) && nearT(h.first.max, s.lmax) && nearT(h.second.min, s.rmin) && h.second.max.bitEqual(s.mx));
+    ++i;
   }
   // per-kind bounds
   Shape cyl = Shape::cylinder();
   cyl.ymin = -5;
   cyl.ymax = 3;
-  report("cylinder.zig:341", "cylinder_bounds",
+  report("cylinder.zig:342", "cylinder_bounds",
          cyl.bounds().min.bitEqual(Tuple::point(-1, -5, -1)) && cyl.bounds().max.bitEqual(Tuple::point(1, 3, 1)));
   {  // cone.zig:241-260 (the reference's second test is named "A bounded cylinder ..." but builds a cone)
     const Shape unbounded = Shape::cone();
@@ -142,6 +144,21 @@ static void boxKats() {
     cone.ymax = 3;
     report("cone.zig:249", "cone_bounds",
            cone.bounds().min.bitEqual(Tuple::point(-5, -5, -5)) && cone.bounds().max.bitEqual(Tuple::point(5, 3, 5)));
+  }
+  {  // the three-line bounds() tests: sphere.zig:186, cube.zig:211, shape.zig:631, cylinder.zig:334, triangle.zig:344
+    auto unit = [](const Shape& sh) {
+      return sh.bounds().min.bitEqual(Tuple::point(-1, -1, -1)) && sh.bounds().max.bitEqual(Tuple::point(1, 1, 1));
+    };
+    report("sphere.zig:186", "sphere_bounds", unit(Shape::sphere()));
+    report("cube.zig:211", "cube_bounds", unit(Shape::cube()));
+    report("shape.zig:631", "test_shape_bounds", unit(Shape::testShape()));
+    const Shape open_cyl = Shape::cylinder();
+    report("cylinder.zig:334", "unbounded_cylinder_bounds",
+           open_cyl.bounds().min.bitEqual(Tuple::point(-1, -kInf, -1)) && open_cyl.bounds().max.bitEqual(Tuple::point(1, kInf, 1)));
+    const Shape st = Shape::smoothTriangle(Tuple::point(-3, 7, 2), Tuple::point(6, 2, -4), Tuple::point(2, -1, -1), Tuple::vec3(0, 0, 0),
+                                           Tuple::vec3(0, 0, 0), Tuple::vec3(0, 0, 0));
+    report("triangle.zig:344", "smooth_triangle_bounds",
+           st.bounds().min.bitEqual(Tuple::point(-3, -1, -4)) && st.bounds().max.bitEqual(Tuple::point(6, 7, 2)));
   }
   const Shape pl = Shape::plane();
   report("plane.zig:109", "plane_bounds", pl.bounds().min.x == -kInf && pl.bounds().min.y == 0 && pl.bounds().max.z == kInf);
@@ -156,6 +173,22 @@ static void boxKats() {
 }
 
 static void groupKats() {
+  {  // group.zig:139-147 Creating a new group; :149-161 Adding a child; shape.zig:441-462 ids and setTransform
+    Shape g = Shape::group();
+    report("group.zig:139", "new_group", [&] { const Matrix4 id = Matrix4::identity(); return std::memcmp(&g.transform, &id, sizeof id) == 0; }() && g.children.empty());
+    const Shape t = Shape::testShape();
+    g.addChild(t);
+    report("group.zig:149", "add_child", g.children.size() == 1 && g.children[0].id == t.id && g.children[0].kind == ShapeKind::TestShape);
+    const Shape s1 = Shape::sphere(), s2 = Shape::sphere(), s3 = Shape::testShape();
+    report("shape.zig:441", "id_uniqueness", s1.id != s2.id && s2.id != s3.id && s3.id != s1.id);
+    Shape moved = Shape::testShape();
+    moved.setTransform(Matrix4::identity().translate(2, 3, 4));
+    const Matrix4 want = Matrix4::identity().translate(-2, -3, -4);
+    bool ok = true;
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) ok = ok && std::fabs(moved.inverse.d[r][c] - want.d[r][c]) < 1e-5;
+    report("shape.zig:450", "creation_set_transform", ok);
+  }
   {  // group.zig:219-241
     Shape s = Shape::sphere();
     s.setTransform(Matrix4::identity().scale(2, 2, 2).translate(2, 5, -3));
@@ -366,7 +399,7 @@ static void objKats() {  // obj.zig:288-544
   {
     ObjParser p;
     p.loadObj("vn 0 0 1\nvn 0.707 0 -0.707\nvn 1 2 3", {}, false);
-    report("obj.zig:481", "normals", p.normals.size() == 3 && p.normals[1].bitEqual(Tuple::vec3(0.707, 0, -0.707)));
+    report("obj.zig:482", "normals", p.normals.size() == 3 && p.normals[1].bitEqual(Tuple::vec3(0.707, 0, -0.707)));
   }
   {
     ObjParser p;
@@ -376,7 +409,7 @@ static void objKats() {  // obj.zig:288-544
     if (ok)
       ok = c[0].n1.bitEqual(p.normals[2]) && c[0].n2.bitEqual(p.normals[0]) && c[0].n3.bitEqual(p.normals[1]) &&
            c[1].n1.bitEqual(c[0].n1) && c[1].n2.bitEqual(c[0].n2) && c[1].p3.bitEqual(c[0].p3);
-    report("obj.zig:510", "faces_with_normals", ok);
+    report("obj.zig:511", "faces_with_normals", ok);
   }
   {  // normalisation: offset = box centre, scale = half the longest extent; w becomes 1/scale (obj.zig:66)
     ObjParser p;
@@ -403,6 +436,57 @@ static void canvasKats() {  // canvas.zig:258-303
                      "255 204 153 255 204 153 255 204 153 255 204 153 255 204 153 255 204\n"
                      "153 255 204 153 255 204 153 255 204 153 255 204 153\n");
   report("canvas.zig:132", "pixel_out_of_range", c.getPixelPointer(5, 0) == nullptr && c.getPixelPointer(0, 3) == nullptr);
+
+  // canvas.zig:305-422 - the P3 reader
+  auto errorOf = [](const std::string& text) -> std::string {
+    try {
+      Canvas::fromPpm(text);
+    } catch (const Error& e) {
+      return e.name;
+    }
+    return "";
+  };
+  auto px = [](const Canvas& cv, size_t x, size_t y, double r, double g, double b) {
+    const Color* p = cv.getPixelPointer(x, y);
+    return p && std::fabs(p->r - r) < 1e-5 && std::fabs(p->g - g) < 1e-5 && std::fabs(p->b - b) < 1e-5;
+  };
+  report("canvas.zig:305", "ppm_wrong_magic", errorOf("P32\n1 1\n255\n0 0 0") == "InvalidMagicNumber");
+  {
+    std::string text = "P3\n10 2\n255\n";
+    for (int row = 0; row < 4; ++row) text += "0 0 0  0 0 0  0 0 0  0 0 0  0 0 0\n";
+    const Canvas r = Canvas::fromPpm(text);
+    report("canvas.zig:317", "ppm_size", r.width == 10 && r.height == 2 && r.pixels.size() == 20);
+  }
+  {
+    const Canvas r = Canvas::fromPpm("P3\n4 3\n255\n255 127 0  0 127 255  127 255 0  255 255 255\n0 0 0  255 0 0  0 255 0  0 0 255\n"
+                                     "255 255 0  0 255 255  255 0 255  127 127 127");
+    report("canvas.zig:337", "ppm_pixels",
+           px(r, 0, 0, 1, 0.49804, 0) && px(r, 1, 0, 0, 0.49804, 1) && px(r, 2, 0, 0.49804, 1, 0) && px(r, 3, 0, 1, 1, 1) &&
+               px(r, 0, 1, 0, 0, 0) && px(r, 1, 1, 1, 0, 0) && px(r, 2, 1, 0, 1, 0) && px(r, 3, 1, 0, 0, 1) && px(r, 0, 2, 1, 1, 0) &&
+               px(r, 1, 2, 0, 1, 1) && px(r, 2, 2, 1, 0, 1) && px(r, 3, 2, 0.49804, 0.49804, 0.49804));
+  }
+  {
+    const Canvas r = Canvas::fromPpm("P3\n# this is a comment\n2 1\n# this, too\n255\n# another comment\n255 255 255\n"
+                                     "# oh, no, comments in the pixel data!\n255 0 255");
+    report("canvas.zig:366", "ppm_comments", px(r, 0, 0, 1, 1, 1) && px(r, 1, 0, 1, 0, 1));
+  }
+  {
+    const Canvas r = Canvas::fromPpm("P3\n1 1\n255\n51\n153\n\n204");
+    report("canvas.zig:388", "ppm_triple_spans_lines", px(r, 0, 0, 0.2, 0.6, 0.8));
+  }
+  {
+    const Canvas r = Canvas::fromPpm("P3\n2 2\n100\n100 100 100  50 50 50\n75 50 25  0 0 0");
+    report("canvas.zig:407", "ppm_scale", px(r, 0, 1, 0.75, 0.5, 0.25));
+  }
+  // (canvas.zig:48-121 beyond its tests: what the other error names are for, and that ppm() reads back)
+  report("canvas.zig:58", "ppm_no_dimensions", errorOf("P3\n# only a comment") == "InvalidDimensions" && errorOf("P3\n3\n255\n") == "InvalidDimensions" &&
+                                                     errorOf("P3\n1 1 1\n255\n0 0 0") == "InvalidDimensions");
+  report("canvas.zig:78", "ppm_no_scale", errorOf("P3\n1 1\n") == "InvalidScale" && errorOf("P3\n1 1\n255 255\n0 0 0") == "InvalidScale");
+  report("canvas.zig:116", "ppm_sample_count", errorOf("P3\n2 1\n255\n0 0 0") == "InvalidDimensions" && errorOf("P3\n1 1\n255\n0 0 x") == "InvalidCharacter");
+  {
+    const Canvas back = Canvas::fromPpm(c2.ppm());
+    report("canvas.zig:181", "ppm_round_trip", back.width == 10 && back.height == 2 && px(back, 9, 1, 1.0, 0.8, 0.6));
+  }
 }
 
 static void flattenKats() {

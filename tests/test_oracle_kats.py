@@ -30,7 +30,7 @@ def test_oracle_kats_all_pass():
                  "triangle.zig", "group.zig", "bounding_box.zig", "shape.zig", "material.zig", "pattern.zig",
                  "checkers.zig", "stripes.zig", "world.zig", "camera.zig"]:
         assert area in areas, area
-    assert len(lines) >= 450
+    assert len(lines) >= 490
     # the oracle's OWN scene build (rtc_oracle_scene.hpp) is held to the reference's vectors too, not only to the product
     # loader: partition / makeSubgroup / divide x 2 (group.zig:246-381), the four splits (bounding_box.zig:365-423), the
     # OBJ parser's cases (obj.zig:288-544), parseScene (scene.zig:664-774)
