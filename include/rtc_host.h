@@ -34,6 +34,9 @@ const char *rtch_last_error(void);
 
 /* Parses a scene description; files it names (OBJ meshes, PNG textures) are read from data_dir + name. */
 int rtch_scene_load(const char *scene_json, const char *data_dir, void **out_handle);
+/* Threads rtch_scene_load may build the scene's objects on: 0 (the default) = what the process may use, at most 16;
+ * 1 = one loop over "objects", as scene.zig:650-655.  The description is the same to the bit either way. */
+void rtch_set_loader_threads(uint32_t threads);
 void rtch_scene_free(void *handle);
 /* The flattened World, valid while the handle lives; pass it to rtc_scene_create. */
 const rtc_scene_desc *rtch_scene_desc(void *handle);

@@ -98,7 +98,7 @@ RTC_SYMBOLS = ["rtc_scene_create", "rtc_scene_clone", "rtc_scene_destroy", "rtc_
 # (... and include/rtc_diag.h: diagnostics and tuning, for the tests, bench.py and tools/)
 RTC_DIAG_SYMBOLS = ["rtc_set_option", "rtc_last_kernel_name", "rtc_get_schedule", "rtc_get_chunk_times", "rtc_diag_build_tables", "rtc_diag_root_boxes"]
 HOST_SYMBOLS = ["rtch_last_error", "rtch_scene_load", "rtch_scene_free", "rtch_scene_desc", "rtch_scene_camera",
-                "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render"]
+                "rtch_camera_rotate", "rtch_camera_move", "rtch_camera_make", "rtch_canvas_ppm", "rtch_canvas_rgba8", "rtch_scene_render", "rtch_set_loader_threads"]
 
 MULTI_SYMBOLS = ["rtc_multi_create", "rtc_multi_destroy", "rtc_multi_render", "rtc_multi_render_rgba8", "rtc_multi_render_device", "rtc_multi_render_rgba8_device",
                  "rtc_multi_synchronize", "rtc_multi_stream", "rtc_multi_get_stats", "rtc_multi_balance", "rtc_multi_last_error"]
@@ -188,6 +188,8 @@ def host_lib():
         lib.rtch_scene_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]
         lib.rtch_scene_free.argtypes = [C.c_void_p]
         lib.rtch_scene_free.restype = None
+        lib.rtch_set_loader_threads.argtypes = [C.c_uint32]
+        lib.rtch_set_loader_threads.restype = None
         lib.rtch_scene_desc.argtypes = [C.c_void_p]
         lib.rtch_scene_desc.restype = C.POINTER(SceneDesc)
         lib.rtch_scene_camera.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(Camera)]
@@ -508,6 +510,11 @@ def root_boxes(desc):
 def set_option(name, value):
     """rtc_set_option: a process-wide tuning / test option of the library (include/rtc_diag.h lists them)."""
     _check_hip(hip_lib().rtc_set_option(name.encode(), float(value)))
+
+
+def set_loader_threads(threads):
+    """rtch_set_loader_threads: threads HostScene's loader may build a scene's objects on (0: automatic, 1: one loop)."""
+    host_lib().rtch_set_loader_threads(int(threads))
 
 
 def canvas_ppm(rgb):

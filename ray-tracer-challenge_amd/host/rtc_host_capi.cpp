@@ -54,6 +54,10 @@ int rtch_scene_load(const char* scene_json, const char* data_dir, void** out) {
   });
 }
 
+// Threads parseScene may build a scene's objects on (0: what the process may use, at most 16; 1: one loop, as the
+// reference).  The scene description does not depend on it.
+void rtch_set_loader_threads(uint32_t threads) { rtc::setLoaderThreads(threads); }
+
 void rtch_scene_free(void* h) { delete static_cast<HostScene*>(h); }
 
 const rtc_scene_desc* rtch_scene_desc(void* h) { return &static_cast<HostScene*>(h)->desc; }

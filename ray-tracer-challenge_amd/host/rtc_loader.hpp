@@ -25,6 +25,12 @@ struct SceneInfo {  // scene.zig:608-610
 // scene.zig:612-661.  Throws rtc::Error whose .name is the Zig error name
 // (UnknownDefinition, NotInvertible, MissingField, UnknownField, ...).
 SceneInfo parseScene(const std::string& scene_json, const FileLoader& load_file_data);
+// The entries of "objects" are independent of each other (definitions are read-only, an object's transform, material and
+// divide(8) are its own): parseScene builds them on up to this many threads - 0: what the process may use (CPU affinity,
+// cgroup quota), at most 16; 1: the reference's one loop.  The World is the same to the bit whatever the count (ids
+// included: ShapeIdScope); `load_file_data` must then be callable from several threads at once (directoryLoader is).
+void setLoaderThreads(unsigned threads);
+unsigned loaderThreads();
 
 // obj.zig:11-286
 class ObjParser {

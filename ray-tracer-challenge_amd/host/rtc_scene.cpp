@@ -9,11 +9,22 @@
 
 namespace rtc {
 
+namespace {
+// shape.zig:123-130 keeps a non-atomic static; the loader is single-threaded there.
+std::atomic<size_t> g_next_id{0};
+thread_local size_t* tl_scope_counter = nullptr;
+}  // namespace
+
 size_t nextShapeId() {
-  // shape.zig:123-130 keeps a non-atomic static; the loader is single-threaded
-  // there.  An atomic costs nothing and keeps ids unique if callers use threads.
-  static std::atomic<size_t> id{0};
-  return id.fetch_add(1);
+  if (tl_scope_counter) return (*tl_scope_counter)++;
+  return g_next_id.fetch_add(1);
+}
+ShapeIdScope::ShapeIdScope() : outer_(tl_scope_counter) { tl_scope_counter = &drawn; }
+ShapeIdScope::~ShapeIdScope() { tl_scope_counter = outer_; }
+size_t reserveShapeIds(size_t count) { return g_next_id.fetch_add(count); }
+void offsetShapeIds(Shape& tree, size_t base) {
+  tree.id += base;
+  for (Shape& child : tree.children) offsetShapeIds(child, base);
 }
 
 BoundingBox Shape::bounds() const {

@@ -166,6 +166,22 @@ enum class ShapeKind : uint8_t {
 enum class CsgOp : uint8_t { Union = 1, Intersection = 2, Difference = 3 };  // csg.zig:16-20 (== RTC_CSG_*)
 
 size_t nextShapeId();  // shape.zig:123-130 — process-wide counter (also bumped by bounding boxes)
+// The loader builds the objects of a scene on several threads (rtc_loader.cpp): inside a ShapeIdScope the ids drawn on
+// this thread count from 0; when the object is done it gets the block of process-wide ids the reference's one counter
+// would have handed it at that point (reserveShapeIds, in the objects' order) and offsetShapeIds() moves its tree there.
+struct ShapeIdScope {
+  ShapeIdScope();
+  ~ShapeIdScope();
+  ShapeIdScope(const ShapeIdScope&) = delete;
+  ShapeIdScope& operator=(const ShapeIdScope&) = delete;
+  size_t drawn = 0;
+
+ private:
+  size_t* outer_;
+};
+size_t reserveShapeIds(size_t count);  // the first id of a block of `count`
+struct Shape;
+void offsetShapeIds(Shape& tree, size_t base);
 
 struct Shape {
   size_t id = 0;                                   // shape.zig:113
