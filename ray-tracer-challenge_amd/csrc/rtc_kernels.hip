@@ -117,6 +117,35 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #endif
 
 #ifndef RTC_ROOT_NODE_IN_REC
+// Wave priority by phase of the iteration (s_setprio, round 5; profiles/r05/wave_priority.md).  The three waves of a SIMD
+// are at different places of the same loop; which of them issues when more than one could is the arbiter's choice, and
+// with equal priorities it serves them alike.  Here a wave says what it is doing: fetching work (RTC_PRIO_DEAL: popping its
+// stacks, the LDS mailbox, claiming and reading the next packet - short, serial, and what every lane of the wave waits
+// for) goes first; the two phases that are FP32 arithmetic on data that is being waited for (phase 1 of the root loop,
+// RTC_PRIO_CULL; the node steps of a BVH walk, RTC_PRIO_NODE) go last; the exact FP64 tests and the shading in between
+// (RTC_PRIO_WORK).  Only the order matters (levels 1 / 2 / 3 for the middle measured the same); a fixed priority per
+// work-group instead starves waves (cover + 16 %).  cover - 3.1 %, reflection_and_refraction - 4.7 %, cubes - 3.5 %,
+// dragons 4K - 2.5 %, teapot - 3.8 %, nefertiti - 5.5 %.  -DRTC_SETPRIO=0 builds the kernels without it.
+#ifndef RTC_SETPRIO
+#define RTC_SETPRIO 1
+#endif
+#ifndef RTC_PRIO_DEAL
+#define RTC_PRIO_DEAL 3
+#endif
+#ifndef RTC_PRIO_WORK
+#define RTC_PRIO_WORK 1
+#endif
+#ifndef RTC_PRIO_CULL
+#define RTC_PRIO_CULL 0
+#endif
+#ifndef RTC_PRIO_NODE
+#define RTC_PRIO_NODE 0
+#endif
+#if RTC_SETPRIO
+#define RTC_PRIO_PHASE(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define RTC_PRIO_PHASE(x) ((void)0)
+#endif
 #define RTC_ROOT_NODE_IN_REC 1  // a group's World.objects record carries a copy of the root node of its candidate BVH (traverse_bvh8)
 #endif
 #ifndef RTC_LB2
@@ -869,6 +898,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
   unsigned long long pw_t = __builtin_amdgcn_s_memtime(), pw_t_nodes = 0, pw_t_leaves = 0;  // wave cycles in the two phases
 #endif
   for (;;) {
+    RTC_PRIO_PHASE(RTC_PRIO_NODE);
     while (l_hits == 0u && !vis.done()) {
       if ((g_bits & 0xFFu) == 0u) {
         if (sp == 0) break;
@@ -982,6 +1012,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
     }
 #endif
     if (l_hits == 0u) break;  // nothing left (or the visitor is done)
+    RTC_PRIO_PHASE(RTC_PRIO_WORK);
     while (l_hits != 0u) {
       const uint32_t k = static_cast<uint32_t>(__builtin_ctz(l_hits));
       l_hits &= l_hits - 1u;
@@ -1003,6 +1034,7 @@ __device__ __forceinline__ void traverse_bvh8(const DevScene& S, const uint32_t 
     }
 #endif
   }
+  RTC_PRIO_PHASE(RTC_PRIO_WORK);  // (a walk ends in its node phase)
 #ifdef RTC_PROFILE  // walks of the wave, their lanes, wave steps at nodes / at leaves, lanes at nodes / at leaves (summed over the steps)
   RTC_AUX_ADD(5, pw_t_nodes);
   RTC_AUX_ADD(6, pw_t_leaves);
@@ -1203,6 +1235,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
     unsigned long long mine = 0ull;
+    RTC_PRIO_PHASE(RTC_PRIO_CULL);
     // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
     for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
       unsigned long long k;
@@ -1216,6 +1249,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       mine |= k << i;
     }
     if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
+    RTC_PRIO_PHASE(RTC_PRIO_WORK);
     // Phase 2, one kind at a time.  The table is sorted [spheres][planes][cubes][everything else] (rtc_scene_create), so
     // a kind is a range of bits.  A wave that walks its lanes' survivors in table order runs the plane, the sphere AND
     // the cube code in almost every step (some lane holds one of each); kind by kind it runs each test's code only as
@@ -1980,6 +2014,7 @@ template <bool LDS, bool CSG, int WORLD = 0, int WAVES = 2, bool COOP = false, b
 __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& cam, const DevPixelMap& map,
                                             const uint32_t max_depth, double* __restrict__ out,
                                             DevStats* __restrict__ stats, DevStats* __restrict__ next_stats) {
+  RTC_PRIO_PHASE(RTC_PRIO_WORK);
 #ifndef RTC_PROFILE
   if (blockIdx.x == 0u) {  // the next launch's counters (see DevStats)
     uint32_t* z = reinterpret_cast<uint32_t*>(next_stats);
@@ -2127,6 +2162,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
 #endif
   for (;;) {
     RTC_STAMP(0);
+    RTC_PRIO_PHASE(RTC_PRIO_DEAL);
     // ---- 1. a lane without a ray pops its stack; an empty stack means its share of the pixel is done.
     // Shares of one pixel may finish in several lanes (step 2a): those are ADDED to the pixel, which the
     // first hand-out zeroed; a pixel whose whole ray tree stayed in one lane (most of them) is stored once.
@@ -2471,7 +2507,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
         trace<CSG, WORLD, BehindVisitor, TRAV, BOX>(S, recs, cull, ray, bv, it_overflow, trav_stack, member, stride);
         RTC_HIST_END(2);
       }
-      RTC_STAMP(6);
+        RTC_STAMP(6);
       bv.flush();
       const double hit_ior = mats[mat_index].ior;
       if (bv.best_leaf != RTC_NO_LEAF) n1 = mats[bv.best_mat].ior;
@@ -2628,7 +2664,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
             trace<CSG, WORLD, ShadowVisitor, TRAV, BOX>(S, recs, cull, sray, sv, it_overflow, trav_stack, s_member, s_stride);
             RTC_HIST_END(1);
           }
-          RTC_STAMP(4);
+                RTC_STAMP(4);
           shadowed = sv.shadowed;
         }
         // Material.lighting (material.zig:40-74)
