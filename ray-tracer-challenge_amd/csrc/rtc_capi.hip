@@ -558,6 +558,9 @@ int ensureScratch(rtc_scene* s, DevPixelMap& map, uint32_t blocks, uint32_t max_
   // 3.29 / 3.24 / 3.16 / 3.05 / 2.84 ms, dragons 4K 8.33 / 7.99 / 7.59 / 7.18 / 6.60 ms: a wave that finishes its
   // packet before it starts the next keeps neighbouring pixels (the same objects, materials, BVH paths) together;
   // the lanes that run out early are fed by the work sharing of step 2a, not by pixels of another chunk.
+  // (Round 5, with the wave priorities: frames that do NOT measure pulling at 60 / 56 / 48 / 32 idle lanes - so that the
+  // schedule is still packed from clean packet times -: cover 0.471 / 0.471 / 0.473 / 0.472 against 0.471, dragons 4K
+  // 1.707 / 1.707 / 1.709 / 1.708 against 1.706: nothing.  profiles/r05/pull_early_times.txt)
   const uint32_t pull_min = static_cast<uint32_t>(std::max(1.0, static_cast<double>(rtcOptions().pull_min_idle)));
   map.pull_min_idle = std::max(1u, std::min(64u, pull_min));
   s->dev.csg_buf = nullptr;
