@@ -1,7 +1,8 @@
 #!/bin/bash
 # ThreadSanitizer over the host half of rtc_scene_create (CPU only, runs in the build container): the candidate BVHs are
 # built on threads - one top-level group each (dragons.json: six), the threads left over inside a group's own build
-# (nefertiti.json: one group), the plain tables copied beside them.  Same trick as sanitize_host.sh: the HIP sources are
+# (nefertiti.json: one group), the plain tables copied beside them - and over the loader in front of it, which builds the
+# entries of a scene's "objects" side by side (parseScene: dragons.json's six dragons, ShapeIdScope).  Same trick as sanitize_host.sh: the HIP sources are
 # compiled --cuda-host-only and the device code object is replaced by an empty one; rtc_scene_create comes back with
 # NoDevice after the host work is done.
 set -e
