@@ -1036,7 +1036,7 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
   root_recs.assign(d.n_roots, RootRec{});
   // padded to a multiple of 4 with entries no ray keeps (r2 = -inf), see trace() phase 1
   root_cull.assign((d.n_roots + 3u) & ~3u, RootCull{0.0f, 0.0f, 0.0f, -INFINITY});
-  T.root_box.assign((d.n_roots + 3u) & ~3u, RootBox{});
+  T.root_box.assign((d.n_roots + 7u) & ~7u, RootBox{});  // (phase 1 of the root loop takes the boxes in blocks of eight roots)
   T.cull_bmax = 0.0f;
   T.root_weight.assign((d.n_roots + 3u) & ~3u, 0.0f);
   cull_cmax = 0.0f;
@@ -1835,12 +1835,12 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   std::vector<RootBoxPair> root_box_pairs(T.root_box.size() / 2u);
   for (size_t i = 0; i < root_box_pairs.size(); ++i) {
     const RootBox &a = T.root_box[2 * i], &b = T.root_box[2 * i + 1];
+    RootBoxPair::Pair* const axis[3] = {root_box_pairs[i].x, root_box_pairs[i].y, root_box_pairs[i].z};
     for (int k = 0; k < 3; ++k) {
-      root_box_pairs[i].lo[k] = {a.lo[k], b.lo[k]};
-      root_box_pairs[i].hi[k] = {a.hi[k], b.hi[k]};
+      axis[k][0] = axis[k][2] = {a.lo[k], b.lo[k]};
+      axis[k][1] = {a.hi[k], b.hi[k]};
     }
     root_box_pairs[i].line_only = {a.line_only, b.line_only};
-    root_box_pairs[i].pad_ = {0.0f, 0.0f};
   }
   HIP_TRY(s->tab->root_box.upload(root_box_pairs));
   HIP_TRY(s->tab->root_weight.upload(T.root_weight));

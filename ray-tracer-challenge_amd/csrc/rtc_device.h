@@ -63,15 +63,16 @@ struct RootCullPair {
 // The same bound as an axis-aligned WORLD-space box (round 5): what the render kernels' root loop tests since the box of an
 // axis-aligned cube IS the cube (its bounding sphere lets half of the rays through that miss it), a group's box is far
 // tighter than the sphere around it, and the interval a ray spends inside a box also says whether the root lies behind
-// the origin or beyond a shadow ray's light.  Two roots per record, plane by plane: [lo_x][lo_y][lo_z][hi_x][hi_y][hi_z],
-// each a pair of floats (root 0, root 1) - a lane reads the NEAR and the FAR plane of an axis from the offsets its ray's
-// direction signs pick (no selects, no min / max), and the two roots are the two halves of packed FP32 FMAs.  Planes
-// rounded outward; no finite bound: -3e38 / +3e38 (always kept); table padding: +3e38 / -3e38 (never kept).
-struct RootBoxPair {  // 64 B
+// the origin or beyond a shadow ray's light.  Two roots per record, axis by axis: [lo_x][hi_x][lo_x] [lo_y][hi_y][lo_y]
+// [lo_z][hi_z][lo_z], each a pair of floats (root 0, root 1).  A lane reads the NEAR and the FAR plane of an axis as two
+// NEIGHBOURING pairs from the offset its ray's direction sign picks - lo, hi for a ray that travels up the axis, hi, lo
+// (the repeated lo) for one that travels down: no selects, no min / max, ONE per-lane address per axis for a whole block of
+// records (the rest are immediate offsets), and the two roots are the two halves of packed FP32 FMAs.  Planes rounded
+// outward; no finite bound: -3e38 / +3e38 (always kept); table padding (to a multiple of EIGHT roots): +3e38 / -3e38 (never kept).
+struct RootBoxPair {  // 80 B
   typedef float Pair __attribute__((ext_vector_type(2)));
-  Pair lo[3], hi[3];
+  Pair x[3], y[3], z[3];  // lo, hi, lo
   Pair line_only;  // != 0: entries of this root may lie outside its box (a cone in a group): only "the line misses the box" culls it
-  Pair pad_;
 };
 struct alignas(16) RootRec {
   double inv[12];        // rows 0..2 of the leaf's inverse; a group: a copy of the root Bvh8Node of its candidate BVH (80 bytes: a walk's first node comes from this record - in LDS - not from the node table)

@@ -1138,7 +1138,7 @@ __device__ __forceinline__ uint32_t roots_kept(const RootCullPair& R, const RayF
 struct RayB {
   float ix, iy, iz;                       // 1 / d (a component of zero: 1e30 of its sign)
   float cnx, cny, cnz, cfx, cfy, cfz;     // -o / d - margin (near planes), -o / d + margin (far planes)
-  uint32_t onx, ony, onz;                 // byte offsets of the near planes' pairs in a RootBoxPair (the far plane of an axis: the other of lo / hi)
+  uint32_t onx, ony, onz;                 // byte offsets of the near planes' pairs in a RootBoxPair (the far plane of an axis: the next pair)
   float t_lo, t_hi;                       // the parameter range in which an entry can matter to the visitor
 };
 
@@ -1164,21 +1164,23 @@ __device__ __forceinline__ RayB ray_box(const Ray& r, const DevScene& S, const V
   b.cfy = cy + my;
   b.cfz = cz + mz;
   const bool nx = dx < 0.0f, ny = dy < 0.0f, nz = dz < 0.0f;
-  b.onx = nx ? 24u : 0u;
-  b.ony = ny ? 32u : 8u;
-  b.onz = nz ? 40u : 16u;
+  b.onx = nx ? 8u : 0u;     // RootBoxPair: [lo][hi][lo] per axis - near, far = lo, hi or hi, lo
+  b.ony = ny ? 32u : 24u;
+  b.onz = nz ? 56u : 48u;
   vis.box_limits(b.t_lo, b.t_hi);
   return b;
 }
 
-// Two roots.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.
+// Two roots.  Returns bit 0 / bit 1 = root 0 / 1 of the pair must be tested.  `pair`: the record; ax / ay / az: the record's
+// address + the ray's near-plane offsets (RayB::onx ...), formed ONCE per block of records by the caller - from there the
+// records of a block are immediate offsets, and phase 1 has no address arithmetic left (it had twelve integer
+// instructions per four roots, a fifth of the loop: the loop is a third of cover's vector instructions).
 template <class V, bool GROUPS>
-__device__ __forceinline__ uint32_t roots_kept_box(const char* __restrict__ pair, const RayB& rb) {
-  const Float2 nx = *reinterpret_cast<const Float2*>(pair + rb.onx), ny = *reinterpret_cast<const Float2*>(pair + rb.ony),
-               nz = *reinterpret_cast<const Float2*>(pair + rb.onz);
-  // (lo_x at 0, hi_x at 24: the far plane's offset is 24 - the near one's; y: 8 / 32 -> 40 - ; z: 16 / 40 -> 56 -)
-  const Float2 fx = *reinterpret_cast<const Float2*>(pair + (24u - rb.onx)), fy = *reinterpret_cast<const Float2*>(pair + (40u - rb.ony)),
-               fz = *reinterpret_cast<const Float2*>(pair + (56u - rb.onz));
+__device__ __forceinline__ uint32_t roots_kept_box(const char* __restrict__ pair, const char* __restrict__ ax, const char* __restrict__ ay,
+                                                   const char* __restrict__ az, const RayB& rb) {
+  const Float2 nx = *reinterpret_cast<const Float2*>(ax), fx = *reinterpret_cast<const Float2*>(ax + 8);
+  const Float2 ny = *reinterpret_cast<const Float2*>(ay), fy = *reinterpret_cast<const Float2*>(ay + 8);
+  const Float2 nz = *reinterpret_cast<const Float2*>(az), fz = *reinterpret_cast<const Float2*>(az + 8);
   const Float2 tnx = __builtin_elementwise_fma(nx, Float2(rb.ix), Float2(rb.cnx)), tny = __builtin_elementwise_fma(ny, Float2(rb.iy), Float2(rb.cny)),
                tnz = __builtin_elementwise_fma(nz, Float2(rb.iz), Float2(rb.cnz));
   const Float2 tfx = __builtin_elementwise_fma(fx, Float2(rb.ix), Float2(rb.cfx)), tfy = __builtin_elementwise_fma(fy, Float2(rb.iy), Float2(rb.cfy)),
@@ -1190,10 +1192,43 @@ __device__ __forceinline__ uint32_t roots_kept_box(const char* __restrict__ pair
     bool culled = fmaxf(tn, rb.t_lo) > fminf(tf, rb.t_hi);  // the line misses the box, or meets it only where no entry matters
     if constexpr (GROUPS) {
       // (entries of this root may lie outside its box - a cone in a group: only the line's missing the box holds)
-      const float line_only = (*reinterpret_cast<const Float2*>(pair + 48))[e];
+      const float line_only = (*reinterpret_cast<const Float2*>(pair + 72))[e];
       culled = line_only != 0.0f ? tn > tf : culled;
     }
     kept |= culled ? 0u : (1u << e);
+  }
+  return kept;
+}
+
+// Four roots - two neighbouring records -, all twelve plane pairs fetched before any is used (the loads of a record wait
+// for nothing but each other: taken one record at a time, every record's arithmetic waited for its own three loads).
+template <class V, bool GROUPS>
+__device__ __forceinline__ uint32_t roots_kept_box4(const char* __restrict__ pair, const char* __restrict__ ax, const char* __restrict__ ay,
+                                                    const char* __restrict__ az, const RayB& rb) {
+  constexpr uint32_t NEXT = sizeof(RootBoxPair);
+  const Float2 nx[2] = {*reinterpret_cast<const Float2*>(ax), *reinterpret_cast<const Float2*>(ax + NEXT)};
+  const Float2 fx[2] = {*reinterpret_cast<const Float2*>(ax + 8), *reinterpret_cast<const Float2*>(ax + NEXT + 8)};
+  const Float2 ny[2] = {*reinterpret_cast<const Float2*>(ay), *reinterpret_cast<const Float2*>(ay + NEXT)};
+  const Float2 fy[2] = {*reinterpret_cast<const Float2*>(ay + 8), *reinterpret_cast<const Float2*>(ay + NEXT + 8)};
+  const Float2 nz[2] = {*reinterpret_cast<const Float2*>(az), *reinterpret_cast<const Float2*>(az + NEXT)};
+  const Float2 fz[2] = {*reinterpret_cast<const Float2*>(az + 8), *reinterpret_cast<const Float2*>(az + NEXT + 8)};
+  uint32_t kept = 0u;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const Float2 tnx = __builtin_elementwise_fma(nx[r], Float2(rb.ix), Float2(rb.cnx)), tny = __builtin_elementwise_fma(ny[r], Float2(rb.iy), Float2(rb.cny)),
+                 tnz = __builtin_elementwise_fma(nz[r], Float2(rb.iz), Float2(rb.cnz));
+    const Float2 tfx = __builtin_elementwise_fma(fx[r], Float2(rb.ix), Float2(rb.cfx)), tfy = __builtin_elementwise_fma(fy[r], Float2(rb.iy), Float2(rb.cfy)),
+                 tfz = __builtin_elementwise_fma(fz[r], Float2(rb.iz), Float2(rb.cfz));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float tn = fmaxf(fmaxf(tnx[e], tny[e]), tnz[e]), tf = fminf(fminf(tfx[e], tfy[e]), tfz[e]);
+      bool culled = fmaxf(tn, rb.t_lo) > fminf(tf, rb.t_hi);
+      if constexpr (GROUPS) {
+        const float line_only = (*reinterpret_cast<const Float2*>(pair + r * NEXT + 72))[e];
+        culled = line_only != 0.0f ? tn > tf : culled;
+      }
+      kept |= culled ? 0u : (1u << (2 * r + e));
+    }
   }
   return kept;
 }
@@ -1236,17 +1271,42 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     const uint32_t n = min(64u, S.n_roots - base);
     unsigned long long mine = 0ull;
     RTC_PRIO_PHASE(RTC_PRIO_CULL);
-    // the cull table is padded to a multiple of 4 with never-kept entries (r2 = -inf)
-    for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
-      unsigned long long k;
+    // the tables are padded with entries no ray keeps: the spheres to a multiple of four roots (r2 = -inf), the boxes to eight (lo > hi)
+    if (BOX && FLAT && stride == 1u) {
+      // (the kernels of worlds without groups, but for their cooperative iterations: four roots - two records - per step
+      // off three per-lane addresses that move from step to step.  The kernels that walk groups have few top-level
+      // objects and no registers for twelve plane pairs in flight: dragons 4K + 0.9 % with this form, so they keep the loop below)
       if constexpr (BOX) {
-        const char* const p0 = reinterpret_cast<const char*>(cull.box + ((base + i) >> 1));
-        k = roots_kept_box<V, !FLAT>(p0, rf) | (roots_kept_box<V, !FLAT>(p0 + sizeof(RootBoxPair), rf) << 2);
-      } else {
-        const RootCullPair p0 = cull.sphere[(base + i) >> 1], p1 = cull.sphere[((base + i) >> 1) + 1u];
-        k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
+        // (the block loop itself is NOT unrolled: the simple kernels are 42 KB of code and run without a single
+        // instruction-cache miss; unrolled eight times they were 60 KB and cover took twice as long)
+        const char* block = reinterpret_cast<const char*>(cull.box + (base >> 1));
+        const char* ax = block + rf.onx;
+        const char* ay = block + rf.ony;
+        const char* az = block + rf.onz;
+#pragma unroll 1
+        for (uint32_t first = 0; first < n; first += 4u) {
+          const uint32_t k = roots_kept_box4<V, !FLAT>(block, ax, ay, az, rf);
+          mine |= static_cast<unsigned long long>(k) << first;
+          block += 2u * sizeof(RootBoxPair);
+          ax += 2u * sizeof(RootBoxPair);
+          ay += 2u * sizeof(RootBoxPair);
+          az += 2u * sizeof(RootBoxPair);
+        }
       }
-      mine |= k << i;
+    } else {
+      for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
+        unsigned long long k;
+        if constexpr (BOX) {
+          const char* const p0 = reinterpret_cast<const char*>(cull.box + ((base + i) >> 1));
+          const char* const p1 = p0 + sizeof(RootBoxPair);
+          k = roots_kept_box<V, !FLAT>(p0, p0 + rf.onx, p0 + rf.ony, p0 + rf.onz, rf) |
+              (roots_kept_box<V, !FLAT>(p1, p1 + rf.onx, p1 + rf.ony, p1 + rf.onz, rf) << 2);
+        } else {
+          const RootCullPair p0 = cull.sphere[(base + i) >> 1], p1 = cull.sphere[((base + i) >> 1) + 1u];
+          k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
+        }
+        mine |= k << i;
+      }
     }
     if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
     RTC_PRIO_PHASE(RTC_PRIO_WORK);
@@ -2073,7 +2133,7 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
       for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
     };
     stage(lds_recs, S.root_recs, S.n_roots * (sizeof(RootRec) / 8u));
-    if constexpr (BOX) stage(lds_box, S.root_box, ((S.n_roots + 3u) & ~3u) / 2u * (sizeof(RootBoxPair) / 8u));
+    if constexpr (BOX) stage(lds_box, S.root_box, ((S.n_roots + 7u) & ~7u) / 2u * (sizeof(RootBoxPair) / 8u));
     else stage(lds_cull, S.root_cull, ((S.n_roots + 3u) & ~3u) / 2u * (sizeof(RootCullPair) / 8u));
     stage(lds_mat, S.mat, S.n_materials * (sizeof(DevMaterial) / 8u));
     stage(lds_pat, S.pat, S.n_patterns * (sizeof(DevPattern) / 8u));
