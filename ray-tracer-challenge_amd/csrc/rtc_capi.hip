@@ -1989,6 +1989,12 @@ int uploadTables(const rtc_scene_desc& d, const SceneTraits& traits, const HostT
   D.node_range = s->tab->node_range.p;
   D.bvh_mag = bvh_mag;
   D.chain_nested = T.chain_nested ? 1u : 0u;
+  D.all_solid = 1u;
+  for (uint32_t i = 0; i < d.n_patterns; ++i)
+    if (d.pat_kind[i] != RTC_PAT_SOLID) D.all_solid = 0u;
+#ifdef RTC_NO_ALL_SOLID
+  D.all_solid = 0u;
+#endif
   D.csg_entries = RTC_CSG_ENTRIES;
   D.node_box = s->tab->node_box.p;
   D.node_kids = s->tab->node_kids.p;

@@ -249,6 +249,7 @@ struct DevScene {
                     // direction component below 1e-5 in object space, so an entry may lie that far - times the ray parameter - outside the cube)
   float bvh_mag;    // max |coordinate| of any finite BVH box: scale of the FP32 traversal margin
   uint32_t chain_nested;  // every reference Group box lies inside its parent's: a ray that passes the innermost passes all
+  uint32_t all_solid;     // every pattern of the world is a solid colour: a hit's colour needs no object-space point (cover, dragons, groups)
 };
 
 struct DevCamera {

@@ -126,6 +126,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 // (RTC_PRIO_WORK).  Only the order matters (levels 1 / 2 / 3 for the middle measured the same); a fixed priority per
 // work-group instead starves waves (cover + 16 %).  cover - 3.1 %, reflection_and_refraction - 4.7 %, cubes - 3.5 %,
 // dragons 4K - 2.5 %, teapot - 3.8 %, nefertiti - 5.5 %.  -DRTC_SETPRIO=0 builds the kernels without it.
+#ifndef RTC_ALL_SOLID_FORM
+#define RTC_ALL_SOLID_FORM 1
+#endif
 #ifndef RTC_SETPRIO
 #define RTC_SETPRIO 1
 #endif
@@ -2671,16 +2674,26 @@ __device__ __forceinline__ void render_body(const DevScene& S, const DevCamera& 
     RTC_STAMP(11);
     const double eps = 1e-5;
     const double ovx = ptx + nx * eps, ovy = pty + ny * eps, ovz = ptz + nz * eps;  // over_point
-    // Pattern.patternAtShape (pattern.zig:128-131) looks the colour up at over_point in object space
-    const double opx = row_pt(M + 0, ovx, ovy, ovz);
-    const double opy = row_pt(M + 4, ovx, ovy, ovz);
-    const double opz = row_pt(M + 8, ovx, ovy, ovz);
-
     // ---- World.shadeHit, lights loop (world.zig:89-96)
     double sr = 0.0, sg = 0.0, sb = 0.0;
     {
       const DevMaterial& mat = mats[mat_index];
-      const Rgb color = pattern_at<CSG>(S, pats, mat.pattern, opx, opy, opz);
+      // Pattern.patternAtShape (pattern.zig:128-131) looks the colour up at over_point in object space - but a world all of
+      // whose patterns are solid colours (cover, dragons, groups; DevScene::all_solid, a branch of the wave, not of its
+      // lanes: solid.zig:20-24 looks at no point) needs neither the point nor the pattern code: cover 0.462 -> 0.446 ms,
+      // cubes - 1.4 % (the form alone), dragons 4K - 1.1 %, nefertiti - 1.3 %.  The simple kernels that cull by spheres keep
+      // the plain form: with the branch reflection_and_refraction lost 3-5 % to the register allocator (HISTORY).
+      constexpr bool SOLID_PATH = RTC_ALL_SOLID_FORM != 0 && !(WORLD == 2 && !BOX);
+      Rgb color;
+      if (SOLID_PATH && S.all_solid != 0u) {
+        const DevPattern& P = pats[mat.pattern];
+        color = {P.rgb[0], P.rgb[1], P.rgb[2]};
+      } else {
+        const double opx = row_pt(M + 0, ovx, ovy, ovz);
+        const double opy = row_pt(M + 4, ovx, ovy, ovz);
+        const double opz = row_pt(M + 8, ovx, ovy, ovz);
+        color = pattern_at<CSG>(S, pats, mat.pattern, opx, opy, opz);
+      }
       RTC_STAMP(12);
       // With diffuse == 0 and specular == 0 lighting() returns `ambient` whether or not the
       // point is shadowed (material.zig:55-73), so the shadow ray cannot change the result.
