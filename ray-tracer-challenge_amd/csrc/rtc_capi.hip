@@ -878,7 +878,7 @@ struct HostTables {
   std::vector<double> node_box;
   std::vector<double> light;
   uint32_t n_live = 0;
-  uint32_t n_root_kind[3] = {0, 0, 0};  // spheres, planes, cubes at the head of root_recs (in that order)
+  uint32_t n_root_kind[3] = {0, 0, 0};  // top-level spheres, planes, cubes (the table: [spheres][cubes][the rest][planes])
   float bvh_mag = 0.0f;
   float cull_cmax = 0.0f;
 };
@@ -1216,16 +1216,18 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
       C = RootCull{0.0f, 0.0f, 0.0f, INFINITY};
     }
   }
-  // Sorted by kind for the kernel's root loop (trace() phase 2 runs one kind at a time): spheres, planes, cubes, the
-  // rest; World.objects order inside a kind.  The record carries everything that depends on the object's identity
-  // (depth-first leaf index, material), so the table order is free.
+  // Sorted by kind for the kernel's root loop (trace() phase 2 runs one kind at a time): spheres, cubes, the rest, and the
+  // PLANES LAST; World.objects order inside a kind.  The record carries everything that depends on the object's identity
+  // (depth-first leaf index, material), so the table order is free.  A plane has no bound: phase 1 of the root loop has
+  // nothing to reject it by and, with the planes at the table's tail, does not look at them at all
+  // (reflection_and_refraction: seven spheres in a room of six planes - two steps of four roots per trace instead of four).
   auto klass = [&](const RootRec& R) -> int {
-    if (R.kind_flags & RTC_ROOT_IS_GROUP) return 3;
+    if (R.kind_flags & RTC_ROOT_IS_GROUP) return 2;
     switch (R.kind_flags & 0xFFu) {
-      case RTC_SPHERE: return 0;  // (first: the head of the table is what the root loop rejects by bounding SPHERES - a sphere's own
-      case RTC_PLANE: return 1;   //  outline - and everything behind it by world boxes: trace())
-      case RTC_CUBE: return 2;
-      default: return 3;
+      case RTC_SPHERE: return 0;
+      case RTC_CUBE: return 1;
+      case RTC_PLANE: return 3;
+      default: return 2;
     }
   };
   std::vector<uint32_t> perm(d.n_roots);
@@ -1241,8 +1243,12 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
     cull2[i] = root_cull[perm[i]];
     box2[i] = T.root_box[perm[i]];
     weight2[i] = T.root_weight[perm[i]];
-    const int k = klass(recs2[i]);
-    if (k < 3) T.n_root_kind[k]++;
+    if (!(recs2[i].kind_flags & RTC_ROOT_IS_GROUP)) {
+      const uint32_t kind = recs2[i].kind_flags & 0xFFu;
+      if (kind == RTC_SPHERE) T.n_root_kind[0]++;
+      if (kind == RTC_PLANE) T.n_root_kind[1]++;
+      if (kind == RTC_CUBE) T.n_root_kind[2]++;
+    }
   }
   T.root_order = perm;
   root_recs.swap(recs2);

@@ -240,8 +240,9 @@ struct DevScene {
   const uint32_t* __restrict__ kids;
   const double* __restrict__ light;     // [n_lights][6]
   uint32_t n_roots, n_leaves, n_nodes, n_lights, n_materials, n_patterns;
-  // root_recs / root_cull / root_box are sorted by kind: [spheres][planes][cubes][every other leaf kind and the groups] (the
-  // order inside a kind is World.objects order; nothing depends on the table order, see trace())
+  // root_recs / root_cull / root_box are sorted by kind: [spheres][cubes][every other leaf kind and the groups][planes] (the
+  // order inside a kind is World.objects order; nothing depends on the table order, see trace(); the planes, which have no
+  // bound, are the tail that phase 1 of the root loop does not read)
   uint32_t n_root_planes, n_root_spheres, n_root_cubes;
   float cull_cmax;  // max over bounded roots of |centre|: scale of the FP32 rounding margin
   float cull_bmax;  // max |coordinate| of any finite root box: scale of the box test's FP32 margin

@@ -1270,8 +1270,11 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     if constexpr (BOX) return ray_box(ray, S, vis);
     else return ray_f32(ray, S.cull_cmax);
   }();
+  // (the table is sorted [spheres][cubes][the rest][planes]: a plane has no bound, phase 1 stops where the planes begin)
+  const uint32_t n_bounded = S.n_roots - S.n_root_planes;
   for (uint32_t base = 0; base < S.n_roots; base += 64u) {
     const uint32_t n = min(64u, S.n_roots - base);
+    const uint32_t nc = n_bounded > base ? min(n, n_bounded - base) : 0u;  // roots of this block that phase 1 tests
     unsigned long long mine = 0ull;
     RTC_PRIO_PHASE(RTC_PRIO_CULL);
     // the tables are padded with entries no ray keeps: the spheres to a multiple of four roots (r2 = -inf), the boxes to eight (lo > hi)
@@ -1287,7 +1290,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         const char* ay = block + rf.ony;
         const char* az = block + rf.onz;
 #pragma unroll 1
-        for (uint32_t first = 0; first < n; first += 4u) {
+        for (uint32_t first = 0; first < nc; first += 4u) {
           const uint32_t k = roots_kept_box4<V, !FLAT>(block, ax, ay, az, rf);
           mine |= static_cast<unsigned long long>(k) << first;
           block += 2u * sizeof(RootBoxPair);
@@ -1297,7 +1300,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         }
       }
     } else {
-      for (uint32_t i = 4u * member; i < n; i += 4u * stride) {
+      for (uint32_t i = 4u * member; i < nc; i += 4u * stride) {
         unsigned long long k;
         if constexpr (BOX) {
           const char* const p0 = reinterpret_cast<const char*>(cull.box + ((base + i) >> 1));
@@ -1311,9 +1314,19 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         mine |= k << i;
       }
     }
-    if (n < 64u) mine &= (1ull << n) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
+    if (nc < 64u) mine &= (1ull << nc) - 1ull;  // (the padding is never kept; a NaN ray must not reach past the table either)
+    if (nc < n) {  // the block's planes: kept as they are (what the bound of a plane, none, always said)
+      unsigned long long planes = (n < 64u ? (1ull << n) - 1ull : ~0ull) & ~((1ull << nc) - 1ull);
+      if (stride != 1u) {  // (a cooperative trace: root r is lane ((r / 4) % stride)'s, as in the loop above)
+        unsigned long long own = 0xFull << (4u * member);
+        if (stride == 4u) own |= own << 16;
+        own |= own << 32;
+        planes &= own;
+      }
+      mine |= planes;
+    }
     RTC_PRIO_PHASE(RTC_PRIO_WORK);
-    // Phase 2, one kind at a time.  The table is sorted [spheres][planes][cubes][everything else] (rtc_scene_create), so
+    // Phase 2, one kind at a time.  The table is sorted [spheres][cubes][everything else][planes] (rtc_scene_create), so
     // a kind is a range of bits.  A wave that walks its lanes' survivors in table order runs the plane, the sphere AND
     // the cube code in almost every step (some lane holds one of each); kind by kind it runs each test's code only as
     // often as the lane with the most survivors of that kind needs it, and the compiler drops what a kind does not use
@@ -1342,12 +1355,12 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     // cover 0.730 -> 0.698; in the kernels that also carry the group traversal the three extra loops cost the mesh
     // scenes 1-2 % and their worlds have few top-level objects.)
     if constexpr (FLAT) {
-      const uint32_t k1 = S.n_root_spheres, k2 = k1 + S.n_root_planes, k3 = k2 + S.n_root_cubes;
-      leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(k1, k2));
+      const uint32_t k1 = S.n_root_spheres, k2 = k1 + S.n_root_cubes;
+      leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(n_bounded, S.n_roots));
       leaves_of_kind(std::integral_constant<uint32_t, 0u>{}, mine & range(0u, k1));
-      leaves_of_kind(std::integral_constant<uint32_t, 2u>{}, mine & range(k2, k3));
+      leaves_of_kind(std::integral_constant<uint32_t, 2u>{}, mine & range(k1, k2));
       if constexpr (SIMPLE) continue;  // (a simple world has nothing else)
-      mine &= range(k3, S.n_roots);    // the other leaf kinds: cylinders, cones, triangles
+      mine &= range(k2, n_bounded);    // the other leaf kinds: cylinders, cones, triangles
     }
     while (mine != 0ull && !vis.done()) {
       const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mine));
