@@ -1337,18 +1337,21 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       const unsigned long long below_a = a >= 64u ? ~0ull : (1ull << a) - 1ull;
       return below_b & ~below_a;
     };
-    auto leaves_of_kind = [&](auto kind_tag, unsigned long long m) {
+    auto leaf_of_kind = [&](auto kind_tag, const uint32_t root) {
       constexpr uint32_t KIND = decltype(kind_tag)::value;
+      const RootRec& R = recs[root];
+      const uint32_t kf = R.kind_flags;
+      const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
+      const CylParams cy{0.0, 0.0, false};
+      const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
+      vis.set_root(root);
+      leaf_entries<SIMPLE>(KIND, cy, nullptr, lr, [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
+    };
+    auto leaves_of_kind = [&](auto kind_tag, unsigned long long m) {
       while (m != 0ull && !vis.done()) {
         const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(m));
         m &= m - 1ull;
-        const RootRec& R = recs[base + bit];
-        const uint32_t kf = R.kind_flags;
-        const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
-        const CylParams cy{0.0, 0.0, false};
-        const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
-        vis.set_root(base + bit);
-        leaf_entries<SIMPLE>(KIND, cy, nullptr, lr, [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
+        leaf_of_kind(kind_tag, base + bit);
       }
     };
     // (The kernels without group traversal are built this way: reflection_and_refraction depth 8 2.74 -> 2.22 ms,
@@ -1356,7 +1359,18 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     // scenes 1-2 % and their worlds have few top-level objects.)
     if constexpr (FLAT) {
       const uint32_t k1 = S.n_root_spheres, k2 = k1 + S.n_root_cubes;
-      leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(n_bounded, S.n_roots));
+      if (stride == 1u) {
+        // Every lane holds every plane of the block (phase 1 has no say about them): the loop over them is the WAVE's -
+        // one record address for all lanes, no per-lane bit scan, no integer multiply for a per-lane record address
+        // (reflection_and_refraction runs six plane tests in every one of its 45 M traces).
+        const uint32_t p1 = base + n;
+        for (uint32_t root = max(n_bounded, base); root < p1; ++root) {
+          if (__all(vis.done())) break;
+          if (!vis.done()) leaf_of_kind(std::integral_constant<uint32_t, 1u>{}, root);
+        }
+      } else {
+        leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(n_bounded, S.n_roots));
+      }
       leaves_of_kind(std::integral_constant<uint32_t, 0u>{}, mine & range(0u, k1));
       leaves_of_kind(std::integral_constant<uint32_t, 2u>{}, mine & range(k1, k2));
       if constexpr (SIMPLE) continue;  // (a simple world has nothing else)
