@@ -126,6 +126,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 // (RTC_PRIO_WORK).  Only the order matters (levels 1 / 2 / 3 for the middle measured the same); a fixed priority per
 // work-group instead starves waves (cover + 16 %).  cover - 3.1 %, reflection_and_refraction - 4.7 %, cubes - 3.5 %,
 // dragons 4K - 2.5 %, teapot - 3.8 %, nefertiti - 5.5 %.  -DRTC_SETPRIO=0 builds the kernels without it.
+#ifndef RTC_PLANE_EARLY_OUT
+#define RTC_PLANE_EARLY_OUT 1
+#endif
 #ifndef RTC_ALL_SOLID_FORM
 #define RTC_ALL_SOLID_FORM 1
 #endif
@@ -1345,7 +1348,26 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       const CylParams cy{0.0, 0.0, false};
       const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
       vis.set_root(root);
-      leaf_entries<SIMPLE>(KIND, cy, nullptr, lr, [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
+      if constexpr (KIND == 1u && V::kFrontOnly && RTC_PLANE_EARLY_OUT) {
+        // A plane's one entry is t = -o.y / d.y (plane.zig:25-36), and the division is 13 of the test's ~35 instructions.
+        // A closest-hit or a shadow trace looks at an entry only if 0 <= t and t < (or <=) its limit - the best hit so
+        // far, the light's distance - and BOTH can be decided without the quotient, exactly:
+        //   * o.y and d.y of one sign: the quotient is negative - and, with |o.y| >= 1e-290 and |d.y| <= 1e10, at least
+        //     1e-300 in magnitude, so it cannot round to -0 (which `t >= 0` would let through);
+        //   * |o.y| > limit x |d.y| x (1 + 1e-12): the exact quotient exceeds limit x (1 + 0.9997e-12) (two roundings of
+        //     2^-53 in the product), so the correctly rounded one exceeds the limit.  An infinite limit or an overflowing
+        //     product compares false: the division runs.
+        // A light inside a room never has a wall between itself and a point of the room: EVERY plane test of EVERY shadow ray
+        // of reflection_and_refraction ends here, for the whole wave.
+        if (__builtin_fabs(lr.dy) > 1e-5) {
+          const double ao = __builtin_fabs(lr.oy), ad = __builtin_fabs(lr.dy);
+          const bool negative = ((lr.oy > 0.0) == (lr.dy > 0.0)) & (ao >= 1e-290) & (ad <= 1e10);
+          const bool beyond = ao > (vis.t_limit() * ad) * (1.0 + 1e-12);
+          if (!(negative | beyond)) vis.entry(leaf, shadow, material, -lr.oy / lr.dy, 0.0, 0.0);
+        }
+      } else {
+        leaf_entries<SIMPLE>(KIND, cy, nullptr, lr, [&](double t, double u, double v) { vis.entry(leaf, shadow, material, t, u, v); });
+      }
     };
     auto leaves_of_kind = [&](auto kind_tag, unsigned long long m) {
       while (m != 0ull && !vis.done()) {

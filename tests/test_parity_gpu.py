@@ -1082,6 +1082,80 @@ def test_rays_along_cube_faces(rtc, variant, kernel):
             break
 
 
+def _room_of_planes_scene(variant):
+    """Planes where a plane test decides without its quotient (round 5: the division is skipped when the entry provably lies
+    behind the ray or beyond the trace's limit): walls of a room around the lights (no shadow ray ever reaches one), a wall THROUGH
+    a light (t equals the light's distance to the last bit or so), a plane through the camera's origin and along its central
+    row (o.y = 0, d.y = 0 in the plane's space), planes a hair in front of and behind a ray's origin, a tilted mirror, a glass
+    sheet (the containers pass looks at entries BEHIND the origin), and enough other shapes that the planes are the tail of
+    a table with steps of four.  variant: "simple", "flat" (+ cylinder, cone), "group" (+ a group, so the general kernel runs)."""
+    import json
+    def plane(transform, **material):
+        return {"type": {"plane": {}}, "transform": transform, "material": dict({"diffuse": 0.7, "specular": 0.3}, **material)}
+    half_pi = 1.5707963267948966
+    objs = [
+        plane([{"translate": [0, -2, 0]}], reflective=0.3),                                   # floor
+        plane([{"translate": [0, 9, 0]}]),                                                    # ceiling, through the first light
+        plane([{"rotate-x": half_pi}, {"translate": [0, 0, 12]}], reflective=0.2),            # back wall
+        plane([{"rotate-x": half_pi}, {"translate": [0, 0, -10]}]),                           # the wall the camera stands in
+        plane([{"rotate-z": half_pi}, {"translate": [-8, 0, 0]}]),                            # left wall
+        plane([{"rotate-z": half_pi}, {"translate": [8, 0, 0]}], transparency=0.6, **{"refractive-index": 1.2}),   # right wall: glass
+        plane([{"translate": [0, 1e-9, 0]}], transparency=0.9, reflective=0.1, **{"refractive-index": 1.0}),       # a sheet a hair above y = 0
+        plane([{"rotate-z": 0.3}, {"rotate-x": 0.2}, {"translate": [0, 4, 6]}], reflective=0.8, diffuse=0.1),      # tilted mirror
+        {"type": {"sphere": {}}, "transform": [{"translate": [-2, 0, 2]}], "material": {"transparency": 0.8, "refractive-index": 1.5, "reflective": 0.3}},
+        {"type": {"sphere": {}}, "transform": [{"scale": [0.5, 0.5, 0.5]}, {"translate": [2, -1.5, 0]}]},
+        {"type": {"cube": {}}, "transform": [{"translate": [3, -1, 4]}], "material": {"reflective": 0.4}},
+        {"type": {"cube": {}}, "transform": [{"scale": [0.5, 2, 0.5]}, {"translate": [-4, 0, 5]}]},
+        {"type": {"sphere": {}}, "transform": [{"translate": [0, 3, 4]}], "casts-shadow": False},
+    ]
+    if variant in ("flat", "group"):
+        objs.append({"type": {"cylinder": {"min": -2, "max": 1, "closed": True}}, "transform": [{"translate": [5, 0, 2]}]})
+        objs.append({"type": {"cone": {"min": -1, "max": 0, "closed": True}}, "transform": [{"translate": [-5, -1, 0]}]})
+    if variant == "group":
+        objs.append({"type": {"group": [{"type": {"sphere": {}}, "transform": [{"translate": [1, 1, 1]}]},
+                                        plane([{"translate": [0, -1.5, 0]}]),
+                                        {"type": {"cube": {}}, "transform": [{"translate": [-1, 0, 7]}]}]}})
+    lights = [{"point-light": {"position": [0, 9, 1], "intensity": [0.5, 0.5, 0.5]}},       # ON the ceiling plane
+              {"point-light": {"position": [-3, 5, -4], "intensity": [0.4, 0.4, 0.4]}},
+              {"point-light": {"position": [8, 2, 3], "intensity": [0.3, 0.3, 0.3]}}]        # ON the glass wall
+    return json.dumps({"camera": {"width": 121, "height": 81, "field-of-view": 1.3, "from": [0, 0, -10], "to": [0, 0, 0], "up": [0, 1, 0]},
+                       "lights": lights, "objects": objs})
+
+
+@pytest.mark.parametrize("variant,kernel", [("simple", "rtc_render_kernel_simple"), ("flat", "rtc_render_kernel_flat"), ("group", "rtc_render_kernel")])
+def test_planes_decided_without_their_quotient(rtc, variant, kernel):
+    """Whole image and every counter against the oracle, on the sphere- and the box-culling simple kernels, two and three
+    waves per SIMD, the flat and the general kernel (the planes are the tail of the World.objects table and phase 1 of the
+    root loop does not look at them; a plane test skips its division where the entry cannot matter)."""
+    hs = rtc.HostScene(_room_of_planes_scene(variant))
+    cam = hs.camera()
+    want, counters = ob.OracleScene(hs.desc).render(cam, 6)
+    forms = {"simple": [(), (("box_cull", 1),), (("simple3_min_chunks", 0),), (("box_cull", 1), ("simple3_min_chunks", 0))],
+             "flat": [()], "group": [(), (("waves3", 1),)]}[variant]
+    names = set()
+    for options in forms:
+        for name, value in options:
+            rtc.set_option(name, value)
+        try:
+            gpu = rtc.GpuScene(hs.desc)
+            got = gpu.render(cam, 6)
+            st = gpu.stats()
+            names.add(gpu.last_kernel_name())
+        finally:
+            for name, _ in options:
+                rtc.set_option(name, -1)
+        if not options:
+            assert gpu.last_kernel_name() == kernel, gpu.last_kernel_name()
+        delta = np.abs(got - want)
+        assert delta.max() < TOL, (variant, options, delta.max(), np.unravel_index(np.argmax(delta), delta.shape))
+        assert [st["overflow"], st["primary"], st["secondary"], st["shadow_calls"]] == \
+            [0, counters["primary"], counters["secondary"], counters["shadow"]], (variant, options)
+    if variant == "simple":
+        assert names == {"rtc_render_kernel_simple", "rtc_render_kernel_simple_b", "rtc_render_kernel_simple3", "rtc_render_kernel_simple3_b"}, names
+    if variant == "group":
+        assert names == {"rtc_render_kernel", "rtc_render_kernel3"}, names
+
+
 def _random_scene(seed):
     """Random world through the JSON loader: every in-scope primitive, nested groups (some large enough to be
     divided), planes inside groups, glass inside glass, every pattern kind the kernel implements."""
