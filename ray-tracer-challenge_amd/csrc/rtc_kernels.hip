@@ -126,6 +126,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 // (RTC_PRIO_WORK).  Only the order matters (levels 1 / 2 / 3 for the middle measured the same); a fixed priority per
 // work-group instead starves waves (cover + 16 %).  cover - 3.1 %, reflection_and_refraction - 4.7 %, cubes - 3.5 %,
 // dragons 4K - 2.5 %, teapot - 3.8 %, nefertiti - 5.5 %.  -DRTC_SETPRIO=0 builds the kernels without it.
+#ifndef RTC_CULL_HALF_STEP
+#define RTC_CULL_HALF_STEP 1
+#endif
 #ifndef RTC_PLANE_EARLY_OUT
 #define RTC_PLANE_EARLY_OUT 1
 #endif
@@ -1292,8 +1295,13 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         const char* ax = block + rf.onx;
         const char* ay = block + rf.ony;
         const char* az = block + rf.onz;
+#if RTC_CULL_HALF_STEP
+        const uint32_t whole = (nc & 3u) > 2u ? nc : (nc & ~3u);  // (a remainder of one or two roots: one record, not two)
+#else
+        const uint32_t whole = nc;
+#endif
 #pragma unroll 1
-        for (uint32_t first = 0; first < nc; first += 4u) {
+        for (uint32_t first = 0; first < whole; first += 4u) {
           const uint32_t k = roots_kept_box4<V, !FLAT>(block, ax, ay, az, rf);
           mine |= static_cast<unsigned long long>(k) << first;
           block += 2u * sizeof(RootBoxPair);
@@ -1301,6 +1309,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
           ay += 2u * sizeof(RootBoxPair);
           az += 2u * sizeof(RootBoxPair);
         }
+#if RTC_CULL_HALF_STEP
+        if (whole < nc) mine |= static_cast<unsigned long long>(roots_kept_box<V, !FLAT>(block, ax, ay, az, rf)) << whole;
+#endif
       }
     } else {
       for (uint32_t i = 4u * member; i < nc; i += 4u * stride) {
