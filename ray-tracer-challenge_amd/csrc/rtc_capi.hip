@@ -1131,6 +1131,16 @@ void buildRootTables(const rtc_scene_desc& d, const std::vector<uint32_t>& dfs_o
         R.ymax = d.cyl_max[g];
         if (d.cyl_closed[g]) R.kind_flags |= 0x200u;
       }
+      if (k == RTC_CUBE && d.n_lights > 0) {  // a room: every light strictly inside the cube (object space)
+        bool room = true;
+        for (uint32_t l = 0; l < d.n_lights && room; ++l)
+          for (int r = 0; r < 3 && room; ++r) {
+            const double* m = R.inv + 4 * r;
+            const double c = ((m[0] * d.light_pos[3ull * l] + m[1] * d.light_pos[3ull * l + 1]) + m[2] * d.light_pos[3ull * l + 2]) + m[3];
+            room = std::fabs(c) <= 1.0 - 1e-6;
+          }
+        if (room) R.kind_flags |= RTC_ROOT_ROOM;
+      }
       R.index = dfs_of[ref];
       R.material = d.leaf_material[ref];
       R.geom = (k == RTC_TRIANGLE || k == RTC_SMOOTH_TRIANGLE) ? g : 0u;

@@ -77,7 +77,7 @@ struct RootBoxPair {  // 80 B
 struct alignas(16) RootRec {
   double inv[12];        // rows 0..2 of the leaf's inverse; a group: a copy of the root Bvh8Node of its candidate BVH (80 bytes: a walk's first node comes from this record - in LDS - not from the node table)
   double ymin, ymax;     // cylinder / cone
-  uint32_t kind_flags;   // kind | casts_shadow<<8 | closed<<9 | is_group<<15
+  uint32_t kind_flags;   // kind | casts_shadow<<8 | closed<<9 | room<<10 | is_group<<15
   uint32_t index;        // leaf index (depth-first) or group node index
   uint32_t material;
   uint32_t geom;         // a group: root node of its candidate BVH
@@ -86,6 +86,7 @@ struct alignas(16) RootRec {
 };
 #define RTC_ROOT_IS_GROUP 0x8000u
 #define RTC_ROOT_IS_CSG 0x4000u  // with IS_GROUP: the root is a csg unit, `index` its node
+#define RTC_ROOT_ROOM 0x400u     // a top-level cube with every light of the world inside it: most shadow rays never reach its faces (trace())
 // Small-world limits: scenes within all four get their tables staged in LDS (50.7 KB per work-group with the mailbox);
 // anything larger runs the same kernel reading the tables from memory.
 #ifndef RTC_LDS_ROOTS

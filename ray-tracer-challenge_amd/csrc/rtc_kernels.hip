@@ -126,6 +126,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 // (RTC_PRIO_WORK).  Only the order matters (levels 1 / 2 / 3 for the middle measured the same); a fixed priority per
 // work-group instead starves waves (cover + 16 %).  cover - 3.1 %, reflection_and_refraction - 4.7 %, cubes - 3.5 %,
 // dragons 4K - 2.5 %, teapot - 3.8 %, nefertiti - 5.5 %.  -DRTC_SETPRIO=0 builds the kernels without it.
+#ifndef RTC_ROOM_EARLY_OUT
+#define RTC_ROOM_EARLY_OUT 1
+#endif
 #ifndef RTC_CULL_HALF_STEP
 #define RTC_CULL_HALF_STEP 1
 #endif
@@ -276,6 +279,25 @@ __device__ __forceinline__ bool cube_slab(const Ray& r, double& tmin, double& tm
   tmin = zmax(xtmin, zmax(ytmin, ztmin));
   tmax = zmin(xtmax, zmin(ytmax, ztmax));
   return !(tmin > tmax);
+}
+
+// A shadow ray that starts inside a cube and whose light is nearer than every face ahead of it: both of the cube's
+// entries are irrelevant to it - tmin < 0, tmax > the light's distance - and both can be known WITHOUT the six quotients
+// of cube_slab, exactly: the origin inside by 1e-9 (object space) puts a face behind it on every axis that is not
+// "parallel" (each of those quotients is negative and no smaller than 1e-9 / 2^200: it cannot round to -0), and
+// 1 -+ o > limit x |d| x (1 + 1e-12) puts the face ahead beyond the limit after rounding (see the plane's early-out); an
+// axis the reference treats as parallel (|d| < 1e-5, or a NaN: cube.zig:28-35) gives -inf / +inf and constrains nothing.
+// Run for the cubes rtc_scene_create marks as rooms (every light inside: teapot.json, nefertiti.json): for any other
+// cube the three compares of `inside` would be paid by every test and fail.
+__device__ __forceinline__ bool segment_stays_inside_cube(const Ray& r, double limit) {
+  const double in = 1.0 - 1e-9;
+  const bool inside = (__builtin_fabs(r.ox) <= in) & (__builtin_fabs(r.oy) <= in) & (__builtin_fabs(r.oz) <= in);
+  auto clear = [&](double o, double d) {
+    const double ad = __builtin_fabs(d);
+    const double ahead = d > 0.0 ? 1.0 - o : 1.0 + o;  // to the face the ray travels towards
+    return !(ad >= 1e-5) | (ahead > (limit * ad) * (1.0 + 1e-12));
+  };
+  return inside & clear(r.ox, r.dx) & clear(r.oy, r.dy) & clear(r.oz, r.dz);
 }
 
 // Emits the entries a leaf's localIntersect appends, in the reference's order, as f(t, u, v).
@@ -1359,6 +1381,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       const CylParams cy{0.0, 0.0, false};
       const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
       vis.set_root(root);
+      if constexpr (KIND == 2u && V::kAnyHit && RTC_ROOM_EARLY_OUT) {
+        if ((kf & RTC_ROOT_ROOM) && segment_stays_inside_cube(lr, vis.t_limit())) return;
+      }
       if constexpr (KIND == 1u && V::kFrontOnly && RTC_PLANE_EARLY_OUT) {
         // A plane's one entry is t = -o.y / d.y (plane.zig:25-36), and the division is 13 of the test's ~35 instructions.
         // A closest-hit or a shadow trace looks at an entry only if 0 <= t and t < (or <=) its limit - the best hit so
@@ -1417,6 +1442,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
       if (FLAT || !(kf & RTC_ROOT_IS_GROUP)) {
         if (!FLAT && V::kAnyHit && ((kf >> 8) & 1u) == 0u) continue;  // (a shadow trace: a shape that casts no shadow, see visit_leaf)
         const Ray lr = xform_ray(R.inv, ray);  // Shape.intersect: ray.transform(_inverse_transform)
+        if constexpr (V::kAnyHit && RTC_ROOM_EARLY_OUT) {
+          if ((kf & RTC_ROOT_ROOM) && segment_stays_inside_cube(lr, vis.t_limit())) continue;
+        }
         const CylParams cy{R.ymin, R.ymax, ((kf >> 9) & 1u) != 0u};
         const uint32_t leaf = R.index, shadow = (kf >> 8) & 1u, material = R.material;
         vis.set_root(base + bit);

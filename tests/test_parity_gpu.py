@@ -1156,6 +1156,64 @@ def test_planes_decided_without_their_quotient(rtc, variant, kernel):
         assert names == {"rtc_render_kernel", "rtc_render_kernel3"}, names
 
 
+def _rooms_scene(variant):
+    """Cubes with every light inside (rtc_scene_create marks them as rooms: a shadow ray that starts inside one and whose
+    light is nearer than the faces ahead skips the cube's six quotients): a big room, a tilted room inside it, a glass
+    case around one light only (NOT a room: the other lights are outside), a light a hair from a wall, things on the
+    walls, in the corners and outside the rooms.  variant: "simple", "flat" (+ a cylinder), "group" (+ a group)."""
+    import json
+    def cube(scale, translate, extra=None, **material):
+        return {"type": {"cube": {}}, "transform": [{"scale": scale}] + (extra or []) + [{"translate": translate}],
+                "material": dict({"diffuse": 0.7, "specular": 0.2}, **material)}
+    objs = [
+        cube([10, 6, 12], [0, 4, 0], pattern={"type": {"checkers": [{"type": {"solid": [0.9, 0.9, 0.9]}}, {"type": {"solid": [0.3, 0.3, 0.4]}}]},
+                                              "transform": [{"scale": [0.1, 0.2, 0.1]}]}),               # the room
+        cube([7, 5, 8], [0, 4, 1], extra=[{"rotate-y": 0.3}], transparency=0.7, reflective=0.1, **{"refractive-index": 1.05}),   # a tilted glass room inside it
+        cube([0.5, 0.5, 0.5], [-3, 7, -2], transparency=0.9, **{"refractive-index": 1.0}),              # a case around the first light only
+        cube([1, 1, 1], [9, -1, 11]),                                                                    # in a corner of the room
+        cube([1, 0.2, 1], [0, -1.8, 0], reflective=0.5),                                                 # on the floor
+        {"type": {"sphere": {}}, "transform": [{"translate": [2, 0, 2]}], "material": {"reflective": 0.3}},
+        {"type": {"sphere": {}}, "transform": [{"scale": [0.7, 0.7, 0.7]}, {"translate": [-2, -1.3, 3]}], "material": {"transparency": 0.8, "refractive-index": 1.5}},
+        {"type": {"sphere": {}}, "transform": [{"translate": [0, 30, 0]}]},                               # outside every room
+        {"type": {"plane": {}}, "transform": [{"translate": [0, -2.5, 0]}]},                              # below the room's floor
+    ]
+    if variant in ("flat", "group"):
+        objs.append({"type": {"cylinder": {"min": -2, "max": 2, "closed": True}}, "transform": [{"scale": [0.5, 1, 0.5]}, {"translate": [4, 0, -3]}]})
+    if variant == "group":
+        objs.append({"type": {"group": [cube([0.5, 0.5, 0.5], [-4, -1.5, 5]), {"type": {"sphere": {}}, "transform": [{"translate": [-5, 0, 6]}]}]}})
+    lights = [{"point-light": {"position": [-3, 7, -2], "intensity": [0.5, 0.5, 0.5]}},
+              {"point-light": {"position": [4, 5, -6], "intensity": [0.4, 0.4, 0.4]}},
+              {"point-light": {"position": [0, 9.99999, 3], "intensity": [0.3, 0.3, 0.3]}}]    # a hair under the room's ceiling (y = 10)
+    return json.dumps({"camera": {"width": 121, "height": 81, "field-of-view": 1.4, "from": [0, 3, -11], "to": [0, 2, 0], "up": [0, 1, 0]},
+                       "lights": lights, "objects": objs})
+
+
+@pytest.mark.parametrize("variant", ["simple", "flat", "group"])
+def test_rooms_around_the_lights(rtc, variant):
+    """Whole image and every counter against the oracle for worlds inside cubes that contain the lights, on every kernel
+    form the world can run."""
+    hs = rtc.HostScene(_rooms_scene(variant))
+    cam = hs.camera()
+    want, counters = ob.OracleScene(hs.desc).render(cam, 6)
+    forms = {"simple": [(), (("box_cull", 0),), (("simple3_min_chunks", 0),), (("box_cull", 0), ("simple3_min_chunks", 0))],
+             "flat": [()], "group": [(), (("waves3", 1),)]}[variant]
+    for options in forms:
+        for name, value in options:
+            rtc.set_option(name, value)
+        try:
+            gpu = rtc.GpuScene(hs.desc)
+            got = gpu.render(cam, 6)
+            st = gpu.stats()
+        finally:
+            for name, _ in options:
+                rtc.set_option(name, -1)
+        delta = np.abs(got - want)
+        assert delta.max() < TOL, (variant, options, gpu.last_kernel_name(), delta.max(), np.unravel_index(np.argmax(delta), delta.shape))
+        assert [st["overflow"], st["primary"], st["secondary"], st["shadow_calls"]] == \
+            [0, counters["primary"], counters["secondary"], counters["shadow"]], (variant, options)
+        assert st["shadow_traced"] > 0
+
+
 def _random_scene(seed):
     """Random world through the JSON loader: every in-scope primitive, nested groups (some large enough to be
     divided), planes inside groups, glass inside glass, every pattern kind the kernel implements."""
