@@ -153,6 +153,9 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #ifndef RTC_PRIO_NODE
 #define RTC_PRIO_NODE 0
 #endif
+#ifndef RTC_PRIO_CULL_SPHERES
+#define RTC_PRIO_CULL_SPHERES 3  // (the simple kernels that cull by spheres: reflection_and_refraction's handles settle 1.36-1.38 ms
+#endif                         //  instead of 1.37-1.43 with the phase at 0; the other worlds on these kernels +- 0.5 %)
 #if RTC_SETPRIO
 #define RTC_PRIO_PHASE(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -1304,7 +1307,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
     const uint32_t n = min(64u, S.n_roots - base);
     const uint32_t nc = n_bounded > base ? min(n, n_bounded - base) : 0u;  // roots of this block that phase 1 tests
     unsigned long long mine = 0ull;
-    RTC_PRIO_PHASE(RTC_PRIO_CULL);
+    RTC_PRIO_PHASE(BOX ? RTC_PRIO_CULL : RTC_PRIO_CULL_SPHERES);
     // the tables are padded with entries no ray keeps: the spheres to a multiple of four roots (r2 = -inf), the boxes to eight (lo > hi)
     if (BOX && FLAT && stride == 1u) {
       // (the kernels of worlds without groups, but for their cooperative iterations: four roots - two records - per step
