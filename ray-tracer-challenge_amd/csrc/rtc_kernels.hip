@@ -1429,6 +1429,7 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
           if (__all(vis.done())) break;
           if (!vis.done()) leaf_of_kind(std::integral_constant<uint32_t, 1u>{}, root);
         }
+
       } else {
         leaves_of_kind(std::integral_constant<uint32_t, 1u>{}, mine & range(n_bounded, S.n_roots));
       }
