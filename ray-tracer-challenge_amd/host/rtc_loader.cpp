@@ -19,6 +19,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <exception>
+#include <system_error>
 #include <thread>
 #include <cstdlib>
 #include <cstring>
@@ -636,7 +637,12 @@ SceneInfo parseScene(const std::string& scene_json, const FileLoader& load_file_
       }
     };
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    pool.reserve(n_threads);
+    try {
+      for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+    } catch (const std::system_error&) {
+      // (no more threads to be had: the ones that started and this one share the work)
+    }
     work();
     for (std::thread& t : pool) t.join();
     for (size_t i = 0; i < n_objects; ++i) {
