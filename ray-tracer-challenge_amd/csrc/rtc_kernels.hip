@@ -1344,8 +1344,9 @@ __device__ __forceinline__ void trace(const DevScene& S, const RootRec* __restri
         if constexpr (BOX) {
           const char* const p0 = reinterpret_cast<const char*>(cull.box + ((base + i) >> 1));
           const char* const p1 = p0 + sizeof(RootBoxPair);
-          k = roots_kept_box<V, !FLAT>(p0, p0 + rf.onx, p0 + rf.ony, p0 + rf.onz, rf) |
-              (roots_kept_box<V, !FLAT>(p1, p1 + rf.onx, p1 + rf.ony, p1 + rf.onz, rf) << 2);
+          k = roots_kept_box<V, !FLAT>(p0, p0 + rf.onx, p0 + rf.ony, p0 + rf.onz, rf);
+          // (a remainder of one or two roots - teapot.json has two top-level objects, dragons.json six - is one record's work)
+          if (i + 2u < nc) k |= roots_kept_box<V, !FLAT>(p1, p1 + rf.onx, p1 + rf.ony, p1 + rf.onz, rf) << 2;
         } else {
           const RootCullPair p0 = cull.sphere[(base + i) >> 1], p1 = cull.sphere[((base + i) >> 1) + 1u];
           k = roots_kept<V, !FLAT>(p0, rf) | (roots_kept<V, !FLAT>(p1, rf) << 2);
