@@ -116,7 +116,22 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #define RTC_EXPERIMENT 0
 #endif
 
+// ---- round 5's build switches: 1 = as shipped, 0 = the kernels without it (A/B builds: tools/variants.py "x=-DRTC_...=0") ----
 #ifndef RTC_ROOT_NODE_IN_REC
+#define RTC_ROOT_NODE_IN_REC 1  // a group's World.objects record carries a copy of the root node of its candidate BVH (traverse_bvh8)
+#endif
+#ifndef RTC_ALL_SOLID_FORM
+#define RTC_ALL_SOLID_FORM 1    // a world of solid colours takes a hit's colour from its material (render_body, SOLID_PATH)
+#endif
+#ifndef RTC_CULL_HALF_STEP
+#define RTC_CULL_HALF_STEP 1    // phase 1 of the root loop: a remainder of one or two roots is one record's work (trace())
+#endif
+#ifndef RTC_PLANE_EARLY_OUT
+#define RTC_PLANE_EARLY_OUT 1   // a plane test decides 0 <= t < limit without its quotient where that is exact (trace(), leaf_of_kind)
+#endif
+#ifndef RTC_ROOM_EARLY_OUT
+#define RTC_ROOM_EARLY_OUT 1    // shadow rays inside a cube that contains every light (segment_stays_inside_cube)
+#endif
 // Wave priority by phase of the iteration (s_setprio, round 5; profiles/r05/wave_priority.md).  The three waves of a SIMD
 // are at different places of the same loop; which of them issues when more than one could is the arbiter's choice, and
 // with equal priorities it serves them alike.  Here a wave says what it is doing: fetching work (RTC_PRIO_DEAL: popping its
@@ -126,18 +141,6 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 // (RTC_PRIO_WORK).  Only the order matters (levels 1 / 2 / 3 for the middle measured the same); a fixed priority per
 // work-group instead starves waves (cover + 16 %).  cover - 3.1 %, reflection_and_refraction - 4.7 %, cubes - 3.5 %,
 // dragons 4K - 2.5 %, teapot - 3.8 %, nefertiti - 5.5 %.  -DRTC_SETPRIO=0 builds the kernels without it.
-#ifndef RTC_ROOM_EARLY_OUT
-#define RTC_ROOM_EARLY_OUT 1
-#endif
-#ifndef RTC_CULL_HALF_STEP
-#define RTC_CULL_HALF_STEP 1
-#endif
-#ifndef RTC_PLANE_EARLY_OUT
-#define RTC_PLANE_EARLY_OUT 1
-#endif
-#ifndef RTC_ALL_SOLID_FORM
-#define RTC_ALL_SOLID_FORM 1
-#endif
 #ifndef RTC_SETPRIO
 #define RTC_SETPRIO 1
 #endif
@@ -160,8 +163,6 @@ __shared__ unsigned long long rtc_prof_counts[4][40];
 #define RTC_PRIO_PHASE(x) __builtin_amdgcn_s_setprio(x)
 #else
 #define RTC_PRIO_PHASE(x) ((void)0)
-#endif
-#define RTC_ROOT_NODE_IN_REC 1  // a group's World.objects record carries a copy of the root node of its candidate BVH (traverse_bvh8)
 #endif
 #ifndef RTC_LB2
 #define RTC_LB2 2  // minimum waves per SIMD the register allocator must leave room for
